@@ -1,0 +1,54 @@
+"""ORACLE (test infrastructure, not product): numpy restatement of the reference's spectral metrics,
+which define the north-star parity yardstick ("within 1e-3 LSD").
+
+Parity status: PINNED against fixture G7 (tests/golden/g7_*), captured from the reference.
+Follows egregora_audio_eval_pack.py:389-429 (duplicate at egregora_null_test_suite.py:167-189).
+"""
+import numpy as np
+
+
+def stft_mag(x, n_fft=2048, hop=512):
+    """|rFFT| of Hann(n_fft, symmetric, float32)-windowed frames, hop, no centring, mono downmix by
+    mean over channels, frames = 1 + max(0,(N-n_fft)//hop), short frame zero-padded.
+    Output [n_fft/2+1, frames] float32.  egregora_audio_eval_pack.py:389-402."""
+    x = np.asarray(x)
+    mono = x if x.ndim == 1 else x.mean(axis=0)
+    N = mono.shape[0]
+    k = np.arange(n_fft, dtype=np.float64)
+    win = (0.5 - 0.5 * np.cos(2 * np.pi * k / (n_fft - 1))).astype(np.float32)
+    frames = 1 + max(0, (N - n_fft) // hop)
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(frames)[:, None]
+    padded = mono if N >= n_fft else np.pad(mono, (0, n_fft - N))
+    fr = padded[idx] * win[None, :]           # float32 product as in the reference
+    X = np.fft.rfft(fr, axis=1)               # float64 transform (numpy upcasts), like the reference
+    return np.abs(X).astype(np.float32).T.copy()
+
+
+def lsd(SA, SB):
+    """(mean, p95) over frames of sqrt(mean_bins((20log10(A+eps)-20log10(B+eps))^2)+1e-12).  :405-411."""
+    eps = 1e-12
+    LA = 20 * np.log10(SA + eps)
+    LB = 20 * np.log10(SB + eps)
+    per = np.sqrt(np.mean((LA - LB) ** 2, axis=0) + 1e-12)
+    return float(np.mean(per)), float(np.percentile(per, 95))
+
+
+def lsd_audio(a, b, n_fft=2048, hop=512):
+    n = min(a.shape[-1], b.shape[-1])
+    return lsd(stft_mag(a[..., :n], n_fft, hop), stft_mag(b[..., :n], n_fft, hop))
+
+
+def si_sdr(s, s_hat):
+    """Scale-invariant SDR in dB on the mono downmix, float64.  :414-429."""
+    s = np.asarray(s, np.float64)
+    s_hat = np.asarray(s_hat, np.float64)
+    if s.ndim > 1:
+        s = s.mean(axis=0)
+    if s_hat.ndim > 1:
+        s_hat = s_hat.mean(axis=0)
+    n = min(s.shape[-1], s_hat.shape[-1])
+    s, s_hat = s[:n], s_hat[:n]
+    alpha = np.dot(s_hat, s) / (np.dot(s, s) + 1e-20)
+    tgt = alpha * s
+    err = s_hat - tgt
+    return 10.0 * np.log10((np.dot(tgt, tgt) + 1e-20) / (np.dot(err, err) + 1e-20))

@@ -1,0 +1,31 @@
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def gjson(name):
+    return json.loads((GOLDEN / f"{name}.json").read_text(encoding="utf-8"))
+
+
+def gnpz(name):
+    return np.load(GOLDEN / f"{name}.npz")
+
+
+@pytest.fixture(scope="session")
+def pack():
+    """The product package (hyphenated directory, loaded the way ComfyUI loads a custom node)."""
+    from packload import load_pack
+    return load_pack()
