@@ -1,0 +1,24 @@
+"""ComfyUI custom-node pack: MI355X-native (gfx950) backend for Egregora Audio Super Resolution.
+
+Drop-in for the reference pack's three core nodes (reference __init__.py:33-43): same mapping keys, same
+display names, same INPUT_TYPES / RETURN_TYPES / FUNCTION surface.  Compute runs in libegregora_amd.so
+(hand-written HIP, C ABI in include/egregora_amd.h); importing this package needs neither the library
+nor a GPU -- the nodes raise at run() time when either is missing.
+"""
+from .egregora_audio_super_resolution import EgregoraAudioSuperResolution
+from .egregora_fat_llama_cpu import EgregoraFatLlamaCPU
+from .egregora_fat_llama_gpu import EgregoraFatLlamaGPU
+
+NODE_CLASS_MAPPINGS = {
+    "EgregoraAudioUpscaler": EgregoraAudioSuperResolution,
+    "EgregoraFatLlamaGPU": EgregoraFatLlamaGPU,
+    "EgregoraFatLlamaCPU": EgregoraFatLlamaCPU,
+}
+
+NODE_DISPLAY_NAME_MAPPINGS = {
+    "EgregoraAudioUpscaler": "🎧 Audio Super Resolution (FlashSR)",
+    "EgregoraFatLlamaGPU": "🎛️ Spectral Enhance (Fat Llama — GPU)",
+    "EgregoraFatLlamaCPU": "🎛️ Spectral Enhance (Fat Llama — CPU/FFTW)",
+}
+
+__all__ = ["NODE_CLASS_MAPPINGS", "NODE_DISPLAY_NAME_MAPPINGS"]

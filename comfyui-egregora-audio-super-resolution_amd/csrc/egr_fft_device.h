@@ -1,0 +1,155 @@
+// In-LDS mixed-radix Stockham FFT building blocks for gfx950 (wave64).
+//
+// A "sequence" is one length-L complex series living in LDS at addresses i*es + s*ss (element i of
+// sequence s).  Each stage reads r inputs at stride L/r, applies the stage twiddle W_{Ns*r}^{k*t}
+// (looked up in the global W_L table, L1/L2 resident), does an r-point DFT in registers and writes
+// the autosorted outputs to the other LDS buffer (ping-pong), so input and output are both in natural
+// order and no bit/digit reversal pass exists.  Inverse transforms use swap(FFT(swap(x))).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace egr {
+
+typedef float2 cplx;
+
+#define EGR_MAX_STAGES 14
+
+struct FftDesc {
+    int L;                       // transform length
+    int nst;                     // number of radix stages
+    int radix[EGR_MAX_STAGES];   // radix of stage s
+    int ns[EGR_MAX_STAGES];      // product of the radices of stages < s
+    float inv_ns[EGR_MAX_STAGES];
+};
+
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ cplx cmulc(cplx a, cplx b) {  // a * conj(b)
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+template <int R> struct Trig;
+#include "egr_trig_tables.inc"
+
+template <int R> struct Bfly {
+    // forward DFT of odd prime length R using the (x_n + x_{R-n}), (x_n - x_{R-n}) symmetry
+    static __device__ __forceinline__ void run(cplx (&v)[R]) {
+        constexpr int H = (R - 1) / 2;
+        cplx a[H], b[H];
+#pragma unroll
+        for (int n = 1; n <= H; ++n) {
+            a[n - 1] = cadd(v[n], v[R - n]);
+            b[n - 1] = csub(v[n], v[R - n]);
+        }
+        cplx x0 = v[0];
+        cplx sum = x0;
+#pragma unroll
+        for (int n = 0; n < H; ++n) sum = cadd(sum, a[n]);
+        v[0] = sum;
+#pragma unroll
+        for (int k = 1; k <= H; ++k) {
+            cplx c = x0, s = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int n = 1; n <= H; ++n) {
+                const float cc = Trig<R>::c[(n * k) % R];
+                const float ss = Trig<R>::s[(n * k) % R];
+                c.x += cc * a[n - 1].x; c.y += cc * a[n - 1].y;
+                s.x += ss * b[n - 1].x; s.y += ss * b[n - 1].y;
+            }
+            // X_k = c - i*s ; X_{R-k} = c + i*s
+            v[k] = make_float2(c.x + s.y, c.y - s.x);
+            v[R - k] = make_float2(c.x - s.y, c.y + s.x);
+        }
+    }
+};
+
+template <> struct Bfly<2> {
+    static __device__ __forceinline__ void run(cplx (&v)[2]) {
+        cplx a = v[0], b = v[1];
+        v[0] = cadd(a, b);
+        v[1] = csub(a, b);
+    }
+};
+
+template <> struct Bfly<4> {
+    static __device__ __forceinline__ void run(cplx (&v)[4]) {
+        cplx t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+        cplx t2 = cadd(v[1], v[3]), t3 = csub(v[1], v[3]);
+        v[0] = cadd(t0, t2);
+        v[2] = csub(t0, t2);
+        v[1] = make_float2(t1.x + t3.y, t1.y - t3.x);   // t1 - i*t3
+        v[3] = make_float2(t1.x - t3.y, t1.y + t3.x);   // t1 + i*t3
+    }
+};
+
+// One radix-R stage over `nseq` sequences.  SEQFAST: sequence index is the fastest thread index
+// (column tiles, nseq = 1<<seq_log2); otherwise nseq is 1 or 2 and the butterfly index is fastest.
+template <int R, bool SEQFAST>
+__device__ __forceinline__ void fft_stage(const cplx* __restrict__ in, cplx* __restrict__ out, int L, int Ns,
+                                          float inv_ns, const cplx* __restrict__ tw, int nseq, int seq_log2,
+                                          int es, int ss, bool swap_in, bool swap_out) {
+    const int nb = L / R;
+    const int total = nb * nseq;
+    const int twstep = L / (Ns * R);
+    for (int b = threadIdx.x; b < total; b += blockDim.x) {
+        int s, j;
+        if (SEQFAST) {
+            s = b & (nseq - 1);
+            j = b >> seq_log2;
+        } else {
+            s = (b >= nb) ? 1 : 0;
+            j = b - s * nb;
+        }
+        // k = j mod Ns, exact for j,Ns < 2^13 (see DESIGN.md "integer division by float reciprocal")
+        const int q = (int)(((float)j + 0.5f) * inv_ns);
+        const int k = j - q * Ns;
+        cplx v[R];
+        const cplx* src = in + s * ss;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            cplx x = src[(j + t * nb) * es];
+            v[t] = swap_in ? make_float2(x.y, x.x) : x;
+        }
+        if (Ns > 1) {
+            const int base = k * twstep;
+#pragma unroll
+            for (int t = 1; t < R; ++t) v[t] = cmul(v[t], tw[base * t]);
+        }
+        Bfly<R>::run(v);
+        cplx* dst = out + s * ss + ((j - k) * R + k) * es;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            cplx x = v[t];
+            dst[t * Ns * es] = swap_out ? make_float2(x.y, x.x) : x;
+        }
+    }
+    __syncthreads();
+}
+
+// Full transform of the sequences in `cur`; result ends in `cur` (pointers are swapped per stage).
+// Caller must __syncthreads() after filling `cur`.
+template <bool SEQFAST>
+__device__ __forceinline__ void lds_fft(cplx*& cur, cplx*& alt, const FftDesc& d, const cplx* __restrict__ tw,
+                                        int nseq, int seq_log2, int es, int ss, bool inverse) {
+    for (int s = 0; s < d.nst; ++s) {
+        const bool si = inverse && (s == 0);
+        const bool so = inverse && (s == d.nst - 1);
+        const int Ns = d.ns[s];
+        const float inv = d.inv_ns[s];
+        switch (d.radix[s]) {
+            case 2: fft_stage<2, SEQFAST>(cur, alt, d.L, Ns, inv, tw, nseq, seq_log2, es, ss, si, so); break;
+            case 3: fft_stage<3, SEQFAST>(cur, alt, d.L, Ns, inv, tw, nseq, seq_log2, es, ss, si, so); break;
+            case 4: fft_stage<4, SEQFAST>(cur, alt, d.L, Ns, inv, tw, nseq, seq_log2, es, ss, si, so); break;
+            case 5: fft_stage<5, SEQFAST>(cur, alt, d.L, Ns, inv, tw, nseq, seq_log2, es, ss, si, so); break;
+            case 7: fft_stage<7, SEQFAST>(cur, alt, d.L, Ns, inv, tw, nseq, seq_log2, es, ss, si, so); break;
+            case 11: fft_stage<11, SEQFAST>(cur, alt, d.L, Ns, inv, tw, nseq, seq_log2, es, ss, si, so); break;
+            default: fft_stage<13, SEQFAST>(cur, alt, d.L, Ns, inv, tw, nseq, seq_log2, es, ss, si, so); break;
+        }
+        cplx* t = cur; cur = alt; alt = t;
+    }
+}
+
+}  // namespace egr

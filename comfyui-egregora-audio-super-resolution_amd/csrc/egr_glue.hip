@@ -1,0 +1,213 @@
+// Host-glue arithmetic of the reference moved onto the device: PCM_16 round trip, chunk slice/pad,
+// Hann WOLA stitch (as a deterministic gather) and the STFT-magnitude used by the LSD yardstick.
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "egr_common.h"
+#include "egr_fft_device.h"
+#include "egr_plan.h"
+
+namespace egr {
+
+__global__ __launch_bounds__(256) void k_pcm16(const float* __restrict__ x, float* __restrict__ y, long long n,
+                                                float ws, float rd) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long q = (long long)rintf(__fmul_rn(x[i], ws));
+        q = ((q + 32768) & 65535) - 32768;
+        y[i] = __fdiv_rn((float)q, rd);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_chunk_gather(const float* __restrict__ x, int C, long long total,
+                                                       long long win, long long hop, int chunk_begin,
+                                                       float* __restrict__ chunks) {
+    const int k = blockIdx.y / C, c = blockIdx.y % C;
+    const long long start = (long long)(chunk_begin + k) * hop;
+    const float* xc = x + (size_t)c * total;
+    float* dst = chunks + ((size_t)k * C + c) * win;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < win;
+         j += (long long)gridDim.x * blockDim.x) {
+        const long long i = start + j;
+        dst[j] = (i < total) ? xc[i] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wola(const float* __restrict__ preds, int nchunks, int C, long long lp,
+                                               long long total, long long win, long long hop,
+                                               const float* __restrict__ window, float* __restrict__ out) {
+    const int c = blockIdx.y;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long k_lo = (i < win) ? 0 : (i - win) / hop + 1;
+        long long k_hi = i / hop;
+        if (k_hi > nchunks - 1) k_hi = nchunks - 1;
+        float acc = 0.f, ws = 0.f;
+        for (long long k = k_lo; k <= k_hi; ++k) {
+            const long long start = k * hop;
+            long long L = total - start;
+            if (L > win) L = win;
+            if (L > lp) L = lp;
+            const long long j = i - start;
+            if (j < L) {
+                const float w = window[j];
+                const float y = preds[((size_t)k * C + c) * lp + j];
+                acc = __fadd_rn(acc, __fmul_rn(y, w));
+                ws = __fadd_rn(ws, w);
+            }
+        }
+        if (ws == 0.f) ws = 1.f;
+        out[(size_t)c * total + i] = __fdiv_rn(acc, ws);
+    }
+}
+
+// One workgroup per frame: mono downmix, window, half-length complex FFT in LDS, real split, |X|.
+__global__ __launch_bounds__(256) void k_stft_mag(const float* __restrict__ x, int C, long long n, int n_fft, int hop,
+                                                   const float* __restrict__ window, FftDesc fd,
+                                                   const cplx* __restrict__ tw, const cplx* __restrict__ wsplit,
+                                                   float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int Mh = n_fft / 2;
+    cplx* cur = (cplx*)smem;
+    cplx* alt = cur + Mh;
+    const long long f = blockIdx.x;
+    const long long s0 = f * hop;
+    const float invC = (float)C;
+    for (int e = threadIdx.x; e < Mh; e += blockDim.x) {
+        float v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long t = s0 + 2 * e + h;
+            float m = 0.f;
+            if (t < n) {
+                m = x[t];
+                if (C > 1) {
+                    for (int c = 1; c < C; ++c) m = __fadd_rn(m, x[(size_t)c * n + t]);
+                    m = __fdiv_rn(m, invC);
+                }
+            }
+            v[h] = __fmul_rn(m, window[2 * e + h]);
+        }
+        cur[e] = make_float2(v[0], v[1]);
+    }
+    __syncthreads();
+    lds_fft<false>(cur, alt, fd, tw, 1, 0, 1, Mh, false);
+    float* o = out + (size_t)f * (Mh + 1);
+    for (int k = threadIdx.x; k <= Mh; k += blockDim.x) {
+        const cplx Za = cur[k == Mh ? 0 : k];
+        const cplx Zb = cur[(k == 0 || k == Mh) ? 0 : Mh - k];
+        const cplx E = make_float2(0.5f * (Za.x + Zb.x), 0.5f * (Za.y - Zb.y));
+        const cplx O = make_float2(0.5f * (Za.y + Zb.y), -0.5f * (Za.x - Zb.x));
+        const cplx X = cadd(E, cmul(wsplit[k], O));
+        o[k] = sqrtf(X.x * X.x + X.y * X.y);
+    }
+}
+
+struct StftTables {
+    FftDesc fd;
+    cplx *tw, *wsplit;
+};
+static std::mutex g_stft_mu;
+static std::map<std::pair<int, int>, StftTables> g_stft;   // (device, n_fft)
+
+static int stft_tables(int n_fft, StftTables* out) {
+    int dev = 0;
+    EGR_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_stft_mu);
+    auto it = g_stft.find({dev, n_fft});
+    if (it != g_stft.end()) { *out = it->second; return EGR_OK; }
+    StftTables t;
+    const int Mh = n_fft / 2;
+    EGR_CHECK(make_schedule(Mh, &t.fd), EGR_ERR_UNSUPPORTED, "n_fft=%d: n_fft/2 must be {2,3,5,7,11,13}-smooth", n_fft);
+    std::vector<float2> h;
+    make_twiddles(h, Mh, 1, Mh);
+    EGR_HIP(hipMalloc((void**)&t.tw, h.size() * sizeof(float2)));
+    EGR_HIP(hipMemcpy(t.tw, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice));
+    make_twiddles(h, Mh + 1, 1, n_fft);
+    EGR_HIP(hipMalloc((void**)&t.wsplit, h.size() * sizeof(float2)));
+    EGR_HIP(hipMemcpy(t.wsplit, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice));
+    g_stft[{dev, n_fft}] = t;
+    *out = t;
+    return EGR_OK;
+}
+
+static inline int grid_for(long long n) {
+    long long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace egr
+
+using namespace egr;
+
+extern "C" int egr_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        set_error("hipGetDeviceCount -> %s", hipGetErrorString(e));
+        return -EGR_ERR_HIP;
+    }
+    return n;
+}
+
+extern "C" int egr_device_arch(int dev, char* buf, size_t buflen) {
+    EGR_CHECK(buf && buflen > 0, EGR_ERR_ARG, "null buffer");
+    hipDeviceProp_t prop;
+    EGR_HIP(hipGetDeviceProperties(&prop, dev));
+    strncpy(buf, prop.gcnArchName, buflen - 1);
+    buf[buflen - 1] = 0;
+    return EGR_OK;
+}
+
+extern "C" int egr_pcm16_roundtrip(const float* x, float* y, int64_t n, float write_scale, float read_div,
+                                   void* stream) {
+    EGR_CHECK(x && y && n >= 0 && read_div != 0.f, EGR_ERR_ARG, "bad argument");
+    if (n == 0) return EGR_OK;
+    hipLaunchKernelGGL(k_pcm16, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long long)n, write_scale,
+                       read_div);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_chunk_gather(const float* x, int channels, int64_t total, int64_t win, int64_t hop,
+                                int chunk_begin, int n_chunks, float* chunks, void* stream) {
+    EGR_CHECK(x && chunks && channels >= 1 && total >= 0 && win >= 1 && hop >= 1 && chunk_begin >= 0 && n_chunks >= 0,
+              EGR_ERR_ARG, "bad argument");
+    if (n_chunks == 0) return EGR_OK;
+    EGR_CHECK((int64_t)n_chunks * channels <= 65535, EGR_ERR_ARG, "too many chunk rows for one launch");
+    int gx = grid_for(win);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(k_chunk_gather, dim3(gx, n_chunks * channels), dim3(256), 0, (hipStream_t)stream, x, channels,
+                       (long long)total, (long long)win, (long long)hop, chunk_begin, chunks);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_wola_stitch(const float* preds, int n_chunks, int channels, int64_t lp, int64_t total, int64_t win,
+                               int64_t hop, const float* window, float* out, void* stream) {
+    EGR_CHECK(preds && window && out && n_chunks >= 1 && channels >= 1 && lp >= 1 && total >= 1 && win >= 1 && hop >= 1,
+              EGR_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_wola, dim3(grid_for(total), channels), dim3(256), 0, (hipStream_t)stream, preds, n_chunks,
+                       channels, (long long)lp, (long long)total, (long long)win, (long long)hop, window, out);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_stft_mag(const float* x, int channels, int64_t n, int n_fft, int hop, const float* window,
+                            float* out, void* stream) {
+    EGR_CHECK(x && window && out && channels >= 1 && n >= 0 && hop >= 1, EGR_ERR_ARG, "bad argument");
+    EGR_CHECK(n_fft >= 2 && (n_fft % 2) == 0 && n_fft <= 8192, EGR_ERR_UNSUPPORTED, "n_fft=%d must be even and <= 8192",
+              n_fft);
+    StftTables t;
+    int rc = stft_tables(n_fft, &t);
+    if (rc) return rc;
+    const int64_t frames = 1 + ((n - n_fft) > 0 ? (n - n_fft) / hop : 0);
+    const size_t lds = (size_t)2 * (n_fft / 2) * sizeof(float2);
+    hipLaunchKernelGGL(k_stft_mag, dim3((unsigned)frames), dim3(256), lds, (hipStream_t)stream, x, channels,
+                       (long long)n, n_fft, hop, window, t.fd, t.tw, t.wsplit, out);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}

@@ -1,0 +1,105 @@
+"""Host driver of the device Fat-Llama engine (csrc/egr_fatllama.hip) behind the C ABI.
+
+Stands in for `fat_llama.audio_fattener.feed.upscale` + the temp-file hops of the reference
+(egregora_fat_llama_gpu.py:161-224, :34-37, :291-294).  Sample-rate bookkeeping (a14): the reference takes
+the output rate from the file upstream wrote, i.e. sr * upscale_factor.
+"""
+import ctypes as C
+from collections import OrderedDict
+from typing import Tuple
+
+import torch
+
+from . import native
+
+SAMPLE_WIDTH_BYTES = 2        # temp WAVs are PCM_16 (libsndfile default for float data)
+_PLANS: "OrderedDict[tuple, int]" = OrderedDict()
+_MAX_PLANS = 4
+
+
+def upscale_factor(sr: int, channels: int, target_bitrate_kbps: int) -> int:
+    """round(target bits/s / source bits/s), at least 1 (upstream rule as recalled; see oracle/fatllama.py)."""
+    src_bps = sr * channels * 8 * SAMPLE_WIDTH_BYTES
+    return max(1, int(round((target_bitrate_kbps * 1000.0) / src_bps)))
+
+
+def _plan(n_in: int, channels: int, factor: int, device: int, m1_hint: int = 0, tc_hint: int = 0):
+    key = (n_in, channels, factor, device, m1_hint, tc_hint)
+    h = _PLANS.get(key)
+    if h is not None:
+        _PLANS.move_to_end(key)
+        return h
+    L = native.lib()
+    out = C.c_void_p()
+    native.check(L.egr_fatllama_plan_create(C.byref(out), n_in, channels, factor, m1_hint, tc_hint),
+                 "egr_fatllama_plan_create")
+    _PLANS[key] = out.value
+    while len(_PLANS) > _MAX_PLANS:
+        _, old = _PLANS.popitem(last=False)
+        L.egr_fatllama_plan_destroy(C.c_void_p(old))
+    return out.value
+
+
+def release_plans():
+    L = native.lib()
+    while _PLANS:
+        _, old = _PLANS.popitem(last=False)
+        L.egr_fatllama_plan_destroy(C.c_void_p(old))
+
+
+def plan_info(n_in: int, factor: int, m1_hint: int = 0) -> dict:
+    """Host-only planning query (works without a GPU)."""
+    L = native.lib()
+    info = (C.c_int64 * native.FL_INFO_LEN)()
+    rc = L.egr_fatllama_plan_query(n_in, factor, m1_hint, info)
+    v = list(info)
+    d = {"supported": bool(v[0]) and rc == 0, "N": v[1], "M": v[2], "M1": v[3], "M2": v[4], "TC": v[5],
+         "radix1": [r for r in v[8:8 + v[6]]], "radix2": [r for r in v[22:22 + v[7]]],
+         "lds_col": v[36], "lds_row": v[37]}
+    if rc != 0:
+        d["error"] = native.last_error()
+    return d
+
+
+def enhance_device(x_ct: torch.Tensor, factor: int, max_iterations: int, threshold_value: float,
+                   normalize: bool, autoscale: bool, pcm_in: bool, node_post: bool,
+                   m1_hint: int = 0, tc_hint: int = 0, profile: bool = False):
+    """x_ct: [C,T] float32 CUDA tensor.  Returns [C,T*factor] float32 CUDA tensor (same stream)."""
+    if not (x_ct.is_cuda and x_ct.dtype == torch.float32 and x_ct.dim() == 2):
+        raise RuntimeError("enhance_device wants a [C,T] float32 tensor on the GPU")
+    x_ct = x_ct.contiguous()
+    Cn, T = x_ct.shape
+    if T < 1:
+        raise RuntimeError("empty audio")
+    plan = _plan(T, Cn, factor, x_ct.device.index or 0, m1_hint, tc_hint)
+    out = torch.empty((Cn, T * factor), dtype=torch.float32, device=x_ct.device)
+    flags = ((native.FL_NORMALIZE if normalize else 0) | (native.FL_AUTOSCALE if autoscale else 0) |
+             (native.FL_PCM_IN if pcm_in else 0) | (native.FL_NODE_POST if node_post else 0))
+    L = native.lib()
+    if profile:
+        L.egr_fatllama_set_profiling(C.c_void_p(plan), 1)
+    native.check(L.egr_fatllama_enhance(C.c_void_p(plan), native.ptr(x_ct), native.ptr(out), int(max_iterations),
+                                        float(threshold_value), flags, native.stream_ptr()), "egr_fatllama_enhance")
+    return out
+
+
+def kernel_times(n_in: int, channels: int, factor: int, device: int = 0):
+    L = native.lib()
+    plan = _plan(n_in, channels, factor, device)
+    r, c = C.c_double(), C.c_double()
+    nr, nc = C.c_int64(), C.c_int64()
+    native.check(L.egr_fatllama_kernel_times(C.c_void_p(plan), C.byref(r), C.byref(c), C.byref(nr), C.byref(nc)),
+                 "egr_fatllama_kernel_times")
+    L.egr_fatllama_set_profiling(C.c_void_p(plan), 0)
+    return {"row_ms": r.value, "col_ms": c.value, "row_launches": nr.value, "col_launches": nc.value}
+
+
+def node_run(cs: torch.Tensor, sr: int, max_iterations: int, threshold_value: float, target_bitrate_kbps: int,
+             toggle_normalize: bool, toggle_autoscale: bool) -> Tuple[torch.Tensor, int]:
+    """Whole node arithmetic for one AUDIO: [C,T] float (any device) -> ([C,T*f] float32 CUDA, sr*f)."""
+    native.require_device()
+    x = cs.to("cuda", torch.float32, non_blocking=True).contiguous()
+    f = upscale_factor(int(sr), x.shape[0], int(target_bitrate_kbps))
+    y = enhance_device(x, f, int(max_iterations), float(threshold_value), bool(toggle_normalize),
+                       bool(toggle_autoscale), pcm_in=True, node_post=True)
+    return y, int(sr) * f

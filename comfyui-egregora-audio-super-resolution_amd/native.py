@@ -1,0 +1,94 @@
+"""ctypes binding of libegregora_amd.so (the C ABI declared in include/egregora_amd.h).
+
+There is no CPU fallback: if the shared library or an MI355X is missing, every compute entry point
+raises RuntimeError.  torch is used only to own device memory and streams.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+_LIB = None
+LIB_PATH = Path(__file__).resolve().parent / "libegregora_amd.so"
+
+EGR_OK = 0
+FL_NORMALIZE, FL_AUTOSCALE, FL_PCM_IN, FL_NODE_POST = 0x1, 0x2, 0x4, 0x8
+FL_INFO_LEN = 40
+
+# name -> (restype, argtypes); must list every symbol of include/egregora_amd.h
+_vp, _i, _i64, _f, _u = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint
+SIGNATURES = {
+    "egr_last_error": (C.c_char_p, []),
+    "egr_abi_version": (_i, []),
+    "egr_device_count": (_i, []),
+    "egr_device_arch": (_i, [_i, C.c_char_p, C.c_size_t]),
+    "egr_fatllama_plan_query": (_i, [_i64, _i, _i, C.POINTER(_i64)]),
+    "egr_fatllama_plan_create": (_i, [C.POINTER(_vp), _i64, _i, _i, _i, _i]),
+    "egr_fatllama_plan_destroy": (_i, [_vp]),
+    "egr_fatllama_enhance": (_i, [_vp, _vp, _vp, _i, _f, _u, _vp]),
+    "egr_fatllama_last_peaks": (_i, [_vp, C.POINTER(_f), C.POINTER(_f), _vp]),
+    "egr_fatllama_set_profiling": (_i, [_vp, _i]),
+    "egr_fatllama_kernel_times": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64),
+                                       C.POINTER(_i64)]),
+    "egr_pcm16_roundtrip": (_i, [_vp, _vp, _i64, _f, _f, _vp]),
+    "egr_stft_mag": (_i, [_vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
+    "egr_wola_stitch": (_i, [_vp, _i, _i, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "egr_chunk_gather": (_i, [_vp, _i, _i64, _i64, _i64, _i, _i, _vp, _vp]),
+}
+
+
+def lib():
+    """Load the shared library (once).  Raises RuntimeError with build instructions when absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = Path(os.environ.get("EGREGORA_AMD_LIB", str(LIB_PATH)))
+    if not path.exists():
+        raise RuntimeError(
+            f"libegregora_amd.so not found at {path}. Build it with `make -C {LIB_PATH.parent / 'csrc'}` "
+            "(hipcc, --offload-arch=gfx950). This pack has no CPU fallback.")
+    try:
+        L = C.CDLL(str(path))
+    except OSError as e:
+        raise RuntimeError(f"failed to load {path}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)            # AttributeError here = ABI mismatch, which must be loud
+        fn.restype, fn.argtypes = res, args
+    if L.egr_abi_version() != 1:
+        raise RuntimeError(f"libegregora_amd.so ABI {L.egr_abi_version()} != 1")
+    _LIB = L
+    return L
+
+
+def last_error() -> str:
+    return (lib().egr_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int, what: str):
+    if rc != EGR_OK:
+        raise RuntimeError(f"{what} failed (status {rc}): {last_error()}")
+
+
+def require_device():
+    """Loud check that an MI355X (gfx950) is visible.  Stands in for _ensure_gpu_stack
+    (reference egregora_fat_llama_gpu.py:132-159), minus every CuPy / NVIDIA-wheel concern."""
+    import torch
+    L = lib()
+    n = L.egr_device_count()
+    if n <= 0 or not torch.cuda.is_available():
+        raise RuntimeError("No AMD GPU detected. This pack's compute nodes require an MI355X (gfx950) with ROCm; "
+                           "there is no CPU fallback. " + (last_error() if n < 0 else ""))
+    buf = C.create_string_buffer(256)
+    check(L.egr_device_arch(torch.cuda.current_device(), buf, 256), "egr_device_arch")
+    arch = buf.value.decode()
+    if not arch.startswith("gfx950"):
+        raise RuntimeError(f"GPU architecture {arch!r} is not gfx950 (MI355X); libegregora_amd.so holds gfx950 code only.")
+    return arch
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr())

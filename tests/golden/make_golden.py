@@ -235,7 +235,8 @@ def main():
     # ---------------- G8: node surface ----------------
     def surf(cls):
         import inspect
-        return {"INPUT_TYPES": cls.INPUT_TYPES(), "RETURN_TYPES": list(cls.RETURN_TYPES),
+        it = cls.INPUT_TYPES()
+        return {"INPUT_TYPES": it, "widget_order": {k: list(v.keys()) for k, v in it.items()}, "RETURN_TYPES": list(cls.RETURN_TYPES),
                 "FUNCTION": cls.FUNCTION, "CATEGORY": cls.CATEGORY, "OUTPUT_NODE": cls.OUTPUT_NODE,
                 "run_signature": str(inspect.signature(cls.run))}
     g8 = {

@@ -1,0 +1,150 @@
+"""Numpy model of the HIP Fat-Llama engine's index math (csrc/egr_fatllama.hip): Stockham stages with
+the same (j,k,expand) addressing, the four-step split M = M1*M2 with two-table twiddles, the in-place
+transposed-spectrum layout, and the row-pair real split / threshold / unsplit.  It is vectorised over
+butterflies, uses float64, and exists so the addressing can be validated against numpy.fft on CPU
+(tests/test_kernel_model.py) before/alongside the GPU parity tests.  Not product code.
+"""
+import numpy as np
+
+
+def radix_schedule(L, allowed=(4, 2, 3, 5, 7, 11, 13)):
+    """Same rule as egr::make_schedule: pull 4s first, then a single 2, then odd primes ascending."""
+    rad, n = [], L
+    while n % 4 == 0:
+        rad.append(4); n //= 4
+    if n % 2 == 0:
+        rad.append(2); n //= 2
+    for p in (3, 5, 7, 11, 13):
+        while n % p == 0:
+            rad.append(p); n //= p
+    if n != 1:
+        return None
+    return rad
+
+
+def stockham_fft(x, inverse=False):
+    """x: [..., L] complex. Forward DFT via the kernel's stage addressing. Inverse via the swap trick."""
+    L = x.shape[-1]
+    rad = radix_schedule(L)
+    assert rad is not None, L
+    a = x.astype(np.complex128)
+    if inverse:
+        a = a.imag + 1j * a.real
+    tw = np.exp(-2j * np.pi * np.arange(L) / L)
+    Ns = 1
+    for R in rad:
+        nb = L // R
+        j = np.arange(nb)
+        k = j % Ns
+        out = np.empty_like(a)
+        v = [a[..., j + t * nb] for t in range(R)]
+        twstep = L // (Ns * R)
+        v = [v[t] * tw[(k * t * twstep) % L] for t in range(R)]
+        o = (j - k) * R + k
+        WR = np.exp(-2j * np.pi * np.outer(np.arange(R), np.arange(R)) / R)
+        for q in range(R):
+            acc = 0
+            for t in range(R):
+                acc = acc + WR[q, t] * v[t]
+            out[..., o + q * Ns] = acc
+        a = out
+        Ns *= R
+    if inverse:
+        a = a.imag + 1j * a.real
+    return a
+
+
+class Plan:
+    def __init__(self, N, M1, M2):
+        assert N % 2 == 0 and (N // 2) == M1 * M2
+        self.N, self.M, self.M1, self.M2 = N, N // 2, M1, M2
+        M = self.M
+        self.T1 = np.exp(-2j * np.pi * np.arange(M1) / M1)          # W_M1^q  (= W_M^(q*M2))
+        self.T2 = np.exp(-2j * np.pi * np.arange(M2) / M)           # W_M^s
+        self.T3 = np.exp(-2j * np.pi * np.arange(M1) / N)           # W_N^k1
+        self.T4 = np.exp(-2j * np.pi * np.arange(M2) / (2 * M2))    # W_N^(M1*k2)
+
+    def tw_big(self, n2, k1):
+        r = n2 * k1
+        return self.T1[r // self.M2] * self.T2[r % self.M2]
+
+
+def col_first(p, y, thr):
+    """y real [N] -> A[k1][n2]  (threshold in time, FFT over n1, twiddle)."""
+    d0 = np.where(np.abs(y) > thr, y, 0.0)
+    z = (d0[0::2] + 1j * d0[1::2]).reshape(p.M1, p.M2)
+    A = stockham_fft(z.T).T                                          # FFT along n1 for each column
+    k1 = np.arange(p.M1)[:, None]
+    n2 = np.arange(p.M2)[None, :]
+    return A * p.tw_big(n2, k1)
+
+
+def row_fused(p, A, thr):
+    """A[k1][n2] -> B[k1][n2'] : FFT rows, real split + threshold + unsplit on (k, M-k) pairs, IFFT rows."""
+    M1, M2, M = p.M1, p.M2, p.M
+    Z = stockham_fft(A)                                              # Z[k1][k2] = Z[k1 + M1*k2]
+    Zo = np.empty_like(Z)
+    for ka in range(M1 // 2 + 1):
+        kb = (M1 - ka) % M1
+        if ka > kb:
+            continue
+        if ka != kb:
+            k2 = np.arange(M2)
+            pa, pb = (ka, k2), (kb, M2 - 1 - k2)
+            skip_b = np.zeros(M2, bool)
+        elif ka == 0:
+            k2 = np.arange(M2 // 2 + 1)
+            pa, pb = (0, k2), (0, (M2 - k2) % M2)
+            skip_b = (k2 == (M2 - k2) % M2)
+        else:  # ka == M1/2
+            k2 = np.arange((M2 + 1) // 2)
+            pa, pb = (ka, k2), (ka, M2 - 1 - k2)
+            skip_b = (k2 == M2 - 1 - k2)
+        Za, Zb = Z[pa], Z[pb]
+        W = p.T3[ka] * p.T4[k2]
+        E = 0.5 * (Za + np.conj(Zb))
+        O = -0.5j * (Za - np.conj(Zb))
+        WO = W * O
+        Xk, Xmc = E + WO, E - WO
+        Xk = np.where(np.abs(Xk) > thr, Xk, 0)
+        Xmc = np.where(np.abs(Xmc) > thr, Xmc, 0)
+        E2 = 0.5 * (Xk + Xmc)
+        O2 = np.conj(W) * (0.5 * (Xk - Xmc))
+        Za2 = (E2 + 1j * O2) / M
+        Zb2 = np.conj(E2 - 1j * O2) / M
+        Zo[pa] = Za2
+        idx_b = (np.broadcast_to(pb[0], k2.shape)[~skip_b], pb[1][~skip_b])
+        Zo[idx_b] = Zb2[~skip_b]
+    return stockham_fft(Zo, inverse=True)                            # unnormalised IFFT over k2
+
+
+def col_inverse(p, B):
+    """B[k1][n2] -> time-domain packed z[n1][n2] (real d interleaved)."""
+    k1 = np.arange(p.M1)[:, None]
+    n2 = np.arange(p.M2)[None, :]
+    t = B * np.conj(p.tw_big(n2, k1))
+    z = stockham_fft(t.T, inverse=True).T
+    d = np.empty(p.N)
+    d[0::2] = z.real.reshape(-1)
+    d[1::2] = z.imag.reshape(-1)
+    return d
+
+
+def col_mid(p, B):
+    d = col_inverse(p, B)
+    z = (d[0::2] + 1j * d[1::2]).reshape(p.M1, p.M2)
+    A = stockham_fft(z.T).T
+    k1 = np.arange(p.M1)[:, None]
+    n2 = np.arange(p.M2)[None, :]
+    return A * p.tw_big(n2, k1)
+
+
+def ist(p, y, max_iter, thr):
+    if max_iter == 0:
+        return np.where(np.abs(y) > thr, y, 0.0)
+    A = col_first(p, y, thr)
+    for it in range(max_iter):
+        B = row_fused(p, A, thr)
+        if it + 1 < max_iter:
+            A = col_mid(p, B)
+    return col_inverse(p, B)

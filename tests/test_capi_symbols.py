@@ -1,0 +1,60 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/egregora_amd.h declares;
+host-only planning entry points work (no compute call is made here)."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def declared_symbols():
+    txt = (ROOT / "include" / "egregora_amd.h").read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(egr_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(pack):
+    from egregora_amd import native
+    lib = ctypes.CDLL(str(native.LIB_PATH))
+    syms = declared_symbols()
+    assert len(syms) >= 12
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/egregora_amd.h but not exported"
+        assert s in native.SIGNATURES, f"{s} has no ctypes signature in native.py"
+    assert sorted(native.SIGNATURES) == syms
+
+
+def test_abi_version_and_host_only_planning(pack):
+    from egregora_amd import fatllama_engine as fe, native
+    assert native.lib().egr_abi_version() == 1
+    i = fe.plan_info(2880000, 1)
+    assert i["supported"] and i["M1"] * i["M2"] == 1440000 and i["N"] == 2880000
+    prod = 1
+    for r in i["radix1"]:
+        prod *= r
+    assert prod == i["M1"]
+    assert fe.plan_info(160000, 6)["M"] == 480000
+    bad = fe.plan_info(101, 1)
+    assert not bad["supported"] and "unsupported" in bad["error"]
+    assert fe.plan_info(2880000, 1, 1000)["M1"] == 1000
+    assert i["lds_col"] <= 160 * 1024 and i["lds_row"] <= 160 * 1024
+
+
+def test_planner_matches_python_model_schedule(pack):
+    """The C++ radix schedule equals the numpy kernel model's (tests/kernel_model.py)."""
+    import kernel_model as km
+    from egregora_amd import fatllama_engine as fe
+    for n in (100, 2400, 48000, 245760, 960000, 2880000):
+        i = fe.plan_info(n, 1)
+        assert i["radix1"] == km.radix_schedule(i["M1"]) and i["radix2"] == km.radix_schedule(i["M2"])
+
+
+def test_compute_nodes_fail_loudly_without_gpu(pack):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    node = pack.NODE_CLASS_MAPPINGS["EgregoraFatLlamaGPU"]()
+    with pytest.raises(RuntimeError, match="No AMD GPU|no CPU fallback"):
+        node.run("wav", 1, 0.6, 1411, True, True, AUDIO={"waveform": torch.zeros(1, 1, 64), "sample_rate": 48000})
