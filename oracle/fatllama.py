@@ -74,8 +74,17 @@ def interpolate(x, f):
     return y
 
 
-def ist_loop(y, max_iter, thr, spec=DEFAULT_SPEC, trace=None):
-    """d0 = where(|y|>thr, y, 0); repeat: X=fft(d); X=where(|X|>thr, X, 0); d=ifft(X).real."""
+def ist_loop(y, max_iter, thr, spec=DEFAULT_SPEC, trace=None, exact=False):
+    """d0 = where(|y|>thr, y, 0); repeat: X=fft(d); X=where(|X|>thr, X, 0); d=ifft(X).real.
+    exact=True runs the same loop in float64/complex128 (a yardstick for float32 round-off, not upstream)."""
+    if exact:
+        y = np.asarray(y, np.float64)
+        d = np.where(np.abs(y) > thr, y, 0.0)
+        for it in range(int(max_iter)):
+            X = np.fft.fft(d)
+            X = np.where(np.abs(X) > thr, X, 0)
+            d = np.fft.ifft(X).real
+        return d
     thr = np.float32(thr)
     d = np.where(np.abs(y) > thr, y, np.float32(0)).astype(np.float32)
     for it in range(int(max_iter)):
@@ -92,16 +101,19 @@ def ist_loop(y, max_iter, thr, spec=DEFAULT_SPEC, trace=None):
     return d
 
 
-def enhance_channels(x_ci, factor, max_iter, thr, normalize=True, autoscale=True, spec=DEFAULT_SPEC):
+def enhance_channels(x_ci, factor, max_iter, thr, normalize=True, autoscale=True, spec=DEFAULT_SPEC,
+                     exact=False):
     """x_ci: [C,N] float32 on the *integer* PCM scale (what pydub hands upstream).
-    Returns [C, N*factor] float32 (before the write patch)."""
+    Returns [C, N*factor] float32 (before the write patch); float64 when exact=True (loop only)."""
     x_ci = np.asarray(x_ci, np.float32)
     outs = []
     for c in range(x_ci.shape[0]):
         y = interpolate(x_ci[c], factor)
-        d = ist_loop(y, max_iter, thr, spec)
-        outs.append((y + d).astype(np.float32))
+        d = ist_loop(y, max_iter, thr, spec, exact=exact)
+        outs.append(y.astype(np.float64) + d if exact else (y + d).astype(np.float32))
     out = np.stack(outs, 0)
+    if exact:
+        return out
     if autoscale and spec.autoscale == "match_peak":
         for c in range(out.shape[0]):
             po = float(np.max(np.abs(out[c]))) if out.shape[1] else 0.0
