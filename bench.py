@@ -148,6 +148,13 @@ def main():
         dom = "k_row" if kt["row_ms"] >= kt["col_ms"] else "k_col<1>"
         dom_ms = max(kt["row_ms"], kt["col_ms"])
         achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        try:   # PMC-measured bytes per launch, recorded by tools/profile_round.sh runs (profiles/traffic.json)
+            tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+            if args.iters == 800 and args.m1 == 0 and args.tc == 0:
+                traffic = tj.get("fatllama_c3", {}).get(dom)
+        except Exception:
+            traffic = None
         out = {
             "metric": METRIC, "value": value, "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
@@ -157,7 +164,7 @@ def main():
                                    % args.iters,
                        "arch": arch, "split": [info["M1"], info["M2"]], "tile_cols": info["TC"]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_ms": dom_ms,
                          "k_row_ms": kt["row_ms"], "k_col_ms": kt["col_ms"],
                          "launches": [kt["row_launches"], kt["col_launches"]]},
