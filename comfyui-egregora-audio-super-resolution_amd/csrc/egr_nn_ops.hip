@@ -1,0 +1,494 @@
+// HBM-bound operators of the FlashSR graph (channels-last activations): GroupNorm(+SiLU), LayerNorm, row
+// softmax, element-wise glue, GEGLU, channel concat, anti-aliased snake activation (2x up FIR . snake . 2x
+// down FIR fused), transposed-conv overlap-add, STFT magnitude frames for the mel front-end, Philox noise.
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "egr_common.h"
+#include "egr_fft_device.h"
+#include "egr_plan.h"
+
+namespace egr {
+
+// ---------------------------------------------------------------- GroupNorm over [B][HW][C], G groups
+// pass 1: per (b, g) sum and sum of squares in double (atomics), pass 2: y = x*scale[b][c] + shift[b][c] (+SiLU)
+__global__ __launch_bounds__(256) void k_gn_stats(const float* __restrict__ x, int HW, int C, int G,
+                                                   double* __restrict__ stats /*[B][G][2]*/, int slab) {
+    // block = (slab of positions, b); thread t handles channel (t % C) for C <= 256 strides
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * slab;
+    const int p1 = min(HW, p0 + slab);
+    const int cpg = C / G;
+    const float* xb = x + (size_t)b * HW * C;
+    // each thread walks channels tid, tid+256, ... ; positions p0..p1
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f, ss = 0.f;
+        for (int p = p0; p < p1; ++p) {
+            const float v = xb[(size_t)p * C + c];
+            s += v;
+            ss += v * v;
+        }
+        // combine the cpg channels of a group (adjacent lanes) before touching memory when cpg is a power of 2
+        double ds = s, dss = ss;
+        bool leader = true;
+        if (cpg <= 64 && (cpg & (cpg - 1)) == 0 && (C % 64) == 0) {
+            for (int o = 1; o < cpg; o <<= 1) {
+                ds += __shfl_xor(ds, o);
+                dss += __shfl_xor(dss, o);
+            }
+            leader = (c % cpg) == 0;
+        }
+        if (leader) {
+            atomicAdd(&stats[((size_t)b * G + c / cpg) * 2 + 0], ds);
+            atomicAdd(&stats[((size_t)b * G + c / cpg) * 2 + 1], dss);
+        }
+    }
+}
+
+__global__ void k_gn_coeff(const double* __restrict__ stats, const float* __restrict__ gamma,
+                           const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift,
+                           int B, int C, int G, double count, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C, g = c / (C / G);
+    const double mean = stats[((size_t)b * G + g) * 2] / count;
+    double var = stats[((size_t)b * G + g) * 2 + 1] / count - mean * mean;
+    if (var < 0) var = 0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double sc = rstd * (double)gamma[c];
+    scale[i] = (float)sc;
+    shift[i] = (float)((double)beta[c] - mean * sc);
+}
+
+__global__ __launch_bounds__(256) void k_affine_c(const float* __restrict__ x, const float* __restrict__ scale,
+                                                   const float* __restrict__ shift, float* __restrict__ y,
+                                                   long long n4, int HW, int C, int silu) {
+    // vectorised over 4 channels; C % 4 == 0
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long e = i * 4;
+        const int c = (int)(e % C);
+        const int b = (int)(e / ((long long)HW * C));
+        const float4 v = *(const float4*)(x + e);
+        const float4 sc = *(const float4*)(scale + (size_t)b * C + c);
+        const float4 sh = *(const float4*)(shift + (size_t)b * C + c);
+        float4 o = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+        if (silu) {
+            o.x = o.x / (1.f + __expf(-o.x)); o.y = o.y / (1.f + __expf(-o.y));
+            o.z = o.z / (1.f + __expf(-o.z)); o.w = o.w / (1.f + __expf(-o.w));
+        }
+        *(float4*)(y + e) = o;
+    }
+}
+
+// ---------------------------------------------------------------- LayerNorm over rows of C (one wave per row)
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ g,
+                                                    const float* __restrict__ b, float* __restrict__ y, int rows,
+                                                    int C, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; v += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const float rstd = rsqrtf(v / C + eps);
+    float* yr = y + (size_t)row * C;
+    for (int c = lane; c < C; c += 64) yr[c] = (xr[c] - mean) * rstd * g[c] + b[c];
+}
+
+// ---------------------------------------------------------------- row softmax in place (one workgroup per row)
+__global__ __launch_bounds__(256) void k_softmax(float* __restrict__ x, int cols) {
+    __shared__ float red[4];
+    float* r = x + (size_t)blockIdx.x * cols;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, r[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) { const float e = __expf(r[c] - m); r[c] = e; s += e; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    s = red[0] + red[1] + red[2] + red[3];
+    const float inv = 1.0f / s;
+    for (int c = threadIdx.x; c < cols; c += 256) r[c] *= inv;
+}
+
+// ---------------------------------------------------------------- element-wise
+enum { EW_ADD = 0, EW_AXPBY = 1, EW_SILU = 2, EW_SCALE = 3, EW_COPY = 4 };
+__global__ __launch_bounds__(256) void k_eltwise(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ y, long long n, int op, float s0, float s1) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float v;
+        switch (op) {
+            case EW_ADD: v = a[i] + b[i]; break;
+            case EW_AXPBY: v = s0 * a[i] + s1 * b[i]; break;
+            case EW_SILU: v = a[i] / (1.f + __expf(-a[i])); break;
+            case EW_SCALE: v = s0 * a[i]; break;
+            default: v = a[i]; break;
+        }
+        y[i] = v;
+    }
+}
+
+// GEGLU: u [rows][2*D] -> y [rows][D] = u[:, :D] * gelu(u[:, D:])   (exact erf GELU)
+__global__ __launch_bounds__(256) void k_geglu(const float* __restrict__ u, float* __restrict__ y, long long rows, int D) {
+    const long long n = rows * D;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / D;
+        const int d = (int)(i - r * D);
+        const float a = u[r * 2 * D + d], g = u[r * 2 * D + D + d];
+        y[i] = a * (0.5f * g * (1.0f + erff(g * 0.70710678118654752f)));
+    }
+}
+
+// channel concat: y[m][0..C1) = a[m], y[m][C1..C1+C2) = b[m]
+__global__ __launch_bounds__(256) void k_concat(const float* __restrict__ a, const float* __restrict__ b,
+                                                 float* __restrict__ y, long long M, int C1, int C2) {
+    const int C = C1 + C2;
+    const long long n = M * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / C;
+        const int c = (int)(i - m * C);
+        y[i] = c < C1 ? a[m * C1 + c] : b[m * C2 + (c - C1)];
+    }
+}
+
+// [B][C][H][W] <-> [B][H][W][C] style permutes are done by the host once (weights, tiny tensors); the only
+// runtime layout change is the latent/noise NCHW<->NHWC, handled by this generic 2-D transpose per batch.
+__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ x, float* __restrict__ y, int R, int Cc) {
+    __shared__ float t[32][33];
+    const size_t off = (size_t)blockIdx.z * R * Cc;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8)
+        if (r0 + k < R && c0 + tx < Cc) t[k][tx] = x[off + (size_t)(r0 + k) * Cc + c0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (c0 + k < Cc && r0 + tx < R) y[off + (size_t)(c0 + k) * R + r0 + tx] = t[tx][k];
+}
+
+// ---------------------------------------------------------------- anti-aliased snake over [B][L][C]
+// u[i] = 2 * sum_n xp[n] f[i+15-2n] (xp = replicate-pad-5 of x), s = u + sin^2(a u)/(b+1e-9),
+// y[l] = sum_k f[k] s[clamp(2l+k-5, 0, 2L-1)]          (12-tap kaiser-sinc, see oracle/flashsr_torch._act_aa)
+__global__ __launch_bounds__(256) void k_snake_aa(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                   const float* __restrict__ beta, const float* __restrict__ filt,
+                                                   float* __restrict__ y, int L, int C, int K) {
+    __shared__ float f[32];
+    if (threadIdx.x < K) f[threadIdx.x] = filt[threadIdx.x];
+    __syncthreads();
+    const int b = blockIdx.z;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int l = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (c >= C || l >= L) return;
+    const float* xb = x + (size_t)b * L * C + c;
+    const float a = __expf(alpha[c]), ib = 1.0f / (__expf(beta[c]) + 1e-9f);
+    const int pad = K / 2 - 1;                 // 5
+    const int pl = pad * 2 + (K - 2) / 2;      // 15
+    const int L2 = 2 * L;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+        int i = 2 * l + k - (K / 2 - 1);
+        i = i < 0 ? 0 : (i > L2 - 1 ? L2 - 1 : i);
+        // u[i]: taps n with 0 <= i + pl - 2n <= K-1
+        const int t = i + pl;
+        int n_lo = (t - (K - 1) + 1) >> 1;     // ceil((t-K+1)/2), t-K+1 may be negative
+        if (2 * n_lo < t - (K - 1)) ++n_lo;
+        const int n_hi = t >> 1;
+        float u = 0.f;
+        for (int n = n_lo; n <= n_hi; ++n) {
+            int src = n - pad;
+            src = src < 0 ? 0 : (src > L - 1 ? L - 1 : src);
+            u += xb[(size_t)src * C] * f[t - 2 * n];
+        }
+        u *= 2.0f;
+        const float sn = __sinf(u * a);
+        acc += f[k] * (u + ib * sn * sn);
+    }
+    y[(size_t)b * L * C + (size_t)l * C + c] = acc;
+}
+
+// ---------------------------------------------------------------- ConvTranspose1d overlap-add (gather form)
+// Y [B][Lin][K][Co] (GEMM output), out[b][o][co] = bias[co] + (add ? add[b][o][co] : 0)
+//                                              + sum_{k == (o+pad) mod r, i=(o+pad-k)/r in [0,Lin)} Y[b][i][k][co]
+__global__ __launch_bounds__(256) void k_col2im1d(const float* __restrict__ Y, const float* __restrict__ bias,
+                                                   const float* __restrict__ add, float* __restrict__ out, int Lin,
+                                                   int Lout, int Co, int K, int r, int pad, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Co);
+        const long long t = i / Co;
+        const int o = (int)(t % Lout);
+        const long long b = t / Lout;
+        float v = bias ? bias[co] : 0.f;
+        if (add) v += add[i];
+        const int q = o + pad;
+        for (int k = q % r; k < K; k += r) {
+            const int ii = (q - k) / r;
+            if (q - k >= 0 && ii < Lin) v += Y[(((size_t)b * Lin + ii) * K + k) * Co + co];
+        }
+        out[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------- mel front-end: STFT magnitude frames
+// x [B][L] -> mag [B][T][ldm] (ldm >= n_fft/2+1, tail zero-filled), reflect padding of `rpad` samples on both
+// sides, caller-supplied window; frames t >= t_valid are zero (they become log(floor) after the mel GEMM).
+__global__ __launch_bounds__(256) void k_stft_frames(const float* __restrict__ x, int L, int n_fft, int hop, int rpad,
+                                                      int T, int t_valid, int ldm, const float* __restrict__ window,
+                                                      FftDesc fd, const cplx* __restrict__ tw,
+                                                      const cplx* __restrict__ wsplit, float* __restrict__ mag) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int Mh = n_fft / 2;
+    cplx* cur = (cplx*)smem;
+    cplx* alt = cur + Mh;
+    const int t = blockIdx.x, b = blockIdx.y;
+    float* o = mag + ((size_t)b * T + t) * ldm;
+    if (t >= t_valid) {
+        for (int k = threadIdx.x; k < ldm; k += blockDim.x) o[k] = 0.f;
+        return;
+    }
+    const float* xb = x + (size_t)b * L;
+    const int s0 = t * hop - rpad;
+    for (int e = threadIdx.x; e < Mh; e += blockDim.x) {
+        float v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int i = s0 + 2 * e + h;
+            if (i < 0) i = -i;                      // reflect (no edge repeat), as F.pad(mode="reflect")
+            if (i > L - 1) i = 2 * (L - 1) - i;
+            i = i < 0 ? 0 : (i > L - 1 ? L - 1 : i);
+            v[h] = xb[i] * window[2 * e + h];
+        }
+        cur[e] = make_float2(v[0], v[1]);
+    }
+    __syncthreads();
+    lds_fft<false>(cur, alt, fd, tw, 1, 0, 1, Mh, false);
+    for (int k = threadIdx.x; k < ldm; k += blockDim.x) {
+        float r = 0.f;
+        if (k <= Mh) {
+            const cplx Za = cur[k == Mh ? 0 : k];
+            const cplx Zb = cur[(k == 0 || k == Mh) ? 0 : Mh - k];
+            const cplx E = make_float2(0.5f * (Za.x + Zb.x), 0.5f * (Za.y - Zb.y));
+            const cplx O = make_float2(0.5f * (Za.y + Zb.y), -0.5f * (Za.x - Zb.x));
+            const cplx X = cadd(E, cmul(wsplit[k], O));
+            r = sqrtf(X.x * X.x + X.y * X.y);
+        }
+        o[k] = r;
+    }
+}
+
+// ---------------------------------------------------------------- Philox4x32-10 standard normals
+// element e of stream (seed, row) is a pure function of (seed, row, e): results do not depend on rank count.
+__device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0,
+                                             unsigned k1) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+__global__ __launch_bounds__(256) void k_randn(float* __restrict__ out, long long per_row, int rows,
+                                                unsigned long long seed, const long long* __restrict__ row_ids) {
+    const long long quads = (per_row + 3) / 4;
+    const long long n = quads * rows;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / quads);
+        const long long q = i - (long long)r * quads;
+        const unsigned long long rid = row_ids ? (unsigned long long)row_ids[r] : (unsigned long long)r;
+        unsigned c0 = (unsigned)q, c1 = (unsigned)(q >> 32), c2 = (unsigned)rid, c3 = (unsigned)(rid >> 32);
+        unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+        for (int it = 0; it < 10; ++it) {
+            philox_round(c0, c1, c2, c3, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        // two Box-Muller pairs
+        const float u0 = ((float)c0 + 0.5f) * 2.3283064365386963e-10f, u1 = ((float)c1 + 0.5f) * 2.3283064365386963e-10f;
+        const float u2 = ((float)c2 + 0.5f) * 2.3283064365386963e-10f, u3 = ((float)c3 + 0.5f) * 2.3283064365386963e-10f;
+        const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+        float z[4];
+        z[0] = r0 * cosf(6.283185307179586f * u1);
+        z[1] = r0 * sinf(6.283185307179586f * u1);
+        z[2] = r1 * cosf(6.283185307179586f * u3);
+        z[3] = r1 * sinf(6.283185307179586f * u3);
+        float* o = out + (size_t)r * per_row + q * 4;
+        for (int j = 0; j < 4; ++j)
+            if (q * 4 + j < per_row) o[j] = z[j];
+    }
+}
+
+struct FrameTables { FftDesc fd; cplx *tw, *wsplit; };
+static std::mutex g_mu;
+static std::map<std::pair<int, int>, FrameTables> g_tabs;
+
+static int frame_tables(int n_fft, FrameTables* out) {
+    int dev = 0;
+    EGR_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_tabs.find({dev, n_fft});
+    if (it != g_tabs.end()) { *out = it->second; return EGR_OK; }
+    FrameTables t;
+    const int Mh = n_fft / 2;
+    EGR_CHECK(make_schedule(Mh, &t.fd), EGR_ERR_UNSUPPORTED, "n_fft=%d: n_fft/2 must be {2,3,5,7,11,13}-smooth", n_fft);
+    std::vector<float2> h;
+    make_twiddles(h, Mh, 1, Mh);
+    EGR_HIP(hipMalloc((void**)&t.tw, h.size() * sizeof(float2)));
+    EGR_HIP(hipMemcpy(t.tw, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice));
+    make_twiddles(h, Mh + 1, 1, n_fft);
+    EGR_HIP(hipMalloc((void**)&t.wsplit, h.size() * sizeof(float2)));
+    EGR_HIP(hipMemcpy(t.wsplit, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice));
+    g_tabs[{dev, n_fft}] = t;
+    *out = t;
+    return EGR_OK;
+}
+
+static inline int grid1d(long long n) {
+    long long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace egr
+
+using namespace egr;
+
+extern "C" int egr_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, float* y, int B, int HW, int C,
+                                  int G, float eps, int silu, void* workspace, void* stream) {
+    EGR_CHECK(x && gamma && beta && y && workspace, EGR_ERR_ARG, "null argument");
+    EGR_CHECK(B >= 1 && HW >= 1 && C >= 4 && G >= 1 && C % G == 0 && C % 4 == 0, EGR_ERR_ARG, "bad groupnorm geometry");
+    hipStream_t st = (hipStream_t)stream;
+    // workspace layout: double stats[B*G*2] | float scale[B*C] | float shift[B*C]
+    double* stats = (double*)workspace;
+    float* scale = (float*)(stats + (size_t)B * G * 2);
+    float* shift = scale + (size_t)B * C;
+    EGR_HIP(hipMemsetAsync(stats, 0, sizeof(double) * B * G * 2, st));
+    int slab = (HW + 255) / 256;
+    if (slab < 16) slab = HW < 16 ? HW : 16;
+    const int nslab = (HW + slab - 1) / slab;
+    hipLaunchKernelGGL(k_gn_stats, dim3(nslab, B), dim3(C < 256 ? ((C + 63) / 64) * 64 : 256), 0, st, x, HW, C, G, stats, slab);
+    hipLaunchKernelGGL(k_gn_coeff, dim3((B * C + 255) / 256), dim3(256), 0, st, stats, gamma, beta, scale, shift, B, C, G,
+                       (double)HW * (C / G), eps);
+    const long long n4 = (long long)B * HW * C / 4;
+    hipLaunchKernelGGL(k_affine_c, dim3(grid1d(n4)), dim3(256), 0, st, x, scale, shift, y, n4, HW, C, silu);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" size_t egr_groupnorm_workspace_bytes(int B, int C, int G) {
+    return sizeof(double) * (size_t)B * G * 2 + sizeof(float) * 2 * (size_t)B * C + 64;
+}
+
+extern "C" int egr_layernorm_rows(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C,
+                                  float eps, void* stream) {
+    EGR_CHECK(x && gamma && beta && y && rows >= 1 && C >= 1, EGR_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+                       (int)rows, C, eps);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_softmax_rows(float* x, int64_t rows, int cols, void* stream) {
+    EGR_CHECK(x && rows >= 1 && cols >= 1, EGR_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_softmax, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, cols);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_eltwise(const float* a, const float* b, float* y, int64_t n, int op, float s0, float s1, void* stream) {
+    EGR_CHECK(a && y && n >= 0 && op >= 0 && op <= 4, EGR_ERR_ARG, "bad argument");
+    EGR_CHECK(b || (op != EW_ADD && op != EW_AXPBY), EGR_ERR_ARG, "binary op needs b");
+    if (n == 0) return EGR_OK;
+    hipLaunchKernelGGL(k_eltwise, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, (long long)n, op, s0, s1);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_geglu(const float* u, float* y, int64_t rows, int D, void* stream) {
+    EGR_CHECK(u && y && rows >= 1 && D >= 1, EGR_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_geglu, dim3(grid1d(rows * D)), dim3(256), 0, (hipStream_t)stream, u, y, (long long)rows, D);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_concat_channels(const float* a, const float* b, float* y, int64_t M, int C1, int C2, void* stream) {
+    EGR_CHECK(a && b && y && M >= 1 && C1 >= 1 && C2 >= 1, EGR_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_concat, dim3(grid1d(M * (C1 + C2))), dim3(256), 0, (hipStream_t)stream, a, b, y, (long long)M, C1,
+                       C2);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_transpose_batched(const float* x, float* y, int batch, int R, int Cc, void* stream) {
+    EGR_CHECK(x && y && batch >= 1 && batch <= 65535 && R >= 1 && Cc >= 1, EGR_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_transpose, dim3((Cc + 31) / 32, (R + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream, x, y, R,
+                       Cc);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_snake_aa(const float* x, const float* alpha, const float* beta, const float* filt, float* y, int B,
+                            int L, int C, int K, void* stream) {
+    EGR_CHECK(x && alpha && beta && filt && y && B >= 1 && B <= 65535 && L >= 1 && C >= 1 && K >= 2 && K <= 32 && K % 2 == 0,
+              EGR_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_snake_aa, dim3((C + 63) / 64, (L + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, x, alpha, beta,
+                       filt, y, L, C, K);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_col2im_convtr1d(const float* Y, const float* bias, const float* add, float* out, int B, int Lin,
+                                   int Lout, int Co, int K, int r, int pad, void* stream) {
+    EGR_CHECK(Y && out && B >= 1 && Lin >= 1 && Lout >= 1 && Co >= 1 && K >= 1 && r >= 1 && pad >= 0, EGR_ERR_ARG,
+              "bad argument");
+    const long long n = (long long)B * Lout * Co;
+    hipLaunchKernelGGL(k_col2im1d, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, Y, bias, add, out, Lin, Lout, Co, K,
+                       r, pad, n);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_stft_frames(const float* x, int B, int L, int n_fft, int hop, int rpad, int T, int t_valid, int ldm,
+                               const float* window, float* mag, void* stream) {
+    EGR_CHECK(x && window && mag && B >= 1 && B <= 65535 && L >= 2 && hop >= 1 && T >= 1 && t_valid >= 0 && t_valid <= T,
+              EGR_ERR_ARG, "bad argument");
+    EGR_CHECK(n_fft >= 4 && n_fft % 2 == 0 && n_fft <= 8192 && ldm >= n_fft / 2 + 1 && rpad < L, EGR_ERR_UNSUPPORTED,
+              "bad STFT geometry");
+    FrameTables t;
+    int rc = frame_tables(n_fft, &t);
+    if (rc) return rc;
+    const size_t lds = (size_t)2 * (n_fft / 2) * sizeof(float2);
+    hipLaunchKernelGGL(k_stft_frames, dim3(T, B), dim3(256), lds, (hipStream_t)stream, x, L, n_fft, hop, rpad, T, t_valid,
+                       ldm, window, t.fd, t.tw, t.wsplit, mag);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_randn(float* out, int64_t per_row, int rows, uint64_t seed, const int64_t* row_ids, void* stream) {
+    EGR_CHECK(out && per_row >= 1 && rows >= 1, EGR_ERR_ARG, "bad argument");
+    const long long n = ((per_row + 3) / 4) * rows;
+    hipLaunchKernelGGL(k_randn, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, out, (long long)per_row, rows,
+                       (unsigned long long)seed, (const long long*)row_ids);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}

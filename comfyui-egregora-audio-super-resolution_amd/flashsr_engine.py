@@ -1,10 +1,422 @@
-"""FlashSR engine front (placeholder until the device model lands in this round)."""
+"""FlashSR on the MI355X: executes the layer table of flashsr_arch.py with the HIP operators of
+libegregora_amd.so (csrc/egr_nn_gemm.hip, csrc/egr_nn_ops.hip).  Stands in for the reference's
+`_FlashSRRunner` (egregora_audio_super_resolution.py:254-369): build once per process (the reference rebuilds per
+call, :393), `infer` on [rows, 245760] where rows = chunks x channels ride the batch dimension (:366-368).
+
+Activations are channels-last ([B][H][W][C] / [B][L][C]) float32; every dense contraction runs on
+v_mfma_f32_32x32x2_f32 through egr_conv_nhwc / egr_bgemm; torch only owns the buffers.
+PARITY UNPINNED vs upstream (see flashsr_arch.py); checked against oracle/flashsr_torch.py (same table, torch fp32).
+"""
+import ctypes as C
+import math
+import os
+from typing import Dict, List, Optional
+
+import numpy as np
 import torch
 
+from . import device_ops, flashsr_arch as arch, native, shard
 
-def ensure_ready():
-    raise RuntimeError("FlashSR device model is not built yet in this revision")
+ACT_NONE, ACT_SILU, ACT_TANH, ACT_LEAKY, ACT_LOGCLAMP = 0, 1, 2, 3, 4
+EW_ADD, EW_AXPBY, EW_SILU, EW_SCALE, EW_COPY = 0, 1, 2, 3, 4
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class FlashSREngine:
+    def __init__(self, cfg: arch.FlashSRConfig, params: Dict[str, torch.Tensor], device="cuda"):
+        native.require_device()
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        self.L = native.lib()
+        self.flops = 0.0            # dense-contraction flops of the last forward (per call, all rows)
+        self.count_flops = False
+        self.blocks = arch.unet_blocks(cfg)
+        self.w: Dict[str, torch.Tensor] = {}
+        self._pack(params)
+        self.window = torch.hann_window(cfg.n_fft, periodic=True, dtype=torch.float32).to(self.dev)
+        self.filt = torch.from_numpy(arch.kaiser_sinc_filter(cfg.aa_taps)).to(self.dev)
+        nb = cfg.n_fft // 2 + 1
+        self.ldm = ((nb + 15) // 16) * 16
+        fb = torch.zeros(self.ldm, cfg.n_mels)
+        fb[:nb] = torch.from_numpy(arch.mel_filterbank(cfg)).t()
+        self.w["mel_fb"] = fb.contiguous().to(self.dev)
+        self.alpha, self.sigma = arch.cosine_alpha_sigma(cfg, cfg.t_steps - 1)
+        self._gn_ws = None
+        self._fold_time_embedding()
+
+    # ------------------------------------------------------------------ weight packing
+    def _pack(self, P):
+        for k, v in P.items():
+            v = v.detach().float()
+            if k.endswith(".weight") and v.dim() == 4:                      # conv2d [Co,Ci,kh,kw] -> [kh][kw][Ci][Co]
+                v = v.permute(2, 3, 1, 0)
+            elif k.startswith("voc.ups.") and k.endswith(".weight"):        # convT1d [Ci,Co,k] -> [Ci][k*Co]
+                v = v.permute(0, 2, 1).reshape(v.shape[0], -1)
+            elif k.endswith(".weight") and v.dim() == 3:                    # conv1d [Co,Ci,k] -> [k][Ci][Co]
+                v = v.permute(2, 1, 0)
+            elif k.endswith(".weight") and v.dim() == 2:                    # linear [Co,Ci] -> [Ci][Co]
+                v = v.t()
+            self.w[k] = v.contiguous().to(self.dev)
+
+    # ------------------------------------------------------------------ op wrappers
+    def _st(self):
+        return native.stream_ptr()
+
+    def conv(self, x, wkey, B, H, W, Cin, OH, OW, Cout, KH, KW, stride=1, dil=1, pad_t=0, pad_l=0, up2=0, act=ACT_NONE,
+             bias=True, bias_t=None, res=None, act_param=0.0, w=None):
+        y = torch.empty((B, OH, OW, Cout), dtype=torch.float32, device=self.dev)
+        wt = w if w is not None else self.w[wkey + ".weight"]
+        bt = bias_t if bias_t is not None else (self.w.get(wkey + ".bias") if bias else None)
+        native.check(self.L.egr_conv_nhwc(_p(x), _p(wt), _p(bt), _p(None), _p(res), _p(y), B, H, W, Cin, OH, OW, Cout, KH,
+                                          KW, stride, dil, pad_t, pad_l, up2, act, float(act_param), self._st()),
+                     "egr_conv_nhwc")
+        if self.count_flops:
+            self.flops += 2.0 * B * OH * OW * Cout * KH * KW * Cin
+        return y
+
+    def conv3(self, x, key, stride=1, up2=0, act=ACT_NONE, res=None, pad=1, bias_t=None):
+        B, H, W, Cin = x.shape
+        Cout = self.w[key + ".weight"].shape[3]
+        LH, LW = (2 * H, 2 * W) if up2 else (H, W)
+        OH, OW = (LH // stride, LW // stride)
+        return self.conv(x, key, B, H, W, Cin, OH, OW, Cout, 3, 3, stride, 1, pad, pad, up2, act, res=res, bias_t=bias_t)
+
+    def conv1x1(self, x, key, res=None, act=ACT_NONE):
+        B, H, W, Cin = x.shape
+        Cout = self.w[key + ".weight"].shape[3]
+        return self.conv(x, key, B, H, W, Cin, H, W, Cout, 1, 1, res=res, act=act)
+
+    def linear(self, x2, key, res=None, act=ACT_NONE, bias=True):
+        rows, Cin = x2.shape
+        wt = self.w[key + ".weight"]
+        Cout = wt.shape[1]
+        y = self.conv(x2, key, rows, 1, 1, Cin, 1, 1, Cout, 1, 1, res=res, act=act, bias=bias)
+        return y.view(rows, Cout)
+
+    def conv1d(self, x, key, k, stride=1, dil=1, pad=0, act=ACT_NONE, res=None):
+        B, L, Cin = x.shape
+        Cout = self.w[key + ".weight"].shape[2]
+        OL = (L + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        y = self.conv(x, key, B, 1, L, Cin, 1, OL, Cout, 1, k, stride, dil, 0, pad, 0, act, res=res)
+        return y.view(B, OL, Cout)
+
+    def groupnorm(self, x, key, eps, silu):
+        B = x.shape[0]
+        Cc = x.shape[-1]
+        HW = x.numel() // (B * Cc)
+        G = self.cfg.gn_groups
+        need = self.L.egr_groupnorm_workspace_bytes(B, Cc, G)
+        if self._gn_ws is None or self._gn_ws.numel() < need:
+            self._gn_ws = torch.empty(int(need) + 1024, dtype=torch.uint8, device=self.dev)
+        y = torch.empty_like(x)
+        native.check(self.L.egr_groupnorm_nhwc(_p(x), _p(self.w[key + ".weight"]), _p(self.w[key + ".bias"]), _p(y), B, HW,
+                                               Cc, G, eps, 1 if silu else 0, _p(self._gn_ws), self._st()),
+                     "egr_groupnorm_nhwc")
+        return y
+
+    def layernorm(self, x2, key):
+        rows, Cc = x2.shape
+        y = torch.empty_like(x2)
+        native.check(self.L.egr_layernorm_rows(_p(x2), _p(self.w[key + ".weight"]), _p(self.w[key + ".bias"]), _p(y), rows,
+                                               Cc, 1e-5, self._st()), "egr_layernorm_rows")
+        return y
+
+    def eltwise(self, a, b, op, s0=0.0, s1=0.0):
+        y = torch.empty_like(a)
+        native.check(self.L.egr_eltwise(_p(a), _p(b), _p(y), a.numel(), op, s0, s1, self._st()), "egr_eltwise")
+        return y
+
+    def attention(self, q, k, v, B, T, Cc, heads):
+        """q,k,v [B*T, C] -> [B*T, C]; softmax(q k^T / sqrt(d)) v per head."""
+        d = Cc // heads
+        S = torch.empty((B, heads, T, T), dtype=torch.float32, device=self.dev)
+        native.check(self.L.egr_bgemm(_p(q), _p(k), _p(S), B, heads, T, T, d, Cc, Cc, T, T * Cc, d, T * Cc, d,
+                                      heads * T * T, T * T, 1, d ** -0.5, self._st()), "egr_bgemm(QK^T)")
+        native.check(self.L.egr_softmax_rows(_p(S), B * heads * T, T, self._st()), "egr_softmax_rows")
+        o = torch.empty((B * T, Cc), dtype=torch.float32, device=self.dev)
+        native.check(self.L.egr_bgemm(_p(S), _p(v), _p(o), B, heads, T, d, T, T, Cc, Cc, heads * T * T, T * T, T * Cc, d,
+                                      T * Cc, d, 0, 1.0, self._st()), "egr_bgemm(PV)")
+        if self.count_flops:
+            self.flops += 4.0 * B * heads * T * T * d
+        return o
+
+    def snake(self, x, akey, bkey):
+        B, L, Cc = x.shape
+        y = torch.empty_like(x)
+        native.check(self.L.egr_snake_aa(_p(x), _p(self.w[akey]), _p(self.w[bkey]), _p(self.filt), _p(y), B, L, Cc,
+                                         self.cfg.aa_taps, self._st()), "egr_snake_aa")
+        return y
+
+    # ------------------------------------------------------------------ constant sub-graph: time embedding at t = T-1
+    def _fold_time_embedding(self):
+        cfg = self.cfg
+        half = cfg.unet_ch // 2
+        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+        args = float(cfg.t_steps - 1) * freqs
+        emb = torch.cat([torch.cos(args), torch.sin(args)])[None].contiguous().to(self.dev)
+        t = self.linear(emb, "unet.time_embed.0", act=ACT_SILU)
+        t = self.linear(t, "unet.time_embed.2", act=ACT_SILU)            # silu(temb), shared by all res-blocks
+        for name, cin, cout, attn in self.blocks:
+            if name.endswith(".block"):
+                base = f"unet.{name}"
+                e = self.linear(t, base + ".res.emb")                    # [1, cout]
+                # conv bias + time bias, both per output channel and identical for every row at fixed t
+                self.w[base + ".res.in_conv.bias_t"] = self.eltwise(self.w[base + ".res.in_conv.bias"].view(1, -1), e,
+                                                                    EW_ADD).view(-1)
+        torch.cuda.synchronize()
+
+    # ------------------------------------------------------------------ stages
+    def log_mel(self, x):
+        cfg = self.cfg
+        B, L = x.shape
+        rpad = (cfg.n_fft - cfg.hop) // 2
+        t_valid = min(cfg.n_frames, (L + 2 * rpad - cfg.n_fft) // cfg.hop + 1)
+        mag = torch.empty((B, cfg.n_frames, self.ldm), dtype=torch.float32, device=self.dev)
+        native.check(self.L.egr_stft_frames(_p(x), B, L, cfg.n_fft, cfg.hop, rpad, cfg.n_frames, t_valid, self.ldm,
+                                            _p(self.window), _p(mag), self._st()), "egr_stft_frames")
+        mel = self.conv(mag, None, B * cfg.n_frames, 1, 1, self.ldm, 1, 1, cfg.n_mels, 1, 1, act=ACT_LOGCLAMP,
+                        act_param=cfg.log_floor, bias=False, w=self.w["mel_fb"])
+        return mel.view(B, cfg.n_frames, cfg.n_mels, 1)
+
+    def _vae_res(self, x, name):
+        h = self.conv3(self.groupnorm(x, name + ".norm1", 1e-6, True), name + ".conv1")
+        h = self.groupnorm(h, name + ".norm2", 1e-6, True)
+        sc = self.conv1x1(x, name + ".nin_shortcut") if (name + ".nin_shortcut.weight") in self.w else x
+        return self.conv3(h, name + ".conv2", res=sc)
+
+    def _vae_attn(self, x, name):
+        B, H, W, Cc = x.shape
+        h = self.groupnorm(x, name + ".norm", 1e-6, False)
+        q = self.conv1x1(h, name + ".q").view(B * H * W, Cc)
+        k = self.conv1x1(h, name + ".k").view(B * H * W, Cc)
+        v = self.conv1x1(h, name + ".v").view(B * H * W, Cc)
+        o = self.attention(q, k, v, B, H * W, Cc, 1).view(B, H, W, Cc)
+        return self.conv1x1(o, name + ".proj_out", res=x)
+
+    def vae_encode(self, mel):
+        cfg = self.cfg
+        h = self.conv3(mel, "vae.encoder.conv_in")
+        n = len(cfg.vae_mult)
+        for lv in range(n):
+            for b in range(cfg.vae_res):
+                h = self._vae_res(h, f"vae.encoder.down.{lv}.block.{b}")
+            if lv != n - 1:
+                h = self.conv3(h, f"vae.encoder.down.{lv}.downsample.conv", stride=2, pad=0)
+        h = self._vae_res(h, "vae.encoder.mid.block_1")
+        h = self._vae_attn(h, "vae.encoder.mid.attn_1")
+        h = self._vae_res(h, "vae.encoder.mid.block_2")
+        h = self.conv3(self.groupnorm(h, "vae.encoder.norm_out", 1e-6, True), "vae.encoder.conv_out")
+        mom = self.conv1x1(h, "vae.quant_conv")
+        return mom[..., :cfg.z_ch].contiguous()
+
+    def vae_decode(self, z):
+        cfg = self.cfg
+        h = self.conv1x1(z, "vae.post_quant_conv")
+        h = self.conv3(h, "vae.decoder.conv_in")
+        h = self._vae_res(h, "vae.decoder.mid.block_1")
+        h = self._vae_attn(h, "vae.decoder.mid.attn_1")
+        h = self._vae_res(h, "vae.decoder.mid.block_2")
+        for lv in reversed(range(len(cfg.vae_mult))):
+            for b in range(cfg.vae_res + 1):
+                h = self._vae_res(h, f"vae.decoder.up.{lv}.block.{b}")
+            if lv != 0:
+                h = self.conv3(h, f"vae.decoder.up.{lv}.upsample.conv", up2=1)
+        return self.conv3(self.groupnorm(h, "vae.decoder.norm_out", 1e-6, True), "vae.decoder.conv_out")
+
+    def _unet_block(self, x, base, has_attn):
+        cfg = self.cfg
+        h = self.conv3(self.groupnorm(x, base + ".res.in_norm", 1e-5, True), base + ".res.in_conv",
+                       bias_t=self.w[base + ".res.in_conv.bias_t"])
+        h = self.groupnorm(h, base + ".res.out_norm", 1e-5, True)
+        sc = self.conv1x1(x, base + ".res.skip") if (base + ".res.skip.weight") in self.w else x
+        x = self.conv3(h, base + ".res.out_conv", res=sc)
+        if has_attn:
+            B, H, W, Cc = x.shape
+            T = H * W
+            heads = Cc // cfg.head_dim
+            t = self.conv1x1(self.groupnorm(x, base + ".st.norm", 1e-6, False), base + ".st.proj_in").view(B * T, Cc)
+            for a in ("attn1", "attn2"):
+                n_ = self.layernorm(t, f"{base}.st.{a}_ln")
+                q = self.linear(n_, f"{base}.st.{a}.to_q", bias=False)
+                k = self.linear(n_, f"{base}.st.{a}.to_k", bias=False)
+                v = self.linear(n_, f"{base}.st.{a}.to_v", bias=False)
+                o = self.attention(q, k, v, B, T, Cc, heads)
+                t = self.linear(o, f"{base}.st.{a}.to_out", res=t)
+            u = self.linear(self.layernorm(t, base + ".st.ff_ln"), base + ".st.ff.geglu")
+            g = torch.empty((B * T, 4 * Cc), dtype=torch.float32, device=self.dev)
+            native.check(self.L.egr_geglu(_p(u), _p(g), B * T, 4 * Cc, self._st()), "egr_geglu")
+            t = self.linear(g, base + ".st.ff.out", res=t)
+            x = self.conv1x1(t.view(B, H, W, Cc), base + ".st.proj_out", res=x)
+        return x
+
+    def concat(self, a, b):
+        B, H, W, C1 = a.shape
+        C2 = b.shape[3]
+        y = torch.empty((B, H, W, C1 + C2), dtype=torch.float32, device=self.dev)
+        native.check(self.L.egr_concat_channels(_p(a), _p(b), _p(y), B * H * W, C1, C2, self._st()), "egr_concat_channels")
+        return y
+
+    def unet(self, x):
+        skips: List[torch.Tensor] = []
+        h = x
+        for name, cin, cout, attn in self.blocks:
+            part, _, kind = name.split(".")
+            base = f"unet.{name}"
+            if kind == "conv_in":
+                h = self.conv3(h, base)
+                skips.append(h)
+            elif kind == "down":
+                h = self.conv3(h, base + ".conv", stride=2, pad=1)
+                skips.append(h)
+            elif kind == "up":
+                h = self.conv3(h, base + ".conv", up2=1)
+            else:
+                if part == "out":
+                    h = self.concat(h, skips.pop())
+                h = self._unet_block(h, base, attn)
+                if part == "in":
+                    skips.append(h)
+        return self.conv3(self.groupnorm(h, "unet.out_norm", 1e-5, True), "unet.out_conv")
+
+    def _amp(self, h, j):
+        cfg = self.cfg
+        acc = None
+        for ki, k in enumerate(cfg.voc_kernels):
+            x = h
+            for di, d in enumerate(cfg.voc_dils):
+                b = f"voc.amp.{j}.{ki}.{di}"
+                xt = self.snake(x, b + ".alpha1", b + ".beta1")
+                xt = self.conv1d(xt, b + ".conv1", k, dil=d, pad=d * (k - 1) // 2)
+                xt = self.snake(xt, b + ".alpha2", b + ".beta2")
+                x = self.conv1d(xt, b + ".conv2", k, pad=(k - 1) // 2, res=x)
+            acc = x if acc is None else self.eltwise(acc, x, EW_ADD)
+        return self.eltwise(acc, None, EW_SCALE, 1.0 / len(cfg.voc_kernels))
+
+    def vocoder(self, mel_hat, wave):
+        cfg = self.cfg
+        B, T, Fm, _ = mel_hat.shape
+        n = len(cfg.voc_rates)
+        feats = []
+        e = wave.view(B, -1, 1)
+        for i, r in enumerate(reversed(cfg.voc_rates)):
+            e = self.conv1d(e, f"voc.wave_enc.{i}", 2 * r + 1, stride=r, pad=r, act=ACT_LEAKY)
+            feats.append(e)
+        h = self.conv1d(mel_hat.view(B, T, Fm), "voc.conv_pre", 7, pad=3, res=feats[n - 1])
+        for j, r in enumerate(cfg.voc_rates):
+            kt = arch.up_kernel(r)
+            Bc, Lin, Ci = h.shape
+            wt = self.w[f"voc.ups.{j}.weight"]
+            Co = wt.shape[1] // kt
+            Y = self.conv(h, None, Bc * Lin, 1, 1, Ci, 1, 1, kt * Co, 1, 1, bias=False, w=wt)
+            out = torch.empty((Bc, Lin * r, Co), dtype=torch.float32, device=self.dev)
+            add = feats[n - 2 - j] if j <= n - 2 else None
+            native.check(self.L.egr_col2im_convtr1d(_p(Y), _p(self.w[f"voc.ups.{j}.bias"]), _p(add), _p(out), Bc, Lin,
+                                                    Lin * r, Co, kt, r, (kt - r) // 2, self._st()), "egr_col2im_convtr1d")
+            h = self._amp(out, j)
+        h = self.snake(h, "voc.post.alpha", "voc.post.beta")
+        y = self.conv1d(h, "voc.conv_post", 7, pad=3, act=ACT_TANH)
+        return y.view(B, -1)
+
+    # ------------------------------------------------------------------ whole model
+    def noise(self, rows: int, row_ids: Optional[torch.Tensor], seed: int) -> torch.Tensor:
+        h, w = self.cfg.lat_hw
+        out = torch.empty((rows, h, w, self.cfg.z_ch), dtype=torch.float32, device=self.dev)
+        native.check(self.L.egr_randn(_p(out), h * w * self.cfg.z_ch, rows, int(seed) & (2 ** 64 - 1), _p(row_ids),
+                                      self._st()), "egr_randn")
+        return out
+
+    def forward_rows(self, x: torch.Tensor, noise: torch.Tensor, stages: Optional[dict] = None) -> torch.Tensor:
+        """x [R, chunk] float32 CUDA, noise [R, h, w, z] (channels-last) -> y [R, chunk]."""
+        x = x.contiguous()
+        mel = self.log_mel(x)
+        z_c = self.vae_encode(mel)
+        v = self.unet(self.concat(noise, z_c))
+        z0 = self.eltwise(noise, v, EW_AXPBY, self.alpha, -self.sigma)
+        mel_hat = self.vae_decode(z0)
+        y = self.vocoder(mel_hat, x)
+        if stages is not None:
+            stages.update(mel=mel, z_cond=z_c, v=v, z0=z0, mel_hat=mel_hat, y=y)
+        return y[:, :x.shape[1]]
+
+    def flop_count(self, rows: int = 1) -> float:
+        """Dense-contraction flops of one forward over `rows` rows (dry run with counting on)."""
+        x = torch.zeros((rows, self.cfg.chunk), dtype=torch.float32, device=self.dev)
+        self.count_flops, self.flops = True, 0.0
+        self.forward_rows(x, self.noise(rows, None, 0))
+        torch.cuda.synchronize()
+        self.count_flops = False
+        return self.flops
+
+
+# ---------------------------------------------------------------------------------------------------- module state
+_ENGINE: Optional[FlashSREngine] = None
+ROWS_PER_PASS = int(os.environ.get("EGREGORA_FLASHSR_ROWS", "8"))
+SEED = int(os.environ.get("EGREGORA_FLASHSR_SEED", "0"))
+
+
+def _weights_missing_error():
+    return RuntimeError(
+        "FlashSR weights missing. Place these in models/audio/flashsr: student_ldm.pth, sr_vocoder.pth, vae.pth "
+        "(upstream checkpoints must first be converted to this pack's layer table with "
+        "EGREGORA_FLASHSR_WEIGHTS=<state_dict.pt>); set EGREGORA_FLASHSR_SYNTHETIC=1 to run the declared architecture "
+        "with seeded synthetic weights (benchmarking only).")
+
+
+def ensure_ready() -> FlashSREngine:
+    """Build the engine once per process.  Weight sources, in order: EGREGORA_FLASHSR_WEIGHTS (a torch state
+    dict using flashsr_arch names), else synthetic weights iff EGREGORA_FLASHSR_SYNTHETIC=1, else the reference's
+    'weights missing' error (reference :314-317)."""
+    global _ENGINE
+    if _ENGINE is not None:
+        return _ENGINE
+    native.require_device()
+    cfg = arch.FlashSRConfig()
+    path = os.environ.get("EGREGORA_FLASHSR_WEIGHTS", "")
+    if path:
+        if not os.path.exists(path):
+            raise RuntimeError(f"EGREGORA_FLASHSR_WEIGHTS={path} (missing).")
+        params = torch.load(path, map_location="cpu", weights_only=True)
+    elif os.environ.get("EGREGORA_FLASHSR_SYNTHETIC", "") == "1":
+        params = arch.init_params(cfg, seed=0)
+    else:
+        raise _weights_missing_error()
+    _ENGINE = FlashSREngine(cfg, params)
+    return _ENGINE
+
+
+def set_engine(engine: Optional[FlashSREngine]):
+    global _ENGINE
+    _ENGINE = engine
+
+
+def infer_rows(eng: FlashSREngine, rows_x: torch.Tensor, row_ids: torch.Tensor, seed: int) -> torch.Tensor:
+    """rows_x [R, chunk] -> [R, chunk], processed ROWS_PER_PASS rows at a time; noise keyed by global row id."""
+    outs = []
+    for lo in range(0, rows_x.shape[0], ROWS_PER_PASS):
+        xs = rows_x[lo:lo + ROWS_PER_PASS]
+        ids = row_ids[lo:lo + ROWS_PER_PASS].contiguous()
+        outs.append(eng.forward_rows(xs, eng.noise(xs.shape[0], ids, seed)))
+    return torch.cat(outs, 0)
 
 
 def infer_spans(x_ct: torch.Tensor, n_chunks: int, win: int, hop: int, lowpass: bool) -> torch.Tensor:
-    ensure_ready()
+    """[C,T] @48 kHz on the GPU -> predictions [n_chunks, C, win].  Chunks are sharded over the ranks of the
+    default process group when one exists (contiguous blocks, one all-gather; shard.py)."""
+    if lowpass:
+        raise RuntimeError("lowpass_input=True is not built yet in this revision (the default is False)")
+    eng = ensure_ready()
+    Cn = x_ct.shape[0]
+    if win != eng.cfg.chunk:
+        raise RuntimeError(f"chunk length {win} != model chunk {eng.cfg.chunk}")
+
+    def run_block(lo: int, hi: int) -> torch.Tensor:
+        chunks = device_ops.chunk_gather(x_ct, win, hop, lo, hi - lo)                 # [n, C, win]
+        ids = (torch.arange(lo, hi, device=x_ct.device, dtype=torch.int64)[:, None] * Cn +
+               torch.arange(Cn, device=x_ct.device, dtype=torch.int64)[None, :]).reshape(-1)
+        y = infer_rows(eng, chunks.view(-1, win), ids, SEED)
+        return y.view(hi - lo, Cn, win)
+
+    return shard.sharded_chunks(run_block, n_chunks, (Cn, win), x_ct.device)

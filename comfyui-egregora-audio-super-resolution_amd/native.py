@@ -33,6 +33,20 @@ SIGNATURES = {
     "egr_stft_mag": (_i, [_vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
     "egr_wola_stitch": (_i, [_vp, _i, _i, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "egr_chunk_gather": (_i, [_vp, _i, _i64, _i64, _i64, _i, _i, _vp, _vp]),
+    "egr_conv_nhwc": (_i, [_vp] * 6 + [_i] * 15 + [_f, _vp]),
+    "egr_bgemm": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_i64] * 6 + [_i, _f, _vp]),
+    "egr_groupnorm_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
+    "egr_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "egr_layernorm_rows": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
+    "egr_softmax_rows": (_i, [_vp, _i64, _i, _vp]),
+    "egr_eltwise": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _vp]),
+    "egr_geglu": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "egr_concat_channels": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "egr_transpose_batched": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "egr_snake_aa": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "egr_col2im_convtr1d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "egr_stft_frames": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "egr_randn": (_i, [_vp, _i64, _i, C.c_uint64, _vp, _vp]),
 }
 
 

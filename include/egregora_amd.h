@@ -112,6 +112,56 @@ int egr_wola_stitch(const float* preds, int n_chunks, int channels, int64_t lp, 
 int egr_chunk_gather(const float* x, int channels, int64_t total, int64_t win, int64_t hop, int chunk_begin,
                      int n_chunks, float* chunks, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * FlashSR network operators (channels-last activations, exact fp32).  Together they stand in for the
+ * upstream call `self._model(x, lowpass_input=...)` at egregora_audio_super_resolution.py:366-369; the
+ * graph that strings them together is flashsr_engine.py (layer table: flashsr_arch.py).
+ * ---------------------------------------------------------------------------------------------- */
+#define EGR_ACT_NONE 0
+#define EGR_ACT_SILU 1
+#define EGR_ACT_TANH 2
+#define EGR_ACT_LEAKY01 3
+#define EGR_ACT_LOGCLAMP 4 /* log(max(v, act_param)) */
+
+/* Implicit-GEMM convolution on the matrix cores (v_mfma_f32_32x32x2_f32).
+ *   x [B][H][W][Cin], w [KH][KW][Cin][Cout], y [B][OH][OW][Cout];
+ *   input coordinate = o*stride + k*(dil for W, 1 for H) - pad; out-of-range reads are zero;
+ *   up2 != 0: the logical input is the nearest-neighbour 2x upsampling of x (read at coord>>1);
+ *   epilogue: + bias[Cout] + bias_b[B][Cout] + res[B][OH][OW][Cout] (each optional), then activation.
+ * 1-D convolutions use H = KH = 1; Linear layers use H = W = KH = KW = 1 with B = rows. */
+int egr_conv_nhwc(const float* x, const float* w, const float* bias, const float* bias_b, const float* res, float* y,
+                  int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil,
+                  int pad_t, int pad_l, int up2, int act, float act_param, void* stream);
+
+/* Strided batched GEMM for attention: C[b1][b2] = alpha * A[b1][b2] (MxK) * (transB ? B^T : B). */
+int egr_bgemm(const float* a, const float* b, float* c, int nb1, int nb2, int M, int N, int K, int lda, int ldb,
+              int ldc, int64_t sa1, int64_t sa2, int64_t sb1, int64_t sb2, int64_t sc1, int64_t sc2, int transB,
+              float alpha, void* stream);
+
+/* GroupNorm over [B][HW][C] with G groups (+ optional SiLU); workspace >= egr_groupnorm_workspace_bytes. */
+size_t egr_groupnorm_workspace_bytes(int B, int C, int G);
+int egr_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, float* y, int B, int HW, int C, int G,
+                       float eps, int silu, void* workspace, void* stream);
+int egr_layernorm_rows(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C, float eps,
+                       void* stream);
+int egr_softmax_rows(float* x, int64_t rows, int cols, void* stream);
+/* op: 0 a+b, 1 s0*a+s1*b, 2 silu(a), 3 s0*a, 4 copy */
+int egr_eltwise(const float* a, const float* b, float* y, int64_t n, int op, float s0, float s1, void* stream);
+int egr_geglu(const float* u, float* y, int64_t rows, int D, void* stream);
+int egr_concat_channels(const float* a, const float* b, float* y, int64_t M, int C1, int C2, void* stream);
+int egr_transpose_batched(const float* x, float* y, int batch, int R, int Cc, void* stream);
+/* Anti-aliased snake over [B][L][C]: 2x up (K-tap FIR, replicate pad) . x + sin^2(e^alpha x)/(e^beta+1e-9) . 2x down. */
+int egr_snake_aa(const float* x, const float* alpha, const float* beta, const float* filt, float* y, int B, int L, int C,
+                 int K, void* stream);
+/* ConvTranspose1d as GEMM + gather: Y [B][Lin][K][Co] -> out [B][Lout][Co] (+bias, + optional add). */
+int egr_col2im_convtr1d(const float* Y, const float* bias, const float* add, float* out, int B, int Lin, int Lout, int Co,
+                        int K, int r, int pad, void* stream);
+/* Mel front-end STFT: x [B][L] -> |STFT| frames [B][T][ldm], reflect padding rpad, frames >= t_valid zeroed. */
+int egr_stft_frames(const float* x, int B, int L, int n_fft, int hop, int rpad, int T, int t_valid, int ldm,
+                    const float* window, float* mag, void* stream);
+/* Standard normals: element e of row r is a function of (seed, row_ids[r] or r, e) only (Philox4x32-10). */
+int egr_randn(float* out, int64_t per_row, int rows, uint64_t seed, const int64_t* row_ids, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,270 @@
+"""GPU numerics of the FlashSR operators and of the assembled engine against plain PyTorch fp32 of the same
+op / the same layer table (oracle/flashsr_torch.py, run on the CPU in float32).
+
+Tolerances (float32 both sides; only summation order and exp/sin approximations differ):
+  single operators : max|diff| <= 2e-5 * max|ref| (+ 1e-6)
+  assembled stages : relative L2 error <= 2e-4 per stage at the toy config, <= 1e-3 for the final waveform
+  output LSD (reference metric) between engine and torch reference waveforms <= 0.05 dB at the toy config
+Upstream FlashSR itself is absent: parity with it is unpinned (see flashsr_arch.py).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def close(got, want, tol=2e-5):
+    got, want = got.detach().cpu().float(), want.detach().cpu().float()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    err = float((got - want).abs().max())
+    ref = float(want.abs().max())
+    assert err <= tol * ref + 1e-6, (err, ref)
+
+
+def rel_l2(got, want):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    return float((got - want).norm() / (want.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def eng(pack):
+    from egregora_amd import flashsr_arch as A, flashsr_engine as E
+    cfg = A.tiny_config()
+    P = A.init_params(cfg, 0)
+    return E.FlashSREngine(cfg, P), cfg, P
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad, up2
+    (2, 16, 24, 32, 48, 3, 1, 1, 0),
+    (1, 33, 17, 16, 128, 3, 1, 1, 0),      # ragged M, BN=128
+    (2, 16, 16, 64, 64, 3, 2, 1, 0),       # UNet downsample
+    (2, 16, 16, 32, 32, 3, 2, 0, 0),       # VAE downsample: pad (0,1,0,1)
+    (2, 8, 12, 48, 40, 3, 1, 1, 1),        # nearest 2x + conv
+    (3, 10, 10, 1, 32, 3, 1, 1, 0),        # Cin = 1 (generic gather path)
+    (2, 12, 12, 32, 1, 3, 1, 1, 0),        # Cout = 1 (scalar weight path)
+    (2, 9, 7, 130, 200, 1, 1, 0, 0),       # 1x1, Cin not a multiple of 16
+    (1, 64, 32, 256, 256, 3, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,k,s,pad,up", CONV_CASES)
+def test_conv_nhwc_vs_torch(eng, B, H, W, Ci, Co, k, s, pad, up):
+    e, cfg, P = eng
+    g = torch.Generator().manual_seed(H * 131 + Ci)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) / math.sqrt(Ci * k * k)
+    b = torch.randn(Co, generator=g)
+    xi = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    if s == 2 and pad == 0:
+        want = F.conv2d(F.pad(xi, (0, 1, 0, 1)), w, b, stride=2)
+    else:
+        want = F.conv2d(xi, w, b, stride=s, padding=pad)
+    res = torch.randn(want.shape, generator=g)
+    want = F.silu(want + res)
+    OH, OW = want.shape[2], want.shape[3]
+    e.w["t.weight"] = w.permute(2, 3, 1, 0).contiguous().cuda()
+    e.w["t.bias"] = b.cuda()
+    got = e.conv(nhwc(x).cuda(), "t", B, H, W, Ci, OH, OW, Co, k, k, s, 1, pad, pad, up, 1, res=nhwc(res).cuda())
+    close(nchw(got), want)
+
+
+@pytest.mark.parametrize("k,dil,stride", [(3, 1, 1), (7, 3, 1), (11, 5, 1), (5, 1, 2), (13, 1, 6)])
+def test_conv1d_vs_torch(eng, k, dil, stride):
+    e, cfg, P = eng
+    g = torch.Generator().manual_seed(k)
+    B, L, Ci, Co = 2, 600, 32, 48
+    x = torch.randn(B, Ci, L, generator=g)
+    w = torch.randn(Co, Ci, k, generator=g) / math.sqrt(Ci * k)
+    b = torch.randn(Co, generator=g)
+    pad = dil * (k - 1) // 2 if stride == 1 else (k - 1) // 2
+    want = F.conv1d(x, w, b, stride=stride, dilation=dil, padding=pad)
+    e.w["t1.weight"] = w.permute(2, 1, 0).contiguous().cuda()
+    e.w["t1.bias"] = b.cuda()
+    got = e.conv1d(x.permute(0, 2, 1).contiguous().cuda(), "t1", k, stride=stride, dil=dil, pad=pad)
+    close(got.permute(0, 2, 1), want)
+
+
+def test_groupnorm_layernorm_softmax_geglu(eng):
+    e, cfg, P = eng
+    g = torch.Generator().manual_seed(3)
+    for (B, H, W, Cc, G) in [(2, 16, 8, 32, 8), (1, 37, 5, 64, 8), (3, 4, 4, 256, 8)]:
+        x = torch.randn(B, Cc, H, W, generator=g) * 3 + 1.5
+        ga, be = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+        e.w["gn.weight"], e.w["gn.bias"] = ga.cuda(), be.cuda()
+        old = e.cfg.gn_groups
+        e.cfg.gn_groups = G
+        for silu in (False, True):
+            want = F.group_norm(x, G, ga, be, 1e-6)
+            want = F.silu(want) if silu else want
+            close(nchw(e.groupnorm(nhwc(x).cuda(), "gn", 1e-6, silu)), want, 3e-5)
+        e.cfg.gn_groups = old
+    x = torch.randn(50, 96, generator=g) * 2 + 0.3
+    ga, be = torch.randn(96, generator=g), torch.randn(96, generator=g)
+    e.w["ln.weight"], e.w["ln.bias"] = ga.cuda(), be.cuda()
+    close(e.layernorm(x.cuda(), "ln"), F.layer_norm(x, (96,), ga, be), 3e-5)
+    s = torch.randn(37, 300, generator=g) * 4
+    sc = s.clone().cuda()
+    from egregora_amd import native
+    native.check(e.L.egr_softmax_rows(C.c_void_p(sc.data_ptr()), 37, 300, native.stream_ptr()), "softmax")
+    close(sc, torch.softmax(s, -1), 2e-5)
+    u = torch.randn(20, 64, generator=g)
+    out = torch.empty(20, 32, device="cuda")
+    native.check(e.L.egr_geglu(C.c_void_p(u.cuda().data_ptr()), C.c_void_p(out.data_ptr()), 20, 32, native.stream_ptr()), "geglu")
+    a, gate = u.chunk(2, -1)
+    close(out, a * F.gelu(gate))
+
+
+@pytest.mark.parametrize("B,T,Cc,heads", [(2, 64, 32, 2), (1, 200, 64, 1), (2, 128, 96, 3)])
+def test_attention_vs_torch(eng, B, T, Cc, heads):
+    e, cfg, P = eng
+    g = torch.Generator().manual_seed(T)
+    q, k, v = (torch.randn(B, T, Cc, generator=g) for _ in range(3))
+    d = Cc // heads
+    sp = lambda t: t.reshape(B, T, heads, d).permute(0, 2, 1, 3)
+    w = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * d ** -0.5, -1)
+    want = (w @ sp(v)).permute(0, 2, 1, 3).reshape(B * T, Cc)
+    got = e.attention(q.reshape(-1, Cc).cuda(), k.reshape(-1, Cc).cuda(), v.reshape(-1, Cc).cuda(), B, T, Cc, heads)
+    close(got, want)
+
+
+def test_snake_aa_and_convtranspose_vs_torch(eng):
+    e, cfg, P = eng
+    from oracle import flashsr_torch as R
+    g = torch.Generator().manual_seed(9)
+    for (B, L, Cc) in [(2, 100, 8), (1, 257, 70), (2, 12, 3)]:
+        x = torch.randn(B, Cc, L, generator=g)
+        al, be = 0.3 * torch.randn(Cc, generator=g), 0.3 * torch.randn(Cc, generator=g)
+        e.w["sa"], e.w["sb"] = al.cuda(), be.cuda()
+        want = R._act_aa(x, al, be, e.filt.cpu())
+        got = e.snake(x.permute(0, 2, 1).contiguous().cuda(), "sa", "sb")
+        close(got.permute(0, 2, 1), want, 3e-5)
+    from egregora_amd import flashsr_arch as A, native
+    for r in (2, 3, 5, 6):
+        kt = A.up_kernel(r)
+        B, Lin, Ci, Co = 2, 40, 32, 24
+        x = torch.randn(B, Ci, Lin, generator=g)
+        w = torch.randn(Ci, Co, kt, generator=g) / math.sqrt(Ci * 2)
+        b = torch.randn(Co, generator=g)
+        add = torch.randn(B, Co, Lin * r, generator=g)
+        want = F.conv_transpose1d(x, w, b, stride=r, padding=(kt - r) // 2) + add
+        wt = w.permute(0, 2, 1).reshape(Ci, kt * Co).contiguous().cuda()
+        Y = e.conv(x.permute(0, 2, 1).contiguous().cuda(), None, B * Lin, 1, 1, Ci, 1, 1, kt * Co, 1, 1, bias=False, w=wt)
+        out = torch.empty(B, Lin * r, Co, device="cuda")
+        p = lambda t: C.c_void_p(t.data_ptr())
+        native.check(e.L.egr_col2im_convtr1d(p(Y), p(b.cuda()), p(add.permute(0, 2, 1).contiguous().cuda()), p(out), B, Lin,
+                                             Lin * r, Co, kt, r, (kt - r) // 2, native.stream_ptr()), "col2im")
+        close(out.permute(0, 2, 1), want)
+
+
+def test_logmel_vs_torch(eng):
+    e, cfg, P = eng
+    from oracle import flashsr_torch as R
+    from egregora_amd import flashsr_arch as A
+    g = torch.Generator().manual_seed(4)
+    x = 0.3 * torch.randn(3, cfg.chunk, generator=g)
+    want = R.log_mel(x, cfg, torch.from_numpy(A.mel_filterbank(cfg)))
+    got = e.log_mel(x.cuda())
+    close(got.permute(0, 3, 1, 2), want, 5e-5)
+
+
+def test_randn_is_rank_independent_and_normal(eng):
+    e, cfg, P = eng
+    ids = torch.tensor([5, 6, 7, 1000], dtype=torch.int64, device="cuda")
+    a = e.noise(4, ids, 123)
+    b = e.noise(2, ids[1:3].contiguous(), 123)
+    assert torch.equal(a[1:3], b)                         # a row depends only on (seed, global row id)
+    c = e.noise(4, ids, 124)
+    assert not torch.equal(a, c)
+    big = torch.empty(8, 100000, device="cuda")
+    from egregora_amd import native
+    native.check(e.L.egr_randn(C.c_void_p(big.data_ptr()), 100000, 8, 7, C.c_void_p(0), native.stream_ptr()), "randn")
+    assert abs(float(big.mean())) < 5e-3 and abs(float(big.std()) - 1.0) < 5e-3
+    assert abs(float((big ** 4).mean()) - 3.0) < 0.05
+
+
+def test_engine_matches_torch_reference_stage_by_stage(eng):
+    e, cfg, P = eng
+    from oracle import flashsr_torch as R
+    from egregora_amd import flashsr_arch as A
+    g = torch.Generator().manual_seed(1)
+    B = 3
+    x = 0.3 * torch.randn(B, cfg.chunk, generator=g)
+    ids = torch.arange(B, dtype=torch.int64, device="cuda")
+    noise = e.noise(B, ids, 0)
+    got_st, want_st = {}, {}
+    y = e.forward_rows(x.cuda(), noise, got_st)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        want = R.flashsr_forward(x, nchw(noise.cpu()), P, cfg, A.unet_blocks(cfg), torch.from_numpy(A.mel_filterbank(cfg)),
+                                 torch.from_numpy(A.kaiser_sinc_filter(cfg.aa_taps)), want_st)
+    for k in ("mel", "z_cond", "v", "z0", "mel_hat"):
+        gt = got_st[k]
+        gt = gt.permute(0, 3, 1, 2) if gt.dim() == 4 else gt
+        assert rel_l2(gt, want_st[k]) <= 2e-4, (k, rel_l2(gt, want_st[k]))
+    assert rel_l2(y, want) <= 1e-3
+    from oracle import metrics as om
+    assert om.lsd_audio(want.numpy().reshape(-1), y.cpu().numpy().reshape(-1), 256, 64)[0] <= 0.05
+
+
+def test_node_end_to_end_with_synthetic_engine(pack, eng):
+    """The ComfyUI node drives chunking -> engine -> WOLA on the device; checked against the oracle glue wrapped
+    around the torch reference graph (toy config: chunk 3840, hop scaled likewise)."""
+    e, cfg, P = eng
+    from egregora_amd import audio_glue as ag, device_ops as ops, flashsr_engine as E
+    from oracle import flashsr_torch as R, glue as og
+    from egregora_amd import flashsr_arch as A
+    win, hop = cfg.chunk, cfg.chunk - 375
+    total = 2 * hop + 1000
+    g = torch.Generator().manual_seed(2)
+    x = 0.3 * torch.randn(2, total, generator=g)
+    E.set_engine(e)
+    try:
+        sp = ag.spans(total, win, hop)
+        preds = E.infer_spans(x.cuda(), len(sp), win, hop, False)
+        got = ops.wola_stitch(preds, total, win, hop).cpu().numpy()
+    finally:
+        E.set_engine(None)
+    fb, filt = torch.from_numpy(A.mel_filterbank(cfg)), torch.from_numpy(A.kaiser_sinc_filter(cfg.aa_taps))
+    idx = [0]
+
+    def model(c):
+        k = idx[0]; idx[0] += 1
+        ids = torch.tensor([k * 2, k * 2 + 1], dtype=torch.int64, device="cuda")
+        nz = nchw(e.noise(2, ids, E.SEED).cpu())
+        with torch.no_grad():
+            return R.flashsr_forward(torch.from_numpy(c), nz, P, cfg, A.unet_blocks(cfg), fb, filt).numpy()
+    want = og.flashsr_node_glue(x.numpy(), model, win, hop)
+    assert got.shape == want.shape
+    assert float(np.abs(got - want).max()) <= 2e-3 * float(np.abs(want).max())
+
+
+def test_full_size_engine_shapes_and_determinism(pack):
+    """Declared full-size architecture with synthetic weights: one row, shapes + finite output + same-seed repeatability."""
+    from egregora_amd import flashsr_arch as A, flashsr_engine as E
+    cfg = A.FlashSRConfig()
+    e = E.FlashSREngine(cfg, A.init_params(cfg, 0))
+    x = 0.2 * torch.randn(1, cfg.chunk, generator=torch.Generator().manual_seed(5))
+    ids = torch.zeros(1, dtype=torch.int64, device="cuda")
+    st = {}
+    y1 = e.forward_rows(x.cuda(), e.noise(1, ids, 0), st)
+    y2 = e.forward_rows(x.cuda(), e.noise(1, ids, 0))
+    torch.cuda.synchronize()
+    assert y1.shape == (1, cfg.chunk) and torch.isfinite(y1).all()
+    assert st["mel"].shape == (1, 512, 256, 1) and st["z_cond"].shape == (1, 64, 32, 16) and st["mel_hat"].shape == (1, 512, 256, 1)
+    assert torch.equal(y1, y2)
+    fl = e.flop_count(1)
+    assert 1e12 < fl < 1e13

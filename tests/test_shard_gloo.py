@@ -1,0 +1,65 @@
+"""N>1 path on CPU: world_size-2 (and 3) gloo process groups exercise shard.sharded_chunks exactly as the GPU
+path uses it (contiguous chunk blocks, one all-gather, results independent of rank count)."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _worker(rank, world, port, n, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from packload import load_pack
+    load_pack()
+    from egregora_amd import shard
+    calls = []
+
+    def run_block(lo, hi):
+        calls.append((lo, hi))
+        idx = torch.arange(lo, hi, dtype=torch.float32)
+        return (idx[:, None, None] * 10.0 + torch.arange(2)[None, :, None] + torch.zeros(1, 1, 5)).contiguous()
+
+    out = shard.sharded_chunks(run_block, n, (2, 5), torch.device("cpu"))
+    q.put((rank, out.numpy(), calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 13), (2, 4), (3, 7), (2, 1)])
+def test_sharded_chunks_equals_single_rank(world, n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500) + world * 7 + n
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = (np.arange(n, dtype=np.float32)[:, None, None] * 10.0 + np.arange(2)[None, :, None] + np.zeros((1, 1, 5), np.float32))
+    covered = []
+    for rank, out, calls in res:
+        np.testing.assert_array_equal(out, want)
+        covered += calls
+    spans = sorted(c for c in covered)
+    assert sum(hi - lo for lo, hi in spans) == n          # every chunk computed exactly once across ranks
+    assert spans[0][0] == 0 and spans[-1][1] == n
+
+
+def test_block_bounds():
+    sys.path.insert(0, str(ROOT))
+    from packload import load_pack
+    load_pack()
+    from egregora_amd import shard
+    assert shard.block_bounds(130, 8) == [(0, 17), (17, 34), (34, 51), (51, 68), (68, 85), (85, 102), (102, 119), (119, 130)]
+    assert shard.block_bounds(3, 8)[:4] == [(0, 1), (1, 2), (2, 3), (3, 3)]
+    assert shard.block_bounds(0, 2) == [(0, 0), (0, 0)]
