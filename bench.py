@@ -4,12 +4,16 @@
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch of synthetic audio already resident in HBM:
-  workload "fatllama_c3": Fat-Llama iterative spectral enhance of 60 s stereo 48 kHz, max_iterations=800,
-                          threshold 0.6, normalise on, autoscale off (BASELINE.json configs[2]; every
-                          iteration is executed).  Fat-Llama does not chunk, so N>1 runs N independent
-                          replicas (one file per rank, "replicas only", scaling = weak).
-value = audio-seconds processed by all ranks / max-over-ranks wall time of the K timed steps.
+Workload "chain60" (the two stages BASELINE.json's metric names, in the order of the reference's example workflow
+LoadAudio -> EgregoraAudioUpscaler -> EgregoraFatLlamaGPU): per GPU 60 s of stereo 48 kHz audio resident in HBM.
+  stage 1  FlashSR: ONE file of N x 60 s is windowed into 5.12 s chunks (hop 4.62 s); rank r runs the contiguous
+           block r of the chunk list (rows = chunks x 2 channels batched through student_ldm 1-step UNet + VAE +
+           sr_vocoder, declared architecture with seeded synthetic weights), ONE RCCL all-gather of the prediction
+           blocks, Hann WOLA on every rank.
+  stage 2  Fat-Llama: each rank enhances its own 60 s slice of the stage-1 output, max_iterations = 800,
+           threshold 0.6, normalise on, autoscale off, factor 1, PCM_16 hops included, every iteration executed.
+A step = stage 1 + stage 2; value = N x 60 audio-seconds / max-over-ranks step time  (weak scaling: per-GPU work
+is fixed as N grows).  `parts` reports each stage alone plus BASELINE configs[1] (one stereo 5.12 s chunk).
 """
 import argparse
 import json
@@ -25,28 +29,28 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 METRIC = "audio-sec/sec (xRT) FlashSR 48kHz + Fat-Llama 800-iter at 1/2/4/8 MI355X"
-HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+SR = 48000
+SEG = 60 * SR                # samples per GPU
 
 
-def synth_c3(seed=303, n=2880000, sr=48000):
-    """SURVEY 8(d) C3 input: decorrelated stereo, sum of 8 log-spaced sines + noise, peak 0.5 FS."""
+def synth(seed, n, channels=2):
+    """SURVEY 8(d) recipe: decorrelated channels, 8 log-spaced sines 80 Hz..6 kHz (1/k) + noise, peak 0.5 FS."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    t = np.arange(n, dtype=np.float64) / sr
+    t = np.arange(n, dtype=np.float64) / SR
     chans = []
-    for c in range(2):
+    for c in range(channels):
         f = np.geomspace(80.0, 6000.0, 8) * (1.0 + 0.013 * c)
         x = sum(np.sin(2 * np.pi * fk * t + rng.uniform(0, 2 * np.pi)) / (k + 1) for k, fk in enumerate(f))
-        x = x + rng.standard_normal(n) * 0.01
-        chans.append(x)
+        chans.append(x + rng.standard_normal(n) * 0.01)
     x = np.stack(chans)
-    x = 0.5 * x / np.max(np.abs(x))
-    return x.astype(np.float32)
+    return (0.5 * x / np.max(np.abs(x))).astype(np.float32)
 
 
-def cpu_baseline_fatllama(x, sr, budget_s=20.0):
-    """Oracle restatement (scipy pocketfft, complex64, one whole-signal FFT + threshold + IFFT per iteration
-    per channel) timed on the host cores on a bounded sample: full-length channels, as many iterations as fit
-    the budget (at least 2), then scaled to the 800-iteration workload."""
+def cpu_baseline_fatllama(x, budget_s=20.0):
+    """Oracle restatement of the Fat-Llama loop (scipy pocketfft complex64: one whole-signal FFT + threshold +
+    IFFT per iteration per channel) timed on the host cores on a bounded sample, scaled to 800 iterations x C."""
     import scipy.fft as sfft
     from oracle import fatllama as ofl
     cores = os.cpu_count() or 1
@@ -63,24 +67,24 @@ def cpu_baseline_fatllama(x, sr, budget_s=20.0):
             el = time.perf_counter() - t0
             if (el > budget_s and it >= 2) or it >= 800:
                 break
-    per_iter_ch = el / it
-    total = per_iter_ch * 800 * x.shape[0]
-    return {"value": (x.shape[1] / sr) / total, "unit": "audio-sec/sec", "cores": cores, "kind": "port",
-            "sample": f"{it} iterations of one 2,880,000-sample channel ({el:.1f} s), scaled to 800 iterations x "
-                      f"{x.shape[0]} channels; scipy.fft complex64, workers={cores}",
-            "sec_per_iteration_channel": per_iter_ch}
+    per = el / it
+    return {"value": (x.shape[1] / SR) / (per * 800 * x.shape[0]), "unit": "audio-sec/sec", "cores": cores,
+            "kind": "port",
+            "sample": f"Fat-Llama stage only: {it} iterations of one {x.shape[1]}-sample channel ({el:.1f} s) scaled to 800 "
+                      f"iterations x {x.shape[0]} channels; oracle/fatllama.py loop on scipy.fft complex64, workers={cores}",
+            "sec_per_iteration_channel": per}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--iters", type=int, default=800, help="Fat-Llama max_iterations (headline = 800)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--m1", type=int, default=0)
-    ap.add_argument("--tc", type=int, default=0)
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--rows", type=int, default=0, help="FlashSR rows per pass (default: engine setting)")
+    ap.add_argument("--only", default="", help="'flashsr' or 'fatllama': time one stage only (dev)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -95,82 +99,114 @@ def main():
 
     from packload import load_pack
     load_pack()
-    from egregora_amd import fatllama_engine as fe, native
+    from egregora_amd import (audio_glue as ag, device_ops as ops, fatllama_engine as fe, flashsr_arch as A,
+                              flashsr_engine as E, native)
+    from egregora_amd.egregora_audio_super_resolution import upscale_48k
     arch = native.require_device()
+    if args.rows > 0:
+        E.ROWS_PER_PASS = args.rows
 
-    sr = 48000
-    x = synth_c3(seed=303 + rank)
-    xd = torch.from_numpy(x).cuda()
-    C, n = x.shape
-    flags = dict(normalize=True, autoscale=False, pcm_in=True, node_post=True, m1_hint=args.m1, tc_hint=args.tc)
+    cfg = A.FlashSRConfig()
+    eng = E.FlashSREngine(cfg, A.init_params(cfg, seed=0))
+    E.set_engine(eng)
 
-    def step(profile=False):
-        return fe.enhance_device(xd, 1, args.iters, 0.6, profile=profile, **flags)
+    total = world * SEG
+    x_all = torch.from_numpy(synth(404, total)).cuda()          # the whole file is replicated on every rank
+    C = x_all.shape[0]
+    n_chunks = len(ag.spans(total))
+    fl_flags = dict(normalize=True, autoscale=False, pcm_in=True, node_post=True)
+
+    def stage_flashsr():
+        return upscale_48k(x_all, False)                          # [C, total] on every rank
+
+    def stage_fatllama(y48):
+        seg = y48[:, rank * SEG:(rank + 1) * SEG].contiguous()
+        return fe.enhance_device(seg, 1, args.iters, 0.6, **fl_flags)
+
+    def step():
+        if args.only == "fatllama":
+            return stage_fatllama(x_all)
+        y = stage_flashsr()
+        return y if args.only == "flashsr" else stage_fatllama(y)
+
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist:
+            tt = torch.tensor([el], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, r
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        y = step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([el], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
+    el, _ = timed(step, args.steps)
 
-    # per-kernel HIP-event timing of the two loop kernels on the launch stream (separate, untimed pass)
-    step(profile=True)
-    kt = fe.kernel_times(n, C, 1, local_rank) if (args.m1 == 0 and args.tc == 0) else None
-    if kt is None:
-        from egregora_amd.fatllama_engine import _plan
-        import ctypes as Cc
-        L = native.lib()
-        plan = _plan(n, C, 1, local_rank, args.m1, args.tc)
-        r, c = Cc.c_double(), Cc.c_double()
-        nr, nc = Cc.c_int64(), Cc.c_int64()
-        L.egr_fatllama_kernel_times(Cc.c_void_p(plan), Cc.byref(r), Cc.byref(c), Cc.byref(nr), Cc.byref(nc))
-        kt = {"row_ms": r.value, "col_ms": c.value, "row_launches": nr.value, "col_launches": nc.value}
+    # ---- untimed extras: per-stage times, configs[1], per-kernel HIP-event timing for the rooflines ----
+    el_fs, y48 = timed(stage_flashsr, 1)
+    el_fl, _ = timed(lambda: stage_fatllama(y48), 1)
+    x_c2 = x_all[:, :cfg.chunk].contiguous()
+    upscale_48k(x_c2, False)
+    el_c2, _ = timed(lambda: upscale_48k(x_c2, False), 3)
+    eng.prof = []
+    stage_flashsr()
+    prof = eng.prof_summary()
+    eng.prof = None
+    fe.enhance_device(y48[:, rank * SEG:(rank + 1) * SEG].contiguous(), 1, args.iters, 0.6, profile=True, **fl_flags)
+    kt = fe.kernel_times(SEG, C, 1, local_rank)
 
     if rank == 0:
-        info = fe.plan_info(n, 1, args.m1)
-        audio_s = n / sr
-        value = world * args.steps * audio_s / el
-        # algorithmic bytes per launch of a loop kernel: read 4N + write 4N bytes per channel
-        bytes_per_launch = 8.0 * n * C
-        dom = "k_row" if kt["row_ms"] >= kt["col_ms"] else "k_col<1>"
+        audio_s = total / SR
+        nconv, fconv, tconv = prof.get("k_conv_igemm", (0, 0.0, 0.0))
+        conv_tfs = fconv / (tconv * 1e-3) / 1e12 if tconv > 0 else 0.0
+        row_bytes = 8.0 * SEG * C
         dom_ms = max(kt["row_ms"], kt["col_ms"])
-        achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        dom = "k_row" if kt["row_ms"] >= kt["col_ms"] else "k_col<1>"
+        hbm_ach = row_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
-        try:   # PMC-measured bytes per launch, recorded by tools/profile_round.sh runs (profiles/traffic.json)
-            tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
-            if args.iters == 800 and args.m1 == 0 and args.tc == 0:
-                traffic = tj.get("fatllama_c3", {}).get(dom)
+        try:
+            traffic = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get("fatllama_c3", {}).get(dom)
         except Exception:
-            traffic = None
+            pass
+        info = fe.plan_info(SEG, 1)
         out = {
-            "metric": METRIC, "value": value, "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+            "metric": METRIC, "value": world * args.steps * (SEG / SR) / el, "unit": "audio-sec/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "fatllama_c3: Fat-Llama 60 s stereo 48 kHz, max_iterations=%d, thr=0.6, "
-                                   "normalize on, autoscale off, factor 1 (BASELINE configs[2]); one file per rank"
-                                   % args.iters,
-                       "arch": arch, "split": [info["M1"], info["M2"]], "tile_cols": info["TC"]},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_launch": bytes_per_launch, "avg_launch_ms": dom_ms,
-                         "k_row_ms": kt["row_ms"], "k_col_ms": kt["col_ms"],
-                         "launches": [kt["row_launches"], kt["col_launches"]]},
+            "config": {"workload": "chain60: per GPU 60 s stereo 48 kHz; FlashSR (5.12 s chunks, hop 4.62 s, student_ldm "
+                                   "1-step + VAE + sr_vocoder, declared architecture, synthetic weights, chunk-sharded with one "
+                                   "all-gather, WOLA) then Fat-Llama max_iterations=%d thr=0.6 normalize on autoscale off" % args.iters
+                                   + (f" [only={args.only}]" if args.only else ""),
+                       "arch": arch, "chunks": n_chunks, "rows_per_pass": E.ROWS_PER_PASS,
+                       "fatllama_split": [info["M1"], info["M2"]]},
+            "parts": {
+                "flashsr_stage_xrt": audio_s / el_fs, "flashsr_stage_ms": 1e3 * el_fs,
+                "fatllama_stage_xrt": audio_s / el_fl, "fatllama_stage_ms": 1e3 * el_fl,
+                "configs1_flashsr_single_chunk_stereo_xrt": 3 * 5.12 / el_c2, "configs1_ms": 1e3 * el_c2 / 3,
+                "flashsr_flops_per_row": fconv / max(1, (len(ag.spans(total)) + world - 1) // world * C) if fconv else None,
+            },
+            # dominant kernel of the step: the implicit-GEMM convolution (all dense contractions of FlashSR)
+            "roofline": {"bound": "mfma", "kernel": "k_conv_igemm", "achieved": conv_tfs, "peak": MFMA_F32_PEAK_TFS,
+                         "unit": "TFLOP/s", "frac": conv_tfs / MFMA_F32_PEAK_TFS, "traffic": None,
+                         "launches": nconv, "flops_total": fconv, "ms_total": tconv,
+                         "avg_flops_per_launch": fconv / max(1, nconv), "avg_launch_ms": tconv / max(1, nconv)},
+            "roofline_fatllama": {"bound": "hbm", "kernel": dom, "achieved": hbm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": hbm_ach / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": row_bytes,
+                                  "avg_launch_ms": dom_ms, "k_row_ms": kt["row_ms"], "k_col_ms": kt["col_ms"],
+                                  "launches": [kt["row_launches"], kt["col_launches"]]},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline_fatllama(x, sr, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline_fatllama(x_all[:, :SEG].cpu().numpy(), args.cpu_budget)
         print(json.dumps(out))
     if dist:
         dist.destroy_process_group()

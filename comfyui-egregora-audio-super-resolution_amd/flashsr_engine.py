@@ -33,6 +33,7 @@ class FlashSREngine:
         self.L = native.lib()
         self.flops = 0.0            # dense-contraction flops of the last forward (per call, all rows)
         self.count_flops = False
+        self.prof = None            # when a list: (kind, flops, start_event, end_event) per MFMA kernel launch
         self.blocks = arch.unet_blocks(cfg)
         self.w: Dict[str, torch.Tensor] = {}
         self._pack(params)
@@ -70,12 +71,38 @@ class FlashSREngine:
         y = torch.empty((B, OH, OW, Cout), dtype=torch.float32, device=self.dev)
         wt = w if w is not None else self.w[wkey + ".weight"]
         bt = bias_t if bias_t is not None else (self.w.get(wkey + ".bias") if bias else None)
+        fl = 2.0 * B * OH * OW * Cout * KH * KW * Cin
+        ev = self._prof_begin()
         native.check(self.L.egr_conv_nhwc(_p(x), _p(wt), _p(bt), _p(None), _p(res), _p(y), B, H, W, Cin, OH, OW, Cout, KH,
                                           KW, stride, dil, pad_t, pad_l, up2, act, float(act_param), self._st()),
                      "egr_conv_nhwc")
+        self._prof_end(ev, "k_conv_igemm", fl)
         if self.count_flops:
-            self.flops += 2.0 * B * OH * OW * Cout * KH * KW * Cin
+            self.flops += fl
         return y
+
+    def _prof_begin(self):
+        if self.prof is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()                      # torch's current stream == the stream the kernel is launched on
+        return ev
+
+    def _prof_end(self, ev, kind, flops):
+        if ev is None:
+            return
+        e2 = torch.cuda.Event(enable_timing=True)
+        e2.record()
+        self.prof.append((kind, flops, ev, e2))
+
+    def prof_summary(self):
+        """{kind: (launches, total_flops, total_ms)} from the events collected while self.prof was a list."""
+        torch.cuda.synchronize()
+        out = {}
+        for kind, fl, a, b in self.prof or []:
+            n, f, t = out.get(kind, (0, 0.0, 0.0))
+            out[kind] = (n + 1, f + fl, t + a.elapsed_time(b))
+        return out
 
     def conv3(self, x, key, stride=1, up2=0, act=ACT_NONE, res=None, pad=1, bias_t=None):
         B, H, W, Cin = x.shape
