@@ -226,6 +226,59 @@ __global__ __launch_bounds__(256) void k_snake_aa(const float* __restrict__ x, c
     y[(size_t)b * L * C + (size_t)l * C + c] = acc;
 }
 
+
+// LDS-tiled version (C % CB == 0): a workgroup owns TL output positions x CB channels.  The x tile (+5 halo,
+// replicate-clamped), then every 2x-rate sample s[i] it needs (2*TL+10 per channel, ONE sin each), are staged in
+// LDS; the down FIR reads them back.  ~2.3 snake evaluations per output instead of 12.
+template <int CB, int TL>
+__global__ __launch_bounds__(256) void k_snake_aa_tiled(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                        const float* __restrict__ beta, const float* __restrict__ filt,
+                                                        float* __restrict__ y, int L, int C) {
+    constexpr int PL = 256 / CB, K = 12, XT = TL + 10, ST = 2 * TL + 10;
+    __shared__ float xs[XT][CB];
+    __shared__ float ss[ST][CB];
+    __shared__ float f[K];
+    if (threadIdx.x < K) f[threadIdx.x] = filt[threadIdx.x];
+    const int c = threadIdx.x % CB, pl = threadIdx.x / CB;
+    const int c0 = blockIdx.x * CB, l0 = blockIdx.y * TL, b = blockIdx.z;
+    const float* xb = x + (size_t)b * L * C + c0 + c;
+    for (int p = pl; p < XT; p += PL) {
+        int src = l0 - 5 + p;
+        src = src < 0 ? 0 : (src > L - 1 ? L - 1 : src);
+        xs[p][c] = xb[(size_t)src * C];
+    }
+    const float a = __expf(alpha[c0 + c]), ib = 1.0f / (__expf(beta[c0 + c]) + 1e-9f);
+    __syncthreads();
+    const int L2 = 2 * L;
+    for (int q = pl; q < ST; q += PL) {
+        int i = 2 * l0 - 5 + q;
+        i = i < 0 ? 0 : (i > L2 - 1 ? L2 - 1 : i);
+        const int t = i + 15;
+        const int n_hi = t >> 1;                       // taps n_hi-5 .. n_hi, filter index t - 2n
+        float u = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int n = n_hi - j;
+            int p = n - l0;                            // xs row of xp[n] (tile rows are already clamped copies)
+            p = p < 0 ? 0 : (p > XT - 1 ? XT - 1 : p);
+            u += xs[p][c] * f[t - 2 * n];
+        }
+        u *= 2.0f;
+        const float sn = __sinf(u * a);
+        ss[q][c] = u + ib * sn * sn;
+    }
+    __syncthreads();
+    float* yb = y + (size_t)b * L * C + c0 + c;
+    for (int j = pl; j < TL; j += PL) {
+        const int l = l0 + j;
+        if (l >= L) break;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc += f[k] * ss[2 * j + k][c];
+        yb[(size_t)l * C] = acc;
+    }
+}
+
 // ---------------------------------------------------------------- ConvTranspose1d overlap-add (gather form)
 // Y [B][Lin][K][Co] (GEMM output), out[b][o][co] = bias[co] + (add ? add[b][o][co] : 0)
 //                                              + sum_{k == (o+pad) mod r, i=(o+pad-k)/r in [0,Lin)} Y[b][i][k][co]
@@ -451,8 +504,15 @@ extern "C" int egr_snake_aa(const float* x, const float* alpha, const float* bet
                             int L, int C, int K, void* stream) {
     EGR_CHECK(x && alpha && beta && filt && y && B >= 1 && B <= 65535 && L >= 1 && C >= 1 && K >= 2 && K <= 32 && K % 2 == 0,
               EGR_ERR_ARG, "bad argument");
-    hipLaunchKernelGGL(k_snake_aa, dim3((C + 63) / 64, (L + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, x, alpha, beta,
-                       filt, y, L, C, K);
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 12 && C % 64 == 0)
+        hipLaunchKernelGGL((k_snake_aa_tiled<64, 32>), dim3(C / 64, (L + 31) / 32, B), dim3(256), 0, st, x, alpha, beta, filt, y, L, C);
+    else if (K == 12 && C % 32 == 0)
+        hipLaunchKernelGGL((k_snake_aa_tiled<32, 64>), dim3(C / 32, (L + 63) / 64, B), dim3(256), 0, st, x, alpha, beta, filt, y, L, C);
+    else if (K == 12 && C % 16 == 0)
+        hipLaunchKernelGGL((k_snake_aa_tiled<16, 128>), dim3(C / 16, (L + 127) / 128, B), dim3(256), 0, st, x, alpha, beta, filt, y, L, C);
+    else
+        hipLaunchKernelGGL(k_snake_aa, dim3((C + 63) / 64, (L + 3) / 4, B), dim3(256), 0, st, x, alpha, beta, filt, y, L, C, K);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }

@@ -76,7 +76,7 @@ class FlashSREngine:
         native.check(self.L.egr_conv_nhwc(_p(x), _p(wt), _p(bt), _p(None), _p(res), _p(y), B, H, W, Cin, OH, OW, Cout, KH,
                                           KW, stride, dil, pad_t, pad_l, up2, act, float(act_param), self._st()),
                      "egr_conv_nhwc")
-        self._prof_end(ev, "k_conv_igemm", fl)
+        self._prof_end(ev, "k_conv_igemm", fl, (B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, up2))
         if self.count_flops:
             self.flops += fl
         return y
@@ -88,18 +88,18 @@ class FlashSREngine:
         ev.record()                      # torch's current stream == the stream the kernel is launched on
         return ev
 
-    def _prof_end(self, ev, kind, flops):
+    def _prof_end(self, ev, kind, flops, shape=None):
         if ev is None:
             return
         e2 = torch.cuda.Event(enable_timing=True)
         e2.record()
-        self.prof.append((kind, flops, ev, e2))
+        self.prof.append((kind, flops, ev, e2, shape))
 
     def prof_summary(self):
         """{kind: (launches, total_flops, total_ms)} from the events collected while self.prof was a list."""
         torch.cuda.synchronize()
         out = {}
-        for kind, fl, a, b in self.prof or []:
+        for kind, fl, a, b, _ in self.prof or []:
             n, f, t = out.get(kind, (0, 0.0, 0.0))
             out[kind] = (n + 1, f + fl, t + a.elapsed_time(b))
         return out
@@ -380,7 +380,7 @@ class FlashSREngine:
 
 # ---------------------------------------------------------------------------------------------------- module state
 _ENGINE: Optional[FlashSREngine] = None
-ROWS_PER_PASS = int(os.environ.get("EGREGORA_FLASHSR_ROWS", "8"))
+ROWS_PER_PASS = int(os.environ.get("EGREGORA_FLASHSR_ROWS", "32"))
 SEED = int(os.environ.get("EGREGORA_FLASHSR_SEED", "0"))
 
 

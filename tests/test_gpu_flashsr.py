@@ -145,7 +145,7 @@ def test_snake_aa_and_convtranspose_vs_torch(eng):
     e, cfg, P = eng
     from oracle import flashsr_torch as R
     g = torch.Generator().manual_seed(9)
-    for (B, L, Cc) in [(2, 100, 8), (1, 257, 70), (2, 12, 3)]:
+    for (B, L, Cc) in [(2, 100, 8), (1, 257, 70), (2, 12, 3), (2, 300, 64), (1, 1000, 32), (2, 777, 16), (1, 20, 128), (1, 4, 16)]:
         x = torch.randn(B, Cc, L, generator=g)
         al, be = 0.3 * torch.randn(Cc, generator=g), 0.3 * torch.randn(Cc, generator=g)
         e.w["sa"], e.w["sb"] = al.cuda(), be.cuda()
