@@ -4,8 +4,8 @@
 //                  activation epilogue.  Also serves every Linear layer (1x1, H=W=1).
 //   k_bgemm      : strided batched GEMM (QK^T with B transposed, PV) for the attention blocks.
 // Both use v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bitwise an fmaf chain, MI355X_MICROARCH.md
-// "Matrix cores"), a 128 x BN x 16 block tile staged through double-buffered LDS in k-major order so an MFMA
-// operand fetch is two conflict-free 32-lane rows, 4 waves per workgroup each owning TM x TN 32x32 accumulators.
+// "Matrix cores"), a 128 x BN x 16 block tile staged through double-buffered row-major LDS tiles so an MFMA
+// operand fetch is two ds_read_b128 per 32x16 sub-tile, 4 waves per workgroup each owning TM x TN 32x32 accumulators.
 // At 64 cycles per MFMA the pipe, not LDS or HBM, is the bound for Cin*Cout >= 128*128; the roofline for these
 // kernels is the 157.3 TFLOP/s f32 matrix peak.
 #include <string.h>
@@ -20,7 +20,7 @@ enum { ACT_NONE = 0, ACT_SILU = 1, ACT_TANH = 2, ACT_LEAKY01 = 3, ACT_LOGCLAMP =
 
 struct ConvP {
     const float* x;        // [B][H][W][Cin]   (physical; logical input is 2H x 2W when up2 != 0)
-    const float* w;        // [KH][KW][Cin][Cout]
+    const float* w;        // PACKED [ceil(K/16)][Cout][16], K = KH*KW*Cin ordered (ky, kx, ci)
     const float* bias;     // [Cout] or null
     const float* bias_b;   // [B][Cout] or null (time-embedding bias)
     const float* res;      // [M][Cout] or null
@@ -32,7 +32,7 @@ struct ConvP {
 
 #define BM 128
 #define BK 16
-#define LPAD 4
+#define LROW (BK + 4)   // LDS row pitch in floats: 80 B keeps ds_read_b128 of 32 consecutive rows conflict-free
 
 __device__ __forceinline__ float apply_act(float v, int act, float prm) {
     switch (act) {
@@ -44,22 +44,37 @@ __device__ __forceinline__ float apply_act(float v, int act, float prm) {
     }
 }
 
-// acc[tm][tn] += A(32 rows x 2 k) * B(2 k x 32 cols) over one BK slab held in LDS
-template <int TM, int TN, int BN>
-__device__ __forceinline__ void mma_slab(const float (*As)[BM + LPAD], const float (*Bs)[BN + LPAD], int wm0, int wn0,
+// One BK=16 slab.  LDS tiles are row-major [row][k] (k contiguous): lane (li = lane&31, lk = lane>>5) fetches the
+// 8 k-values k = 8*lk .. 8*lk+7 of its row with two ds_read_b128; MFMA step j then multiplies k = j (lanes 0-31)
+// and k = 8+j (lanes 32-63).  The k order inside a slab is irrelevant to the sum as long as A and B agree.
+template <int TM, int TN>
+__device__ __forceinline__ void mma_slab(const float* __restrict__ As, const float* __restrict__ Bs, int wm0, int wn0,
                                          f32x16 (&acc)[TM][TN]) {
     const int lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5;
+    float4 a[TM][2], b[TN][2];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-        float a[TM], b[TN];
+    for (int i = 0; i < TM; ++i) {
+        const float* r = As + (wm0 + i * 32 + li) * LROW + lk * 8;
+        a[i][0] = *(const float4*)r;
+        a[i][1] = *(const float4*)(r + 4);
+    }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = As[kk + lk][wm0 + i * 32 + li];
+    for (int j = 0; j < TN; ++j) {
+        const float* r = Bs + (wn0 + j * 32 + li) * LROW + lk * 8;
+        b[j][0] = *(const float4*)r;
+        b[j][1] = *(const float4*)(r + 4);
+    }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = Bs[kk + lk][wn0 + j * 32 + li];
+    for (int s = 0; s < 8; ++s) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            const float av = ((const float*)&a[i][s >> 2])[s & 3];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) {
+                const float bv = ((const float*)&b[j][s >> 2])[s & 3];
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+            }
+        }
     }
 }
 
@@ -69,63 +84,80 @@ template <> struct TileCfg<128> { static constexpr int WM = 2, WN = 2, TM = 2, T
 template <> struct TileCfg<64> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 1; };
 template <> struct TileCfg<32> { static constexpr int WM = 4, WN = 1, TM = 1, TN = 1; };
 
+template <int TM, int TN>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+
+// Weights arrive PRE-PACKED as [ceil(K/16)][Cout][16] (slab-major, k contiguous per output channel): a B tile is
+// then read exactly like an A tile (one float4 along k per thread) and needs no transposition in LDS.
 template <int BN, bool VEC>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     typedef TileCfg<BN> TC;
-    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + LPAD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + LPAD];
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LROW];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LROW];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int wm0 = (wave / TC::WN) * (BM / TC::WM), wn0 = (wave % TC::WN) * (BN / TC::WN);
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int LH = p.up2 ? 2 * p.H : p.H, LW = p.up2 ? 2 * p.W : p.W;   // logical input extent
 
     f32x16 acc[TC::TM][TC::TN];
-#pragma unroll
-    for (int i = 0; i < TC::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TC::TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    zero_acc<TC::TM, TC::TN>(acc);
 
-    // ---- per-thread A-row bookkeeping ----
-    // VEC: thread owns rows (tid>>2) and (tid>>2)+64, channel quad (tid&3).  Generic: 8 scalars, row = e%128.
-    int rb[2], roy[2], rox[2];
-    bool rvalid[2];
-    if (VEC) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int m = m0 + (tid >> 2) + 64 * h;
-            rvalid[h] = m < p.M;
-            const int mm = rvalid[h] ? m : 0;
-            rox[h] = mm % p.OW;
-            const int t = mm / p.OW;
-            roy[h] = t % p.OH;
-            rb[h] = t / p.OH;
-        }
-    }
     const int ktiles = (p.K + BK - 1) / BK;
-    const int tiles_per_tap = VEC ? p.Cin / BK : 1;
+    const int kq = (tid & 3) * 4;             // this thread's k-quad inside a slab
+    const int r0 = tid >> 2;                  // tile rows r0 and r0 + 64
 
-    float4 ra[2];
+    // ---- A rows owned by this thread (VEC path): decode (b, oy, ox) once ----
+    int a_iy0[2], a_ix0[2];
+    size_t a_base[2];
+    bool a_ok[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int m = m0 + r0 + 64 * h;
+        a_ok[h] = m < p.M;
+        const int mm = a_ok[h] ? m : 0;
+        const int ox = mm % p.OW, t = mm / p.OW, oy = t % p.OH, b = t / p.OH;
+        a_iy0[h] = oy * p.stride - p.pad_t;
+        a_ix0[h] = ox * p.stride - p.pad_l;
+        a_base[h] = (size_t)b * p.H * p.W;
+    }
+    // ---- B rows (output channels) owned by this thread ----
+    constexpr int BQ = BN * 4;                // float4 slots in a B tile
+    bool b_ok[2];
+    size_t b_off[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int slot = tid + 256 * h;
+        const int n = n0 + (slot >> 2);
+        b_ok[h] = slot < BQ && n < p.Cout;
+        b_off[h] = (size_t)(b_ok[h] ? n : 0) * BK + kq;
+    }
+    const size_t b_slab = (size_t)p.Cout * BK;
+
+    float4 ra[2], rb4[2];
     float rs[8];
-    float4 rbv[2];
-    float rbs[8];
+    int tap = 0, c0 = 0;                      // VEC: current (tap, first channel) of the slab being loaded
 
     auto load_tile = [&](int kt) {
         if (VEC) {
-            const int tap = kt / tiles_per_tap, c0 = (kt - tap * tiles_per_tap) * BK + (tid & 3) * 4;
             const int ky = tap / p.KW, kx = tap - ky * p.KW;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int iy = roy[h] * p.stride + ky - p.pad_t;
-                const int ix = rox[h] * p.stride + kx * p.dil - p.pad_l;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rvalid[h] && iy >= 0 && iy < LH && ix >= 0 && ix < LW) {
-                    const int py = p.up2 ? iy >> 1 : iy, px = p.up2 ? ix >> 1 : ix;
-                    v = *(const float4*)(p.x + (((size_t)rb[h] * p.H + py) * p.W + px) * p.Cin + c0);
-                }
-                ra[h] = v;
+                const int iy = a_iy0[h] + ky, ix = a_ix0[h] + kx * p.dil;
+                const bool ok = a_ok[h] && (unsigned)iy < (unsigned)LH && (unsigned)ix < (unsigned)LW;
+                const int py = p.up2 ? iy >> 1 : iy, px = p.up2 ? ix >> 1 : ix;
+                const size_t off = ok ? ((a_base[h] + (size_t)py * p.W + px) * p.Cin + c0 + kq) : (size_t)kq;
+                float4 v = *(const float4*)(p.x + off);          // unconditional load; masked afterwards
+                ra[h] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            c0 += BK;
+            if (c0 >= p.Cin) { c0 = 0; ++tap; }
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -133,8 +165,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
                 const int kg = kt * BK + kk, m = m0 + ml;
                 float v = 0.f;
                 if (kg < p.K && m < p.M) {
-                    const int tap = kg / p.Cin, ci = kg - tap * p.Cin;
-                    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+                    const int tp = kg / p.Cin, ci = kg - tp * p.Cin;
+                    const int ky = tp / p.KW, kx = tp - ky * p.KW;
                     const int ox = m % p.OW, t = m / p.OW, oy = t % p.OH, b = t / p.OH;
                     const int iy = oy * p.stride + ky - p.pad_t, ix = ox * p.stride + kx * p.dil - p.pad_l;
                     if (iy >= 0 && iy < LH && ix >= 0 && ix < LW) {
@@ -145,66 +177,29 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
                 rs[i] = v;
             }
         }
-        // weights: rows kt*BK .. +BK of [K][Cout]
-        if ((p.Cout & 3) == 0) {
-            constexpr int TPR = BN / 4;            // threads per k-row
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int idx = tid + 256 * h;
-                const int kk = idx / TPR, nq = idx - kk * TPR;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kk < BK) {
-                    const int kg = kt * BK + kk, n = n0 + nq * 4;
-                    if (kg < p.K && n < p.Cout) v = *(const float4*)(p.w + (size_t)kg * p.Cout + n);
-                }
-                rbv[h] = v;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int e = tid + 256 * i;
-                float v = 0.f;
-                if (e < BK * BN) {
-                    const int kk = e / BN, nl = e - kk * BN;
-                    const int kg = kt * BK + kk, n = n0 + nl;
-                    if (kg < p.K && n < p.Cout) v = p.w[(size_t)kg * p.Cout + n];
-                }
-                rbs[i] = v;
+        for (int h = 0; h < 2; ++h) {
+            if (256 * h < BQ) {
+                float4 v = *(const float4*)(p.w + (size_t)kt * b_slab + b_off[h]);
+                rb4[h] = b_ok[h] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
     auto store_tile = [&](int buf) {
         if (VEC) {
-            const int kq = (tid & 3) * 4;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int ml = (tid >> 2) + 64 * h;
-                As[buf][kq + 0][ml] = ra[h].x;
-                As[buf][kq + 1][ml] = ra[h].y;
-                As[buf][kq + 2][ml] = ra[h].z;
-                As[buf][kq + 3][ml] = ra[h].w;
-            }
+            for (int h = 0; h < 2; ++h) *(float4*)&As[buf][(r0 + 64 * h) * LROW + kq] = ra[h];
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int e = tid + 256 * i;
-                As[buf][e >> 7][e & (BM - 1)] = rs[i];
+                As[buf][(e & (BM - 1)) * LROW + (e >> 7)] = rs[i];
             }
         }
-        if ((p.Cout & 3) == 0) {
-            constexpr int TPR = BN / 4;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int idx = tid + 256 * h;
-                const int kk = idx / TPR, nq = idx - kk * TPR;
-                if (kk < BK) *(float4*)&Bs[buf][kk][nq * 4] = rbv[h];
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int e = tid + 256 * i;
-                if (e < BK * BN) Bs[buf][e / BN][e % BN] = rbs[i];
-            }
+        for (int h = 0; h < 2; ++h) {
+            const int slot = tid + 256 * h;
+            if (slot < BQ) *(float4*)&Bs[buf][(slot >> 2) * LROW + kq] = rb4[h];
         }
     };
 
@@ -214,7 +209,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     for (int kt = 0; kt < ktiles; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < ktiles) load_tile(kt + 1);
-        mma_slab<TC::TM, TC::TN, BN>(As[cur], Bs[cur], wm0, wn0, acc);
+        mma_slab<TC::TM, TC::TN>(As[cur], Bs[cur], wm0, wn0, acc);
         if (kt + 1 < ktiles) store_tile(cur ^ 1);
         __syncthreads();
     }
@@ -254,8 +249,8 @@ struct GemmP {
 template <int BN>
 __global__ __launch_bounds__(256) void k_bgemm(GemmP p) {
     typedef TileCfg<BN> TC;
-    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + LPAD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + LPAD];
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LROW];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LROW];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int wm0 = (wave / TC::WN) * (BM / TC::WM), wn0 = (wave % TC::WN) * (BN / TC::WN);
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -265,22 +260,18 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmP p) {
     float* Cm = p.c + b1 * p.sc1 + b2 * p.sc2;
 
     f32x16 acc[TC::TM][TC::TN];
-#pragma unroll
-    for (int i = 0; i < TC::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TC::TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    zero_acc<TC::TM, TC::TN>(acc);
 
     const int ktiles = (p.K + BK - 1) / BK;
     float ra[8], rbq[8];
-    // element-wise loaders with bounds checks; k-contiguous operands are read 4 at a time along k by 4 lanes
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {                    // A tile: 128 rows x 16 k ; k fastest across lanes
             const int e = tid + 256 * i, kk = e & (BK - 1), ml = e >> 4;
             const int kg = kt * BK + kk, m = m0 + ml;
-            ra[i] = (kg < p.K && m < p.M) ? A[(size_t)m * p.lda + kg] : 0.f;
+            const bool ok = kg < p.K && m < p.M;
+            const float v = A[ok ? (size_t)m * p.lda + kg : 0];
+            ra[i] = ok ? v : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -290,11 +281,15 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmP p) {
                 if (p.transB) {                          // B^T stored [N][K]: k fastest
                     const int kk = e & (BK - 1), nl = e >> 4;
                     const int kg = kt * BK + kk, n = n0 + nl;
-                    if (kg < p.K && n < p.N) v = Bm[(size_t)n * p.ldb + kg];
+                    const bool ok = kg < p.K && n < p.N;
+                    v = Bm[ok ? (size_t)n * p.ldb + kg : 0];
+                    v = ok ? v : 0.f;
                 } else {                                  // B stored [K][N]: n fastest
                     const int nl = e % BN, kk = e / BN;
                     const int kg = kt * BK + kk, n = n0 + nl;
-                    if (kg < p.K && n < p.N) v = Bm[(size_t)kg * p.ldb + n];
+                    const bool ok = kg < p.K && n < p.N;
+                    v = Bm[ok ? (size_t)kg * p.ldb + n : 0];
+                    v = ok ? v : 0.f;
                 }
             }
             rbq[i] = v;
@@ -304,14 +299,14 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmP p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int e = tid + 256 * i;
-            As[buf][e & (BK - 1)][e >> 4] = ra[i];
+            As[buf][(e >> 4) * LROW + (e & (BK - 1))] = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int e = tid + 256 * i;
             if (e < BK * BN) {
-                if (p.transB) Bs[buf][e & (BK - 1)][e >> 4] = rbq[i];
-                else Bs[buf][e / BN][e % BN] = rbq[i];
+                if (p.transB) Bs[buf][(e >> 4) * LROW + (e & (BK - 1))] = rbq[i];
+                else Bs[buf][(e % BN) * LROW + e / BN] = rbq[i];
             }
         }
     };
@@ -321,7 +316,7 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmP p) {
     for (int kt = 0; kt < ktiles; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < ktiles) load_tile(kt + 1);
-        mma_slab<TC::TM, TC::TN, BN>(As[cur], Bs[cur], wm0, wn0, acc);
+        mma_slab<TC::TM, TC::TN>(As[cur], Bs[cur], wm0, wn0, acc);
         if (kt + 1 < ktiles) store_tile(cur ^ 1);
         __syncthreads();
     }

@@ -36,6 +36,7 @@ class FlashSREngine:
         self.prof = None            # when a list: (kind, flops, start_event, end_event) per MFMA kernel launch
         self.blocks = arch.unet_blocks(cfg)
         self.w: Dict[str, torch.Tensor] = {}
+        self.wshape: Dict[str, tuple] = {}
         self._pack(params)
         self.window = torch.hann_window(cfg.n_fft, periodic=True, dtype=torch.float32).to(self.dev)
         self.filt = torch.from_numpy(arch.kaiser_sinc_filter(cfg.aa_taps)).to(self.dev)
@@ -43,24 +44,47 @@ class FlashSREngine:
         self.ldm = ((nb + 15) // 16) * 16
         fb = torch.zeros(self.ldm, cfg.n_mels)
         fb[:nb] = torch.from_numpy(arch.mel_filterbank(cfg)).t()
-        self.w["mel_fb"] = fb.contiguous().to(self.dev)
+        self.w["mel_fb"] = self.pack_matrix(fb.contiguous()).to(self.dev)
         self.alpha, self.sigma = arch.cosine_alpha_sigma(cfg, cfg.t_steps - 1)
         self._gn_ws = None
         self._fold_time_embedding()
 
     # ------------------------------------------------------------------ weight packing
+    @staticmethod
+    def pack_matrix(w2: torch.Tensor) -> torch.Tensor:
+        """[K][Cout] -> the kernel's slab-major layout [ceil(K/16)][Cout][16] (k contiguous, zero padded)."""
+        K, Co = w2.shape
+        Kp = ((K + 15) // 16) * 16
+        if Kp != K:
+            w2 = torch.cat([w2, w2.new_zeros(Kp - K, Co)], 0)
+        return w2.reshape(Kp // 16, 16, Co).permute(0, 2, 1).contiguous()
+
+    def add_weight(self, key: str, v: torch.Tensor):
+        """Register a weight given in torch layout; self.w[key] holds the packed tensor, self.wshape[key] the
+        logical (KH, KW, Cin, Cout)."""
+        v = v.detach().float()
+        if v.dim() == 4:                                                # conv2d [Co,Ci,kh,kw]
+            Co, Ci, kh, kw = v.shape
+            w2, shp = v.permute(2, 3, 1, 0).reshape(kh * kw * Ci, Co), (kh, kw, Ci, Co)
+        elif key.startswith("voc.ups."):                                # convT1d [Ci,Co,k] -> GEMM [Ci][k*Co]
+            Ci, Co, k = v.shape
+            w2, shp = v.permute(0, 2, 1).reshape(Ci, k * Co), (1, 1, Ci, k * Co)
+        elif v.dim() == 3:                                              # conv1d [Co,Ci,k]
+            Co, Ci, k = v.shape
+            w2, shp = v.permute(2, 1, 0).reshape(k * Ci, Co), (1, k, Ci, Co)
+        else:                                                           # linear [Co,Ci]
+            Co, Ci = v.shape
+            w2, shp = v.t(), (1, 1, Ci, Co)
+        self.w[key] = self.pack_matrix(w2.contiguous()).to(self.dev)
+        self.wshape[key] = shp
+
     def _pack(self, P):
+        self.wshape = {}
         for k, v in P.items():
-            v = v.detach().float()
-            if k.endswith(".weight") and v.dim() == 4:                      # conv2d [Co,Ci,kh,kw] -> [kh][kw][Ci][Co]
-                v = v.permute(2, 3, 1, 0)
-            elif k.startswith("voc.ups.") and k.endswith(".weight"):        # convT1d [Ci,Co,k] -> [Ci][k*Co]
-                v = v.permute(0, 2, 1).reshape(v.shape[0], -1)
-            elif k.endswith(".weight") and v.dim() == 3:                    # conv1d [Co,Ci,k] -> [k][Ci][Co]
-                v = v.permute(2, 1, 0)
-            elif k.endswith(".weight") and v.dim() == 2:                    # linear [Co,Ci] -> [Ci][Co]
-                v = v.t()
-            self.w[k] = v.contiguous().to(self.dev)
+            if k.endswith(".weight") and v.dim() >= 2:
+                self.add_weight(k, v)
+            else:
+                self.w[k] = v.detach().float().contiguous().to(self.dev)
 
     # ------------------------------------------------------------------ op wrappers
     def _st(self):
@@ -106,26 +130,25 @@ class FlashSREngine:
 
     def conv3(self, x, key, stride=1, up2=0, act=ACT_NONE, res=None, pad=1, bias_t=None):
         B, H, W, Cin = x.shape
-        Cout = self.w[key + ".weight"].shape[3]
+        Cout = self.wshape[key + ".weight"][3]
         LH, LW = (2 * H, 2 * W) if up2 else (H, W)
         OH, OW = (LH // stride, LW // stride)
         return self.conv(x, key, B, H, W, Cin, OH, OW, Cout, 3, 3, stride, 1, pad, pad, up2, act, res=res, bias_t=bias_t)
 
     def conv1x1(self, x, key, res=None, act=ACT_NONE):
         B, H, W, Cin = x.shape
-        Cout = self.w[key + ".weight"].shape[3]
+        Cout = self.wshape[key + ".weight"][3]
         return self.conv(x, key, B, H, W, Cin, H, W, Cout, 1, 1, res=res, act=act)
 
     def linear(self, x2, key, res=None, act=ACT_NONE, bias=True):
         rows, Cin = x2.shape
-        wt = self.w[key + ".weight"]
-        Cout = wt.shape[1]
+        Cout = self.wshape[key + ".weight"][3]
         y = self.conv(x2, key, rows, 1, 1, Cin, 1, 1, Cout, 1, 1, res=res, act=act, bias=bias)
         return y.view(rows, Cout)
 
     def conv1d(self, x, key, k, stride=1, dil=1, pad=0, act=ACT_NONE, res=None):
         B, L, Cin = x.shape
-        Cout = self.w[key + ".weight"].shape[2]
+        Cout = self.wshape[key + ".weight"][3]
         OL = (L + 2 * pad - dil * (k - 1) - 1) // stride + 1
         y = self.conv(x, key, B, 1, L, Cin, 1, OL, Cout, 1, k, stride, dil, 0, pad, 0, act, res=res)
         return y.view(B, OL, Cout)
@@ -336,7 +359,7 @@ class FlashSREngine:
             kt = arch.up_kernel(r)
             Bc, Lin, Ci = h.shape
             wt = self.w[f"voc.ups.{j}.weight"]
-            Co = wt.shape[1] // kt
+            Co = self.wshape[f"voc.ups.{j}.weight"][3] // kt
             Y = self.conv(h, None, Bc * Lin, 1, 1, Ci, 1, 1, kt * Co, 1, 1, bias=False, w=wt)
             out = torch.empty((Bc, Lin * r, Co), dtype=torch.float32, device=self.dev)
             add = feats[n - 2 - j] if j <= n - 2 else None

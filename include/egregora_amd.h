@@ -124,7 +124,8 @@ int egr_chunk_gather(const float* x, int channels, int64_t total, int64_t win, i
 #define EGR_ACT_LOGCLAMP 4 /* log(max(v, act_param)) */
 
 /* Implicit-GEMM convolution on the matrix cores (v_mfma_f32_32x32x2_f32).
- *   x [B][H][W][Cin], w [KH][KW][Cin][Cout], y [B][OH][OW][Cout];
+ *   x [B][H][W][Cin], y [B][OH][OW][Cout]; w is PRE-PACKED as [ceil(K/16)][Cout][16] with K = KH*KW*Cin ordered
+ *   (ky, kx, ci) and zero padded (flashsr_engine.FlashSREngine.pack_matrix);
  *   input coordinate = o*stride + k*(dil for W, 1 for H) - pad; out-of-range reads are zero;
  *   up2 != 0: the logical input is the nearest-neighbour 2x upsampling of x (read at coord>>1);
  *   epilogue: + bias[Cout] + bias_b[B][Cout] + res[B][OH][OW][Cout] (each optional), then activation.

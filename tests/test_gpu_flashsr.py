@@ -76,7 +76,7 @@ def test_conv_nhwc_vs_torch(eng, B, H, W, Ci, Co, k, s, pad, up):
     res = torch.randn(want.shape, generator=g)
     want = F.silu(want + res)
     OH, OW = want.shape[2], want.shape[3]
-    e.w["t.weight"] = w.permute(2, 3, 1, 0).contiguous().cuda()
+    e.add_weight("t.weight", w)
     e.w["t.bias"] = b.cuda()
     got = e.conv(nhwc(x).cuda(), "t", B, H, W, Ci, OH, OW, Co, k, k, s, 1, pad, pad, up, 1, res=nhwc(res).cuda())
     close(nchw(got), want)
@@ -92,7 +92,7 @@ def test_conv1d_vs_torch(eng, k, dil, stride):
     b = torch.randn(Co, generator=g)
     pad = dil * (k - 1) // 2 if stride == 1 else (k - 1) // 2
     want = F.conv1d(x, w, b, stride=stride, dilation=dil, padding=pad)
-    e.w["t1.weight"] = w.permute(2, 1, 0).contiguous().cuda()
+    e.add_weight("t1.weight", w)
     e.w["t1.bias"] = b.cuda()
     got = e.conv1d(x.permute(0, 2, 1).contiguous().cuda(), "t1", k, stride=stride, dil=dil, pad=pad)
     close(got.permute(0, 2, 1), want)
@@ -161,7 +161,7 @@ def test_snake_aa_and_convtranspose_vs_torch(eng):
         b = torch.randn(Co, generator=g)
         add = torch.randn(B, Co, Lin * r, generator=g)
         want = F.conv_transpose1d(x, w, b, stride=r, padding=(kt - r) // 2) + add
-        wt = w.permute(0, 2, 1).reshape(Ci, kt * Co).contiguous().cuda()
+        wt = e.pack_matrix(w.permute(0, 2, 1).reshape(Ci, kt * Co).contiguous()).cuda()
         Y = e.conv(x.permute(0, 2, 1).contiguous().cuda(), None, B * Lin, 1, 1, Ci, 1, 1, kt * Co, 1, 1, bias=False, w=wt)
         out = torch.empty(B, Lin * r, Co, device="cuda")
         p = lambda t: C.c_void_p(t.data_ptr())
