@@ -64,6 +64,27 @@ __global__ __launch_bounds__(256) void k_wola(const float* __restrict__ preds, i
     }
 }
 
+// Rational-rate polyphase FIR, same definition and float32 accumulation order as scipy.signal.resample_poly
+// (upfirdn with zero extension): y[m] = sum_k h[m*down - k*up + half] * x[k], k ascending, unfused mul/add.
+__global__ __launch_bounds__(256) void k_resample_poly(const float* __restrict__ x, long long n_in, long long n_out,
+                                                        int up, int down, const float* __restrict__ h, int half,
+                                                        float* __restrict__ y) {
+    const int c = blockIdx.y;
+    const float* xc = x + (size_t)c * n_in;
+    float* yc = y + (size_t)c * n_out;
+    const long long hl = 2LL * half;
+    for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < n_out;
+         m += (long long)gridDim.x * blockDim.x) {
+        const long long t = m * down + half;
+        long long k_hi = t / up;
+        if (k_hi > n_in - 1) k_hi = n_in - 1;
+        long long k_lo = t - hl <= 0 ? 0 : (t - hl + up - 1) / up;
+        float acc = 0.f;
+        for (long long k = k_lo; k <= k_hi; ++k) acc = __fadd_rn(acc, __fmul_rn(xc[k], h[t - k * up]));
+        yc[m] = acc;
+    }
+}
+
 // One workgroup per frame: mono downmix, window, half-length complex FFT in LDS, real split, |X|.
 __global__ __launch_bounds__(256) void k_stft_mag(const float* __restrict__ x, int C, long long n, int n_fft, int hop,
                                                    const float* __restrict__ window, FftDesc fd,
@@ -192,6 +213,17 @@ extern "C" int egr_wola_stitch(const float* preds, int n_chunks, int channels, i
               EGR_ERR_ARG, "bad argument");
     hipLaunchKernelGGL(k_wola, dim3(grid_for(total), channels), dim3(256), 0, (hipStream_t)stream, preds, n_chunks,
                        channels, (long long)lp, (long long)total, (long long)win, (long long)hop, window, out);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_resample_poly(const float* x, int channels, int64_t n_in, int up, int down, const float* h, int half,
+                                 float* y, int64_t n_out, void* stream) {
+    EGR_CHECK(x && h && y && channels >= 1 && channels <= 65535 && n_in >= 1 && up >= 1 && down >= 1 && half >= 0,
+              EGR_ERR_ARG, "bad argument");
+    EGR_CHECK(n_out == (n_in * up + down - 1) / down, EGR_ERR_ARG, "n_out must be ceil(n_in*up/down)");
+    hipLaunchKernelGGL(k_resample_poly, dim3(grid_for(n_out), channels), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)n_in, (long long)n_out, up, down, h, half, y);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }

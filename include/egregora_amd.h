@@ -112,6 +112,14 @@ int egr_wola_stitch(const float* preds, int n_chunks, int channels, int64_t lp, 
 int egr_chunk_gather(const float* x, int channels, int64_t total, int64_t win, int64_t hop, int chunk_begin,
                      int n_chunks, float* chunks, void* stream);
 
+/* Rational-rate polyphase FIR resampler with the definition and float32 accumulation order of
+ * scipy.signal.resample_poly(x, up, down) (zero extension): y[m] = sum_k h[m*down - k*up + half] x[k].
+ *   x [channels][n_in], y [channels][n_out], n_out = ceil(n_in*up/down); h: device float[2*half+1], already
+ *   multiplied by `up` (the host designs it: firwin(2*half+1, 1/max(up,down), kaiser 5.0), half = 10*max(up,down)).
+ * Replaces the scipy branch of _resample_hq at egregora_audio_super_resolution.py:178-187. */
+int egr_resample_poly(const float* x, int channels, int64_t n_in, int up, int down, const float* h, int half, float* y,
+                      int64_t n_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * FlashSR network operators (channels-last activations, exact fp32).  Together they stand in for the
  * upstream call `self._model(x, lowpass_input=...)` at egregora_audio_super_resolution.py:366-369; the

@@ -127,3 +127,18 @@ def test_wav_reader_roundtrip(pack, tmp_path):
     np.testing.assert_array_equal(y, pcm.astype(np.float32) / 32768.0)
     with pytest.raises(RuntimeError):
         wavio.read_wav_bytes(b"fLaC" + b"\0" * 40)
+
+
+def test_resampler_filter_design_equals_scipy(pack):
+    """The host-side FIR design is scipy.signal.firwin's (which the reference reaches through resample_poly)."""
+    from scipy.signal import firwin
+    from egregora_amd import resample
+    for up, down in [(160, 147), (2, 1), (147, 160), (3, 1), (1, 2)]:
+        h, half = resample.design_filter(up, down)
+        mx = max(up, down)
+        want = firwin(2 * 10 * mx + 1, 1.0 / mx, window=("kaiser", 5.0)).astype(np.float32)
+        want *= np.float32(up)
+        assert half == 10 * mx and h.dtype == np.float32
+        assert np.max(np.abs(h - want)) <= 1e-7 * np.max(np.abs(want))
+        assert np.mean(h == want) > 0.99
+    assert resample.rates(44100, 48000) == (160, 147) and resample.rates(48000, 96000) == (2, 1)
