@@ -24,26 +24,36 @@
 
 namespace egr {
 
-struct FlParams {
-    FftDesc f1, f2;
-    int M1, M2;
-    long long M, N;
+// Twiddle W_T^r for r < T as a product of two table entries: thi[r >> sh] * tlo[r & (2^sh - 1)]
+// (tables of ~sqrt(T) entries each, generated in long double and rounded once).
+struct Tw2 {
+    const cplx* hi;
+    const cplx* lo;
+    int sh;
+};
+__device__ __forceinline__ cplx tw2(const Tw2& t, unsigned r) {
+    return cmul(t.hi[r >> t.sh], t.lo[r & ((1u << t.sh) - 1u)]);
+}
+
+// One strided ("column") pass: `nplanes` matrices [L][ncols] (row-major), transform along L for a tile of TC
+// adjacent columns, twiddle W_(L*ncols)^(col*k).
+struct ColP {
+    FftDesc f;
+    int L, ncols, nplanes;
     int TC, TClog2, ntiles, tiles_per_xcd;
-    const cplx* tw1;   // W_M1^q   (stage table of f1; also the high part of the four-step twiddle)
-    const cplx* tw2;   // W_M2^j   (stage table of f2)
-    const cplx* T2;    // W_M^s,  s < M2   (low part of the four-step twiddle)
-    const cplx* T3;    // W_N^k1, k1 < M1  (real-split twiddle, low part)
-    const cplx* T4;    // W_N^(M1*k2), k2 < M2
-    unsigned long long magic_m2;   // ceil(2^44 / M2): r / M2 for r < 2^23
-    float thr, thr2, inv_M;
+    const cplx* tw;        // W_L stage table
+    Tw2 big;               // W_(L*ncols)^r
 };
 
-__device__ __forceinline__ cplx four_step_tw(const FlParams& p, int n2, int k1) {
-    const unsigned r = (unsigned)n2 * (unsigned)k1;            // < M <= 2^22
-    const unsigned q = (unsigned)(((unsigned long long)r * p.magic_m2) >> 44);
-    const unsigned s = r - q * (unsigned)p.M2;
-    return cmul(p.tw1[q], p.T2[s]);
-}
+// The contiguous ("row") pass: R rows of length L; row rho(o) holds Z[o + R*k], o = ka + Ma*kb, rho = ka*Mb + kb.
+struct RowP {
+    FftDesc f;
+    int L, R, Ma, Mb;
+    const cplx* tw;        // W_L stage table
+    Tw2 wo;                // W_N^o, o < R
+    const cplx* wk;        // W_(2L)^k = W_N^(R*k), k < L
+    float thr2, inv_M;
+};
 
 __device__ __forceinline__ void atomic_max_abs(unsigned* slot, float v) {
     // non-negative IEEE floats order like unsigned ints
@@ -62,50 +72,55 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return r;
 }
 
-// MODE 0: first  (y -> time threshold -> FFT_M1 -> twiddle -> A)
-// MODE 1: middle (B -> twiddle^-1 -> IFFT_M1 -> FFT_M1 -> twiddle -> A)
-// MODE 2: last   (B -> twiddle^-1 -> IFFT_M1 -> out = y + d, per-channel max|out|)
+// MODE 0: first   (y -> time threshold -> FFT -> twiddle -> state)          [outermost pass only]
+// MODE 1: middle  (state -> twiddle^-1 -> IFFT -> FFT -> twiddle -> state)  [outermost pass only]
+// MODE 2: last    (state -> twiddle^-1 -> IFFT -> out = y + d, peak)        [outermost pass only]
+// MODE 3: inverse (state -> twiddle^-1 -> IFFT -> state)                    [inner pass of a 3-level plan]
+// MODE 4: forward (state -> FFT -> twiddle -> state)                        [inner pass of a 3-level plan]
 template <int MODE>
-__global__ __launch_bounds__(256) void k_col(FlParams p, cplx* __restrict__ work, float* __restrict__ out,
-                                              unsigned* __restrict__ peak_out) {
+__global__ __launch_bounds__(256) void k_col(ColP p, long long M, long long N, float thr, cplx* __restrict__ work,
+                                              float* __restrict__ out, unsigned* __restrict__ peak_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float red[8];
     // XCD-aware tile order: the dispatcher places block b on XCD b%8; give every XCD a contiguous run
     // of column tiles so the two tiles sharing a 128-byte line hit the same L2.
     const int tile = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
     if (tile >= p.ntiles) return;
-    const int ch = blockIdx.y;
-    const int TC = p.TC, lg = p.TClog2, M1 = p.M1, M2 = p.M2;
+    const int ch = blockIdx.y / p.nplanes, plane = blockIdx.y - ch * p.nplanes;
+    const int TC = p.TC, lg = p.TClog2, L = p.L, nc = p.ncols;
     const int c0 = tile * TC;
     cplx* cur = (cplx*)smem;
-    cplx* alt = cur + (size_t)M1 * TC;
-    cplx* W = work + (size_t)ch * p.M;
-    float2* Y = (float2*)(out + (size_t)ch * p.N);
-    const int nel = M1 * TC;
+    cplx* alt = cur + (size_t)L * TC;
+    const size_t poff = (size_t)plane * L * nc;
+    cplx* W = work + (size_t)ch * M + poff;
+    float2* Y = (float2*)(out + (size_t)ch * N) + poff;
+    const int nel = L * TC;
 
     for (int e = threadIdx.x; e < nel; e += blockDim.x) {
         const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
         cplx v = make_float2(0.f, 0.f);
-        if (col < M2) {
-            const size_t g = (size_t)i * M2 + col;
+        if (col < nc) {
+            const size_t g = (size_t)i * nc + col;
             if (MODE == 0) {
                 const float2 y = Y[g];
-                v.x = fabsf(y.x) > p.thr ? y.x : 0.f;
-                v.y = fabsf(y.y) > p.thr ? y.y : 0.f;
+                v.x = fabsf(y.x) > thr ? y.x : 0.f;
+                v.y = fabsf(y.y) > thr ? y.y : 0.f;
+            } else if (MODE == 4) {
+                v = W[g];
             } else {
-                v = cmulc(W[g], four_step_tw(p, col, i));
+                v = cmulc(W[g], tw2(p.big, (unsigned)col * (unsigned)i));
             }
         }
         cur[e] = v;
     }
     __syncthreads();
-    if (MODE != 0) lds_fft<true>(cur, alt, p.f1, p.tw1, TC, lg, TC, 1, true);
+    if (MODE == 1 || MODE == 2 || MODE == 3) lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, true);
     if (MODE == 2) {
         float mx = 0.f;
         for (int e = threadIdx.x; e < nel; e += blockDim.x) {
             const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
-            if (col < M2) {
-                const size_t g = (size_t)i * M2 + col;
+            if (col < nc) {
+                const size_t g = (size_t)i * nc + col;
                 const float2 y = Y[g];
                 const cplx d = cur[e];
                 const float2 o = make_float2(__fadd_rn(y.x, d.x), __fadd_rn(y.y, d.y));
@@ -117,50 +132,59 @@ __global__ __launch_bounds__(256) void k_col(FlParams p, cplx* __restrict__ work
         if (threadIdx.x == 0) atomic_max_abs(peak_out + ch, mx);
         return;
     }
-    lds_fft<true>(cur, alt, p.f1, p.tw1, TC, lg, TC, 1, false);
+    if (MODE == 3) {
+        for (int e = threadIdx.x; e < nel; e += blockDim.x) {
+            const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
+            if (col < nc) W[(size_t)i * nc + col] = cur[e];
+        }
+        return;
+    }
+    lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, false);
     for (int e = threadIdx.x; e < nel; e += blockDim.x) {
         const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
-        if (col < M2) W[(size_t)i * M2 + col] = cmul(cur[e], four_step_tw(p, col, i));
+        if (col < nc) W[(size_t)i * nc + col] = cmul(cur[e], tw2(p.big, (unsigned)col * (unsigned)i));
     }
 }
 
-// Row-pair kernel: rows ka = pair, kb = M1 - pair of the in-place state.
-__global__ __launch_bounds__(256) void k_row(FlParams p, cplx* __restrict__ work) {
+// Row-pair kernel: outer indices oa = pair, ob = R - pair of the in-place state.
+__global__ __launch_bounds__(256) void k_row(RowP p, long long M, cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int M1 = p.M1, M2 = p.M2;
-    const int ka = blockIdx.x;
-    const int kb = (M1 - ka) % M1;
-    const bool self = (ka == kb);
+    const int L = p.L, R = p.R;
+    const int oa = blockIdx.x;
+    const int ob = (R - oa) % R;
+    const bool self = (oa == ob);
     const int nrows = self ? 1 : 2;
     const int ch = blockIdx.y;
     cplx* cur = (cplx*)smem;
-    cplx* alt = cur + 2 * (size_t)M2;
-    cplx* W = work + (size_t)ch * p.M;
-    cplx* ga = W + (size_t)ka * M2;
-    cplx* gb = W + (size_t)kb * M2;
+    cplx* alt = cur + 2 * (size_t)L;
+    cplx* W = work + (size_t)ch * M;
+    const int ra = (oa % p.Ma) * p.Mb + oa / p.Ma;
+    const int rbw = (ob % p.Ma) * p.Mb + ob / p.Ma;
+    cplx* ga = W + (size_t)ra * L;
+    cplx* gb = W + (size_t)rbw * L;
 
-    for (int e = threadIdx.x; e < M2; e += blockDim.x) {
+    for (int e = threadIdx.x; e < L; e += blockDim.x) {
         cur[e] = ga[e];
-        if (!self) cur[M2 + e] = gb[e];
+        if (!self) cur[L + e] = gb[e];
     }
     __syncthreads();
-    lds_fft<false>(cur, alt, p.f2, p.tw2, nrows, 0, 1, M2, false);
+    lds_fft<false>(cur, alt, p.f, p.tw, nrows, 0, 1, L, false);
 
-    // real-split, threshold, un-split on the (k, M-k) pairs; Z[k1 + M1*k2] sits at row(k1)[k2]
-    const cplx wa = p.T3[ka];
-    int cnt, boff;          // partner of row-a element k2 is row-b element (boff - k2) mod M2
+    // real-split, threshold, un-split on the (k, M-k) pairs; Z[o + R*k] sits at row(o)[k]
+    const cplx wa = tw2(p.wo, (unsigned)oa);
+    int cnt, boff;          // partner of row-a element k is row-b element (boff - k) mod L
     cplx* rb;
-    if (!self) { cnt = M2; boff = M2 - 1; rb = cur + M2; }
-    else if (ka == 0) { cnt = M2 / 2 + 1; boff = M2; rb = cur; }
-    else { cnt = (M2 + 1) / 2; boff = M2 - 1; rb = cur; }
+    if (!self) { cnt = L; boff = L - 1; rb = cur + L; }
+    else if (oa == 0) { cnt = L / 2 + 1; boff = L; rb = cur; }
+    else { cnt = (L + 1) / 2; boff = L - 1; rb = cur; }
     const float thr2 = p.thr2, sc = p.inv_M;
     for (int k2 = threadIdx.x; k2 < cnt; k2 += blockDim.x) {
         int pb = boff - k2;
-        if (pb >= M2) pb -= M2;
+        if (pb >= L) pb -= L;
         const bool same = self && (pb == k2);
         const cplx Za = cur[k2];
         const cplx Zb = rb[pb];
-        const cplx Wk = cmul(wa, p.T4[k2]);
+        const cplx Wk = cmul(wa, p.wk[k2]);
         // E = (Za + conj Zb)/2 ; O = (Za - conj Zb)/(2i)
         const cplx E = make_float2(0.5f * (Za.x + Zb.x), 0.5f * (Za.y - Zb.y));
         const cplx O = make_float2(0.5f * (Za.y + Zb.y), -0.5f * (Za.x - Zb.x));
@@ -177,10 +201,10 @@ __global__ __launch_bounds__(256) void k_row(FlParams p, cplx* __restrict__ work
         if (!same) rb[pb] = make_float2(sc * (E2.x + O2.y), -sc * (E2.y - O2.x));
     }
     __syncthreads();
-    lds_fft<false>(cur, alt, p.f2, p.tw2, nrows, 0, 1, M2, true);
-    for (int e = threadIdx.x; e < M2; e += blockDim.x) {
+    lds_fft<false>(cur, alt, p.f, p.tw, nrows, 0, 1, L, true);
+    for (int e = threadIdx.x; e < L; e += blockDim.x) {
         ga[e] = cur[e];
-        if (!self) gb[e] = cur[M2 + e];
+        if (!self) gb[e] = cur[L + e];
     }
 }
 
@@ -283,19 +307,52 @@ struct egr_fatllama_plan {
     int64_t n_in;
     int C, factor, device;
     FlSplit sp;
-    FlParams prm;
-    cplx *d_tw1, *d_tw2, *d_T2, *d_T3, *d_T4, *d_work;
+    ColP colA, colB;
+    RowP row;
+    std::vector<void*> dev_allocs;
+    cplx* d_work;
     unsigned* d_peaks;   // [2*C]: peak_in[C], peak_out[C]
     bool profiling;
     std::vector<hipEvent_t> ev;   // pairs (start, stop) tagged by kind
-    std::vector<int> ev_kind;     // 0 = row, 1 = col
+    std::vector<int> ev_kind;     // 0 = row, 1 = outer column pass, 2 = inner column pass
 };
 
-static int upload(const std::vector<float2>& h, cplx** d) {
-    EGR_HIP(hipMalloc((void**)d, h.size() * sizeof(float2)));
-    EGR_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice));
+static int upload(egr_fatllama_plan* p, const std::vector<float2>& h, const cplx** d) {
+    void* ptr = nullptr;
+    EGR_HIP(hipMalloc(&ptr, h.size() * sizeof(float2)));
+    p->dev_allocs.push_back(ptr);
+    EGR_HIP(hipMemcpy(ptr, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice));
+    *d = (const cplx*)ptr;
     return EGR_OK;
 }
+
+// tables for W_T^r, r < T
+static int make_tw2(egr_fatllama_plan* p, int64_t T, Tw2* out) {
+    int sh = 0;
+    while ((1LL << (2 * sh)) < T) ++sh;          // 2^sh >= sqrt(T)
+    std::vector<float2> h;
+    int rc;
+    make_twiddles(h, (T >> sh) + 1, 1LL << sh, T);
+    if ((rc = upload(p, h, &out->hi))) return rc;
+    make_twiddles(h, 1LL << sh, 1, T);
+    if ((rc = upload(p, h, &out->lo))) return rc;
+    out->sh = sh;
+    return EGR_OK;
+}
+
+static void fill_info(const FlSplit& sp, int64_t info[EGR_FL_INFO_LEN]) {
+    info[0] = 1;
+    info[3] = sp.M1; info[4] = sp.M2; info[5] = sp.TC; info[6] = sp.f1.nst; info[7] = sp.f2.nst;
+    for (int i = 0; i < EGR_MAX_STAGES; ++i) { info[8 + i] = sp.f1.radix[i]; info[22 + i] = sp.f2.radix[i]; }
+    info[36] = (int64_t)sp.lds_col;
+    info[37] = (int64_t)sp.lds_row;
+    info[38] = sp.M3;
+    info[39] = sp.levels;
+}
+
+static const char* kUnsupported =
+    "length %lld unsupported: needs even N whose half factors into 2 or 3 lengths (columns <= 1024, row <= 4096) with "
+    "prime factors <= 13";
 
 extern "C" int egr_fatllama_plan_query(int64_t n_in, int factor, int m1_hint, int64_t info[EGR_FL_INFO_LEN]) {
     EGR_CHECK(info != nullptr, EGR_ERR_ARG, "info is null");
@@ -306,23 +363,86 @@ extern "C" int egr_fatllama_plan_query(int64_t n_in, int factor, int m1_hint, in
     info[1] = N;
     info[2] = N / 2;
     if (!sp.ok) {
-        set_error("length %lld unsupported: needs even N with N/2 = M1*M2, M1<=1024, M2<=4096, primes<=13", (long long)N);
+        set_error(kUnsupported, (long long)N);
         return EGR_ERR_UNSUPPORTED;
     }
-    info[0] = 1;
-    info[3] = sp.M1; info[4] = sp.M2; info[5] = sp.TC; info[6] = sp.f1.nst; info[7] = sp.f2.nst;
-    for (int i = 0; i < EGR_MAX_STAGES; ++i) { info[8 + i] = sp.f1.radix[i]; info[22 + i] = sp.f2.radix[i]; }
-    info[36] = (int64_t)sp.lds_col;
-    info[37] = (int64_t)sp.lds_row;
+    fill_info(sp, info);
     return EGR_OK;
 }
 
 extern "C" int egr_fatllama_plan_destroy(egr_fatllama_plan* p) {
     if (!p) return EGR_OK;
-    hipFree(p->d_tw1); hipFree(p->d_tw2); hipFree(p->d_T2); hipFree(p->d_T3); hipFree(p->d_T4);
+    for (void* q : p->dev_allocs) hipFree(q);
     hipFree(p->d_work); hipFree(p->d_peaks);
     for (auto e : p->ev) hipEventDestroy(e);
     delete p;
+    return EGR_OK;
+}
+
+static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int factor, const FlSplit& sp) {
+    egr_fatllama_plan* p = new egr_fatllama_plan();
+    p->n_in = n_in; p->C = channels; p->factor = factor; p->sp = sp; p->profiling = false;
+    p->d_work = nullptr;
+    p->d_peaks = nullptr;
+    hipGetDevice(&p->device);
+    const int64_t M = sp.M, N = sp.N;
+    int rc = EGR_OK;
+    std::vector<float2> h;
+    auto fail = [&](int code) { egr_fatllama_plan_destroy(p); return code; };
+    memset(&p->colA, 0, sizeof(ColP)); memset(&p->colB, 0, sizeof(ColP)); memset(&p->row, 0, sizeof(RowP));
+    // ---- outer column pass A: L = M1, columns = M / M1 ----
+    ColP& a = p->colA;
+    a.f = sp.f1; a.L = sp.M1; a.ncols = (int)(M / sp.M1); a.nplanes = 1;
+    a.TC = sp.TC; a.TClog2 = sp.TClog2; a.ntiles = ceil_div(a.ncols, a.TC); a.tiles_per_xcd = ceil_div(a.ntiles, 8);
+    make_twiddles(h, sp.M1, 1, sp.M1);
+    if ((rc = upload(p, h, &a.tw))) return fail(rc);
+    if ((rc = make_tw2(p, M, &a.big))) return fail(rc);
+    // ---- inner column pass B (3 levels): per k1 plane, L = M2, columns = M3 ----
+    RowP& r = p->row;
+    if (sp.levels == 3) {
+        ColP& b = p->colB;
+        b.f = sp.f2; b.L = sp.M2; b.ncols = sp.M3; b.nplanes = sp.M1;
+        b.TC = sp.TCb; b.TClog2 = sp.TCblog2; b.ntiles = ceil_div(b.ncols, b.TC); b.tiles_per_xcd = ceil_div(b.ntiles, 8);
+        make_twiddles(h, sp.M2, 1, sp.M2);
+        if ((rc = upload(p, h, &b.tw))) return fail(rc);
+        if ((rc = make_tw2(p, (int64_t)sp.M2 * sp.M3, &b.big))) return fail(rc);
+        r.f = sp.f3; r.L = sp.M3; r.R = sp.M1 * sp.M2; r.Ma = sp.M1; r.Mb = sp.M2;
+    } else {
+        r.f = sp.f2; r.L = sp.M2; r.R = sp.M1; r.Ma = sp.M1; r.Mb = 1;
+    }
+    make_twiddles(h, r.L, 1, r.L);
+    if ((rc = upload(p, h, &r.tw))) return fail(rc);
+    make_twiddles(h, r.L, 1, 2 * (int64_t)r.L);
+    if ((rc = upload(p, h, &r.wk))) return fail(rc);
+    {   // W_N^o for o < R, as hi/lo tables over the range [0, R)
+        int sh = 0;
+        while ((1LL << (2 * sh)) < r.R) ++sh;
+        make_twiddles(h, ((int64_t)r.R >> sh) + 1, 1LL << sh, N);
+        if ((rc = upload(p, h, &r.wo.hi))) return fail(rc);
+        make_twiddles(h, 1LL << sh, 1, N);
+        if ((rc = upload(p, h, &r.wo.lo))) return fail(rc);
+        r.wo.sh = sh;
+    }
+    r.inv_M = (float)(1.0 / (double)M);
+    if (hipMalloc((void**)&p->d_work, (size_t)channels * M * sizeof(float2)) != hipSuccess ||
+        hipMalloc((void**)&p->d_peaks, 2 * channels * sizeof(unsigned)) != hipSuccess) {
+        set_error("hipMalloc of the %lld-byte loop state failed", (long long)(channels * M * 8));
+        return fail(EGR_ERR_ALLOC);
+    }
+    // dynamic LDS above the 64 KiB default needs an explicit opt-in per kernel
+    const int lc = (int)(sp.lds_col > sp.lds_colb ? sp.lds_col : sp.lds_colb);
+    hipError_t e = hipSuccess;
+    e = hipFuncSetAttribute((const void*)k_col<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_row, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) -> %s", hipGetErrorString(e));
+        return fail(EGR_ERR_HIP);
+    }
+    *out = p;
     return EGR_OK;
 }
 
@@ -335,50 +455,24 @@ extern "C" int egr_fatllama_plan_create(egr_fatllama_plan** out, int64_t n_in, i
     const int64_t N = n_in * factor;
     FlSplit sp = plan_split(N, m1_hint, tc_hint);
     if (!sp.ok) {
-        set_error("length %lld unsupported: needs even N with N/2 = M1*M2, M1<=1024, M2<=4096, primes<=13", (long long)N);
+        set_error(kUnsupported, (long long)N);
         return EGR_ERR_UNSUPPORTED;
     }
-    egr_fatllama_plan* p = new egr_fatllama_plan();
-    p->n_in = n_in; p->C = channels; p->factor = factor; p->sp = sp; p->profiling = false;
-    p->d_tw1 = p->d_tw2 = p->d_T2 = p->d_T3 = p->d_T4 = p->d_work = nullptr;
-    p->d_peaks = nullptr;
-    hipGetDevice(&p->device);
-    std::vector<float2> h;
-    int rc = EGR_OK;
-    const int64_t M = sp.M;
-    make_twiddles(h, sp.M1, 1, sp.M1); if ((rc = upload(h, &p->d_tw1))) { egr_fatllama_plan_destroy(p); return rc; }
-    make_twiddles(h, sp.M2, 1, sp.M2); if ((rc = upload(h, &p->d_tw2))) { egr_fatllama_plan_destroy(p); return rc; }
-    make_twiddles(h, sp.M2, 1, M);     if ((rc = upload(h, &p->d_T2))) { egr_fatllama_plan_destroy(p); return rc; }
-    make_twiddles(h, sp.M1, 1, N);     if ((rc = upload(h, &p->d_T3))) { egr_fatllama_plan_destroy(p); return rc; }
-    make_twiddles(h, sp.M2, 1, 2 * (int64_t)sp.M2); if ((rc = upload(h, &p->d_T4))) { egr_fatllama_plan_destroy(p); return rc; }
-    if (hipMalloc((void**)&p->d_work, (size_t)channels * M * sizeof(float2)) != hipSuccess ||
-        hipMalloc((void**)&p->d_peaks, 2 * channels * sizeof(unsigned)) != hipSuccess) {
-        set_error("hipMalloc of the %lld-byte loop state failed", (long long)(channels * M * 8));
-        egr_fatllama_plan_destroy(p);
-        return EGR_ERR_ALLOC;
+    return build_plan(out, n_in, channels, factor, sp);
+}
+
+extern "C" int egr_fatllama_plan_create_ex(egr_fatllama_plan** out, int64_t n_in, int channels, int factor, int m1,
+                                           int m2, int m3, int tc_hint) {
+    EGR_CHECK(out != nullptr, EGR_ERR_ARG, "out is null");
+    *out = nullptr;
+    EGR_CHECK(n_in >= 1 && factor >= 1 && channels >= 1 && channels <= 64, EGR_ERR_ARG,
+              "n_in=%lld channels=%d factor=%d out of range", (long long)n_in, channels, factor);
+    FlSplit sp = plan_split_explicit(n_in * factor, m1, m2, m3, tc_hint);
+    if (!sp.ok) {
+        set_error("explicit split %d x %d x %d does not fit N=%lld", m1, m2, m3, (long long)(n_in * factor));
+        return EGR_ERR_UNSUPPORTED;
     }
-    FlParams& q = p->prm;
-    memset(&q, 0, sizeof(q));
-    q.f1 = sp.f1; q.f2 = sp.f2; q.M1 = sp.M1; q.M2 = sp.M2; q.M = M; q.N = N;
-    q.TC = sp.TC; q.TClog2 = sp.TClog2;
-    q.ntiles = ceil_div(sp.M2, sp.TC);
-    q.tiles_per_xcd = ceil_div(q.ntiles, 8);
-    q.tw1 = p->d_tw1; q.tw2 = p->d_tw2; q.T2 = p->d_T2; q.T3 = p->d_T3; q.T4 = p->d_T4;
-    q.magic_m2 = ((1ULL << 44) + (unsigned long long)sp.M2 - 1) / (unsigned long long)sp.M2;
-    q.inv_M = (float)(1.0 / (double)M);
-    // dynamic LDS above the 64 KiB default needs an explicit opt-in per kernel
-    hipError_t e = hipSuccess;
-    e = hipFuncSetAttribute((const void*)k_col<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_col);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_col);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_col);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_row, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
-    if (e != hipSuccess) {
-        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) -> %s", hipGetErrorString(e));
-        egr_fatllama_plan_destroy(p);
-        return EGR_ERR_HIP;
-    }
-    *out = p;
-    return EGR_OK;
+    return build_plan(out, n_in, channels, factor, sp);
 }
 
 extern "C" int egr_fatllama_set_profiling(egr_fatllama_plan* p, int enable) {
@@ -410,10 +504,12 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
     EGR_CHECK(p && x && out, EGR_ERR_ARG, "null plan/x/out");
     EGR_CHECK(max_iter >= 0, EGR_ERR_ARG, "max_iter=%d < 0", max_iter);
     hipStream_t st = (hipStream_t)stream;
-    FlParams q = p->prm;
-    q.thr = thr;
-    q.thr2 = thr * thr;
     const int C = p->C;
+    const long long M = p->sp.M, N = p->sp.N;
+    const bool three = p->sp.levels == 3;
+    ColP A = p->colA, B = p->colB;
+    RowP R = p->row;
+    R.thr2 = thr * thr;
     unsigned* peak_in = p->d_peaks;
     unsigned* peak_out = p->d_peaks + C;
     EGR_HIP(hipMemsetAsync(p->d_peaks, 0, 2 * C * sizeof(unsigned), st));
@@ -422,29 +518,41 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         hipLaunchKernelGGL(k_prepare, dim3(nb, C), dim3(256), 0, st, x, out, (long long)p->n_in, p->factor,
                            (flags & EGR_FL_PCM_IN) ? 1 : 0, peak_in);
     }
-    const dim3 gcol(8 * q.tiles_per_xcd, C), grow(q.M1 / 2 + 1, C), blk(256);
-    const size_t lc = p->sp.lds_col, lr = p->sp.lds_row;
+    const dim3 gA(8 * A.tiles_per_xcd, C), gB(8 * B.tiles_per_xcd, C * (three ? B.nplanes : 1)), grow(R.R / 2 + 1, C),
+        blk(256);
+    const size_t lc = p->sp.lds_col, lb = p->sp.lds_colb, lr = p->sp.lds_row;
     size_t slot = 0;
     if (max_iter == 0) {
-        const int nb = (int)((q.N + 255) / 256 < 2048 ? (q.N + 255) / 256 : 2048);
-        hipLaunchKernelGGL(k_noiter, dim3(nb, C), blk, 0, st, out, q.N, thr, peak_out);
+        const int nb = (int)((N + 255) / 256 < 2048 ? (N + 255) / 256 : 2048);
+        hipLaunchKernelGGL(k_noiter, dim3(nb, C), blk, 0, st, out, N, thr, peak_out);
     } else {
-        hipLaunchKernelGGL(k_col<0>, gcol, blk, lc, st, q, p->d_work, out, peak_out);
+        hipLaunchKernelGGL(k_col<0>, gA, blk, lc, st, A, M, N, thr, p->d_work, out, peak_out);
+        if (three) hipLaunchKernelGGL(k_col<4>, gB, blk, lb, st, B, M, N, thr, p->d_work, out, peak_out);
         for (int it = 0; it < max_iter; ++it) {
             prof_begin(p, 0, st, &slot);
-            hipLaunchKernelGGL(k_row, grow, blk, lr, st, q, p->d_work);
+            hipLaunchKernelGGL(k_row, grow, blk, lr, st, R, M, p->d_work);
             prof_end(p, st, &slot);
-            if (it + 1 < max_iter) {
-                prof_begin(p, 1, st, &slot);
-                hipLaunchKernelGGL(k_col<1>, gcol, blk, lc, st, q, p->d_work, out, peak_out);
+            if (three) {
+                prof_begin(p, 2, st, &slot);
+                hipLaunchKernelGGL(k_col<3>, gB, blk, lb, st, B, M, N, thr, p->d_work, out, peak_out);
                 prof_end(p, st, &slot);
             }
+            if (it + 1 < max_iter) {
+                prof_begin(p, 1, st, &slot);
+                hipLaunchKernelGGL(k_col<1>, gA, blk, lc, st, A, M, N, thr, p->d_work, out, peak_out);
+                prof_end(p, st, &slot);
+                if (three) {
+                    prof_begin(p, 2, st, &slot);
+                    hipLaunchKernelGGL(k_col<4>, gB, blk, lb, st, B, M, N, thr, p->d_work, out, peak_out);
+                    prof_end(p, st, &slot);
+                }
+            }
         }
-        hipLaunchKernelGGL(k_col<2>, gcol, blk, lc, st, q, p->d_work, out, peak_out);
+        hipLaunchKernelGGL(k_col<2>, gA, blk, lc, st, A, M, N, thr, p->d_work, out, peak_out);
     }
     if (flags & (EGR_FL_NORMALIZE | EGR_FL_AUTOSCALE | EGR_FL_NODE_POST)) {
-        const int nb = (int)((q.N + 255) / 256 < 2048 ? (q.N + 255) / 256 : 2048);
-        hipLaunchKernelGGL(k_finalize, dim3(nb, C), blk, 0, st, out, q.N, C, flags, peak_in, peak_out);
+        const int nb = (int)((N + 255) / 256 < 2048 ? (N + 255) / 256 : 2048);
+        hipLaunchKernelGGL(k_finalize, dim3(nb, C), blk, 0, st, out, N, C, flags, peak_in, peak_out);
     }
     EGR_HIP(hipGetLastError());
     return EGR_OK;
@@ -465,8 +573,8 @@ extern "C" int egr_fatllama_last_peaks(egr_fatllama_plan* p, float* host_pin, fl
 extern "C" int egr_fatllama_kernel_times(egr_fatllama_plan* p, double* row_ms_avg, double* col_ms_avg,
                                          int64_t* row_launches, int64_t* col_launches) {
     EGR_CHECK(p != nullptr, EGR_ERR_ARG, "plan is null");
-    double sum[2] = {0, 0};
-    int64_t cnt[2] = {0, 0};
+    double sum[3] = {0, 0, 0};
+    int64_t cnt[3] = {0, 0, 0};
     EGR_HIP(hipDeviceSynchronize());
     for (size_t i = 0; i + 1 < p->ev.size(); i += 2) {
         float ms = 0.f;
@@ -475,9 +583,10 @@ extern "C" int egr_fatllama_kernel_times(egr_fatllama_plan* p, double* row_ms_av
         sum[k] += ms;
         cnt[k] += 1;
     }
+    // the inner column pass (3-level plans) is reported together with the outer one
     if (row_ms_avg) *row_ms_avg = cnt[0] ? sum[0] / cnt[0] : 0.0;
-    if (col_ms_avg) *col_ms_avg = cnt[1] ? sum[1] / cnt[1] : 0.0;
+    if (col_ms_avg) *col_ms_avg = (cnt[1] + cnt[2]) ? (sum[1] + sum[2]) / (cnt[1] + cnt[2]) : 0.0;
     if (row_launches) *row_launches = cnt[0];
-    if (col_launches) *col_launches = cnt[1];
+    if (col_launches) *col_launches = cnt[1] + cnt[2];
     return EGR_OK;
 }

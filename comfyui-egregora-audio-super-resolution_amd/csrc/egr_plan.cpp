@@ -76,20 +76,35 @@ static int ilog2(int v) {
     return l;
 }
 
+struct FlSplit;
+static void finish_split_impl(FlSplit& best, int tc_hint);
+static inline void finish_split(FlSplit& best, int tc_hint) { finish_split_impl(best, tc_hint); }
+
+static int pick_tc(int L, int ncols, int hint) {
+    int tc = hint > 0 ? hint : (L > 512 ? 8 : 16);
+    if (L == 1 && hint <= 0) tc = 256;               // degenerate column pass: plain streaming
+    int l2 = ilog2(tc);
+    tc = 1 << l2;
+    while (tc > 1 && tc / 2 >= ncols) tc /= 2;
+    return tc;
+}
+
 FlSplit plan_split(int64_t N, int m1_hint, int tc_hint) {
     FlSplit best;
     memset(&best, 0, sizeof(best));
     best.ok = false;
     best.N = N;
+    best.M3 = 1;
     if (N < 2 || (N & 1)) return best;
     const int64_t M = N / 2;
     best.M = M;
-    const int64_t MAX_M1 = 1024, MAX_M2 = 4096;   // LDS-capacity limits of k_col / k_row
+    const int64_t MAX_COL = 1024, MAX_ROW = 4096;   // LDS-capacity limits of k_col / k_row
     double best_score = 1e300;
-    for (int64_t m1 = 1; m1 <= MAX_M1 && m1 <= M; ++m1) {
+    // ---- two levels: M = M1 * M2 ----
+    for (int64_t m1 = 1; m1 <= MAX_COL && m1 <= M; ++m1) {
         if (M % m1) continue;
         const int64_t m2 = M / m1;
-        if (m2 > MAX_M2) continue;
+        if (m2 > MAX_ROW) continue;
         if (m1_hint > 0 && m1 != m1_hint) continue;
         FftDesc f1, f2;
         if (!make_schedule((int)m1, &f1) || !make_schedule((int)m2, &f2)) continue;
@@ -101,25 +116,77 @@ FlSplit plan_split(int64_t N, int m1_hint, int tc_hint) {
         score += 10.0 * fabs(log((double)m1 * 2.0 / (double)m2));
         if (score < best_score) {
             best_score = score;
-            best.ok = true;
-            best.M1 = (int)m1;
-            best.M2 = (int)m2;
-            best.f1 = f1;
-            best.f2 = f2;
+            best.ok = true; best.levels = 2;
+            best.M1 = (int)m1; best.M2 = (int)m2; best.M3 = 1;
+            best.f1 = f1; best.f2 = f2;
+        }
+    }
+    // ---- three levels: M = M1 * M2 * M3 (only when two do not fit) ----
+    if (!best.ok) {
+        for (int64_t m3 = 2; m3 <= MAX_ROW && m3 <= M; ++m3) {
+            if (M % m3) continue;
+            FftDesc f3;
+            if (!make_schedule((int)m3, &f3)) continue;
+            const int64_t R = M / m3;
+            for (int64_t m1 = 2; m1 <= MAX_COL && m1 <= R; ++m1) {
+                if (R % m1) continue;
+                const int64_t m2 = R / m1;
+                if (m2 > MAX_COL || m2 < 2) continue;
+                if (m1_hint > 0 && m1 != m1_hint) continue;
+                FftDesc f1, f2;
+                if (!make_schedule((int)m1, &f1) || !make_schedule((int)m2, &f2)) continue;
+                double score = 1000.0 * (f1.nst + 2 * f2.nst + f3.nst);   // pass B runs twice per iteration
+                if (m1 > 640) score += 300.0;
+                if (m2 > 640) score += 300.0;
+                if (m3 > 2560) score += 300.0;
+                score += 10.0 * (fabs(log((double)m1 / (double)m2)) + fabs(log((double)m1 * 2.0 / (double)m3)));
+                if (score < best_score) {
+                    best_score = score;
+                    best.ok = true; best.levels = 3;
+                    best.M1 = (int)m1; best.M2 = (int)m2; best.M3 = (int)m3;
+                    best.f1 = f1; best.f2 = f2; best.f3 = f3;
+                }
+            }
         }
     }
     if (!best.ok) return best;
-    int tc = tc_hint > 0 ? tc_hint : (best.M1 > 512 ? 8 : 16);
-    if (best.M1 == 1) tc = tc_hint > 0 ? tc_hint : 256;   // degenerate column pass: plain streaming
-    // power of two, and never wider than the row
-    int l2 = ilog2(tc);
-    tc = 1 << l2;
-    while (tc > 1 && tc / 2 >= best.M2) { tc /= 2; --l2; }
-    best.TC = tc;
-    best.TClog2 = l2;
-    best.lds_col = (size_t)2 * best.M1 * tc * sizeof(float2);
-    best.lds_row = (size_t)2 * 2 * best.M2 * sizeof(float2);
+    finish_split(best, tc_hint);
     return best;
+}
+
+FlSplit plan_split_explicit(int64_t N, int m1, int m2, int m3, int tc_hint) {
+    FlSplit sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.N = N; sp.M = N / 2; sp.M3 = 1;
+    if (N < 2 || (N & 1) || m1 < 1 || m2 < 1 || m3 < 1) return sp;
+    if ((int64_t)m1 * m2 * m3 != sp.M) return sp;
+    sp.levels = m3 > 1 ? 3 : 2;
+    sp.M1 = m1; sp.M2 = m2; sp.M3 = m3;
+    if (m1 > 1024 || (sp.levels == 3 ? (m2 > 1024 || m3 > 4096) : m2 > 4096)) return sp;
+    if (!make_schedule(m1, &sp.f1) || !make_schedule(m2, &sp.f2)) return sp;
+    if (sp.levels == 3 && !make_schedule(m3, &sp.f3)) return sp;
+    sp.ok = true;
+    finish_split(sp, tc_hint);
+    return sp;
+}
+
+static void finish_split_impl(FlSplit& best, int tc_hint) {
+    if (best.levels == 2) {
+        best.TC = pick_tc(best.M1, best.M2, tc_hint);
+        best.TClog2 = ilog2(best.TC);
+        best.TCb = 1; best.TCblog2 = 0;
+        best.lds_col = (size_t)2 * best.M1 * best.TC * sizeof(float2);
+        best.lds_colb = 0;
+        best.lds_row = (size_t)2 * 2 * best.M2 * sizeof(float2);
+    } else {
+        best.TC = pick_tc(best.M1, best.M2 * best.M3, tc_hint);
+        best.TClog2 = ilog2(best.TC);
+        best.TCb = pick_tc(best.M2, best.M3, tc_hint);
+        best.TCblog2 = ilog2(best.TCb);
+        best.lds_col = (size_t)2 * best.M1 * best.TC * sizeof(float2);
+        best.lds_colb = (size_t)2 * best.M2 * best.TCb * sizeof(float2);
+        best.lds_row = (size_t)2 * 2 * best.M3 * sizeof(float2);
+    }
 }
 
 }  // namespace egr

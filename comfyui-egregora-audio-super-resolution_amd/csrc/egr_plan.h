@@ -17,13 +17,18 @@ void make_twiddles(std::vector<float2>& out, int64_t count, int64_t num, int64_t
 
 struct FlSplit {
     bool ok;
+    int levels;               // 2: M = M1*M2 ; 3: M = M1*M2*M3 (long inputs)
     int64_t N, M;
-    int M1, M2, TC, TClog2;
-    FftDesc f1, f2;
-    size_t lds_col, lds_row;
+    int M1, M2, M3;           // M3 = 1 for two levels; the LAST factor is the contiguous row length
+    int TC, TClog2;           // column-tile width of pass A
+    int TCb, TCblog2;         // column-tile width of pass B (3 levels)
+    FftDesc f1, f2, f3;
+    size_t lds_col, lds_colb, lds_row;
 };
 
-// Choose M = M1*M2 for the four-step transform of the packed half-length complex sequence.
+// Choose the factorisation of M = N/2 for the multi-step transform of the packed half-length complex sequence.
 FlSplit plan_split(int64_t N, int m1_hint, int tc_hint);
+// Explicit factorisation (tests / tuning): m3 == 1 selects two levels.  ok == false when it does not fit.
+FlSplit plan_split_explicit(int64_t N, int m1, int m2, int m3, int tc_hint);
 
 }  // namespace egr

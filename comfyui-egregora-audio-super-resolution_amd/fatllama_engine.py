@@ -23,16 +23,21 @@ def upscale_factor(sr: int, channels: int, target_bitrate_kbps: int) -> int:
     return max(1, int(round((target_bitrate_kbps * 1000.0) / src_bps)))
 
 
-def _plan(n_in: int, channels: int, factor: int, device: int, m1_hint: int = 0, tc_hint: int = 0):
-    key = (n_in, channels, factor, device, m1_hint, tc_hint)
+def _plan(n_in: int, channels: int, factor: int, device: int, m1_hint: int = 0, tc_hint: int = 0, split=None):
+    """split = (m1, m2, m3) forces an explicit factorisation of N/2 (m3 = 1: two levels)."""
+    key = (n_in, channels, factor, device, m1_hint, tc_hint, split)
     h = _PLANS.get(key)
     if h is not None:
         _PLANS.move_to_end(key)
         return h
     L = native.lib()
     out = C.c_void_p()
-    native.check(L.egr_fatllama_plan_create(C.byref(out), n_in, channels, factor, m1_hint, tc_hint),
-                 "egr_fatllama_plan_create")
+    if split is not None:
+        native.check(L.egr_fatllama_plan_create_ex(C.byref(out), n_in, channels, factor, int(split[0]), int(split[1]),
+                                                   int(split[2]), tc_hint), "egr_fatllama_plan_create_ex")
+    else:
+        native.check(L.egr_fatllama_plan_create(C.byref(out), n_in, channels, factor, m1_hint, tc_hint),
+                     "egr_fatllama_plan_create")
     _PLANS[key] = out.value
     while len(_PLANS) > _MAX_PLANS:
         _, old = _PLANS.popitem(last=False)
@@ -55,7 +60,7 @@ def plan_info(n_in: int, factor: int, m1_hint: int = 0) -> dict:
     v = list(info)
     d = {"supported": bool(v[0]) and rc == 0, "N": v[1], "M": v[2], "M1": v[3], "M2": v[4], "TC": v[5],
          "radix1": [r for r in v[8:8 + v[6]]], "radix2": [r for r in v[22:22 + v[7]]],
-         "lds_col": v[36], "lds_row": v[37]}
+         "lds_col": v[36], "lds_row": v[37], "M3": v[38], "levels": v[39]}
     if rc != 0:
         d["error"] = native.last_error()
     return d
@@ -63,7 +68,7 @@ def plan_info(n_in: int, factor: int, m1_hint: int = 0) -> dict:
 
 def enhance_device(x_ct: torch.Tensor, factor: int, max_iterations: int, threshold_value: float,
                    normalize: bool, autoscale: bool, pcm_in: bool, node_post: bool,
-                   m1_hint: int = 0, tc_hint: int = 0, profile: bool = False):
+                   m1_hint: int = 0, tc_hint: int = 0, profile: bool = False, split=None):
     """x_ct: [C,T] float32 CUDA tensor.  Returns [C,T*factor] float32 CUDA tensor (same stream)."""
     if not (x_ct.is_cuda and x_ct.dtype == torch.float32 and x_ct.dim() == 2):
         raise RuntimeError("enhance_device wants a [C,T] float32 tensor on the GPU")
@@ -71,7 +76,7 @@ def enhance_device(x_ct: torch.Tensor, factor: int, max_iterations: int, thresho
     Cn, T = x_ct.shape
     if T < 1:
         raise RuntimeError("empty audio")
-    plan = _plan(T, Cn, factor, x_ct.device.index or 0, m1_hint, tc_hint)
+    plan = _plan(T, Cn, factor, x_ct.device.index or 0, m1_hint, tc_hint, split)
     out = torch.empty((Cn, T * factor), dtype=torch.float32, device=x_ct.device)
     flags = ((native.FL_NORMALIZE if normalize else 0) | (native.FL_AUTOSCALE if autoscale else 0) |
              (native.FL_PCM_IN if pcm_in else 0) | (native.FL_NODE_POST if node_post else 0))

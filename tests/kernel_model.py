@@ -148,3 +148,91 @@ def ist(p, y, max_iter, thr):
         if it + 1 < max_iter:
             A = col_mid(p, B)
     return col_inverse(p, B)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Three-level decomposition M = M1*M2*M3 (state [M1][M2][M3]) used for long inputs:
+#   pass A : FFT over n1 (stride M2*M3), twiddle W_M^(c*k1), c = n2*M3+n3         (same kernel as 2-level k_col)
+#   pass B : per k1 plane, FFT over n2 (stride M3), twiddle W_(M2*M3)^(n3*k2)      (k_col, forward-only / inverse-only)
+#   pass C : rows of length M3; frequency k = o + R*k3 with o = k1 + M1*k2, R = M1*M2, stored at row
+#            rho(o) = k1*M2 + k2; the real-split partner of (o, k3) is (R-o, M3-1-k3), or (0, (M3-k3)%M3) for o = 0.
+# ------------------------------------------------------------------------------------------------------------
+class Plan3:
+    def __init__(self, N, M1, M2, M3):
+        assert N % 2 == 0 and N // 2 == M1 * M2 * M3
+        self.N, self.M, self.M1, self.M2, self.M3 = N, N // 2, M1, M2, M3
+        self.R = M1 * M2
+
+    def twA(self, c, k1):            # W_M^(c*k1)
+        return np.exp(-2j * np.pi * ((c * k1) % self.M) / self.M)
+
+    def twB(self, n3, k2):           # W_(M2*M3)^(n3*k2)
+        Mp = self.M2 * self.M3
+        return np.exp(-2j * np.pi * ((n3 * k2) % Mp) / Mp)
+
+    def rho(self, o):
+        return (o % self.M1) * self.M2 + o // self.M1
+
+
+def _passA(p, S, inverse):
+    """S [M1][M2*M3]: (inverse: x conj tw, IFFT over k1) or (forward: FFT over n1, x tw)."""
+    k1 = np.arange(p.M1)[:, None]
+    c = np.arange(p.M2 * p.M3)[None, :]
+    if inverse:
+        return stockham_fft((S * np.conj(p.twA(c, k1))).T, inverse=True).T
+    return stockham_fft(S.T).T * p.twA(c, k1)
+
+
+def _passB(p, S, inverse):
+    """S [M1][M2][M3] planes."""
+    k2 = np.arange(p.M2)[None, :, None]
+    n3 = np.arange(p.M3)[None, None, :]
+    S = S.reshape(p.M1, p.M2, p.M3)
+    if inverse:
+        t = S * np.conj(p.twB(n3, k2))
+        return stockham_fft(np.swapaxes(t, 1, 2), inverse=True).swapaxes(1, 2).reshape(p.M1, -1)
+    t = stockham_fft(np.swapaxes(S, 1, 2)).swapaxes(1, 2)
+    return (t * p.twB(n3, k2)).reshape(p.M1, -1)
+
+
+def _rows3(p, S, thr):
+    M3, R, M, N = p.M3, p.R, p.M, p.N
+    Z = stockham_fft(S.reshape(R, M3))                # row rho holds Z[o + R*k3]
+    Zo = np.empty_like(Z)
+    for o in range(R // 2 + 1):
+        ob = (R - o) % R
+        if o > ob:
+            continue
+        ra, rb = p.rho(o), p.rho(ob)
+        if o != ob:
+            k3 = np.arange(M3); pb = M3 - 1 - k3; skip = np.zeros(M3, bool)
+        elif o == 0:
+            k3 = np.arange(M3 // 2 + 1); pb = (M3 - k3) % M3; skip = (k3 == pb)
+        else:
+            k3 = np.arange((M3 + 1) // 2); pb = M3 - 1 - k3; skip = (k3 == pb)
+        Za, Zb = Z[ra, k3], Z[rb, pb]
+        W = np.exp(-2j * np.pi * (o + R * k3) / N)
+        E = 0.5 * (Za + np.conj(Zb)); O = -0.5j * (Za - np.conj(Zb)); WO = W * O
+        Xk, Xm = E + WO, E - WO
+        Xk = np.where(np.abs(Xk) > thr, Xk, 0); Xm = np.where(np.abs(Xm) > thr, Xm, 0)
+        E2 = 0.5 * (Xk + Xm); O2 = np.conj(W) * (0.5 * (Xk - Xm))
+        Zo[ra, k3] = (E2 + 1j * O2) / M
+        Zo[rb, pb[~skip]] = (np.conj(E2 - 1j * O2) / M)[~skip]
+    return stockham_fft(Zo, inverse=True).reshape(p.M1, -1)
+
+
+def ist3(p, y, max_iter, thr):
+    d0 = np.where(np.abs(y) > thr, y, 0.0)
+    if max_iter == 0:
+        return d0
+    S = (d0[0::2] + 1j * d0[1::2]).reshape(p.M1, -1)
+    S = _passB(p, _passA(p, S, False), False)
+    for it in range(max_iter):
+        S = _passB(p, _rows3(p, S, thr), True)
+        if it + 1 < max_iter:
+            S = _passB(p, _passA(p, _passA(p, S, True), False), False)
+    z = _passA(p, S, True)
+    d = np.empty(p.N)
+    d[0::2] = z.real.reshape(-1)
+    d[1::2] = z.imag.reshape(-1)
+    return d

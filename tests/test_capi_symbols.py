@@ -39,7 +39,11 @@ def test_abi_version_and_host_only_planning(pack):
     bad = fe.plan_info(101, 1)
     assert not bad["supported"] and "unsupported" in bad["error"]
     assert fe.plan_info(2880000, 1, 1000)["M1"] == 1000
-    assert i["lds_col"] <= 160 * 1024 and i["lds_row"] <= 160 * 1024
+    assert i["lds_col"] <= 160 * 1024 and i["lds_row"] <= 160 * 1024 and i["levels"] == 2
+    big = fe.plan_info(172800000, 1)            # BASELINE C5: 30 min at 96 kHz per channel
+    assert big["supported"] and big["levels"] == 3 and big["M1"] * big["M2"] * big["M3"] == 86400000
+    assert max(big["M1"], big["M2"]) <= 1024 and big["M3"] <= 4096
+    assert fe.plan_info(9600000, 1)["levels"] == 3
 
 
 def test_planner_matches_python_model_schedule(pack):

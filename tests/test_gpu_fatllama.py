@@ -73,6 +73,31 @@ def test_loop_matches_oracle(pack, C, n, f, iters, thr):
         assert om.lsd_audio(want, got)[0] <= (1e-3 if f == 1 else 0.25)
 
 
+@pytest.mark.parametrize("n,split", [(420, (6, 5, 7)), (2 * 8 * 9 * 10, (8, 9, 10)), (2 * 16 * 15 * 64, (16, 15, 64)),
+                                     (2 * 4 * 3 * 5, (4, 3, 5)), (48000, (20, 24, 50)), (48000, (40, 600, 1))])
+def test_three_level_plan_matches_oracle(pack, n, split):
+    """Explicit 3-level factorisations (the path long inputs take) against the oracle at small sizes."""
+    x = synth(2, n, seed=n)
+    want = ofl.enhance_channels(x, 1, 4, 0.6, normalize=False, autoscale=False)
+    got = run_gpu(pack, x, 1, 4, 0.6, split=split)
+    scale = float(np.max(np.abs(want)))
+    assert float(np.max(np.abs(got - want))) <= 2e-5 * scale
+
+
+def test_long_input_takes_three_levels(pack):
+    """200 s mono at 48 kHz (9.6 M samples > the two-level limit), 2 iterations, vs the oracle."""
+    from egregora_amd import fatllama_engine as fe
+    n = 9600000
+    info = fe.plan_info(n, 1)
+    assert info["supported"] and info["levels"] == 3 and info["M1"] * info["M2"] * info["M3"] == n // 2
+    x = synth(1, n, seed=77)
+    want = ofl.enhance_channels(x, 1, 2, 0.6, normalize=False, autoscale=False)
+    got = run_gpu(pack, x, 1, 2, 0.6)
+    scale = float(np.max(np.abs(want)))
+    assert float(np.max(np.abs(got - want))) <= 2e-5 * scale
+    assert om.lsd_audio(want[:, :960000], got[:, :960000])[0] <= 1e-3
+
+
 @pytest.mark.parametrize("thr", [50.0, 3000.0])
 def test_large_threshold_actually_gates_bins(pack, thr):
     """With a threshold inside the data range a sizeable share of samples/bins is zeroed; a borderline

@@ -29,3 +29,20 @@ def test_ist_matches_fft_loop(M1, M2, iters):
     p = km.Plan(N, M1, M2)
     got = km.ist(p, y, iters, thr)
     np.testing.assert_allclose(got, d, atol=1e-9 * N)
+
+
+@pytest.mark.parametrize("M1,M2,M3", [(2, 3, 4), (3, 2, 5), (4, 4, 4), (5, 3, 2), (1, 3, 4), (2, 1, 6), (6, 5, 7), (4, 6, 9)])
+@pytest.mark.parametrize("iters", [1, 3])
+def test_ist_three_level_matches_fft_loop(M1, M2, M3, iters):
+    N = 2 * M1 * M2 * M3
+    rng = np.random.default_rng(N * 7 + iters)
+    y = np.rint(rng.standard_normal(N) * 50)
+    y[rng.integers(0, N, N // 4)] = 0.0
+    thr = 20.0
+    d = np.where(np.abs(y) > thr, y, 0.0)
+    for _ in range(iters):
+        X = np.fft.fft(d)
+        X = np.where(np.abs(X) > thr, X, 0)
+        d = np.fft.ifft(X).real
+    got = km.ist3(km.Plan3(N, M1, M2, M3), y, iters, thr)
+    np.testing.assert_allclose(got, d, atol=1e-9 * N)
