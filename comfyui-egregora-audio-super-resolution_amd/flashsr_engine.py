@@ -100,7 +100,10 @@ class FlashSREngine:
         native.check(self.L.egr_conv_nhwc(_p(x), _p(wt), _p(bt), _p(None), _p(res), _p(y), B, H, W, Cin, OH, OW, Cout, KH,
                                           KW, stride, dil, pad_t, pad_l, up2, act, float(act_param), self._st()),
                      "egr_conv_nhwc")
-        self._prof_end(ev, "k_conv_igemm", fl, (B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, up2))
+        if ev is not None:      # same variant selection as egr_conv_nhwc (csrc/egr_nn_gemm.hip)
+            bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
+            vec = "true" if (Cin % 16 == 0 and x.data_ptr() % 16 == 0) else "false"
+            self._prof_end(ev, f"k_conv_igemm<{bn}, {vec}>", fl, (B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, up2))
         if self.count_flops:
             self.flops += fl
         return y

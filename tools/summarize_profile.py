@@ -19,8 +19,9 @@ if st:
     print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
     with open(st) as f:
         rows = list(csv.DictReader(f))
-    for r in rows[:12]:
-        print({k: r[k] for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+    for r in rows[:16]:
+        print("%-86s calls=%6s avg_us=%10.1f total_ms=%9.1f pct=%5.1f" % (r["Name"][:86], r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                                       float(r["TotalDurationNs"]) / 1e6, float(r["Percentage"])))
 for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     p = find(f"{tag}/**/*counter_collection.csv")
     if not p:
@@ -35,7 +36,7 @@ for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
             acc[k][0] += float(r["Counter_Value"])
             acc[k][1] += 1
     print(f"== {ctr} per launch (KiB as reported; bytes; x2-corrected bytes for FETCH) ==")
-    for k, (v, n) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:8]:
+    for k, (v, n) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:10]:
         per = v / max(n, 1)
         print(f"{k[:70]:70s} launches={n:5d} per_launch={per:12.1f} KiB = {per*1024/1e6:9.2f} MB"
               + (f"  (x2: {2*per*1024/1e6:9.2f} MB)" if ctr == "FETCH_SIZE" else ""))
