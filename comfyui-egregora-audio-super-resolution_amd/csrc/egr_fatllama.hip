@@ -208,6 +208,153 @@ __global__ __launch_bounds__(256) void k_row(RowP p, long long M, cplx* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Bluestein fallback for lengths the packed real transform cannot take (odd N, large prime factors):
+// the exact length-N DFT as a cyclic convolution of length P >= 2N-1 (P smooth):
+//   DFT(d)[k] = w[k] * (a (*) b)[k],  a[n] = d[n] w[n],  b[m] = conj(w[m]) for |m| < N,  w[n] = exp(-i pi n^2 / N).
+// The convolution runs on the SAME column/row passes with the state holding P complex points:
+//   k_colz (outer column pass, hook fused at its natural-order midpoint)  +  k_rowconv (row FFT . x Bhat . row IFFT).
+// One loop iteration = spectrum hook (X = w c; threshold; a' = conj(X) w) and time hook (d = Re(w c')/N; a = d w),
+// each followed by a convolution: 4 launches over 8P-byte states instead of 2 over 4N-byte ones (slow path).
+// ------------------------------------------------------------------------------------------------
+struct ChirpP {
+    Tw2 w;                   // W_(2N)^r
+    unsigned long long N;    // transform length
+    float inv_N;
+};
+__device__ __forceinline__ cplx chirp(const ChirpP& c, unsigned long long n) {
+    const unsigned long long r = (n * n) % (2ULL * c.N);
+    return tw2(c.w, (unsigned)r);
+}
+
+// MODE 0: first (y real -> time threshold -> a = d w -> FFT -> twiddle)
+// MODE 1: mid   (twiddle^-1 -> IFFT -> hook -> FFT -> twiddle); HOOK 1 = spectrum side, HOOK 2 = time side
+// MODE 2: last  (twiddle^-1 -> IFFT -> d = Re(w c)/N -> out = y + d, peak)
+template <int MODE, int HOOK>
+__global__ __launch_bounds__(256) void k_colz(ColP p, ChirpP cp, long long P, float thr, float thr2,
+                                               cplx* __restrict__ work, float* __restrict__ out,
+                                               unsigned* __restrict__ peak_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float red[8];
+    const int tile = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile >= p.ntiles) return;
+    const int ch = blockIdx.y;
+    const int TC = p.TC, lg = p.TClog2, L = p.L, nc = p.ncols;
+    const int c0 = tile * TC;
+    cplx* cur = (cplx*)smem;
+    cplx* alt = cur + (size_t)L * TC;
+    cplx* W = work + (size_t)ch * P;
+    float* Y = out + (size_t)ch * cp.N;
+    const int nel = L * TC;
+    const unsigned long long N = cp.N;
+
+    for (int e = threadIdx.x; e < nel; e += blockDim.x) {
+        const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
+        cplx v = make_float2(0.f, 0.f);
+        if (col < nc) {
+            const unsigned long long n = (unsigned long long)i * nc + col;
+            if (MODE == 0) {
+                if (n < N) {
+                    const float y = Y[n];
+                    const float d0 = fabsf(y) > thr ? y : 0.f;
+                    const cplx w = chirp(cp, n);
+                    v = make_float2(d0 * w.x, d0 * w.y);
+                }
+            } else {
+                v = cmulc(W[n], tw2(p.big, (unsigned)col * (unsigned)i));
+            }
+        }
+        cur[e] = v;
+    }
+    __syncthreads();
+    if (MODE != 0) lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, true);
+    if (MODE == 2) {
+        float mx = 0.f;
+        for (int e = threadIdx.x; e < nel; e += blockDim.x) {
+            const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
+            const unsigned long long n = (unsigned long long)i * nc + col;
+            if (col < nc && n < N) {
+                const cplx w = chirp(cp, n);
+                const cplx cc = cur[e];
+                const float d = (w.x * cc.x - w.y * cc.y) * cp.inv_N;
+                const float o = __fadd_rn(Y[n], d);
+                Y[n] = o;
+                mx = fmaxf(mx, fabsf(o));
+            }
+        }
+        mx = block_max(mx, red);
+        if (threadIdx.x == 0) atomic_max_abs(peak_out + ch, mx);
+        return;
+    }
+    if (MODE == 1) {
+        for (int e = threadIdx.x; e < nel; e += blockDim.x) {
+            const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
+            const unsigned long long n = (unsigned long long)i * nc + col;
+            cplx v = make_float2(0.f, 0.f);
+            if (col < nc && n < N) {
+                const cplx w = chirp(cp, n);
+                const cplx cc = cur[e];
+                if (HOOK == 1) {                 // X = w c ; threshold ; a' = conj(X) w
+                    cplx X = cmul(w, cc);
+                    if (!(X.x * X.x + X.y * X.y > thr2)) X = make_float2(0.f, 0.f);
+                    v = cmul(make_float2(X.x, -X.y), w);
+                } else {                         // d = Re(w c)/N ; a = d w
+                    const float d = (w.x * cc.x - w.y * cc.y) * cp.inv_N;
+                    v = make_float2(d * w.x, d * w.y);
+                }
+            }
+            cur[e] = v;
+        }
+        __syncthreads();
+    }
+    lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, false);
+    for (int e = threadIdx.x; e < nel; e += blockDim.x) {
+        const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
+        if (col < nc) W[(size_t)i * nc + col] = cmul(cur[e], tw2(p.big, (unsigned)col * (unsigned)i));
+    }
+}
+
+// rows r0 = 2*blockIdx.x, r0+1 of R rows of length L.  CONV: FFT . x bhat[row][k] . IFFT ; else FFT . x scale
+// (used once to build bhat itself).
+template <bool CONV>
+__global__ __launch_bounds__(256) void k_rowconv(FftDesc f, int L, int R, const cplx* __restrict__ tw,
+                                                  const cplx* __restrict__ bhat, float scale, long long P,
+                                                  cplx* __restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int r0 = 2 * blockIdx.x;
+    const int nrows = (r0 + 1 < R) ? 2 : 1;
+    cplx* cur = (cplx*)smem;
+    cplx* alt = cur + 2 * (size_t)L;
+    cplx* g = work + (size_t)blockIdx.y * P + (size_t)r0 * L;
+    for (int e = threadIdx.x; e < nrows * L; e += blockDim.x) cur[e] = g[e];
+    __syncthreads();
+    lds_fft<false>(cur, alt, f, tw, nrows, 0, 1, L, false);
+    if (CONV) {
+        const cplx* bh = bhat + (size_t)r0 * L;
+        for (int e = threadIdx.x; e < nrows * L; e += blockDim.x) cur[e] = cmul(cur[e], bh[e]);
+        __syncthreads();
+        lds_fft<false>(cur, alt, f, tw, nrows, 0, 1, L, true);
+        for (int e = threadIdx.x; e < nrows * L; e += blockDim.x) g[e] = cur[e];
+    } else {
+        for (int e = threadIdx.x; e < nrows * L; e += blockDim.x) g[e] = make_float2(cur[e].x * scale, cur[e].y * scale);
+    }
+}
+
+// b[j] = conj(w[j]) for j < N, b[P-j] = conj(w[j]) for 0 < j < N, zero elsewhere
+__global__ __launch_bounds__(256) void k_chirp_b(ChirpP cp, long long P, cplx* __restrict__ b) {
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < P; j += (long long)gridDim.x * blockDim.x) {
+        long long m = -1;
+        if ((unsigned long long)j < cp.N) m = j;
+        else if ((unsigned long long)(P - j) < cp.N) m = P - j;
+        cplx v = make_float2(0.f, 0.f);
+        if (m >= 0) {
+            const cplx w = chirp(cp, (unsigned long long)m);
+            v = make_float2(w.x, -w.y);
+        }
+        b[j] = v;
+    }
+}
+
 // x (optionally PCM_16-quantised) -> y = linear up-rate by f, per-channel max|x_q|.
 __global__ __launch_bounds__(256) void k_prepare(const float* __restrict__ x, float* __restrict__ y, long long n_in,
                                                   int f, int pcm_in, unsigned* __restrict__ peak_in) {
@@ -310,6 +457,9 @@ struct egr_fatllama_plan {
     ColP colA, colB;
     RowP row;
     std::vector<void*> dev_allocs;
+    bool bluestein;       // lengths outside the packed-real plans: chirp-z over P = sp.M complex points
+    ChirpP chirp;
+    cplx* d_bhat;         // FFT_P(b) / P in the passes' transposed layout
     cplx* d_work;
     unsigned* d_peaks;   // [2*C]: peak_in[C], peak_out[C]
     bool profiling;
@@ -350,6 +500,8 @@ static void fill_info(const FlSplit& sp, int64_t info[EGR_FL_INFO_LEN]) {
     info[39] = sp.levels;
 }
 
+static bool bluestein_length(int64_t want, FlSplit* sp_out);
+
 static const char* kUnsupported =
     "length %lld unsupported: needs even N whose half factors into 2 or 3 lengths (columns <= 1024, row <= 4096) with "
     "prime factors <= 13";
@@ -363,6 +515,12 @@ extern "C" int egr_fatllama_plan_query(int64_t n_in, int factor, int m1_hint, in
     info[1] = N;
     info[2] = N / 2;
     if (!sp.ok) {
+        if (N >= 2 && bluestein_length(2 * N - 1, &sp)) {      // chirp-z over P = sp.M complex points
+            fill_info(sp, info);
+            info[0] = 2;
+            info[2] = sp.M;
+            return EGR_OK;
+        }
         set_error(kUnsupported, (long long)N);
         return EGR_ERR_UNSUPPORTED;
     }
@@ -373,15 +531,18 @@ extern "C" int egr_fatllama_plan_query(int64_t n_in, int factor, int m1_hint, in
 extern "C" int egr_fatllama_plan_destroy(egr_fatllama_plan* p) {
     if (!p) return EGR_OK;
     for (void* q : p->dev_allocs) hipFree(q);
-    hipFree(p->d_work); hipFree(p->d_peaks);
+    hipFree(p->d_work); hipFree(p->d_peaks); hipFree(p->d_bhat);
     for (auto e : p->ev) hipEventDestroy(e);
     delete p;
     return EGR_OK;
 }
 
-static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int factor, const FlSplit& sp) {
+static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int factor, const FlSplit& sp,
+                      int64_t bluestein_n = 0) {
     egr_fatllama_plan* p = new egr_fatllama_plan();
     p->n_in = n_in; p->C = channels; p->factor = factor; p->sp = sp; p->profiling = false;
+    p->bluestein = bluestein_n > 0;
+    p->d_bhat = nullptr;
     p->d_work = nullptr;
     p->d_peaks = nullptr;
     hipGetDevice(&p->device);
@@ -438,12 +599,62 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_row, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_rowconv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_rowconv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
     if (e != hipSuccess) {
         set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) -> %s", hipGetErrorString(e));
         return fail(EGR_ERR_HIP);
     }
+    if (p->bluestein) {
+        // chirp tables for W_(2N)^r and bhat = FFT_P(b)/P computed once with the plan's own passes
+        ChirpP& c = p->chirp;
+        c.N = (unsigned long long)bluestein_n;
+        c.inv_N = (float)(1.0 / (double)bluestein_n);
+        if ((rc = make_tw2(p, 2 * bluestein_n, &c.w))) return fail(rc);
+        if (hipMalloc((void**)&p->d_bhat, (size_t)M * sizeof(float2)) != hipSuccess) {
+            set_error("hipMalloc of the %lld-byte chirp spectrum failed", (long long)(M * 8));
+            return fail(EGR_ERR_ALLOC);
+        }
+        const dim3 blk(256);
+        hipLaunchKernelGGL(k_chirp_b, dim3(2048), blk, 0, 0, c, (long long)M, p->d_bhat);
+        hipLaunchKernelGGL(k_col<4>, dim3(8 * a.tiles_per_xcd, 1), blk, sp.lds_col, 0, a, (long long)M, (long long)N, 0.f, p->d_bhat,
+                           (float*)nullptr, (unsigned*)nullptr);
+        if (sp.levels == 3)
+            hipLaunchKernelGGL(k_col<4>, dim3(8 * p->colB.tiles_per_xcd, p->colB.nplanes), blk, sp.lds_colb, 0, p->colB,
+                               (long long)M, (long long)N, 0.f, p->d_bhat, (float*)nullptr, (unsigned*)nullptr);
+        hipLaunchKernelGGL(k_rowconv<false>, dim3((r.R + 1) / 2, 1), blk, sp.lds_row, 0, r.f, r.L, r.R, r.tw,
+                           (const cplx*)nullptr, (float)(1.0 / (double)M), (long long)M, p->d_bhat);
+        if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) {
+            set_error("building the Bluestein chirp spectrum failed");
+            return fail(EGR_ERR_HIP);
+        }
+    }
     *out = p;
     return EGR_OK;
+}
+
+// smallest P >= want whose packed plan (M = P) exists; P has only the prime factors 2, 3, 5, 7
+static bool bluestein_length(int64_t want, FlSplit* sp_out) {
+    int64_t best = -1;
+    FlSplit best_sp;
+    for (int64_t p7 = 1; p7 <= 8 * want; p7 *= 7)
+        for (int64_t p5 = p7; p5 <= 8 * want; p5 *= 5)
+            for (int64_t p3 = p5; p3 <= 8 * want; p3 *= 3) {
+                int64_t v = p3;
+                while (v < want) v *= 2;
+                for (int rep = 0; rep < 2; ++rep, v *= 2) {          // v and 2v: the first may not factor into tiles
+                    if (best > 0 && v >= best) break;
+                    FlSplit sp = plan_split(2 * v, 0, 0);
+                    if (sp.ok) { best = v; best_sp = sp; break; }
+                }
+            }
+    if (best < 0) return false;
+    *sp_out = best_sp;
+    return true;
 }
 
 extern "C" int egr_fatllama_plan_create(egr_fatllama_plan** out, int64_t n_in, int channels, int factor,
@@ -455,10 +666,25 @@ extern "C" int egr_fatllama_plan_create(egr_fatllama_plan** out, int64_t n_in, i
     const int64_t N = n_in * factor;
     FlSplit sp = plan_split(N, m1_hint, tc_hint);
     if (!sp.ok) {
+        if (N >= 2 && bluestein_length(2 * N - 1, &sp)) return build_plan(out, n_in, channels, factor, sp, N);
         set_error(kUnsupported, (long long)N);
         return EGR_ERR_UNSUPPORTED;
     }
     return build_plan(out, n_in, channels, factor, sp);
+}
+
+extern "C" int egr_fatllama_plan_create_bluestein(egr_fatllama_plan** out, int64_t n_in, int channels, int factor) {
+    EGR_CHECK(out != nullptr, EGR_ERR_ARG, "out is null");
+    *out = nullptr;
+    EGR_CHECK(n_in >= 1 && factor >= 1 && channels >= 1 && channels <= 64 && n_in * factor >= 2, EGR_ERR_ARG,
+              "n_in=%lld channels=%d factor=%d out of range", (long long)n_in, channels, factor);
+    const int64_t N = n_in * factor;
+    FlSplit sp;
+    if (!bluestein_length(2 * N - 1, &sp)) {
+        set_error("no convolution length found for N=%lld", (long long)N);
+        return EGR_ERR_UNSUPPORTED;
+    }
+    return build_plan(out, n_in, channels, factor, sp, N);
 }
 
 extern "C" int egr_fatllama_plan_create_ex(egr_fatllama_plan** out, int64_t n_in, int channels, int factor, int m1,
@@ -523,8 +749,29 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
     const size_t lc = p->sp.lds_col, lb = p->sp.lds_colb, lr = p->sp.lds_row;
     size_t slot = 0;
     if (max_iter == 0) {
-        const int nb = (int)((N + 255) / 256 < 2048 ? (N + 255) / 256 : 2048);
-        hipLaunchKernelGGL(k_noiter, dim3(nb, C), blk, 0, st, out, N, thr, peak_out);
+        const long long Nr = p->bluestein ? (long long)p->chirp.N : N;
+        const int nb = (int)((Nr + 255) / 256 < 2048 ? (Nr + 255) / 256 : 2048);
+        hipLaunchKernelGGL(k_noiter, dim3(nb, C), blk, 0, st, out, Nr, thr, peak_out);
+    } else if (p->bluestein) {
+        const ChirpP cp = p->chirp;
+        const long long P = M;
+        const dim3 grc((R.R + 1) / 2, C);
+        const float thr2 = thr * thr;
+        auto conv = [&]() {
+            if (three) hipLaunchKernelGGL(k_col<4>, gB, blk, lb, st, B, P, N, thr, p->d_work, out, peak_out);
+            hipLaunchKernelGGL(k_rowconv<true>, grc, blk, lr, st, R.f, R.L, R.R, R.tw, (const cplx*)p->d_bhat, 1.0f, P,
+                               p->d_work);
+            if (three) hipLaunchKernelGGL(k_col<3>, gB, blk, lb, st, B, P, N, thr, p->d_work, out, peak_out);
+        };
+        hipLaunchKernelGGL((k_colz<0, 0>), gA, blk, lc, st, A, cp, P, thr, thr2, p->d_work, out, peak_out);
+        for (int it = 0; it < max_iter; ++it) {
+            conv();
+            hipLaunchKernelGGL((k_colz<1, 1>), gA, blk, lc, st, A, cp, P, thr, thr2, p->d_work, out, peak_out);
+            conv();
+            if (it + 1 < max_iter)
+                hipLaunchKernelGGL((k_colz<1, 2>), gA, blk, lc, st, A, cp, P, thr, thr2, p->d_work, out, peak_out);
+        }
+        hipLaunchKernelGGL((k_colz<2, 0>), gA, blk, lc, st, A, cp, P, thr, thr2, p->d_work, out, peak_out);
     } else {
         hipLaunchKernelGGL(k_col<0>, gA, blk, lc, st, A, M, N, thr, p->d_work, out, peak_out);
         if (three) hipLaunchKernelGGL(k_col<4>, gB, blk, lb, st, B, M, N, thr, p->d_work, out, peak_out);
@@ -551,8 +798,9 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         hipLaunchKernelGGL(k_col<2>, gA, blk, lc, st, A, M, N, thr, p->d_work, out, peak_out);
     }
     if (flags & (EGR_FL_NORMALIZE | EGR_FL_AUTOSCALE | EGR_FL_NODE_POST)) {
-        const int nb = (int)((N + 255) / 256 < 2048 ? (N + 255) / 256 : 2048);
-        hipLaunchKernelGGL(k_finalize, dim3(nb, C), blk, 0, st, out, N, C, flags, peak_in, peak_out);
+        const long long Nr = p->bluestein ? (long long)p->chirp.N : N;
+        const int nb = (int)((Nr + 255) / 256 < 2048 ? (Nr + 255) / 256 : 2048);
+        hipLaunchKernelGGL(k_finalize, dim3(nb, C), blk, 0, st, out, Nr, C, flags, peak_in, peak_out);
     }
     EGR_HIP(hipGetLastError());
     return EGR_OK;

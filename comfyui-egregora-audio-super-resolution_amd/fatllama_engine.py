@@ -24,7 +24,8 @@ def upscale_factor(sr: int, channels: int, target_bitrate_kbps: int) -> int:
 
 
 def _plan(n_in: int, channels: int, factor: int, device: int, m1_hint: int = 0, tc_hint: int = 0, split=None):
-    """split = (m1, m2, m3) forces an explicit factorisation of N/2 (m3 = 1: two levels)."""
+    """split = (m1, m2, m3) forces an explicit factorisation of N/2 (m3 = 1: two levels); split = "bluestein" forces
+    the chirp-z path that lengths without a packed-real plan take automatically."""
     key = (n_in, channels, factor, device, m1_hint, tc_hint, split)
     h = _PLANS.get(key)
     if h is not None:
@@ -32,7 +33,10 @@ def _plan(n_in: int, channels: int, factor: int, device: int, m1_hint: int = 0, 
         return h
     L = native.lib()
     out = C.c_void_p()
-    if split is not None:
+    if split == "bluestein":
+        native.check(L.egr_fatllama_plan_create_bluestein(C.byref(out), n_in, channels, factor),
+                     "egr_fatllama_plan_create_bluestein")
+    elif split is not None:
         native.check(L.egr_fatllama_plan_create_ex(C.byref(out), n_in, channels, factor, int(split[0]), int(split[1]),
                                                    int(split[2]), tc_hint), "egr_fatllama_plan_create_ex")
     else:
@@ -58,7 +62,7 @@ def plan_info(n_in: int, factor: int, m1_hint: int = 0) -> dict:
     info = (C.c_int64 * native.FL_INFO_LEN)()
     rc = L.egr_fatllama_plan_query(n_in, factor, m1_hint, info)
     v = list(info)
-    d = {"supported": bool(v[0]) and rc == 0, "N": v[1], "M": v[2], "M1": v[3], "M2": v[4], "TC": v[5],
+    d = {"supported": bool(v[0]) and rc == 0, "bluestein": v[0] == 2, "N": v[1], "M": v[2], "M1": v[3], "M2": v[4], "TC": v[5],
          "radix1": [r for r in v[8:8 + v[6]]], "radix2": [r for r in v[22:22 + v[7]]],
          "lds_col": v[36], "lds_row": v[37], "M3": v[38], "levels": v[39]}
     if rc != 0:

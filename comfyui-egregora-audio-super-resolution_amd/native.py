@@ -24,6 +24,7 @@ SIGNATURES = {
     "egr_fatllama_plan_query": (_i, [_i64, _i, _i, C.POINTER(_i64)]),
     "egr_fatllama_plan_create": (_i, [C.POINTER(_vp), _i64, _i, _i, _i, _i]),
     "egr_fatllama_plan_create_ex": (_i, [C.POINTER(_vp), _i64, _i, _i, _i, _i, _i, _i]),
+    "egr_fatllama_plan_create_bluestein": (_i, [C.POINTER(_vp), _i64, _i, _i]),
     "egr_fatllama_plan_destroy": (_i, [_vp]),
     "egr_fatllama_enhance": (_i, [_vp, _vp, _vp, _i, _f, _u, _vp]),
     "egr_fatllama_last_peaks": (_i, [_vp, C.POINTER(_f), C.POINTER(_f), _vp]),

@@ -55,7 +55,8 @@ typedef struct egr_fatllama_plan egr_fatllama_plan;
 #define EGR_FL_NODE_POST 0x8u  /* apply write patch (/32768 iff max>1) + PCM_16 write + float read  */
 
 /* Host-only planning query (no GPU needed): fills info[] =
- *   {supported, N, M, M1, M2, TC, nst1, nst2, radix1[0..13], radix2[0..13], lds_col, lds_row, M3, levels}.
+ *   {supported (1 = packed real plan, 2 = Bluestein over M = P complex points), N, M, M1, M2, TC, nst1, nst2,
+ *    radix1[0..13], radix2[0..13], lds_col, lds_row, M3, levels}.
  * m1_hint <= 0 lets the planner choose. */
 #define EGR_FL_INFO_LEN 40
 int egr_fatllama_plan_query(int64_t n_in, int factor, int m1_hint, int64_t info[EGR_FL_INFO_LEN]);
@@ -65,6 +66,9 @@ int egr_fatllama_plan_create(egr_fatllama_plan** out, int64_t n_in, int channels
 /* Explicit factorisation N/2 = m1*m2*m3 (m3 = 1: two levels); used by tests and tuning. */
 int egr_fatllama_plan_create_ex(egr_fatllama_plan** out, int64_t n_in, int channels, int factor, int m1, int m2, int m3,
                                 int tc_hint);
+/* Force the chirp-z (Bluestein) path, which egr_fatllama_plan_create selects by itself for lengths the packed real
+ * transform cannot take (odd, or N/2 with a prime factor > 13): exact length-N DFTs as length-P convolutions. */
+int egr_fatllama_plan_create_bluestein(egr_fatllama_plan** out, int64_t n_in, int channels, int factor);
 int egr_fatllama_plan_destroy(egr_fatllama_plan* plan);
 
 /* x: [channels][n_in] float32, out: [channels][n_in*factor] float32 (both device).

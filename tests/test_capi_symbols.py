@@ -36,7 +36,10 @@ def test_abi_version_and_host_only_planning(pack):
         prod *= r
     assert prod == i["M1"]
     assert fe.plan_info(160000, 6)["M"] == 480000
-    bad = fe.plan_info(101, 1)
+    odd = fe.plan_info(101, 1)                 # no packed-real plan: chirp-z over P >= 2N-1 complex points
+    assert odd["supported"] and odd["bluestein"] and odd["M"] >= 201
+    assert not fe.plan_info(2880000, 1)["bluestein"]
+    bad = fe.plan_info(1, 1)
     assert not bad["supported"] and "unsupported" in bad["error"]
     assert fe.plan_info(2880000, 1, 1000)["M1"] == 1000
     assert i["lds_col"] <= 160 * 1024 and i["lds_row"] <= 160 * 1024 and i["levels"] == 2
