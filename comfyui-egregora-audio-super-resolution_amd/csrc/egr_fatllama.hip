@@ -53,6 +53,7 @@ struct RowP {
     Tw2 wo;                // W_N^o, o < R
     const cplx* wk;        // W_(2L)^k = W_N^(R*k), k < L
     float thr2, inv_M;
+    const float* gain;     // optional [C][M+1] real gain per half-spectrum bin (replaces the threshold)
 };
 
 __device__ __forceinline__ void atomic_max_abs(unsigned* slot, float v) {
@@ -77,6 +78,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // MODE 2: last    (state -> twiddle^-1 -> IFFT -> out = y + d, peak)        [outermost pass only]
 // MODE 3: inverse (state -> twiddle^-1 -> IFFT -> state)                    [inner pass of a 3-level plan]
 // MODE 4: forward (state -> FFT -> twiddle -> state)                        [inner pass of a 3-level plan]
+// MODE 5: last, plain (state -> twiddle^-1 -> IFFT -> out = d)               [spectral-gain filter]
 template <int MODE>
 __global__ __launch_bounds__(256) void k_col(ColP p, long long M, long long N, float thr, cplx* __restrict__ work,
                                               float* __restrict__ out, unsigned* __restrict__ peak_out) {
@@ -114,7 +116,14 @@ __global__ __launch_bounds__(256) void k_col(ColP p, long long M, long long N, f
         cur[e] = v;
     }
     __syncthreads();
-    if (MODE == 1 || MODE == 2 || MODE == 3) lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, true);
+    if (MODE == 1 || MODE == 2 || MODE == 3 || MODE == 5) lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, true);
+    if (MODE == 5) {
+        for (int e = threadIdx.x; e < nel; e += blockDim.x) {
+            const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
+            if (col < nc) Y[(size_t)i * nc + col] = cur[e];
+        }
+        return;
+    }
     if (MODE == 2) {
         float mx = 0.f;
         for (int e = threadIdx.x; e < nel; e += blockDim.x) {
@@ -191,8 +200,15 @@ __global__ __launch_bounds__(256) void k_row(RowP p, long long M, cplx* __restri
         const cplx WO = cmul(Wk, O);
         cplx Xk = cadd(E, WO);      // X[k]
         cplx Xm = csub(E, WO);      // conj X[M-k]
-        if (!(Xk.x * Xk.x + Xk.y * Xk.y > thr2)) Xk = make_float2(0.f, 0.f);
-        if (!(Xm.x * Xm.x + Xm.y * Xm.y > thr2)) Xm = make_float2(0.f, 0.f);
+        if (p.gain) {
+            const long long k = (long long)oa + (long long)R * k2;
+            const float* g = p.gain + (size_t)ch * (M + 1);
+            const float gk = g[k], gm = g[M - k];
+            Xk.x *= gk; Xk.y *= gk; Xm.x *= gm; Xm.y *= gm;
+        } else {
+            if (!(Xk.x * Xk.x + Xk.y * Xk.y > thr2)) Xk = make_float2(0.f, 0.f);
+            if (!(Xm.x * Xm.x + Xm.y * Xm.y > thr2)) Xm = make_float2(0.f, 0.f);
+        }
         const cplx E2 = make_float2(0.5f * (Xk.x + Xm.x), 0.5f * (Xk.y + Xm.y));
         const cplx H = make_float2(0.5f * (Xk.x - Xm.x), 0.5f * (Xk.y - Xm.y));
         const cplx O2 = cmulc(H, Wk);
@@ -598,6 +614,7 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_row, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
@@ -836,5 +853,27 @@ extern "C" int egr_fatllama_kernel_times(egr_fatllama_plan* p, double* row_ms_av
     if (col_ms_avg) *col_ms_avg = (cnt[1] + cnt[2]) ? (sum[1] + sum[2]) / (cnt[1] + cnt[2]) : 0.0;
     if (row_launches) *row_launches = cnt[0];
     if (col_launches) *col_launches = cnt[1] + cnt[2];
+    return EGR_OK;
+}
+
+// y = irfft(rfft(x) * gain): one forward transform, a real per-bin gain, one inverse, on the plan's passes.
+extern "C" int egr_spectral_gain(egr_fatllama_plan* p, const float* x, const float* gain, float* y, void* stream) {
+    EGR_CHECK(p && x && gain && y, EGR_ERR_ARG, "null argument");
+    EGR_CHECK(!p->bluestein && p->factor == 1, EGR_ERR_UNSUPPORTED, "spectral gain needs a packed-real plan with factor 1");
+    hipStream_t st = (hipStream_t)stream;
+    const int C = p->C;
+    const long long M = p->sp.M, N = p->sp.N;
+    const bool three = p->sp.levels == 3;
+    ColP A = p->colA, B = p->colB;
+    RowP R = p->row;
+    R.gain = gain;
+    const dim3 gA(8 * A.tiles_per_xcd, C), gB(8 * B.tiles_per_xcd, C * (three ? B.nplanes : 1)), grow(R.R / 2 + 1, C), blk(256);
+    const size_t lc = p->sp.lds_col, lb = p->sp.lds_colb, lr = p->sp.lds_row;
+    hipLaunchKernelGGL(k_col<0>, gA, blk, lc, st, A, M, N, -1.0f, p->d_work, const_cast<float*>(x), (unsigned*)nullptr);
+    if (three) hipLaunchKernelGGL(k_col<4>, gB, blk, lb, st, B, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
+    hipLaunchKernelGGL(k_row, grow, blk, lr, st, R, M, p->d_work);
+    if (three) hipLaunchKernelGGL(k_col<3>, gB, blk, lb, st, B, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
+    hipLaunchKernelGGL(k_col<5>, gA, blk, lc, st, A, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
+    EGR_HIP(hipGetLastError());
     return EGR_OK;
 }

@@ -392,6 +392,53 @@ __global__ __launch_bounds__(256) void k_randn(float* __restrict__ out, long lon
     }
 }
 
+// ---------------------------------------------------------------- input low-pass (lowpass_input=True)
+// cutoff bin per row from STFT magnitudes mag [B][T][ldm]: e[k] = sum_t mag[t][k]; c = cumsum(e); the cutoff is the
+// highest bin whose cumulative energy is still below pct * c[nb-1] (scanning down from the top), plus one.
+__global__ __launch_bounds__(256) void k_cutoff_bin(const float* __restrict__ mag, int T, int ldm, int nb, float pct,
+                                                     int* __restrict__ cut) {
+    extern __shared__ float e[];
+    const int b = blockIdx.x;
+    const float* m = mag + (size_t)b * T * ldm;
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) {
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) s += m[(size_t)t * ldm + k];
+        e[k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double c = 0.0;
+        for (int k = 0; k < nb; ++k) c += e[k];
+        const double lim = c * (double)pct;
+        double run = c;
+        int res = 0;
+        for (int i = 1; i < nb; ++i) {          // run = cumulative energy up to bin nb-i
+            if (run < lim) { res = nb - i; break; }
+            run -= e[nb - i];
+        }
+        cut[b] = res;
+    }
+}
+
+// zero-phase (forward-backward) Chebyshev-I low-pass amplitude gain 1 / (1 + eps^2 T_n^2(W/Wc)), W = tan(pi f/fs)
+__global__ __launch_bounds__(256) void k_cheby_gain(const int* __restrict__ cut, int nb_stft, float sr, int order,
+                                                     float eps2, long long nbins, float* __restrict__ gain) {
+    const int b = blockIdx.y;
+    const float fc = fmaxf(1.0f, fminf((float)cut[b] / (float)(nb_stft - 1), 0.999f) * 0.5f * sr);
+    const float wc = tanf(3.14159265358979f * fc / sr);
+    float* g = gain + (size_t)b * nbins;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nbins; k += (long long)gridDim.x * blockDim.x) {
+        const float f = 0.5f * sr * (float)k / (float)(nbins - 1);
+        float v = 0.f;
+        if (f < 0.4999f * sr) {
+            const float xw = tanf(3.14159265358979f * f / sr) / wc;
+            const float tn = xw <= 1.f ? cosf(order * acosf(xw)) : coshf(order * acoshf(xw));
+            v = 1.0f / (1.0f + eps2 * tn * tn);
+        }
+        g[k] = v;
+    }
+}
+
 struct FrameTables { FftDesc fd; cplx *tw, *wsplit; };
 static std::mutex g_mu;
 static std::map<std::pair<int, int>, FrameTables> g_tabs;
@@ -549,6 +596,19 @@ extern "C" int egr_randn(float* out, int64_t per_row, int rows, uint64_t seed, c
     const long long n = ((per_row + 3) / 4) * rows;
     hipLaunchKernelGGL(k_randn, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, out, (long long)per_row, rows,
                        (unsigned long long)seed, (const long long*)row_ids);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_lowpass_gain(const float* mag, int B, int T, int ldm, int nb, float pct, float sr, int order,
+                                float ripple_db, int64_t nbins, int* cut_out, float* gain, void* stream) {
+    EGR_CHECK(mag && cut_out && gain && B >= 1 && B <= 65535 && T >= 1 && nb >= 2 && nb <= ldm && nbins >= 2 && order >= 1,
+              EGR_ERR_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_cutoff_bin, dim3(B), dim3(256), nb * sizeof(float), st, mag, T, ldm, nb, pct, cut_out);
+    const float eps2 = powf(10.0f, ripple_db / 10.0f) - 1.0f;
+    hipLaunchKernelGGL(k_cheby_gain, dim3(grid1d(nbins), B), dim3(256), 0, st, cut_out, nb, sr, order, eps2, (long long)nbins,
+                       gain);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }

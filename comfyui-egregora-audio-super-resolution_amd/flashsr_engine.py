@@ -234,6 +234,32 @@ class FlashSREngine:
                         act_param=cfg.log_floor, bias=False, w=self.w["mel_fb"])
         return mel.view(B, cfg.n_frames, cfg.n_mels, 1)
 
+    # input low-pass (lowpass_input=True): cutoff from the STFT energy, zero-phase 8th-order Chebyshev-I gain applied
+    # in the frequency domain on the Fat-Llama transform passes (UPSTREAM-RECALL of FlashSR's cheby/filtfilt
+    # pre-filter; edge handling differs from a time-domain filtfilt by construction).
+    LP_PCT, LP_ORDER, LP_RIPPLE_DB = 0.985, 8, 0.05
+
+    def lowpass(self, x):
+        from . import fatllama_engine as fe
+        cfg = self.cfg
+        B, L = x.shape
+        rpad = (cfg.n_fft - cfg.hop) // 2
+        T = (L + 2 * rpad - cfg.n_fft) // cfg.hop + 1
+        nb = cfg.n_fft // 2 + 1
+        mag = torch.empty((B, T, self.ldm), dtype=torch.float32, device=self.dev)
+        native.check(self.L.egr_stft_frames(_p(x), B, L, cfg.n_fft, cfg.hop, rpad, T, T, self.ldm, _p(self.window), _p(mag),
+                                            self._st()), "egr_stft_frames")
+        cut = torch.empty((B,), dtype=torch.int32, device=self.dev)
+        nbins = L // 2 + 1
+        gain = torch.empty((B, nbins), dtype=torch.float32, device=self.dev)
+        native.check(self.L.egr_lowpass_gain(_p(mag), B, T, self.ldm, nb, self.LP_PCT, float(cfg.sr), self.LP_ORDER,
+                                             self.LP_RIPPLE_DB, nbins, _p(cut), _p(gain), self._st()), "egr_lowpass_gain")
+        plan = fe._plan(L, B, 1, self.dev.index or 0)
+        y = torch.empty_like(x)
+        native.check(self.L.egr_spectral_gain(C.c_void_p(plan), _p(x), _p(gain), _p(y), self._st()), "egr_spectral_gain")
+        self.last_cutoff_bins = cut
+        return y
+
     def _vae_res(self, x, name):
         h = self.conv3(self.groupnorm(x, name + ".norm1", 1e-6, True), name + ".conv1")
         h = self.groupnorm(h, name + ".norm2", 1e-6, True)
@@ -381,9 +407,12 @@ class FlashSREngine:
                                       self._st()), "egr_randn")
         return out
 
-    def forward_rows(self, x: torch.Tensor, noise: torch.Tensor, stages: Optional[dict] = None) -> torch.Tensor:
+    def forward_rows(self, x: torch.Tensor, noise: torch.Tensor, stages: Optional[dict] = None,
+                     lowpass: bool = False) -> torch.Tensor:
         """x [R, chunk] float32 CUDA, noise [R, h, w, z] (channels-last) -> y [R, chunk]."""
         x = x.contiguous()
+        if lowpass:
+            x = self.lowpass(x)
         mel = self.log_mel(x)
         z_c = self.vae_encode(mel)
         v = self.unet(self.concat(noise, z_c))
@@ -445,21 +474,20 @@ def set_engine(engine: Optional[FlashSREngine]):
     _ENGINE = engine
 
 
-def infer_rows(eng: FlashSREngine, rows_x: torch.Tensor, row_ids: torch.Tensor, seed: int) -> torch.Tensor:
+def infer_rows(eng: FlashSREngine, rows_x: torch.Tensor, row_ids: torch.Tensor, seed: int,
+               lowpass: bool = False) -> torch.Tensor:
     """rows_x [R, chunk] -> [R, chunk], processed ROWS_PER_PASS rows at a time; noise keyed by global row id."""
     outs = []
     for lo in range(0, rows_x.shape[0], ROWS_PER_PASS):
         xs = rows_x[lo:lo + ROWS_PER_PASS]
         ids = row_ids[lo:lo + ROWS_PER_PASS].contiguous()
-        outs.append(eng.forward_rows(xs, eng.noise(xs.shape[0], ids, seed)))
+        outs.append(eng.forward_rows(xs, eng.noise(xs.shape[0], ids, seed), lowpass=lowpass))
     return torch.cat(outs, 0)
 
 
 def infer_spans(x_ct: torch.Tensor, n_chunks: int, win: int, hop: int, lowpass: bool) -> torch.Tensor:
     """[C,T] @48 kHz on the GPU -> predictions [n_chunks, C, win].  Chunks are sharded over the ranks of the
     default process group when one exists (contiguous blocks, one all-gather; shard.py)."""
-    if lowpass:
-        raise RuntimeError("lowpass_input=True is not built yet in this revision (the default is False)")
     eng = ensure_ready()
     Cn = x_ct.shape[0]
     if win != eng.cfg.chunk:
@@ -469,7 +497,7 @@ def infer_spans(x_ct: torch.Tensor, n_chunks: int, win: int, hop: int, lowpass: 
         chunks = device_ops.chunk_gather(x_ct, win, hop, lo, hi - lo)                 # [n, C, win]
         ids = (torch.arange(lo, hi, device=x_ct.device, dtype=torch.int64)[:, None] * Cn +
                torch.arange(Cn, device=x_ct.device, dtype=torch.int64)[None, :]).reshape(-1)
-        y = infer_rows(eng, chunks.view(-1, win), ids, SEED)
+        y = infer_rows(eng, chunks.view(-1, win), ids, SEED, lowpass=bool(lowpass))
         return y.view(hi - lo, Cn, win)
 
     return shard.sharded_chunks(run_block, n_chunks, (Cn, win), x_ct.device)

@@ -27,6 +27,7 @@ SIGNATURES = {
     "egr_fatllama_plan_create_bluestein": (_i, [C.POINTER(_vp), _i64, _i, _i]),
     "egr_fatllama_plan_destroy": (_i, [_vp]),
     "egr_fatllama_enhance": (_i, [_vp, _vp, _vp, _i, _f, _u, _vp]),
+    "egr_spectral_gain": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "egr_fatllama_last_peaks": (_i, [_vp, C.POINTER(_f), C.POINTER(_f), _vp]),
     "egr_fatllama_set_profiling": (_i, [_vp, _i]),
     "egr_fatllama_kernel_times": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64),
@@ -49,6 +50,7 @@ SIGNATURES = {
     "egr_snake_aa": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "egr_col2im_convtr1d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "egr_stft_frames": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "egr_lowpass_gain": (_i, [_vp, _i, _i, _i, _i, _f, _f, _i, _f, _i64, _vp, _vp, _vp]),
     "egr_randn": (_i, [_vp, _i64, _i, C.c_uint64, _vp, _vp]),
 }
 

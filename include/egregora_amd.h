@@ -79,6 +79,10 @@ int egr_fatllama_plan_destroy(egr_fatllama_plan* plan);
 int egr_fatllama_enhance(egr_fatllama_plan* plan, const float* x, float* out, int max_iter, float threshold,
                          unsigned flags, void* stream);
 
+/* y = irfft(rfft(x) * gain) per channel on a packed-real plan with factor 1: x, y [channels][N], gain
+ * [channels][N/2+1] (real, one value per half-spectrum bin).  Used by the FlashSR input low-pass. */
+int egr_spectral_gain(egr_fatllama_plan* plan, const float* x, const float* gain, float* y, void* stream);
+
 /* Debug / roofline helpers: the forward transposed half-spectrum after `iters` iterations is not
  * exposed; these run single stages of the loop so tests can bisect. which: 0 = peaks {pin[C], pout[C]}
  * of the last enhance call copied to host (synchronises the stream). */
@@ -175,6 +179,11 @@ int egr_col2im_convtr1d(const float* Y, const float* bias, const float* add, flo
 /* Mel front-end STFT: x [B][L] -> |STFT| frames [B][T][ldm], reflect padding rpad, frames >= t_valid zeroed. */
 int egr_stft_frames(const float* x, int B, int L, int n_fft, int hop, int rpad, int T, int t_valid, int ldm,
                     const float* window, float* mag, void* stream);
+/* FlashSR `lowpass_input=True`: per row, cutoff bin from STFT magnitudes mag [B][T][ldm] (highest bin whose
+ * cumulative time-summed energy is below pct of the total, + 1) -> cut_out[B]; then the zero-phase Chebyshev-I
+ * amplitude gain 1/(1 + eps^2 T_order^2(tan(pi f/sr)/tan(pi fc/sr))) on `nbins` bins 0..sr/2 -> gain [B][nbins]. */
+int egr_lowpass_gain(const float* mag, int B, int T, int ldm, int nb, float pct, float sr, int order, float ripple_db,
+                     int64_t nbins, int* cut_out, float* gain, void* stream);
 /* Standard normals: element e of row r is a function of (seed, row_ids[r] or r, e) only (Philox4x32-10). */
 int egr_randn(float* out, int64_t per_row, int rows, uint64_t seed, const int64_t* row_ids, void* stream);
 

@@ -35,6 +35,41 @@ def log_mel(x, cfg, mel_fb):
     return torch.log(torch.clamp(mel[:, :cfg.n_frames], min=cfg.log_floor))[:, None]
 
 
+def lowpass_ref(x, cfg, pct=0.985, order=8, ripple_db=0.05):
+    """lowpass_input=True as this build defines it: per row, cutoff bin = highest STFT bin whose cumulative
+    (time-summed) magnitude is still below pct of the total, + 1 (the scan of AudioSR's `_find_cutoff`, as recalled);
+    zero-phase Chebyshev-I amplitude gain 1/(1 + eps^2 T_n^2(tan(pi f/sr)/tan(pi fc/sr))) applied to rfft bins."""
+    p = (cfg.n_fft - cfg.hop) // 2
+    xp = F.pad(x[:, None, :], (p, p), mode="reflect")[:, 0]
+    win = torch.hann_window(cfg.n_fft, periodic=True, dtype=x.dtype)
+    mag = torch.fft.rfft(xp.unfold(1, cfg.n_fft, cfg.hop) * win, dim=-1).abs()      # [B,T,nb]
+    e = mag.sum(1).double()
+    nb = e.shape[1]
+    ys, cuts = [], []
+    L = x.shape[1]
+    nbins = L // 2 + 1
+    f = 0.5 * cfg.sr * torch.arange(nbins, dtype=torch.float64) / (nbins - 1)
+    eps2 = 10.0 ** (ripple_db / 10.0) - 1.0
+    for b in range(x.shape[0]):
+        c = torch.cumsum(e[b], 0)
+        lim = c[-1] * pct
+        cut = 0
+        for i in range(1, nb):
+            if c[nb - i] < lim:
+                cut = nb - i
+                break
+        cuts.append(cut)
+        fc = max(1.0, min(cut / (nb - 1), 0.999) * 0.5 * cfg.sr)
+        wc = math.tan(math.pi * fc / cfg.sr)
+        xw = torch.tan(math.pi * torch.clamp(f, max=0.4999 * cfg.sr) / cfg.sr) / wc
+        tn = torch.where(xw <= 1, torch.cos(order * torch.acos(torch.clamp(xw, max=1.0))),
+                         torch.cosh(order * torch.acosh(torch.clamp(xw, min=1.0))))
+        g = 1.0 / (1.0 + eps2 * tn * tn)
+        g = torch.where(f < 0.4999 * cfg.sr, g, torch.zeros_like(g))
+        ys.append(torch.fft.irfft(torch.fft.rfft(x[b].double()) * g, n=L).float())
+    return torch.stack(ys), cuts
+
+
 # ------------------------------------------------------------------ VAE
 def _vae_res(x, P, name, G):
     h = _conv2(F.silu(_gn(x, P, name + ".norm1", G, 1e-6)), P, name + ".conv1")

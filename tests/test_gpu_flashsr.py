@@ -181,6 +181,37 @@ def test_logmel_vs_torch(eng):
     close(got.permute(0, 3, 1, 2), want, 5e-5)
 
 
+def test_lowpass_input_vs_torch(pack):
+    """lowpass_input=True: cutoff detection + zero-phase Chebyshev gain on the device vs the torch definition."""
+    from egregora_amd import flashsr_arch as A, flashsr_engine as E
+    from oracle import flashsr_torch as R
+    import dataclasses
+    cfg = A.tiny_config()
+    cfg = dataclasses.replace(cfg, chunk=3840, n_fft=128, hop=30)
+    e = E.FlashSREngine(cfg, A.init_params(cfg, 0))
+    g = torch.Generator().manual_seed(11)
+    t = torch.arange(cfg.chunk) / cfg.sr
+    # band-limited rows (content below ~6 kHz / ~3 kHz) plus a little wide-band noise
+    x = torch.stack([sum(torch.sin(2 * math.pi * f0 * t + i) / (i + 1) for i, f0 in enumerate((300.0, 1200.0, 2500.0, 5800.0))),
+                     sum(torch.sin(2 * math.pi * f0 * t + i) / (i + 1) for i, f0 in enumerate((200.0, 900.0, 2900.0)))]).float()
+    x = 0.3 * x / x.abs().max() + 1e-4 * torch.randn(2, cfg.chunk, generator=g)
+    want, cuts = R.lowpass_ref(x, cfg)
+    got = e.lowpass(x.cuda())
+    assert e.last_cutoff_bins.cpu().tolist() == cuts and 0 < cuts[1] < cuts[0] < cfg.n_fft // 2
+    close(got, want, 2e-4)
+    # and the full-size chunk length plans too
+    cfgF = A.FlashSRConfig()
+    eF = E.FlashSREngine.__new__(E.FlashSREngine)          # only the pieces lowpass() needs
+    eF.cfg, eF.dev, eF.L = cfgF, torch.device("cuda"), e.L
+    eF.window = torch.hann_window(cfgF.n_fft, periodic=True).cuda()
+    eF.ldm = ((cfgF.n_fft // 2 + 1 + 15) // 16) * 16
+    xf = 0.2 * torch.randn(2, cfgF.chunk, generator=g)
+    wantF, cutsF = R.lowpass_ref(xf, cfgF)
+    gotF = eF.lowpass(xf.cuda())
+    assert eF.last_cutoff_bins.cpu().tolist() == cutsF
+    close(gotF, wantF, 2e-4)
+
+
 def test_randn_is_rank_independent_and_normal(eng):
     e, cfg, P = eng
     ids = torch.tensor([5, 6, 7, 1000], dtype=torch.int64, device="cuda")
