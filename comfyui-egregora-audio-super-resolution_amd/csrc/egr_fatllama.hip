@@ -14,6 +14,7 @@
 // spectrum is never materialised in natural order and nothing is transposed.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -42,6 +43,7 @@ struct ColP {
     int L, ncols, nplanes;
     int TC, TClog2, ntiles, tiles_per_xcd;
     const cplx* tw;        // W_L stage table
+    const dcplx* twd;      // the same table in double precision (power-twiddle path)
     Tw2 big;               // W_(L*ncols)^r
 };
 
@@ -50,6 +52,7 @@ struct RowP {
     FftDesc f;
     int L, R, Ma, Mb;
     const cplx* tw;        // W_L stage table
+    const dcplx* twd;      // the same table in double precision (power-twiddle path)
     Tw2 wo;                // W_N^o, o < R
     const cplx* wk;        // W_(2L)^k = W_N^(R*k), k < L
     float thr2, inv_M;
@@ -80,10 +83,10 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // MODE 4: forward (state -> FFT -> twiddle -> state)                        [inner pass of a 3-level plan]
 // MODE 5: last, plain (state -> twiddle^-1 -> IFFT -> out = d)               [spectral-gain filter]
 template <int MODE>
-__global__ __launch_bounds__(256) void k_col(ColP p, long long M, long long N, float thr, cplx* __restrict__ work,
+__global__ __launch_bounds__(1024) void k_col(ColP p, long long M, long long N, float thr, cplx* __restrict__ work,
                                               float* __restrict__ out, unsigned* __restrict__ peak_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ float red[8];
+    __shared__ float red[16];
     // XCD-aware tile order: the dispatcher places block b on XCD b%8; give every XCD a contiguous run
     // of column tiles so the two tiles sharing a 128-byte line hit the same L2.
     const int tile = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void k_col(ColP p, long long M, long long N, f
         cur[e] = v;
     }
     __syncthreads();
-    if (MODE == 1 || MODE == 2 || MODE == 3 || MODE == 5) lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, true);
+    if (MODE == 1 || MODE == 2 || MODE == 3 || MODE == 5) lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, true, p.twd);
     if (MODE == 5) {
         for (int e = threadIdx.x; e < nel; e += blockDim.x) {
             const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256) void k_col(ColP p, long long M, long long N, f
         }
         return;
     }
-    lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, false);
+    lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, false, p.twd);
     for (int e = threadIdx.x; e < nel; e += blockDim.x) {
         const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
         if (col < nc) W[(size_t)i * nc + col] = cmul(cur[e], tw2(p.big, (unsigned)col * (unsigned)i));
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void k_col(ColP p, long long M, long long N, f
 }
 
 // Row-pair kernel: outer indices oa = pair, ob = R - pair of the in-place state.
-__global__ __launch_bounds__(256) void k_row(RowP p, long long M, cplx* __restrict__ work) {
+__global__ __launch_bounds__(1024) void k_row(RowP p, long long M, cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int L = p.L, R = p.R;
     const int oa = blockIdx.x;
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) void k_row(RowP p, long long M, cplx* __restri
         if (!self) cur[L + e] = gb[e];
     }
     __syncthreads();
-    lds_fft<false>(cur, alt, p.f, p.tw, nrows, 0, 1, L, false);
+    lds_fft<false>(cur, alt, p.f, p.tw, nrows, 0, 1, L, false, p.twd);
 
     // real-split, threshold, un-split on the (k, M-k) pairs; Z[o + R*k] sits at row(o)[k]
     const cplx wa = tw2(p.wo, (unsigned)oa);
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256) void k_row(RowP p, long long M, cplx* __restri
         if (!same) rb[pb] = make_float2(sc * (E2.x + O2.y), -sc * (E2.y - O2.x));
     }
     __syncthreads();
-    lds_fft<false>(cur, alt, p.f, p.tw, nrows, 0, 1, L, true);
+    lds_fft<false>(cur, alt, p.f, p.tw, nrows, 0, 1, L, true, p.twd);
     for (int e = threadIdx.x; e < L; e += blockDim.x) {
         ga[e] = cur[e];
         if (!self) gb[e] = cur[L + e];
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256) void k_colz(ColP p, ChirpP cp, long long P, fl
         cur[e] = v;
     }
     __syncthreads();
-    if (MODE != 0) lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, true);
+    if (MODE != 0) lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, true, p.twd);
     if (MODE == 2) {
         float mx = 0.f;
         for (int e = threadIdx.x; e < nel; e += blockDim.x) {
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(256) void k_colz(ColP p, ChirpP cp, long long P, fl
         }
         __syncthreads();
     }
-    lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, false);
+    lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, false, p.twd);
     for (int e = threadIdx.x; e < nel; e += blockDim.x) {
         const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
         if (col < nc) W[(size_t)i * nc + col] = cmul(cur[e], tw2(p.big, (unsigned)col * (unsigned)i));
@@ -479,6 +482,7 @@ struct egr_fatllama_plan {
     cplx* d_work;
     unsigned* d_peaks;   // [2*C]: peak_in[C], peak_out[C]
     bool profiling;
+    int threads;                  // workgroup size of the loop kernels (256 or 512)
     std::vector<hipEvent_t> ev;   // pairs (start, stop) tagged by kind
     std::vector<int> ev_kind;     // 0 = row, 1 = outer column pass, 2 = inner column pass
 };
@@ -489,6 +493,17 @@ static int upload(egr_fatllama_plan* p, const std::vector<float2>& h, const cplx
     p->dev_allocs.push_back(ptr);
     EGR_HIP(hipMemcpy(ptr, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice));
     *d = (const cplx*)ptr;
+    return EGR_OK;
+}
+
+static int upload_d(egr_fatllama_plan* p, int L, const dcplx** d) {
+    std::vector<double2> h;
+    make_twiddles_d(h, L, 1, L);
+    void* ptr = nullptr;
+    EGR_HIP(hipMalloc(&ptr, h.size() * sizeof(double2)));
+    p->dev_allocs.push_back(ptr);
+    EGR_HIP(hipMemcpy(ptr, h.data(), h.size() * sizeof(double2), hipMemcpyHostToDevice));
+    *d = (const dcplx*)ptr;
     return EGR_OK;
 }
 
@@ -558,6 +573,8 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     egr_fatllama_plan* p = new egr_fatllama_plan();
     p->n_in = n_in; p->C = channels; p->factor = factor; p->sp = sp; p->profiling = false;
     p->bluestein = bluestein_n > 0;
+    p->threads = 512;    // 16 waves per CU at 2 workgroups per CU: measured 1.4x over 256
+    if (const char* e = getenv("EGR_FL_THREADS")) { const int t = atoi(e); if (t == 256 || t == 512 || t == 1024) p->threads = t; }
     p->d_bhat = nullptr;
     p->d_work = nullptr;
     p->d_peaks = nullptr;
@@ -573,6 +590,7 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     a.TC = sp.TC; a.TClog2 = sp.TClog2; a.ntiles = ceil_div(a.ncols, a.TC); a.tiles_per_xcd = ceil_div(a.ntiles, 8);
     make_twiddles(h, sp.M1, 1, sp.M1);
     if ((rc = upload(p, h, &a.tw))) return fail(rc);
+    if ((rc = upload_d(p, sp.M1, &a.twd))) return fail(rc);
     if ((rc = make_tw2(p, M, &a.big))) return fail(rc);
     // ---- inner column pass B (3 levels): per k1 plane, L = M2, columns = M3 ----
     RowP& r = p->row;
@@ -582,6 +600,7 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
         b.TC = sp.TCb; b.TClog2 = sp.TCblog2; b.ntiles = ceil_div(b.ncols, b.TC); b.tiles_per_xcd = ceil_div(b.ntiles, 8);
         make_twiddles(h, sp.M2, 1, sp.M2);
         if ((rc = upload(p, h, &b.tw))) return fail(rc);
+        if ((rc = upload_d(p, sp.M2, &b.twd))) return fail(rc);
         if ((rc = make_tw2(p, (int64_t)sp.M2 * sp.M3, &b.big))) return fail(rc);
         r.f = sp.f3; r.L = sp.M3; r.R = sp.M1 * sp.M2; r.Ma = sp.M1; r.Mb = sp.M2;
     } else {
@@ -589,6 +608,7 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     }
     make_twiddles(h, r.L, 1, r.L);
     if ((rc = upload(p, h, &r.tw))) return fail(rc);
+    if ((rc = upload_d(p, r.L, &r.twd))) return fail(rc);
     make_twiddles(h, r.L, 1, 2 * (int64_t)r.L);
     if ((rc = upload(p, h, &r.wk))) return fail(rc);
     {   // W_N^o for o < R, as hi/lo tables over the range [0, R)
@@ -650,6 +670,11 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
             return fail(EGR_ERR_HIP);
         }
     }
+    {   // stage twiddles W^2..W^(r-1) by multiplication from one loaded W^1 (default) or all loaded (EGR_FL_TWPOW=0)
+        int v = 1;
+        if (const char* e2 = getenv("EGR_FL_TWPOW")) v = atoi(e2);
+        p->colA.f.tw_pow = v; p->colB.f.tw_pow = v; p->row.f.tw_pow = v;
+    }
     *out = p;
     return EGR_OK;
 }
@@ -681,6 +706,8 @@ extern "C" int egr_fatllama_plan_create(egr_fatllama_plan** out, int64_t n_in, i
     EGR_CHECK(n_in >= 1 && factor >= 1 && channels >= 1 && channels <= 64, EGR_ERR_ARG,
               "n_in=%lld channels=%d factor=%d out of range", (long long)n_in, channels, factor);
     const int64_t N = n_in * factor;
+    if (m1_hint <= 0) { if (const char* e = getenv("EGR_FL_M1")) m1_hint = atoi(e); }
+    if (tc_hint <= 0) { if (const char* e = getenv("EGR_FL_TC")) tc_hint = atoi(e); }
     FlSplit sp = plan_split(N, m1_hint, tc_hint);
     if (!sp.ok) {
         if (N >= 2 && bluestein_length(2 * N - 1, &sp)) return build_plan(out, n_in, channels, factor, sp, N);
@@ -762,13 +789,13 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
                            (flags & EGR_FL_PCM_IN) ? 1 : 0, peak_in);
     }
     const dim3 gA(8 * A.tiles_per_xcd, C), gB(8 * B.tiles_per_xcd, C * (three ? B.nplanes : 1)), grow(R.R / 2 + 1, C),
-        blk(256);
+        blk(p->bluestein ? 256 : p->threads), blk256(256);
     const size_t lc = p->sp.lds_col, lb = p->sp.lds_colb, lr = p->sp.lds_row;
     size_t slot = 0;
     if (max_iter == 0) {
         const long long Nr = p->bluestein ? (long long)p->chirp.N : N;
         const int nb = (int)((Nr + 255) / 256 < 2048 ? (Nr + 255) / 256 : 2048);
-        hipLaunchKernelGGL(k_noiter, dim3(nb, C), blk, 0, st, out, Nr, thr, peak_out);
+        hipLaunchKernelGGL(k_noiter, dim3(nb, C), blk256, 0, st, out, Nr, thr, peak_out);
     } else if (p->bluestein) {
         const ChirpP cp = p->chirp;
         const long long P = M;
@@ -817,7 +844,7 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
     if (flags & (EGR_FL_NORMALIZE | EGR_FL_AUTOSCALE | EGR_FL_NODE_POST)) {
         const long long Nr = p->bluestein ? (long long)p->chirp.N : N;
         const int nb = (int)((Nr + 255) / 256 < 2048 ? (Nr + 255) / 256 : 2048);
-        hipLaunchKernelGGL(k_finalize, dim3(nb, C), blk, 0, st, out, Nr, C, flags, peak_in, peak_out);
+        hipLaunchKernelGGL(k_finalize, dim3(nb, C), blk256, 0, st, out, Nr, C, flags, peak_in, peak_out);
     }
     EGR_HIP(hipGetLastError());
     return EGR_OK;

@@ -20,7 +20,13 @@ struct FftDesc {
     int radix[EGR_MAX_STAGES];   // radix of stage s
     int ns[EGR_MAX_STAGES];      // product of the radices of stages < s
     float inv_ns[EGR_MAX_STAGES];
+    int tw_pow;                  // 1: load W^1 (double precision) per butterfly and form W^2..W^(r-1) in fp64
 };
+
+typedef double2 dcplx;
+__device__ __forceinline__ dcplx dcmul(dcplx a, dcplx b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
 
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -85,12 +91,47 @@ template <> struct Bfly<4> {
     }
 };
 
+// Composite radix R = R1*R2 as two nested register DFTs (n = R2*n1 + n2, k = k1 + R1*k2) with compile-time
+// inner twiddles W_R^(n2*k1): halves the number of LDS round trips of a transform.
+template <int R1, int R2> struct BflyComp {
+    static constexpr int R = R1 * R2;
+    static __device__ __forceinline__ void run(cplx (&v)[R]) {
+        cplx y[R];
+#pragma unroll
+        for (int n2 = 0; n2 < R2; ++n2) {
+            cplx t[R1];
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) t[n1] = v[R2 * n1 + n2];
+            Bfly<R1>::run(t);
+#pragma unroll
+            for (int k1 = 0; k1 < R1; ++k1) {
+                const int m = (n2 * k1) % R;
+                y[k1 * R2 + n2] = (m == 0) ? t[k1] : cmul(t[k1], make_float2(Trig<R>::c[m], -Trig<R>::s[m]));
+            }
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) {
+            cplx t[R2];
+#pragma unroll
+            for (int n2 = 0; n2 < R2; ++n2) t[n2] = y[k1 * R2 + n2];
+            Bfly<R2>::run(t);
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = t[k2];
+        }
+    }
+};
+template <> struct Bfly<8> { static __device__ __forceinline__ void run(cplx (&v)[8]) { BflyComp<4, 2>::run(v); } };
+template <> struct Bfly<9> { static __device__ __forceinline__ void run(cplx (&v)[9]) { BflyComp<3, 3>::run(v); } };
+template <> struct Bfly<16> { static __device__ __forceinline__ void run(cplx (&v)[16]) { BflyComp<4, 4>::run(v); } };
+template <> struct Bfly<25> { static __device__ __forceinline__ void run(cplx (&v)[25]) { BflyComp<5, 5>::run(v); } };
+
 // One radix-R stage over `nseq` sequences.  SEQFAST: sequence index is the fastest thread index
 // (column tiles, nseq = 1<<seq_log2); otherwise nseq is 1 or 2 and the butterfly index is fastest.
 template <int R, bool SEQFAST>
 __device__ __forceinline__ void fft_stage(const cplx* __restrict__ in, cplx* __restrict__ out, int L, int Ns,
-                                          float inv_ns, const cplx* __restrict__ tw, int nseq, int seq_log2,
-                                          int es, int ss, bool swap_in, bool swap_out) {
+                                          float inv_ns, const cplx* __restrict__ tw, const dcplx* __restrict__ twd,
+                                          int nseq, int seq_log2, int es, int ss, bool swap_in, bool swap_out,
+                                          bool tw_pow) {
     const int nb = L / R;
     const int total = nb * nseq;
     const int twstep = L / (Ns * R);
@@ -115,8 +156,19 @@ __device__ __forceinline__ void fft_stage(const cplx* __restrict__ in, cplx* __r
         }
         if (Ns > 1) {
             const int base = k * twstep;
+            if (tw_pow) {
+                // ONE 16-byte load of the fp64 table entry; W^t by a depth-log2(t) product tree in fp64, rounded once
+                // to float: as accurate as reading every W^t from a float table, a third / a quarter of the loads.
+                dcplx w[R];
+                w[1] = twd[base];
 #pragma unroll
-            for (int t = 1; t < R; ++t) v[t] = cmul(v[t], tw[base * t]);
+                for (int t = 2; t < R; ++t) w[t] = dcmul(w[t >> 1], w[t - (t >> 1)]);
+#pragma unroll
+                for (int t = 1; t < R; ++t) v[t] = cmul(v[t], make_float2((float)w[t].x, (float)w[t].y));
+            } else {
+#pragma unroll
+                for (int t = 1; t < R; ++t) v[t] = cmul(v[t], tw[base * t]);
+            }
         }
         Bfly<R>::run(v);
         cplx* dst = out + s * ss + ((j - k) * R + k) * es;
@@ -133,20 +185,28 @@ __device__ __forceinline__ void fft_stage(const cplx* __restrict__ in, cplx* __r
 // Caller must __syncthreads() after filling `cur`.
 template <bool SEQFAST>
 __device__ __forceinline__ void lds_fft(cplx*& cur, cplx*& alt, const FftDesc& d, const cplx* __restrict__ tw,
-                                        int nseq, int seq_log2, int es, int ss, bool inverse) {
+                                        int nseq, int seq_log2, int es, int ss, bool inverse,
+                                        const dcplx* __restrict__ twd = nullptr) {
     for (int s = 0; s < d.nst; ++s) {
         const bool si = inverse && (s == 0);
         const bool so = inverse && (s == d.nst - 1);
         const int Ns = d.ns[s];
         const float inv = d.inv_ns[s];
+        const bool tp = d.tw_pow != 0 && twd != nullptr;
         switch (d.radix[s]) {
-            case 2: fft_stage<2, SEQFAST>(cur, alt, d.L, Ns, inv, tw, nseq, seq_log2, es, ss, si, so); break;
-            case 3: fft_stage<3, SEQFAST>(cur, alt, d.L, Ns, inv, tw, nseq, seq_log2, es, ss, si, so); break;
-            case 4: fft_stage<4, SEQFAST>(cur, alt, d.L, Ns, inv, tw, nseq, seq_log2, es, ss, si, so); break;
-            case 5: fft_stage<5, SEQFAST>(cur, alt, d.L, Ns, inv, tw, nseq, seq_log2, es, ss, si, so); break;
-            case 7: fft_stage<7, SEQFAST>(cur, alt, d.L, Ns, inv, tw, nseq, seq_log2, es, ss, si, so); break;
-            case 11: fft_stage<11, SEQFAST>(cur, alt, d.L, Ns, inv, tw, nseq, seq_log2, es, ss, si, so); break;
-            default: fft_stage<13, SEQFAST>(cur, alt, d.L, Ns, inv, tw, nseq, seq_log2, es, ss, si, so); break;
+            case 2: fft_stage<2, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+            case 3: fft_stage<3, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+            case 4: fft_stage<4, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+            case 5: fft_stage<5, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+            case 7: fft_stage<7, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+#ifdef EGR_COMPOSITE_RADIX   // measured slower in round 1: one kernel holding every radix needs 190 VGPRs (occupancy 2)
+            case 8: fft_stage<8, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+            case 9: fft_stage<9, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+            case 16: fft_stage<16, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+            case 25: fft_stage<25, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+#endif
+            case 11: fft_stage<11, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+            default: fft_stage<13, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
         }
         cplx* t = cur; cur = alt; alt = t;
     }

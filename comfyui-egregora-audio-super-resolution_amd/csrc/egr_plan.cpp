@@ -4,6 +4,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -40,6 +41,17 @@ bool make_schedule(int L, FftDesc* d) {
         return true;
     };
     if (L < 1) return false;
+    // Composite register butterflies (16 / 8 / 25 / 9) exist in egr_fft_device.h but are compiled out by default
+    // (EGR_COMPOSITE_RADIX): fewer LDS stages, but the register cost lowered occupancy and measured slower.
+#ifdef EGR_COMPOSITE_RADIX
+    static const bool small_only = [] { const char* e = getenv("EGR_FFT_RADIX"); return e && e[0] == 's'; }();
+#else
+    const bool small_only = true;
+#endif
+    if (!small_only) {
+        while (n % 16 == 0) { if (!push(16)) return false; n /= 16; }
+        if (n % 8 == 0) { if (!push(8)) return false; n /= 8; }
+    }
     while (n % 4 == 0) {
         if (!push(4)) return false;
         n /= 4;
@@ -47,6 +59,10 @@ bool make_schedule(int L, FftDesc* d) {
     if (n % 2 == 0) {
         if (!push(2)) return false;
         n /= 2;
+    }
+    if (!small_only) {
+        while (n % 25 == 0) { if (!push(25)) return false; n /= 25; }
+        while (n % 9 == 0) { if (!push(9)) return false; n /= 9; }
     }
     const int odd[] = {3, 5, 7, 11, 13};
     for (int p : odd) {
@@ -67,6 +83,16 @@ void make_twiddles(std::vector<float2>& out, int64_t count, int64_t num, int64_t
         __int128 r = ((__int128)j * (__int128)num) % (__int128)den;
         long double ang = -two_pi * (long double)(int64_t)r / (long double)den;
         out[(size_t)j] = make_float2((float)cosl(ang), (float)sinl(ang));
+    }
+}
+
+void make_twiddles_d(std::vector<double2>& out, int64_t count, int64_t num, int64_t den) {
+    out.resize((size_t)count);
+    const long double two_pi = 6.283185307179586476925286766559L;
+    for (int64_t j = 0; j < count; ++j) {
+        __int128 r = ((__int128)j * (__int128)num) % (__int128)den;
+        long double ang = -two_pi * (long double)(int64_t)r / (long double)den;
+        out[(size_t)j] = make_double2((double)cosl(ang), (double)sinl(ang));
     }
 }
 

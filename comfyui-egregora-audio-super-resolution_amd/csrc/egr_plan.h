@@ -14,6 +14,7 @@ bool make_schedule(int L, FftDesc* d);
 // W_L^j = exp(-2*pi*i*j/L * mul), j in [0,count), evaluated in double, rounded once to float.
 // (general form: exp(-2*pi*i * j * num / den))
 void make_twiddles(std::vector<float2>& out, int64_t count, int64_t num, int64_t den);
+void make_twiddles_d(std::vector<double2>& out, int64_t count, int64_t num, int64_t den);
 
 struct FlSplit {
     bool ok;

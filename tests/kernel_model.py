@@ -8,7 +8,7 @@ import numpy as np
 
 
 def radix_schedule(L, allowed=(4, 2, 3, 5, 7, 11, 13)):
-    """Same rule as egr::make_schedule: pull 4s first, then a single 2, then odd primes ascending."""
+    """Same rule as egr::make_schedule (default build): 4s, one 2, then odd primes ascending."""
     rad, n = [], L
     while n % 4 == 0:
         rad.append(4); n //= 4
