@@ -28,6 +28,9 @@ struct ConvP {
     int B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act;
     int M, K;
     float act_param;
+    // output placement: pixel (b, oy, ox) of the OH x OW grid is written at (b, oy*osy + ooy, ox*osx + oox) of an
+    // OHF x OWF image (identity by default); lets four 2x2 "phase" convolutions fill a 2x-upsampled output.
+    int osy, osx, ooy, oox, OHF, OWF;
 };
 
 #define BM 128
@@ -223,14 +226,20 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
             const int n = n0 + wn0 + j * 32 + col;
             if (n >= p.Cout) continue;
             const float bv = p.bias ? p.bias[n] : 0.f;
+            const bool ident = (p.osy == 1 && p.osx == 1 && p.OHF == p.OH && p.OWF == p.OW);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
                 if (m >= p.M) continue;
+                size_t mo = (size_t)m;
+                if (!ident) {
+                    const int ox = m % p.OW, t = m / p.OW, oy = t % p.OH, b = t / p.OH;
+                    mo = ((size_t)b * p.OHF + (size_t)oy * p.osy + p.ooy) * p.OWF + (size_t)ox * p.osx + p.oox;
+                }
                 float v = acc[i][j][r] + bv;
                 if (p.bias_b) v += p.bias_b[(size_t)(m / (p.OH * p.OW)) * p.Cout + n];
-                if (p.res) v += p.res[(size_t)m * p.Cout + n];
-                p.y[(size_t)m * p.Cout + n] = apply_act(v, p.act, p.act_param);
+                if (p.res) v += p.res[mo * p.Cout + n];
+                p.y[mo * p.Cout + n] = apply_act(v, p.act, p.act_param);
             }
         }
 }
@@ -339,10 +348,23 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmP p) {
 
 using namespace egr;
 
+extern "C" int egr_conv_nhwc_placed(const float* x, const float* w, const float* bias, const float* bias_b,
+                                    const float* res, float* y, int B, int H, int W, int Cin, int OH, int OW, int Cout,
+                                    int KH, int KW, int stride, int dil, int pad_t, int pad_l, int up2, int act,
+                                    float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF, void* stream);
+
 extern "C" int egr_conv_nhwc(const float* x, const float* w, const float* bias, const float* bias_b, const float* res,
                              float* y, int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
                              int stride, int dil, int pad_t, int pad_l, int up2, int act, float act_param,
                              void* stream) {
+    return egr_conv_nhwc_placed(x, w, bias, bias_b, res, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l,
+                                up2, act, act_param, 1, 1, 0, 0, OH, OW, stream);
+}
+
+extern "C" int egr_conv_nhwc_placed(const float* x, const float* w, const float* bias, const float* bias_b,
+                                    const float* res, float* y, int B, int H, int W, int Cin, int OH, int OW, int Cout,
+                                    int KH, int KW, int stride, int dil, int pad_t, int pad_l, int up2, int act,
+                                    float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF, void* stream) {
     EGR_CHECK(x && w && y, EGR_ERR_ARG, "null x/w/y");
     EGR_CHECK(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && OH >= 1 && OW >= 1 && Cout >= 1 && KH >= 1 && KW >= 1 &&
                   stride >= 1 && dil >= 1,
@@ -355,6 +377,9 @@ extern "C" int egr_conv_nhwc(const float* x, const float* w, const float* bias, 
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW;
     p.stride = stride; p.dil = dil; p.pad_t = pad_t; p.pad_l = pad_l; p.up2 = up2; p.act = act; p.act_param = act_param;
     p.M = (int)M; p.K = KH * KW * Cin;
+    EGR_CHECK(osy >= 1 && osx >= 1 && ooy >= 0 && oox >= 0 && (OH - 1) * osy + ooy < OHF && (OW - 1) * osx + oox < OWF,
+              EGR_ERR_ARG, "bad output placement");
+    p.osy = osy; p.osx = osx; p.ooy = ooy; p.oox = oox; p.OHF = OHF; p.OWF = OWF;
     const bool vec = (Cin % BK) == 0 && (((uintptr_t)x) & 15) == 0;
     const int bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((Cout + bn - 1) / bn));

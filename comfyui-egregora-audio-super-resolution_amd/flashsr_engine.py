@@ -59,6 +59,24 @@ class FlashSREngine:
             w2 = torch.cat([w2, w2.new_zeros(Kp - K, Co)], 0)
         return w2.reshape(Kp // 16, 16, Co).permute(0, 2, 1).contiguous()
 
+    # rows of the 3x3 kernel that collapse onto each of the two source rows, per output phase (a = 0, 1)
+    _PHASE_TAPS = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+
+    def add_upsample_phases(self, key: str, v: torch.Tensor):
+        """nearest-2x upsample followed by a 3x3 conv == four 2x2 convs on the low-res input, one per output phase
+        (a, b): taps that read the same source pixel are pre-summed.  Registers key + '.ph{a}{b}'."""
+        v = v.detach().float()                                           # [Co,Ci,3,3]
+        Co, Ci = v.shape[:2]
+        for a in (0, 1):
+            for b in (0, 1):
+                w = v.new_zeros(Co, Ci, 2, 2)
+                for i, kys in enumerate(self._PHASE_TAPS[a]):
+                    for j, kxs in enumerate(self._PHASE_TAPS[b]):
+                        for ky in kys:
+                            for kx in kxs:
+                                w[:, :, i, j] += v[:, :, ky, kx]
+                self.add_weight(f"{key}.ph{a}{b}", w)
+
     def add_weight(self, key: str, v: torch.Tensor):
         """Register a weight given in torch layout; self.w[key] holds the packed tensor, self.wshape[key] the
         logical (KH, KW, Cin, Cout)."""
@@ -83,6 +101,8 @@ class FlashSREngine:
         for k, v in P.items():
             if k.endswith(".weight") and v.dim() >= 2:
                 self.add_weight(k, v)
+                if ".upsample.conv." in k or (k.startswith("unet.") and ".up.conv." in k):
+                    self.add_upsample_phases(k, v)
             else:
                 self.w[k] = v.detach().float().contiguous().to(self.dev)
 
@@ -134,9 +154,32 @@ class FlashSREngine:
     def conv3(self, x, key, stride=1, up2=0, act=ACT_NONE, res=None, pad=1, bias_t=None):
         B, H, W, Cin = x.shape
         Cout = self.wshape[key + ".weight"][3]
+        if up2 and (key + ".weight.ph00") in self.w and stride == 1 and pad == 1 and res is None and bias_t is None:
+            return self._conv_up2_phases(x, key, act)
         LH, LW = (2 * H, 2 * W) if up2 else (H, W)
         OH, OW = (LH // stride, LW // stride)
         return self.conv(x, key, B, H, W, Cin, OH, OW, Cout, 3, 3, stride, 1, pad, pad, up2, act, res=res, bias_t=bias_t)
+
+    def _conv_up2_phases(self, x, key, act):
+        B, H, W, Cin = x.shape
+        Cout = self.wshape[key + ".weight"][3]
+        y = torch.empty((B, 2 * H, 2 * W, Cout), dtype=torch.float32, device=self.dev)
+        bt = self.w.get(key + ".bias")
+        for a in (0, 1):
+            for b in (0, 1):
+                fl = 2.0 * B * H * W * Cout * 4 * Cin
+                ev = self._prof_begin()
+                native.check(self.L.egr_conv_nhwc_placed(_p(x), _p(self.w[f"{key}.weight.ph{a}{b}"]), _p(bt), _p(None),
+                                                         _p(None), _p(y), B, H, W, Cin, H, W, Cout, 2, 2, 1, 1, 1 - a, 1 - b,
+                                                         0, act, 0.0, 2, 2, a, b, 2 * H, 2 * W, self._st()),
+                             "egr_conv_nhwc_placed")
+                if ev is not None:
+                    bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
+                    vec = "true" if Cin % 16 == 0 else "false"
+                    self._prof_end(ev, f"k_conv_igemm<{bn}, {vec}>", fl, (B, H, W, Cin, H, W, Cout, 2, 2, 1, 1, 2))
+                if self.count_flops:
+                    self.flops += fl
+        return y
 
     def conv1x1(self, x, key, res=None, act=ACT_NONE):
         B, H, W, Cin = x.shape

@@ -153,6 +153,14 @@ int egr_conv_nhwc(const float* x, const float* w, const float* bias, const float
                   int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil,
                   int pad_t, int pad_l, int up2, int act, float act_param, void* stream);
 
+/* Same, with output placement: pixel (b, oy, ox) lands at (b, oy*osy + ooy, ox*osx + oox) of an OHF x OWF image
+ * (res is read at the same place).  Four calls with 2x2 phase kernels and osy = osx = 2 evaluate
+ * "nearest-2x upsample, then 3x3 conv" with 4/9 of the multiplies (flashsr_engine.FlashSREngine.conv3). */
+int egr_conv_nhwc_placed(const float* x, const float* w, const float* bias, const float* bias_b, const float* res, float* y,
+                         int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil,
+                         int pad_t, int pad_l, int up2, int act, float act_param, int osy, int osx, int ooy, int oox,
+                         int OHF, int OWF, void* stream);
+
 /* Strided batched GEMM for attention: C[b1][b2] = alpha * A[b1][b2] (MxK) * (transB ? B^T : B). */
 int egr_bgemm(const float* a, const float* b, float* c, int nb1, int nb2, int M, int N, int K, int lda, int ldb,
               int ldc, int64_t sa1, int64_t sa2, int64_t sb1, int64_t sb2, int64_t sc1, int64_t sc2, int transB,

@@ -82,6 +82,22 @@ def test_conv_nhwc_vs_torch(eng, B, H, W, Ci, Co, k, s, pad, up):
     close(nchw(got), want)
 
 
+def test_upsample_conv_as_four_phase_convs(eng):
+    """nearest-2x + 3x3 conv evaluated as four 2x2 phase convs with pre-summed taps (4/9 of the multiplies)."""
+    e, cfg, P = eng
+    g = torch.Generator().manual_seed(21)
+    for (B, H, W, Ci, Co) in [(2, 8, 12, 32, 48), (1, 5, 7, 16, 130), (3, 16, 4, 64, 32)]:
+        x = torch.randn(B, Ci, H, W, generator=g)
+        w = torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9)
+        b = torch.randn(Co, generator=g)
+        want = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+        e.add_weight("up.weight", w)
+        e.add_upsample_phases("up.weight", w)
+        e.w["up.bias"] = b.cuda()
+        got = e.conv3(nhwc(x).cuda(), "up", up2=1)
+        close(nchw(got), want)
+
+
 @pytest.mark.parametrize("k,dil,stride", [(3, 1, 1), (7, 3, 1), (11, 5, 1), (5, 1, 2), (13, 1, 6)])
 def test_conv1d_vs_torch(eng, k, dil, stride):
     e, cfg, P = eng
