@@ -10,6 +10,9 @@
 // kernels is the 157.3 TFLOP/s f32 matrix peak.
 #include <string.h>
 
+#include <map>
+#include <mutex>
+
 #include "egr_common.h"
 
 namespace egr {
@@ -31,6 +34,9 @@ struct ConvP {
     // output placement: pixel (b, oy, ox) of the OH x OW grid is written at (b, oy*osy + ooy, ox*osx + oox) of an
     // OHF x OWF image (identity by default); lets four 2x2 "phase" convolutions fill a 2x-upsampled output.
     int osy, osx, ooy, oox, OHF, OWF;
+    // split-K (small-M layers): blockIdx.z owns slabs [z*kt_per, ...); raw partial tiles go to ws[z][M][Cout]
+    int ksplit, kt_per;
+    float* ws;
 };
 
 #define BM 128
@@ -112,7 +118,9 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     f32x16 acc[TC::TM][TC::TN];
     zero_acc<TC::TM, TC::TN>(acc);
 
-    const int ktiles = (p.K + BK - 1) / BK;
+    const int ktiles_all = (p.K + BK - 1) / BK;
+    const int kt_begin = p.ksplit > 1 ? blockIdx.z * p.kt_per : 0;
+    const int kt_end = p.ksplit > 1 ? min(ktiles_all, kt_begin + p.kt_per) : ktiles_all;
     const int kq = (tid & 3) * 4;             // this thread's k-quad inside a slab
     const int r0 = tid >> 2;                  // tile rows r0 and r0 + 64
 
@@ -146,6 +154,11 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     float4 ra[2], rb4[2];
     float rs[8];
     int tap = 0, c0 = 0;                      // VEC: current (tap, first channel) of the slab being loaded
+    if (VEC && kt_begin > 0) {
+        const int tpt = p.Cin / BK;
+        tap = kt_begin / tpt;
+        c0 = (kt_begin - tap * tpt) * BK;
+    }
 
     auto load_tile = [&](int kt) {
         if (VEC) {
@@ -206,19 +219,35 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         }
     };
 
-    load_tile(0);
+    load_tile(kt_begin);
     store_tile(0);
     __syncthreads();
-    for (int kt = 0; kt < ktiles; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < ktiles) load_tile(kt + 1);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) load_tile(kt + 1);
         mma_slab<TC::TM, TC::TN>(As[cur], Bs[cur], wm0, wn0, acc);
-        if (kt + 1 < ktiles) store_tile(cur ^ 1);
+        if (kt + 1 < kt_end) store_tile(cur ^ 1);
         __syncthreads();
     }
 
     // ---- epilogue ----
     const int lane = tid & 63, col = lane & 31, rhalf = lane >> 5;
+    if (p.ksplit > 1) {        // raw partial sums; bias / residual / activation are applied by k_splitk_reduce
+        float* wz = p.ws + (size_t)blockIdx.z * p.M * p.Cout;
+#pragma unroll
+        for (int i = 0; i < TC::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TC::TN; ++j) {
+                const int n = n0 + wn0 + j * 32 + col;
+                if (n >= p.Cout) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
+                    if (m < p.M) wz[(size_t)m * p.Cout + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TC::TM; ++i)
 #pragma unroll
@@ -242,6 +271,25 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
                 p.y[mo * p.Cout + n] = apply_act(v, p.act, p.act_param);
             }
         }
+}
+
+// y[place(m)][n] = act(sum_z ws[z][m][n] + bias[n] + bias_b[b][n] + res[place(m)][n])   (fixed summation order)
+__global__ __launch_bounds__(256) void k_splitk_reduce(ConvP p) {
+    const long long total = (long long)p.M * p.Cout;
+    const bool ident = (p.osy == 1 && p.osx == 1 && p.OHF == p.OH && p.OWF == p.OW);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % p.Cout);
+        const int m = (int)(i / p.Cout);
+        float v = 0.f;
+        for (int z = 0; z < p.ksplit; ++z) v += p.ws[(size_t)z * total + i];
+        if (p.bias) v += p.bias[n];
+        size_t mo = (size_t)m;
+        const int ox = m % p.OW, t = m / p.OW, oy = t % p.OH, b = t / p.OH;
+        if (!ident) mo = ((size_t)b * p.OHF + (size_t)oy * p.osy + p.ooy) * p.OWF + (size_t)ox * p.osx + p.oox;
+        if (p.bias_b) v += p.bias_b[(size_t)b * p.Cout + n];
+        if (p.res) v += p.res[mo * p.Cout + n];
+        p.y[mo * p.Cout + n] = apply_act(v, p.act, p.act_param);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -344,6 +392,24 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmP p) {
         }
 }
 
+// per-device scratch for split-K partials (grown on demand; launches on one stream are ordered, so reuse is safe)
+static int splitk_workspace(size_t bytes, float** out) {
+    static std::mutex mu;
+    static std::map<int, std::pair<float*, size_t>> bufs;
+    int dev = 0;
+    EGR_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    auto& b = bufs[dev];
+    if (b.second < bytes) {
+        if (b.first) { EGR_HIP(hipDeviceSynchronize()); EGR_HIP(hipFree(b.first)); }
+        size_t want = bytes < (64u << 20) ? (64u << 20) : bytes;
+        EGR_HIP(hipMalloc((void**)&b.first, want));
+        b.second = want;
+    }
+    *out = b.first;
+    return EGR_OK;
+}
+
 }  // namespace egr
 
 using namespace egr;
@@ -384,11 +450,33 @@ extern "C" int egr_conv_nhwc_placed(const float* x, const float* w, const float*
     const int bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((Cout + bn - 1) / bn));
     hipStream_t st = (hipStream_t)stream;
+    // split-K when the output tiles alone cannot fill the chip and the K loop is long (deep UNet / latent layers)
+    const int tiles = (int)(grid.x * grid.y), ktiles = (p.K + BK - 1) / BK;
+    p.ksplit = 1; p.kt_per = ktiles; p.ws = nullptr;
+    if (tiles < 192 && ktiles >= 32) {
+        int S = (768 + tiles - 1) / tiles;
+        if (S > ktiles / 8) S = ktiles / 8;
+        if (S > 64) S = 64;
+        if (S >= 2) {
+            const int per = (ktiles + S - 1) / S;
+            S = (ktiles + per - 1) / per;
+            float* ws = nullptr;
+            int rc = splitk_workspace((size_t)S * M * Cout * sizeof(float), &ws);
+            if (rc) return rc;
+            p.ksplit = S; p.kt_per = per; p.ws = ws;
+            grid.z = S;
+        }
+    }
 #define LAUNCH(BN_, V_) hipLaunchKernelGGL((k_conv_igemm<BN_, V_>), grid, dim3(256), 0, st, p)
     if (bn == 128) { if (vec) LAUNCH(128, true); else LAUNCH(128, false); }
     else if (bn == 64) { if (vec) LAUNCH(64, true); else LAUNCH(64, false); }
     else { if (vec) LAUNCH(32, true); else LAUNCH(32, false); }
 #undef LAUNCH
+    if (p.ksplit > 1) {
+        long long nb = (M * Cout + 255) / 256;
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)nb), dim3(256), 0, st, p);
+    }
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }
