@@ -37,6 +37,8 @@ struct ConvP {
     // split-K (small-M layers): blockIdx.z owns slabs [z*kt_per, ...); raw partial tiles go to ws[z][M][Cout]
     int ksplit, kt_per;
     float* ws;
+    // independent problems along blockIdx.z (used when ksplit == 1): element offsets added per z
+    long long zx, zw, zy;
 };
 
 #define BM 128
@@ -114,6 +116,11 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     const int wm0 = (wave / TC::WN) * (BM / TC::WM), wn0 = (wave % TC::WN) * (BN / TC::WN);
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int LH = p.up2 ? 2 * p.H : p.H, LW = p.up2 ? 2 * p.W : p.W;   // logical input extent
+    if (p.ksplit <= 1 && gridDim.z > 1) {
+        p.x += (size_t)blockIdx.z * p.zx;
+        p.w += (size_t)blockIdx.z * p.zw;
+        p.y += (size_t)blockIdx.z * p.zy;
+    }
 
     f32x16 acc[TC::TM][TC::TN];
     zero_acc<TC::TM, TC::TN>(acc);
@@ -418,6 +425,10 @@ extern "C" int egr_conv_nhwc_placed(const float* x, const float* w, const float*
                                     const float* res, float* y, int B, int H, int W, int Cin, int OH, int OW, int Cout,
                                     int KH, int KW, int stride, int dil, int pad_t, int pad_l, int up2, int act,
                                     float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF, void* stream);
+static int conv_launch(const float* x, const float* w, const float* bias, const float* bias_b, const float* res, float* y,
+                       int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t,
+                       int pad_l, int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF,
+                       int nz, long long zx, long long zw, long long zy, void* stream);
 
 extern "C" int egr_conv_nhwc(const float* x, const float* w, const float* bias, const float* bias_b, const float* res,
                              float* y, int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
@@ -431,6 +442,22 @@ extern "C" int egr_conv_nhwc_placed(const float* x, const float* w, const float*
                                     const float* res, float* y, int B, int H, int W, int Cin, int OH, int OW, int Cout,
                                     int KH, int KW, int stride, int dil, int pad_t, int pad_l, int up2, int act,
                                     float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF, void* stream) {
+    return conv_launch(x, w, bias, bias_b, res, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act,
+                       act_param, osy, osx, ooy, oox, OHF, OWF, 1, 0, 0, 0, stream);
+}
+
+// nz independent GEMMs y[z] = x[z] * w[z] ([rows][Cin] x [Cin][Cout], weights packed per z), offsets in elements.
+extern "C" int egr_gemm_zbatched(const float* x, const float* w, float* y, int nz, int rows, int Cin, int Cout, int64_t zx,
+                                 int64_t zw, int64_t zy, void* stream) {
+    EGR_CHECK(nz >= 1 && nz <= 65535, EGR_ERR_ARG, "bad nz");
+    return conv_launch(x, w, nullptr, nullptr, nullptr, y, rows, 1, 1, Cin, 1, 1, Cout, 1, 1, 1, 1, 0, 0, 0, 0, 0.f, 1, 1, 0, 0,
+                       1, 1, nz, zx, zw, zy, stream);
+}
+
+static int conv_launch(const float* x, const float* w, const float* bias, const float* bias_b, const float* res, float* y,
+                       int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t,
+                       int pad_l, int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF,
+                       int nz, long long zx, long long zw, long long zy, void* stream) {
     EGR_CHECK(x && w && y, EGR_ERR_ARG, "null x/w/y");
     EGR_CHECK(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && OH >= 1 && OW >= 1 && Cout >= 1 && KH >= 1 && KW >= 1 &&
                   stride >= 1 && dil >= 1,
@@ -453,7 +480,9 @@ extern "C" int egr_conv_nhwc_placed(const float* x, const float* w, const float*
     // split-K when the output tiles alone cannot fill the chip and the K loop is long (deep UNet / latent layers)
     const int tiles = (int)(grid.x * grid.y), ktiles = (p.K + BK - 1) / BK;
     p.ksplit = 1; p.kt_per = ktiles; p.ws = nullptr;
-    if (tiles < 192 && ktiles >= 32) {
+    p.zx = zx; p.zw = zw; p.zy = zy;
+    if (nz > 1) grid.z = nz;
+    if (nz == 1 && tiles < 192 && ktiles >= 32) {
         int S = (768 + tiles - 1) / tiles;
         if (S > ktiles / 8) S = ktiles / 8;
         if (S > 64) S = 64;

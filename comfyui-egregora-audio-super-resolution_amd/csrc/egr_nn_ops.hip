@@ -392,6 +392,99 @@ __global__ __launch_bounds__(256) void k_randn(float* __restrict__ out, long lon
     }
 }
 
+// ---------------------------------------------------------------- Winograd F(2x2,3x3) transforms (stride-1, pad-1 3x3 convs)
+// V[xi][t][c] = (B^T d B)[i][j], xi = 4i+j, d = 4x4 input patch of output tile t = (b, ty, tx) (2x2 outputs), zero padded.
+__global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, int B, int H, int W, int C, int TH, int TW,
+                                                  float* __restrict__ V) {
+    const int C4 = C >> 2;
+    const long long P = (long long)B * TH * TW, total = P * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long long t = i / C4;
+        const int tx = (int)(t % TW), ty = (int)((t / TW) % TH), b = (int)(t / ((long long)TW * TH));
+        float4 d[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int iy = 2 * ty - 1 + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ix = 2 * tx - 1 + q;
+                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const size_t off = ok ? (((size_t)b * H + iy) * W + ix) * C + 4 * c4 : (size_t)(4 * c4);
+                const float4 v = *(const float4*)(x + off);
+                d[r][q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#define F4OP(a, op, b) make_float4(a.x op b.x, a.y op b.y, a.z op b.z, a.w op b.w)
+        float4 r_[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                      // B^T d : combine rows
+            r_[0][q] = F4OP(d[0][q], -, d[2][q]);
+            r_[1][q] = F4OP(d[1][q], +, d[2][q]);
+            r_[2][q] = F4OP(d[2][q], -, d[1][q]);
+            r_[3][q] = F4OP(d[1][q], -, d[3][q]);
+        }
+        float* o = V + (size_t)t * C + 4 * c4;
+        const size_t zs = (size_t)P * C;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                      // (.) B : combine columns
+            *(float4*)(o + (size_t)(4 * r + 0) * zs) = F4OP(r_[r][0], -, r_[r][2]);
+            *(float4*)(o + (size_t)(4 * r + 1) * zs) = F4OP(r_[r][1], +, r_[r][2]);
+            *(float4*)(o + (size_t)(4 * r + 2) * zs) = F4OP(r_[r][2], -, r_[r][1]);
+            *(float4*)(o + (size_t)(4 * r + 3) * zs) = F4OP(r_[r][1], -, r_[r][3]);
+        }
+    }
+}
+
+// y[b][2ty+a][2tx+bb][n] = act((A^T M A)[a][bb] + bias[n] + res[...]),  M[xi][t][n]
+__global__ __launch_bounds__(256) void k_wino_out(const float* __restrict__ Mx, const float* __restrict__ bias,
+                                                   const float* __restrict__ res, int B, int H, int W, int N, int TH, int TW,
+                                                   int act, float* __restrict__ y) {
+    const int N4 = N >> 2;
+    const long long P = (long long)B * TH * TW, total = P * N4;
+    const size_t zs = (size_t)P * N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n4 = (int)(i % N4);
+        const long long t = i / N4;
+        const int tx = (int)(t % TW), ty = (int)((t / TW) % TH), b = (int)(t / ((long long)TW * TH));
+        const float* mi = Mx + (size_t)t * N + 4 * n4;
+        float4 m[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m[r][q] = *(const float4*)(mi + (size_t)(4 * r + q) * zs);
+        float4 s0[4], s1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                      // A^T m
+            s0[q] = F4OP(F4OP(m[0][q], +, m[1][q]), +, m[2][q]);
+            s1[q] = F4OP(F4OP(m[1][q], -, m[2][q]), -, m[3][q]);
+        }
+        float4 o[2][2];
+        o[0][0] = F4OP(F4OP(s0[0], +, s0[1]), +, s0[2]);
+        o[0][1] = F4OP(F4OP(s0[1], -, s0[2]), -, s0[3]);
+        o[1][0] = F4OP(F4OP(s1[0], +, s1[1]), +, s1[2]);
+        o[1][1] = F4OP(F4OP(s1[1], -, s1[2]), -, s1[3]);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bv = *(const float4*)(bias + 4 * n4);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int oy = 2 * ty + a, ox = 2 * tx + c;
+                if (oy >= H || ox >= W) continue;
+                const size_t off = (((size_t)b * H + oy) * W + ox) * N + 4 * n4;
+                float4 v = F4OP(o[a][c], +, bv);
+                if (res) { const float4 rr = *(const float4*)(res + off); v = F4OP(v, +, rr); }
+                if (act == 1) {
+                    v.x = v.x / (1.f + __expf(-v.x)); v.y = v.y / (1.f + __expf(-v.y));
+                    v.z = v.z / (1.f + __expf(-v.z)); v.w = v.w / (1.f + __expf(-v.w));
+                }
+                *(float4*)(y + off) = v;
+            }
+    }
+#undef F4OP
+}
+
 // ---------------------------------------------------------------- input low-pass (lowpass_input=True)
 // cutoff bin per row from STFT magnitudes mag [B][T][ldm]: e[k] = sum_t mag[t][k]; c = cumsum(e); the cutoff is the
 // highest bin whose cumulative energy is still below pct * c[nb-1] (scanning down from the top), plus one.
@@ -609,6 +702,26 @@ extern "C" int egr_lowpass_gain(const float* mag, int B, int T, int ldm, int nb,
     const float eps2 = powf(10.0f, ripple_db / 10.0f) - 1.0f;
     hipLaunchKernelGGL(k_cheby_gain, dim3(grid1d(nbins), B), dim3(256), 0, st, cut_out, nb, sr, order, eps2, (long long)nbins,
                        gain);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_winograd_input(const float* x, int B, int H, int W, int C, float* V, void* stream) {
+    EGR_CHECK(x && V && B >= 1 && H >= 1 && W >= 1 && C >= 4 && C % 4 == 0, EGR_ERR_ARG, "bad argument");
+    const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+    const long long n = (long long)B * TH * TW * (C / 4);
+    hipLaunchKernelGGL(k_wino_in, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C, TH, TW, V);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_winograd_output(const float* M, const float* bias, const float* res, float* y, int B, int H, int W, int N,
+                                   int act, void* stream) {
+    EGR_CHECK(M && y && B >= 1 && H >= 1 && W >= 1 && N >= 4 && N % 4 == 0 && (act == 0 || act == 1), EGR_ERR_ARG,
+              "bad argument");
+    const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+    const long long n = (long long)B * TH * TW * (N / 4);
+    hipLaunchKernelGGL(k_wino_out, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, M, bias, res, B, H, W, N, TH, TW, act, y);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }

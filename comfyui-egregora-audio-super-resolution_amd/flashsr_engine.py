@@ -77,6 +77,41 @@ class FlashSREngine:
                                 w[:, :, i, j] += v[:, :, ky, kx]
                 self.add_weight(f"{key}.ph{a}{b}", w)
 
+    WINO_MIN_CH = int(os.environ.get("EGREGORA_FLASHSR_WINOGRAD_MIN_CH", "512"))
+
+    def add_winograd(self, key: str, v: torch.Tensor):
+        """U = G g G^T for Winograd F(2x2,3x3): 16 [Cin][Cout] matrices, each packed slab-major (key + '.wino')."""
+        v = v.detach().double()                                         # [Co,Ci,3,3]
+        G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+        U = torch.einsum("ik,ockl,jl->ijco", G, v, G)                   # [4,4,Ci,Co]
+        Ci, Co = U.shape[2], U.shape[3]
+        packed = torch.stack([self.pack_matrix(U[i, j].float().contiguous()) for i in range(4) for j in range(4)])
+        self.w[key + ".wino"] = packed.contiguous().to(self.dev)        # [16][Kp/16][Co][16]
+
+    def _conv_winograd(self, x, key, act, res, bias_t):
+        B, H, W, Cin = x.shape
+        Cout = self.wshape[key + ".weight"][3]
+        TH, TW = (H + 1) // 2, (W + 1) // 2
+        P = B * TH * TW
+        V = torch.empty((16, P, Cin), dtype=torch.float32, device=self.dev)
+        native.check(self.L.egr_winograd_input(_p(x), B, H, W, Cin, _p(V), self._st()), "egr_winograd_input")
+        Mx = torch.empty((16, P, Cout), dtype=torch.float32, device=self.dev)
+        wt = self.w[key + ".weight.wino"]
+        fl = 16 * 2.0 * P * Cin * Cout
+        ev = self._prof_begin()
+        native.check(self.L.egr_gemm_zbatched(_p(V), _p(wt), _p(Mx), 16, P, Cin, Cout, P * Cin, wt[0].numel(), P * Cout,
+                                              self._st()), "egr_gemm_zbatched")
+        if ev is not None:
+            bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
+            self._prof_end(ev, f"k_conv_igemm<{bn}, true>", fl, (B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 16))
+        if self.count_flops:
+            self.flops += fl
+        y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=self.dev)
+        bt = bias_t if bias_t is not None else self.w.get(key + ".bias")
+        native.check(self.L.egr_winograd_output(_p(Mx), _p(bt), _p(res), _p(y), B, H, W, Cout, 1 if act == ACT_SILU else 0,
+                                                self._st()), "egr_winograd_output")
+        return y
+
     def add_weight(self, key: str, v: torch.Tensor):
         """Register a weight given in torch layout; self.w[key] holds the packed tensor, self.wshape[key] the
         logical (KH, KW, Cin, Cout)."""
@@ -103,6 +138,9 @@ class FlashSREngine:
                 self.add_weight(k, v)
                 if ".upsample.conv." in k or (k.startswith("unet.") and ".up.conv." in k):
                     self.add_upsample_phases(k, v)
+                if v.dim() == 4 and v.shape[2] == 3 and v.shape[3] == 3 and min(v.shape[0], v.shape[1]) >= self.WINO_MIN_CH \
+                        and "downsample" not in k and ".down.conv" not in k and "upsample" not in k and ".up.conv" not in k:
+                    self.add_winograd(k, v)
             else:
                 self.w[k] = v.detach().float().contiguous().to(self.dev)
 
@@ -156,6 +194,9 @@ class FlashSREngine:
         Cout = self.wshape[key + ".weight"][3]
         if up2 and (key + ".weight.ph00") in self.w and stride == 1 and pad == 1 and res is None and bias_t is None:
             return self._conv_up2_phases(x, key, act)
+        if (key + ".weight.wino") in self.w and not up2 and stride == 1 and pad == 1 and act in (ACT_NONE, ACT_SILU) \
+                and H % 2 == 0 and W % 2 == 0 and Cin % 16 == 0:
+            return self._conv_winograd(x, key, act, res, bias_t)
         LH, LW = (2 * H, 2 * W) if up2 else (H, W)
         OH, OW = (LH // stride, LW // stride)
         return self.conv(x, key, B, H, W, Cin, OH, OW, Cout, 3, 3, stride, 1, pad, pad, up2, act, res=res, bias_t=bias_t)

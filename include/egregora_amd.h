@@ -161,6 +161,17 @@ int egr_conv_nhwc_placed(const float* x, const float* w, const float* bias, cons
                          int pad_t, int pad_l, int up2, int act, float act_param, int osy, int osx, int ooy, int oox,
                          int OHF, int OWF, void* stream);
 
+/* Winograd F(2x2,3x3) for stride-1 pad-1 3x3 convolutions with many channels (2.25x fewer multiplies):
+ *   egr_winograd_input : x [B][H][W][C] -> V [16][P][C], P = B*ceil(H/2)*ceil(W/2) tiles, V[4i+j] = (B^T d B)[i][j]
+ *   egr_gemm_zbatched  : M[xi] = V[xi] ([P][Cin]) x U[xi] ([Cin][Cout], each packed like egr_conv_nhwc weights), xi < nz
+ *   egr_winograd_output: y [B][H][W][N] = act(A^T M A + bias + res)        (act: 0 none, 1 SiLU)
+ * U = G g G^T is prepared by the host once per layer (flashsr_engine.FlashSREngine.add_winograd). */
+int egr_winograd_input(const float* x, int B, int H, int W, int C, float* V, void* stream);
+int egr_gemm_zbatched(const float* x, const float* w, float* y, int nz, int rows, int Cin, int Cout, int64_t zx, int64_t zw,
+                      int64_t zy, void* stream);
+int egr_winograd_output(const float* M, const float* bias, const float* res, float* y, int B, int H, int W, int N, int act,
+                        void* stream);
+
 /* Strided batched GEMM for attention: C[b1][b2] = alpha * A[b1][b2] (MxK) * (transB ? B^T : B). */
 int egr_bgemm(const float* a, const float* b, float* c, int nb1, int nb2, int M, int N, int K, int lda, int ldb,
               int ldc, int64_t sa1, int64_t sa2, int64_t sb1, int64_t sb2, int64_t sc1, int64_t sc2, int transB,

@@ -82,6 +82,28 @@ def test_conv_nhwc_vs_torch(eng, B, H, W, Ci, Co, k, s, pad, up):
     close(nchw(got), want)
 
 
+def test_winograd_conv_vs_torch(eng):
+    """Winograd F(2x2,3x3) path (input transform, 16 z-batched MFMA GEMMs, output transform + epilogue)."""
+    e, cfg, P = eng
+    g = torch.Generator().manual_seed(41)
+    for (B, H, W, Ci, Co, use_res, act) in [(2, 8, 12, 32, 48, True, 1), (1, 16, 16, 64, 128, False, 0), (3, 6, 4, 144, 80, True, 0)]:
+        x = torch.randn(B, Ci, H, W, generator=g)
+        w = torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9)
+        b = torch.randn(Co, generator=g)
+        want = F.conv2d(x, w, b, padding=1)
+        res = torch.randn(want.shape, generator=g)
+        if use_res:
+            want = want + res
+        if act:
+            want = F.silu(want)
+        e.add_weight("wg.weight", w)
+        e.add_winograd("wg.weight", w)
+        e.w["wg.bias"] = b.cuda()
+        got = e._conv_winograd(nhwc(x).cuda(), "wg", act, nhwc(res).cuda() if use_res else None, None)
+        close(nchw(got), want, 3e-5)
+    e.w.pop("wg.weight.wino")
+
+
 def test_upsample_conv_as_four_phase_convs(eng):
     """nearest-2x + 3x3 conv evaluated as four 2x2 phase convs with pre-summed taps (4/9 of the multiplies)."""
     e, cfg, P = eng
