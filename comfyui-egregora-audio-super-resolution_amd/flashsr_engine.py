@@ -77,7 +77,7 @@ class FlashSREngine:
                                 w[:, :, i, j] += v[:, :, ky, kx]
                 self.add_weight(f"{key}.ph{a}{b}", w)
 
-    WINO_MIN_CH = int(os.environ.get("EGREGORA_FLASHSR_WINOGRAD_MIN_CH", "512"))
+    WINO_MIN_CH = int(os.environ.get("EGREGORA_FLASHSR_WINOGRAD_MIN_CH", "256"))   # 128 measured slower (transform traffic)
 
     def add_winograd(self, key: str, v: torch.Tensor):
         """U = G g G^T for Winograd F(2x2,3x3): 16 [Cin][Cout] matrices, each packed slab-major (key + '.wino')."""

@@ -321,6 +321,30 @@ def test_node_end_to_end_with_synthetic_engine(pack, eng):
     assert float(np.abs(got - want).max()) <= 2e-3 * float(np.abs(want).max())
 
 
+def test_full_size_engine_vs_torch_reference_one_row(pack):
+    """The declared full-size architecture (Winograd / phase-conv / split-K paths active) against the PyTorch fp32
+    graph on the host CPU, one row, stage by stage.  Tolerance: relative L2 <= 5e-4 per stage, 2e-3 on the waveform
+    (thousands of fp32 layers with different summation orders on both sides)."""
+    from egregora_amd import flashsr_arch as A, flashsr_engine as E
+    from oracle import flashsr_torch as R
+    cfg = A.FlashSRConfig()
+    P = A.init_params(cfg, 0)
+    e = E.FlashSREngine(cfg, P)
+    x = 0.2 * torch.randn(1, cfg.chunk, generator=torch.Generator().manual_seed(5))
+    nz = e.noise(1, torch.zeros(1, dtype=torch.int64, device="cuda"), 0)
+    got_st, want_st = {}, {}
+    y = e.forward_rows(x.cuda(), nz, got_st)
+    torch.cuda.synchronize()
+    torch.set_num_threads(max(1, min(64, torch.get_num_threads())))
+    with torch.no_grad():
+        want = R.flashsr_forward(x, nchw(nz.cpu()), P, cfg, A.unet_blocks(cfg), torch.from_numpy(A.mel_filterbank(cfg)),
+                                 torch.from_numpy(A.kaiser_sinc_filter(cfg.aa_taps)), want_st)
+    for k in ("mel", "z_cond", "v", "z0", "mel_hat"):
+        gt = got_st[k].permute(0, 3, 1, 2)
+        assert rel_l2(gt, want_st[k]) <= 5e-4, (k, rel_l2(gt, want_st[k]))
+    assert rel_l2(y, want) <= 2e-3, rel_l2(y, want)
+
+
 def test_full_size_engine_shapes_and_determinism(pack):
     """Declared full-size architecture with synthetic weights: one row, shapes + finite output + same-seed repeatability."""
     from egregora_amd import flashsr_arch as A, flashsr_engine as E
