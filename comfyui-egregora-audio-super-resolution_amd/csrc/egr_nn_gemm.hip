@@ -39,6 +39,11 @@ struct ConvP {
     float* ws;
     // independent problems along blockIdx.z (used when ksplit == 1): element offsets added per z
     long long zx, zw, zy;
+    // optional fused input transform (GroupNorm of the producer): x' = x*gn_scale[b][c] + gn_shift[b][c], then SiLU;
+    // zero padding applies AFTER it (the reference pads the normalised tensor).  VEC path only.
+    const float* gn_scale;
+    const float* gn_shift;
+    int gn_silu;
 };
 
 #define BM 128
@@ -107,7 +112,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
 
 // Weights arrive PRE-PACKED as [ceil(K/16)][Cout][16] (slab-major, k contiguous per output channel): a B tile is
 // then read exactly like an A tile (one float4 along k per thread) and needs no transposition in LDS.
-template <int BN, bool VEC>
+template <int BN, bool VEC, bool GN = false>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     typedef TileCfg<BN> TC;
     __shared__ __attribute__((aligned(16))) float As[2][BM * LROW];
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     const int r0 = tid >> 2;                  // tile rows r0 and r0 + 64
 
     // ---- A rows owned by this thread (VEC path): decode (b, oy, ox) once ----
-    int a_iy0[2], a_ix0[2];
+    int a_iy0[2], a_ix0[2], a_b[2];
     size_t a_base[2];
     bool a_ok[2];
 #pragma unroll
@@ -144,6 +149,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         a_iy0[h] = oy * p.stride - p.pad_t;
         a_ix0[h] = ox * p.stride - p.pad_l;
         a_base[h] = (size_t)b * p.H * p.W;
+        a_b[h] = b;
     }
     // ---- B rows (output channels) owned by this thread ----
     constexpr int BQ = BN * 4;                // float4 slots in a B tile
@@ -177,6 +183,15 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
                 const int py = p.up2 ? iy >> 1 : iy, px = p.up2 ? ix >> 1 : ix;
                 const size_t off = ok ? ((a_base[h] + (size_t)py * p.W + px) * p.Cin + c0 + kq) : (size_t)kq;
                 float4 v = *(const float4*)(p.x + off);          // unconditional load; masked afterwards
+                if (GN) {
+                    const size_t go = (size_t)a_b[h] * p.Cin + c0 + kq;
+                    const float4 sc = *(const float4*)(p.gn_scale + go), sh = *(const float4*)(p.gn_shift + go);
+                    v = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+                    if (p.gn_silu) {
+                        v.x = v.x / (1.f + __expf(-v.x)); v.y = v.y / (1.f + __expf(-v.y));
+                        v.z = v.z / (1.f + __expf(-v.z)); v.w = v.w / (1.f + __expf(-v.w));
+                    }
+                }
                 ra[h] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             c0 += BK;
@@ -428,7 +443,8 @@ extern "C" int egr_conv_nhwc_placed(const float* x, const float* w, const float*
 static int conv_launch(const float* x, const float* w, const float* bias, const float* bias_b, const float* res, float* y,
                        int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t,
                        int pad_l, int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF,
-                       int nz, long long zx, long long zw, long long zy, void* stream);
+                       int nz, long long zx, long long zw, long long zy, const float* gn_scale, const float* gn_shift,
+                       int gn_silu, void* stream);
 
 extern "C" int egr_conv_nhwc(const float* x, const float* w, const float* bias, const float* bias_b, const float* res,
                              float* y, int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
@@ -443,7 +459,16 @@ extern "C" int egr_conv_nhwc_placed(const float* x, const float* w, const float*
                                     int KH, int KW, int stride, int dil, int pad_t, int pad_l, int up2, int act,
                                     float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF, void* stream) {
     return conv_launch(x, w, bias, bias_b, res, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act,
-                       act_param, osy, osx, ooy, oox, OHF, OWF, 1, 0, 0, 0, stream);
+                       act_param, osy, osx, ooy, oox, OHF, OWF, 1, 0, 0, 0, nullptr, nullptr, 0, stream);
+}
+
+// egr_conv_nhwc with the producer's GroupNorm (+SiLU) applied to the input while it is loaded.
+extern "C" int egr_conv_nhwc_gn(const float* x, const float* gn_scale, const float* gn_shift, int gn_silu, const float* w,
+                                const float* bias, const float* res, float* y, int B, int H, int W, int Cin, int OH, int OW,
+                                int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int act, void* stream) {
+    EGR_CHECK(gn_scale && gn_shift, EGR_ERR_ARG, "null scale/shift");
+    return conv_launch(x, w, bias, nullptr, res, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, 1, pad_t, pad_l, 0, act, 0.f, 1,
+                       1, 0, 0, OH, OW, 1, 0, 0, 0, gn_scale, gn_shift, gn_silu, stream);
 }
 
 // nz independent GEMMs y[z] = x[z] * w[z] ([rows][Cin] x [Cin][Cout], weights packed per z), offsets in elements.
@@ -451,14 +476,17 @@ extern "C" int egr_gemm_zbatched(const float* x, const float* w, float* y, int n
                                  int64_t zw, int64_t zy, void* stream) {
     EGR_CHECK(nz >= 1 && nz <= 65535, EGR_ERR_ARG, "bad nz");
     return conv_launch(x, w, nullptr, nullptr, nullptr, y, rows, 1, 1, Cin, 1, 1, Cout, 1, 1, 1, 1, 0, 0, 0, 0, 0.f, 1, 1, 0, 0,
-                       1, 1, nz, zx, zw, zy, stream);
+                       1, 1, nz, zx, zw, zy, nullptr, nullptr, 0, stream);
 }
 
 static int conv_launch(const float* x, const float* w, const float* bias, const float* bias_b, const float* res, float* y,
                        int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t,
                        int pad_l, int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF,
-                       int nz, long long zx, long long zw, long long zy, void* stream) {
+                       int nz, long long zx, long long zw, long long zy, const float* gn_scale, const float* gn_shift,
+                       int gn_silu, void* stream) {
     EGR_CHECK(x && w && y, EGR_ERR_ARG, "null x/w/y");
+    EGR_CHECK(!gn_scale || (gn_shift && (Cin % BK) == 0 && (((uintptr_t)x) & 15) == 0), EGR_ERR_ARG,
+              "fused input affine needs Cin %% 16 == 0 and a 16-byte aligned input");
     EGR_CHECK(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && OH >= 1 && OW >= 1 && Cout >= 1 && KH >= 1 && KW >= 1 &&
                   stride >= 1 && dil >= 1,
               EGR_ERR_ARG, "bad conv geometry");
@@ -481,6 +509,7 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
     const int tiles = (int)(grid.x * grid.y), ktiles = (p.K + BK - 1) / BK;
     p.ksplit = 1; p.kt_per = ktiles; p.ws = nullptr;
     p.zx = zx; p.zw = zw; p.zy = zy;
+    p.gn_scale = gn_scale; p.gn_shift = gn_shift; p.gn_silu = gn_silu;
     if (nz > 1) grid.z = nz;
     if (nz == 1 && tiles < 192 && ktiles >= 32) {
         int S = (768 + tiles - 1) / tiles;
@@ -497,6 +526,11 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
         }
     }
 #define LAUNCH(BN_, V_) hipLaunchKernelGGL((k_conv_igemm<BN_, V_>), grid, dim3(256), 0, st, p)
+    if (gn_scale) {        // fused-GroupNorm loader: separate instantiations so the plain kernels pay nothing for it
+        if (bn == 128) hipLaunchKernelGGL((k_conv_igemm<128, true, true>), grid, dim3(256), 0, st, p);
+        else if (bn == 64) hipLaunchKernelGGL((k_conv_igemm<64, true, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_conv_igemm<32, true, true>), grid, dim3(256), 0, st, p);
+    } else
     if (bn == 128) { if (vec) LAUNCH(128, true); else LAUNCH(128, false); }
     else if (bn == 64) { if (vec) LAUNCH(64, true); else LAUNCH(64, false); }
     else { if (vec) LAUNCH(32, true); else LAUNCH(32, false); }

@@ -395,6 +395,7 @@ __global__ __launch_bounds__(256) void k_randn(float* __restrict__ out, long lon
 // ---------------------------------------------------------------- Winograd F(2x2,3x3) transforms (stride-1, pad-1 3x3 convs)
 // V[xi][t][c] = (B^T d B)[i][j], xi = 4i+j, d = 4x4 input patch of output tile t = (b, ty, tx) (2x2 outputs), zero padded.
 __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, int B, int H, int W, int C, int TH, int TW,
+                                                  const float* __restrict__ gsc, const float* __restrict__ gsh, int gsilu,
                                                   float* __restrict__ V) {
     const int C4 = C >> 2;
     const long long P = (long long)B * TH * TW, total = P * C4;
@@ -403,6 +404,11 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, in
         const long long t = i / C4;
         const int tx = (int)(t % TW), ty = (int)((t / TW) % TH), b = (int)(t / ((long long)TW * TH));
         float4 d[4][4];
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gsc) {
+            sc = *(const float4*)(gsc + (size_t)b * C + 4 * c4);
+            sh = *(const float4*)(gsh + (size_t)b * C + 4 * c4);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int iy = 2 * ty - 1 + r;
@@ -411,7 +417,14 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, in
                 const int ix = 2 * tx - 1 + q;
                 const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
                 const size_t off = ok ? (((size_t)b * H + iy) * W + ix) * C + 4 * c4 : (size_t)(4 * c4);
-                const float4 v = *(const float4*)(x + off);
+                float4 v = *(const float4*)(x + off);
+                if (gsc) {      // producer's GroupNorm (+SiLU) fused into the transform; padding stays zero
+                    v = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+                    if (gsilu) {
+                        v.x = v.x / (1.f + __expf(-v.x)); v.y = v.y / (1.f + __expf(-v.y));
+                        v.z = v.z / (1.f + __expf(-v.z)); v.w = v.w / (1.f + __expf(-v.w));
+                    }
+                }
                 d[r][q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -588,6 +601,25 @@ extern "C" int egr_groupnorm_nhwc(const float* x, const float* gamma, const floa
     return EGR_OK;
 }
 
+// statistics + per-(b, c) scale/shift only; the normalisation itself is applied by the consumer
+// (egr_conv_nhwc_gn / egr_winograd_input) while it loads the tensor.
+extern "C" int egr_groupnorm_coeff(const float* x, const float* gamma, const float* beta, int B, int HW, int C, int G,
+                                   float eps, void* workspace, float* scale, float* shift, void* stream) {
+    EGR_CHECK(x && gamma && beta && workspace && scale && shift, EGR_ERR_ARG, "null argument");
+    EGR_CHECK(B >= 1 && HW >= 1 && C >= 4 && G >= 1 && C % G == 0, EGR_ERR_ARG, "bad groupnorm geometry");
+    hipStream_t st = (hipStream_t)stream;
+    double* stats = (double*)workspace;
+    EGR_HIP(hipMemsetAsync(stats, 0, sizeof(double) * B * G * 2, st));
+    int slab = (HW + 255) / 256;
+    if (slab < 16) slab = HW < 16 ? HW : 16;
+    const int nslab = (HW + slab - 1) / slab;
+    hipLaunchKernelGGL(k_gn_stats, dim3(nslab, B), dim3(C < 256 ? ((C + 63) / 64) * 64 : 256), 0, st, x, HW, C, G, stats, slab);
+    hipLaunchKernelGGL(k_gn_coeff, dim3((B * C + 255) / 256), dim3(256), 0, st, stats, gamma, beta, scale, shift, B, C, G,
+                       (double)HW * (C / G), eps);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
 extern "C" size_t egr_groupnorm_workspace_bytes(int B, int C, int G) {
     return sizeof(double) * (size_t)B * G * 2 + sizeof(float) * 2 * (size_t)B * C + 64;
 }
@@ -706,11 +738,14 @@ extern "C" int egr_lowpass_gain(const float* mag, int B, int T, int ldm, int nb,
     return EGR_OK;
 }
 
-extern "C" int egr_winograd_input(const float* x, int B, int H, int W, int C, float* V, void* stream) {
-    EGR_CHECK(x && V && B >= 1 && H >= 1 && W >= 1 && C >= 4 && C % 4 == 0, EGR_ERR_ARG, "bad argument");
+extern "C" int egr_winograd_input(const float* x, const float* gn_scale, const float* gn_shift, int gn_silu, int B, int H,
+                                  int W, int C, float* V, void* stream) {
+    EGR_CHECK(x && V && B >= 1 && H >= 1 && W >= 1 && C >= 4 && C % 4 == 0 && (!gn_scale || gn_shift), EGR_ERR_ARG,
+              "bad argument");
     const int TH = (H + 1) / 2, TW = (W + 1) / 2;
     const long long n = (long long)B * TH * TW * (C / 4);
-    hipLaunchKernelGGL(k_wino_in, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C, TH, TW, V);
+    hipLaunchKernelGGL(k_wino_in, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C, TH, TW, gn_scale,
+                       gn_shift, gn_silu, V);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }

@@ -88,13 +88,15 @@ class FlashSREngine:
         packed = torch.stack([self.pack_matrix(U[i, j].float().contiguous()) for i in range(4) for j in range(4)])
         self.w[key + ".wino"] = packed.contiguous().to(self.dev)        # [16][Kp/16][Co][16]
 
-    def _conv_winograd(self, x, key, act, res, bias_t):
+    def _conv_winograd(self, x, key, act, res, bias_t, gn=None):
         B, H, W, Cin = x.shape
         Cout = self.wshape[key + ".weight"][3]
         TH, TW = (H + 1) // 2, (W + 1) // 2
         P = B * TH * TW
         V = torch.empty((16, P, Cin), dtype=torch.float32, device=self.dev)
-        native.check(self.L.egr_winograd_input(_p(x), B, H, W, Cin, _p(V), self._st()), "egr_winograd_input")
+        gsc, gsh, gsilu = gn if gn is not None else (None, None, 0)
+        native.check(self.L.egr_winograd_input(_p(x), _p(gsc), _p(gsh), gsilu, B, H, W, Cin, _p(V), self._st()),
+                     "egr_winograd_input")
         Mx = torch.empty((16, P, Cout), dtype=torch.float32, device=self.dev)
         wt = self.w[key + ".weight.wino"]
         fl = 16 * 2.0 * P * Cin * Cout
@@ -254,6 +256,49 @@ class FlashSREngine:
                      "egr_groupnorm_nhwc")
         return y
 
+    def gn_coeff(self, x, key, eps):
+        """GroupNorm statistics only -> (scale [B,C], shift [B,C]); the consumer conv applies them while loading."""
+        B = x.shape[0]
+        Cc = x.shape[-1]
+        HW = x.numel() // (B * Cc)
+        G = self.cfg.gn_groups
+        need = self.L.egr_groupnorm_workspace_bytes(B, Cc, G)
+        if self._gn_ws is None or self._gn_ws.numel() < need:
+            self._gn_ws = torch.empty(int(need) + 1024, dtype=torch.uint8, device=self.dev)
+        sc = torch.empty((B, Cc), dtype=torch.float32, device=self.dev)
+        sh = torch.empty((B, Cc), dtype=torch.float32, device=self.dev)
+        native.check(self.L.egr_groupnorm_coeff(_p(x), _p(self.w[key + ".weight"]), _p(self.w[key + ".bias"]), B, HW, Cc, G,
+                                                eps, _p(self._gn_ws), _p(sc), _p(sh), self._st()), "egr_groupnorm_coeff")
+        return sc, sh
+
+    def gn_conv3(self, x, norm_key, eps, conv_key, res=None, bias_t=None):
+        """conv3x3(silu(groupnorm(x))) with the normalisation fused into the conv's input path when possible."""
+        B, H, W, Cin = x.shape
+        Cout = self.wshape[conv_key + ".weight"][3]
+        wino = (conv_key + ".weight.wino") in self.w and H % 2 == 0 and W % 2 == 0
+        # Fusing into the Winograd input transform is free (HBM-bound kernel).  Fusing into the direct conv's loader
+        # recomputes the SiLU once per tap and measured slower (conv 104 -> 91 TFLOP/s), so it is opt-in ("all").
+        fused_ok = self.FUSE_GN != "0" and Cin % 16 == 0 and Cin % self.cfg.gn_groups == 0 and (wino or self.FUSE_GN == "all")
+        if not fused_ok:
+            return self.conv3(self.groupnorm(x, norm_key, eps, True), conv_key, res=res, bias_t=bias_t)
+        sc, sh = self.gn_coeff(x, norm_key, eps)
+        if wino:
+            return self._conv_winograd(x, conv_key, ACT_NONE, res, bias_t, gn=(sc, sh, 1))
+        y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=self.dev)
+        bt = bias_t if bias_t is not None else self.w.get(conv_key + ".bias")
+        fl = 2.0 * B * H * W * Cout * 9 * Cin
+        ev = self._prof_begin()
+        native.check(self.L.egr_conv_nhwc_gn(_p(x), _p(sc), _p(sh), 1, _p(self.w[conv_key + ".weight"]), _p(bt), _p(res), _p(y),
+                                             B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 1, ACT_NONE, self._st()), "egr_conv_nhwc_gn")
+        if ev is not None:
+            bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
+            self._prof_end(ev, f"k_conv_igemm<{bn}, true>", fl, (B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 0))
+        if self.count_flops:
+            self.flops += fl
+        return y
+
+    FUSE_GN = os.environ.get("EGREGORA_FLASHSR_FUSE_GN", "1")      # "0" off, "1" Winograd consumers only, "all"
+
     def layernorm(self, x2, key):
         rows, Cc = x2.shape
         y = torch.empty_like(x2)
@@ -345,10 +390,9 @@ class FlashSREngine:
         return y
 
     def _vae_res(self, x, name):
-        h = self.conv3(self.groupnorm(x, name + ".norm1", 1e-6, True), name + ".conv1")
-        h = self.groupnorm(h, name + ".norm2", 1e-6, True)
+        h = self.gn_conv3(x, name + ".norm1", 1e-6, name + ".conv1")
         sc = self.conv1x1(x, name + ".nin_shortcut") if (name + ".nin_shortcut.weight") in self.w else x
-        return self.conv3(h, name + ".conv2", res=sc)
+        return self.gn_conv3(h, name + ".norm2", 1e-6, name + ".conv2", res=sc)
 
     def _vae_attn(self, x, name):
         B, H, W, Cc = x.shape
@@ -391,11 +435,9 @@ class FlashSREngine:
 
     def _unet_block(self, x, base, has_attn):
         cfg = self.cfg
-        h = self.conv3(self.groupnorm(x, base + ".res.in_norm", 1e-5, True), base + ".res.in_conv",
-                       bias_t=self.w[base + ".res.in_conv.bias_t"])
-        h = self.groupnorm(h, base + ".res.out_norm", 1e-5, True)
+        h = self.gn_conv3(x, base + ".res.in_norm", 1e-5, base + ".res.in_conv", bias_t=self.w[base + ".res.in_conv.bias_t"])
         sc = self.conv1x1(x, base + ".res.skip") if (base + ".res.skip.weight") in self.w else x
-        x = self.conv3(h, base + ".res.out_conv", res=sc)
+        x = self.gn_conv3(h, base + ".res.out_norm", 1e-5, base + ".res.out_conv", res=sc)
         if has_attn:
             B, H, W, Cc = x.shape
             T = H * W

@@ -39,7 +39,9 @@ SIGNATURES = {
     "egr_resample_poly": (_i, [_vp, _i, _i64, _i, _i, _vp, _i, _vp, _i64, _vp]),
     "egr_conv_nhwc": (_i, [_vp] * 6 + [_i] * 15 + [_f, _vp]),
     "egr_conv_nhwc_placed": (_i, [_vp] * 6 + [_i] * 15 + [_f] + [_i] * 6 + [_vp]),
-    "egr_winograd_input": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "egr_winograd_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "egr_groupnorm_coeff": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "egr_conv_nhwc_gn": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
     "egr_gemm_zbatched": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _vp]),
     "egr_winograd_output": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "egr_bgemm": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_i64] * 6 + [_i, _f, _vp]),

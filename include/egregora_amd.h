@@ -166,11 +166,21 @@ int egr_conv_nhwc_placed(const float* x, const float* w, const float* bias, cons
  *   egr_gemm_zbatched  : M[xi] = V[xi] ([P][Cin]) x U[xi] ([Cin][Cout], each packed like egr_conv_nhwc weights), xi < nz
  *   egr_winograd_output: y [B][H][W][N] = act(A^T M A + bias + res)        (act: 0 none, 1 SiLU)
  * U = G g G^T is prepared by the host once per layer (flashsr_engine.FlashSREngine.add_winograd). */
-int egr_winograd_input(const float* x, int B, int H, int W, int C, float* V, void* stream);
+int egr_winograd_input(const float* x, const float* gn_scale, const float* gn_shift, int gn_silu, int B, int H, int W, int C,
+                       float* V, void* stream);   /* gn_*: optional fused producer GroupNorm (+SiLU), [B][C] each */
 int egr_gemm_zbatched(const float* x, const float* w, float* y, int nz, int rows, int Cin, int Cout, int64_t zx, int64_t zw,
                       int64_t zy, void* stream);
 int egr_winograd_output(const float* M, const float* bias, const float* res, float* y, int B, int H, int W, int N, int act,
                         void* stream);
+
+/* GroupNorm split in two: egr_groupnorm_coeff computes the statistics and the per-(b, c) scale/shift ([B][C] each);
+ * egr_conv_nhwc_gn is egr_conv_nhwc (no dilation / upsample / placement) with x*scale + shift (+SiLU) applied to the
+ * input while it is loaded (zero padding after it), so the normalised tensor is never materialised. */
+int egr_groupnorm_coeff(const float* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps,
+                        void* workspace, float* scale, float* shift, void* stream);
+int egr_conv_nhwc_gn(const float* x, const float* gn_scale, const float* gn_shift, int gn_silu, const float* w,
+                     const float* bias, const float* res, float* y, int B, int H, int W, int Cin, int OH, int OW, int Cout,
+                     int KH, int KW, int stride, int pad_t, int pad_l, int act, void* stream);
 
 /* Strided batched GEMM for attention: C[b1][b2] = alpha * A[b1][b2] (MxK) * (transB ? B^T : B). */
 int egr_bgemm(const float* a, const float* b, float* c, int nb1, int nb2, int M, int N, int K, int lda, int ldb,

@@ -104,6 +104,35 @@ def test_winograd_conv_vs_torch(eng):
     e.w.pop("wg.weight.wino")
 
 
+def test_fused_groupnorm_conv_vs_torch(eng):
+    """conv3x3(silu(groupnorm(x))) with the normalisation applied in the conv loader / the Winograd input transform."""
+    e, cfg, P = eng
+    g = torch.Generator().manual_seed(43)
+    old, oldf = e.cfg.gn_groups, type(e).FUSE_GN
+    e.cfg.gn_groups = 8
+    type(e).FUSE_GN = "all"
+    try:
+        for wino in (False, True):
+            for (B, H, W, Ci, Co) in [(2, 8, 12, 32, 48), (3, 6, 4, 64, 80)]:
+                x = torch.randn(B, Ci, H, W, generator=g) * 2 + 0.5
+                ga, be = 1 + 0.1 * torch.randn(Ci, generator=g), 0.1 * torch.randn(Ci, generator=g)
+                w = torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9)
+                b = torch.randn(Co, generator=g)
+                res = torch.randn(B, Co, H, W, generator=g)
+                want = F.conv2d(F.silu(F.group_norm(x, 8, ga, be, 1e-6)), w, b, padding=1) + res
+                e.w["fg.weight"], e.w["fg.bias"] = ga.cuda(), be.cuda()
+                e.add_weight("fc.weight", w)
+                e.w["fc.bias"] = b.cuda()
+                if wino:
+                    e.add_winograd("fc.weight", w)
+                got = e.gn_conv3(nhwc(x).cuda(), "fg", 1e-6, "fc", res=nhwc(res).cuda())
+                close(nchw(got), want, 4e-5)
+                e.w.pop("fc.weight.wino", None)
+    finally:
+        e.cfg.gn_groups = old
+        type(e).FUSE_GN = oldf
+
+
 def test_upsample_conv_as_four_phase_convs(eng):
     """nearest-2x + 3x3 conv evaluated as four 2x2 phase convs with pre-summed taps (4/9 of the multiplies)."""
     e, cfg, P = eng
