@@ -12,6 +12,9 @@
 // (k1, M1-k1), all in LDS) followed by k_col (twiddle^-1 . IFFT_M1 . [time domain] . FFT_M1 . twiddle on a
 // tile of TC adjacent columns, all in LDS).  Each launch reads 4N and writes 4N bytes per channel; the
 // spectrum is never materialised in natural order and nothing is transposed.
+// Long inputs add a third factor (state [M1][M2][M3], inner column pass k_col<3>/<4>); lengths without a packed
+// plan (odd, large primes) run the chirp-z path further down (k_colz, k_rowconv); egr_spectral_gain reuses the
+// passes as a zero-phase filter.  DESIGN.md section 2 has the derivations.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -15,11 +15,11 @@ The table below follows the published AudioSR / FlashSR design as recalled (UPST
   VAE decoder     : mirror of the encoder with 3 res-blocks/level + mid attention                -> [1,512,256]
   SR vocoder      : BigVGAN-style generator (snake + anti-aliased resampling AMP blocks, transposed-conv
                     up-rates 6*5*4*2*2 = 480) with a strided-conv encoder of the LR waveform added U-Net style
-Every dimension is a field of `FlashSRConfig`; `config_from_state_dicts` re-derives them from checkpoint tensor
+Every dimension is a field of `FlashSRConfig`; `config_from_params` re-derives the widths from checkpoint tensor
 shapes when real weights are supplied, and `init_params` produces seeded synthetic weights of the same shapes
 for benchmarking (BASELINE: "random-init weights of that architecture").  The same table drives the HIP engine
 (flashsr_engine.py), the PyTorch fp32 reference (oracle/flashsr_torch.py) and the FLOP count used for the MFMA
-roofline.
+roofline (FlashSREngine.flop_count walks the executed graph).
 """
 import math
 from dataclasses import dataclass, field
@@ -320,7 +320,26 @@ def unet_blocks(cfg: FlashSRConfig) -> List[Tuple[str, int, int, bool]]:
     return blocks
 
 
-def count_flops(cfg: FlashSRConfig, P: Dict[str, torch.Tensor]) -> Dict[str, float]:
-    """Dense-contraction flops per 5.12 s chunk-row, from the table (2*Cin*Cout*Kh*Kw*Hout*Wout per conv,
-    2*Cin*Cout*T per linear, 4*T^2*d per attention).  Filled by the engines' dry run; see flashsr_engine."""
-    raise NotImplementedError("use flashsr_engine.flop_table(cfg) which walks the executed graph")
+def config_from_params(P: Dict[str, torch.Tensor], base: FlashSRConfig = None) -> FlashSRConfig:
+    """Re-derive the width / depth fields of the table from the tensor shapes of a state dict that uses this
+    module's names (what `EGREGORA_FLASHSR_WEIGHTS` supplies).  Fields that shapes cannot reveal (sample rate, hop,
+    schedule length, dilations) keep the values of `base`."""
+    import dataclasses
+    base = base or FlashSRConfig()
+    vae_ch = P["vae.encoder.conv_in.weight"].shape[0]
+    z_ch = P["vae.post_quant_conv.weight"].shape[0]
+    levels = 1 + max(int(k.split(".")[3]) for k in P if k.startswith("vae.encoder.down."))
+    vae_mult = tuple(P[f"vae.encoder.down.{lv}.block.0.conv1.weight"].shape[0] // vae_ch for lv in range(levels))
+    vae_res = 1 + max(int(k.split(".")[5]) for k in P if k.startswith("vae.encoder.down.0.block."))
+    unet_ch = P["unet.time_embed.0.weight"].shape[1]
+    voc_ch = P["voc.conv_pre.weight"].shape[0]
+    n_mels = P["voc.conv_pre.weight"].shape[1]
+    n_up = 1 + max(int(k.split(".")[2]) for k in P if k.startswith("voc.ups."))
+    rates = []
+    for i in range(n_up):
+        kt = P[f"voc.ups.{i}.weight"].shape[2]
+        rates.append(kt // 2)                                   # kernel = 2r (+1 for odd r)
+    n_k = 1 + max(int(k.split(".")[3]) for k in P if k.startswith("voc.amp.0."))
+    kernels = tuple(P[f"voc.amp.0.{j}.0.conv1.weight"].shape[2] for j in range(n_k))
+    return dataclasses.replace(base, vae_ch=vae_ch, z_ch=z_ch, vae_mult=vae_mult, vae_res=vae_res, unet_ch=unet_ch,
+                               voc_ch=voc_ch, n_mels=n_mels, voc_rates=tuple(rates), voc_kernels=kernels)

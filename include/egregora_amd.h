@@ -83,9 +83,8 @@ int egr_fatllama_enhance(egr_fatllama_plan* plan, const float* x, float* out, in
  * [channels][N/2+1] (real, one value per half-spectrum bin).  Used by the FlashSR input low-pass. */
 int egr_spectral_gain(egr_fatllama_plan* plan, const float* x, const float* gain, float* y, void* stream);
 
-/* Debug / roofline helpers: the forward transposed half-spectrum after `iters` iterations is not
- * exposed; these run single stages of the loop so tests can bisect. which: 0 = peaks {pin[C], pout[C]}
- * of the last enhance call copied to host (synchronises the stream). */
+/* Per-channel peaks of the last enhance call copied to host: host_pin[c] = max|x_c| on the integer scale (after
+ * the optional PCM_16 quantisation), host_pout[c] = max|y_c + d_c| before autoscale / normalise.  Synchronises `stream`. */
 int egr_fatllama_last_peaks(egr_fatllama_plan* plan, float* host_pin, float* host_pout, void* stream);
 /* Average HIP-event duration (ms) and launch count of the two loop kernels over the last enhance
  * call when profiling was enabled with egr_fatllama_set_profiling(plan, 1). Synchronises. */

@@ -221,7 +221,6 @@ def _act_aa(x, alpha, beta, filt):
 
 def vocoder(mel, wave, P, cfg, filt):
     """mel [B,1,T,F] (log-mel image), wave [B,L] (the LR input) -> [B,L]."""
-    from importlib import import_module
     n = len(cfg.voc_rates)
     m = mel[:, 0].permute(0, 2, 1)                                    # [B,F,T]
     h = F.conv1d(m, P["voc.conv_pre.weight"], P["voc.conv_pre.bias"], padding=3)
@@ -259,7 +258,6 @@ def flashsr_forward(x, noise, P, cfg, blocks, mel_fb, filt, stages=None):
     mel = log_mel(x, cfg, mel_fb)
     z_c = vae_encode(mel, P, cfg)
     t = cfg.t_steps - 1
-    import importlib
     s = 0.008
     f = lambda u: math.cos((u / cfg.t_steps + s) / (1 + s) * math.pi / 2) ** 2
     abar = min(max(f(t + 1) / f(0), 1e-5), 0.99999)

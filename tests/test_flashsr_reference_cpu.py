@@ -43,3 +43,9 @@ def test_full_table_shapes(pack):
     assert abs(a * a + s * s - 1) < 1e-12 and a < 0.01
     for r in cfg.voc_rates:
         assert (A.up_kernel(r) - r) % 2 == 0
+
+
+def test_config_round_trips_through_parameter_shapes(pack):
+    from egregora_amd import flashsr_arch as A
+    cfg = A.tiny_config()
+    assert A.config_from_params(A.init_params(cfg, 0), cfg) == cfg
