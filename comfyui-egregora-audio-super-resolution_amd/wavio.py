@@ -57,3 +57,18 @@ def read_wav_bytes(buf: bytes) -> Tuple[np.ndarray, int]:
 def read_wav(path: str) -> Tuple[np.ndarray, int]:
     with open(path, "rb") as f:
         return read_wav_bytes(f.read())
+
+
+def write_wav_pcm16(path: str, frames_first: np.ndarray, sr: int) -> None:
+    """[S] or [S,C] float -> PCM_16 RIFF/WAVE with libsndfile's default float conversion (rint(x*32767), wrap)."""
+    a = np.asarray(frames_first, dtype=np.float32)
+    if a.ndim == 1:
+        a = a[:, None]
+    q = np.rint(a * np.float32(32767.0)).astype(np.int64)
+    q = ((q + 32768) % 65536 - 32768).astype("<i2")
+    ch = q.shape[1]
+    body = q.tobytes()
+    hdr = (b"RIFF" + struct.pack("<I", 36 + len(body)) + b"WAVEfmt " +
+           struct.pack("<IHHIIHH", 16, 1, ch, int(sr), int(sr) * ch * 2, ch * 2, 16) + b"data" + struct.pack("<I", len(body)))
+    with open(path, "wb") as f:
+        f.write(hdr + body)

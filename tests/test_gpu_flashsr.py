@@ -390,3 +390,20 @@ def test_full_size_engine_shapes_and_determinism(pack):
     assert torch.equal(y1, y2)
     fl = e.flop_count(1)
     assert 1e12 < fl < 1e13
+
+
+def test_flashsr_min_cli_runs_the_node(pack, eng, tmp_path, monkeypatch):
+    """The flashsr_min-shaped CLI reads a WAV, runs the upscaler node on the device and writes a PCM_16 WAV."""
+    e, cfg, P = eng
+    from egregora_amd import audio_glue as ag, flashsr_engine as E, flashsr_min, wavio
+    x = (0.3 * np.sin(2 * np.pi * 440 * np.arange(9000) / 48000)).astype(np.float32)
+    wavio.write_wav_pcm16(str(tmp_path / "in.wav"), np.stack([x, 0.5 * x], 1), 48000)
+    monkeypatch.setattr(ag, "CHUNK_SAMPLES", cfg.chunk)
+    monkeypatch.setattr(ag, "HOP_SAMPLES", cfg.chunk - 375)
+    E.set_engine(e)
+    try:
+        flashsr_min.main(["--ckpt-dir", str(tmp_path), "--in", str(tmp_path / "in.wav"), "--out", str(tmp_path / "out.wav")])
+    finally:
+        E.set_engine(None)
+    y, sr = wavio.read_wav(str(tmp_path / "out.wav"))
+    assert sr == 48000 and y.shape == (9000, 2) and np.isfinite(y).all() and float(np.abs(y).max()) > 0
