@@ -60,38 +60,50 @@ __device__ __forceinline__ float apply_act(float v, int act, float prm) {
     }
 }
 
-// One BK=16 slab.  LDS tiles are row-major [row][k] (k contiguous): lane (li = lane&31, lk = lane>>5) fetches the
-// 8 k-values k = 8*lk .. 8*lk+7 of its row with two ds_read_b128; MFMA step j then multiplies k = j (lanes 0-31)
-// and k = 8+j (lanes 32-63).  The k order inside a slab is irrelevant to the sum as long as A and B agree.
+// One BK=16 slab is consumed as two half-slabs of 4 MFMA k-steps.  LDS tiles are row-major [row][k] (k contiguous):
+// lane (li = lane&31, lk = lane>>5) fetches, for half hs, the 4 k-values k = 8*lk + 4*hs .. +3 of its row with ONE
+// ds_read_b128; MFMA step j then multiplies k = 4*hs + j (lanes 0-31) and k = 8 + 4*hs + j (lanes 32-63).  The k order
+// inside a slab is irrelevant to the sum as long as A and B agree.
 template <int TM, int TN>
-__device__ __forceinline__ void mma_slab(const float* __restrict__ As, const float* __restrict__ Bs, int wm0, int wn0,
-                                         f32x16 (&acc)[TM][TN]) {
+struct HalfOps {
+    float4 a[TM], b[TN];
+};
+
+template <int TM, int TN>
+__device__ __forceinline__ void read_half(const float* __restrict__ As, const float* __restrict__ Bs, int wm0, int wn0, int hs,
+                                          HalfOps<TM, TN>& o) {
     const int lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5;
-    float4 a[TM][2], b[TN][2];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const float* r = As + (wm0 + i * 32 + li) * LROW + lk * 8;
-        a[i][0] = *(const float4*)r;
-        a[i][1] = *(const float4*)(r + 4);
-    }
+    for (int i = 0; i < TM; ++i) o.a[i] = *(const float4*)(As + (wm0 + i * 32 + li) * LROW + lk * 8 + hs * 4);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const float* r = Bs + (wn0 + j * 32 + li) * LROW + lk * 8;
-        b[j][0] = *(const float4*)r;
-        b[j][1] = *(const float4*)(r + 4);
-    }
+    for (int j = 0; j < TN; ++j) o.b[j] = *(const float4*)(Bs + (wn0 + j * 32 + li) * LROW + lk * 8 + hs * 4);
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void mma_half(const HalfOps<TM, TN>& o, f32x16 (&acc)[TM][TN]) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const float av = ((const float*)&a[i][s >> 2])[s & 3];
+            const float av = ((const float*)&o.a[i])[s];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const float bv = ((const float*)&b[j][s >> 2])[s & 3];
+                const float bv = ((const float*)&o.b[j])[s];
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
             }
         }
     }
+}
+
+// whole slab in one go (used by k_bgemm)
+template <int TM, int TN>
+__device__ __forceinline__ void mma_slab(const float* __restrict__ As, const float* __restrict__ Bs, int wm0, int wn0,
+                                         f32x16 (&acc)[TM][TN]) {
+    HalfOps<TM, TN> h0, h1;
+    read_half<TM, TN>(As, Bs, wm0, wn0, 0, h0);
+    read_half<TM, TN>(As, Bs, wm0, wn0, 1, h1);
+    mma_half<TM, TN>(h0, acc);
+    mma_half<TM, TN>(h1, acc);
 }
 
 // BN = 128: waves 2x2, each 64x64 (TM=2,TN=2); BN = 64: waves 2x2, each 64x32 (2,1); BN = 32: waves 4x1, each 32x32.
@@ -241,15 +253,27 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         }
     };
 
+    // Software pipeline (one barrier per slab, placed MID-slab):
+    //   start of iteration kt : tile kt+1 (global loads issued one iteration ago) -> LDS buf[cur^1]; issue loads of tile kt+2
+    //   first half            : MFMAs on the operands fetched during the previous iteration || LDS reads of the second half
+    //   barrier               : (RAW) tile kt+1 visible; (WAR) nobody reads buf[cur] first halves / buf[cur^1] any more
+    //   second half           : MFMAs || LDS reads of slab kt+1's first half from buf[cur^1]
+    // so the matrix pipe never waits on an LDS fetch issued after a barrier.
+    HalfOps<TC::TM, TC::TN> opA, opB;
     load_tile(kt_begin);
     store_tile(0);
     __syncthreads();
+    read_half<TC::TM, TC::TN>(As[0], Bs[0], wm0, wn0, 0, opA);
+    if (kt_begin + 1 < kt_end) load_tile(kt_begin + 1);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
-        if (kt + 1 < kt_end) load_tile(kt + 1);
-        mma_slab<TC::TM, TC::TN>(As[cur], Bs[cur], wm0, wn0, acc);
         if (kt + 1 < kt_end) store_tile(cur ^ 1);
+        if (kt + 2 < kt_end) load_tile(kt + 2);
+        read_half<TC::TM, TC::TN>(As[cur], Bs[cur], wm0, wn0, 1, opB);
+        mma_half<TC::TM, TC::TN>(opA, acc);
         __syncthreads();
+        if (kt + 1 < kt_end) read_half<TC::TM, TC::TN>(As[cur ^ 1], Bs[cur ^ 1], wm0, wn0, 0, opA);
+        mma_half<TC::TM, TC::TN>(opB, acc);
     }
 
     // ---- epilogue ----
