@@ -407,3 +407,38 @@ def test_flashsr_min_cli_runs_the_node(pack, eng, tmp_path, monkeypatch):
         E.set_engine(None)
     y, sr = wavio.read_wav(str(tmp_path / "out.wav"))
     assert sr == 48000 and y.shape == (9000, 2) and np.isfinite(y).all() and float(np.abs(y).max()) > 0
+
+
+def test_node_run_with_rate_conversion_both_sides(pack, eng, monkeypatch):
+    """EgregoraAudioSuperResolution.run end to end on the device: 44.1 kHz stereo in -> polyphase to 48 kHz -> chunked
+    engine + WOLA -> polyphase to 96 kHz, against the oracle glue (scipy resample_poly, torch reference graph, numpy WOLA)."""
+    e, cfg, P = eng
+    from egregora_amd import audio_glue as ag, flashsr_arch as A, flashsr_engine as E
+    from oracle import flashsr_torch as R, glue as og
+    win, hop = cfg.chunk, cfg.chunk - 375
+    monkeypatch.setattr(ag, "CHUNK_SAMPLES", win)
+    monkeypatch.setattr(ag, "HOP_SAMPLES", hop)
+    g = torch.Generator().manual_seed(8)
+    x = 0.3 * torch.randn(1, 2, 7000, generator=g)
+    E.set_engine(e)
+    try:
+        node = pack.NODE_CLASS_MAPPINGS["EgregoraAudioUpscaler"]()
+        (res,) = node.run(audio={"waveform": x, "sample_rate": 44100}, lowpass_input=False, output_sr="96000")
+    finally:
+        E.set_engine(None)
+    assert res["sample_rate"] == 96000 and res["waveform"].dtype == torch.float32 and res["waveform"].dim() == 3
+    fb, filt = torch.from_numpy(A.mel_filterbank(cfg)), torch.from_numpy(A.kaiser_sinc_filter(cfg.aa_taps))
+    x48 = og.resample_hq(x[0].numpy(), 44100, 48000)
+    idx = [0]
+
+    def model(c):
+        k = idx[0]; idx[0] += 1
+        ids = torch.tensor([k * 2, k * 2 + 1], dtype=torch.int64, device="cuda")
+        nz = nchw(e.noise(2, ids, E.SEED).cpu())
+        with torch.no_grad():
+            return R.flashsr_forward(torch.from_numpy(c), nz, P, cfg, A.unet_blocks(cfg), fb, filt).numpy()
+    y48 = og.flashsr_node_glue(x48, model, win, hop)
+    want = og.resample_hq(y48, 48000, 96000)
+    got = res["waveform"][0].numpy()
+    assert got.shape == want.shape
+    assert float(np.abs(got - want).max()) <= 3e-3 * float(np.abs(want).max())
