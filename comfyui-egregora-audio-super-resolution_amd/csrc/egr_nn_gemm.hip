@@ -44,6 +44,7 @@ struct ConvP {
     const float* gn_scale;
     const float* gn_shift;
     int gn_silu;
+    const float* zeros;    // >= 64 zero floats: out-of-image / out-of-range rows read from here (no select needed)
 };
 
 #define BM 128
@@ -176,7 +177,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     }
     const size_t b_slab = (size_t)p.Cout * BK;
 
-    float4 ra[2], rb4[2];
+    float4 ra0, ra1, rb0, rb1;                // staged tile registers (scalars: arrays here ended up in scratch)
+    ra0 = ra1 = rb0 = rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
     float rs[8];
     int tap = 0, c0 = 0;                      // VEC: current (tap, first channel) of the slab being loaded
     if (VEC && kt_begin > 0) {
@@ -184,18 +186,43 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         tap = kt_begin / tpt;
         c0 = (kt_begin - tap * tpt) * BK;
     }
+    // VEC loader state (plain scalars on purpose: arrays captured by the lambdas below end up in scratch): per owned
+    // row a pointer to channel kq of the current tap's pixel, or into the zero page when the tap falls outside the
+    // image / the row is past M.  Recomputed only when the tap changes; a steady-state slab is one 16-byte load per row.
+    const float* aptr0 = p.zeros;
+    const float* aptr1 = p.zeros;
+    int astep0 = 0, astep1 = 0;               // 1 when the row is real (advance by c0), 0 when it reads the zero page
+#define EGR_SET_TAP(TP)                                                                                              \
+    {                                                                                                                \
+        const int ky_ = (TP) / p.KW, kx_ = (TP) - ky_ * p.KW;                                                        \
+        {                                                                                                            \
+            const int iy = a_iy0[0] + ky_, ix = a_ix0[0] + kx_ * p.dil;                                              \
+            const bool ok = a_ok[0] && (unsigned)iy < (unsigned)LH && (unsigned)ix < (unsigned)LW;                   \
+            const int py = p.up2 ? iy >> 1 : iy, px = p.up2 ? ix >> 1 : ix;                                          \
+            aptr0 = ok ? p.x + (a_base[0] + (size_t)py * p.W + px) * p.Cin + kq : p.zeros + kq;                      \
+            astep0 = ok ? 1 : 0;                                                                                     \
+        }                                                                                                            \
+        {                                                                                                            \
+            const int iy = a_iy0[1] + ky_, ix = a_ix0[1] + kx_ * p.dil;                                              \
+            const bool ok = a_ok[1] && (unsigned)iy < (unsigned)LH && (unsigned)ix < (unsigned)LW;                   \
+            const int py = p.up2 ? iy >> 1 : iy, px = p.up2 ? ix >> 1 : ix;                                          \
+            aptr1 = ok ? p.x + (a_base[1] + (size_t)py * p.W + px) * p.Cin + kq : p.zeros + kq;                      \
+            astep1 = ok ? 1 : 0;                                                                                     \
+        }                                                                                                            \
+    }
+    if (VEC) EGR_SET_TAP(tap)
+    const float* bptr0 = b_ok[0] ? p.w + (size_t)kt_begin * b_slab + b_off[0] : p.zeros + kq;
+    const float* bptr1 = b_ok[1] ? p.w + (size_t)kt_begin * b_slab + b_off[1] : p.zeros + kq;
+    const size_t bstep0 = b_ok[0] ? b_slab : 0, bstep1 = b_ok[1] ? b_slab : 0;
 
     auto load_tile = [&](int kt) {
         if (VEC) {
-            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            float4 v0 = *(const float4*)(aptr0 + astep0 * c0);
+            float4 v1 = *(const float4*)(aptr1 + astep1 * c0);
+            if (GN) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int iy = a_iy0[h] + ky, ix = a_ix0[h] + kx * p.dil;
-                const bool ok = a_ok[h] && (unsigned)iy < (unsigned)LH && (unsigned)ix < (unsigned)LW;
-                const int py = p.up2 ? iy >> 1 : iy, px = p.up2 ? ix >> 1 : ix;
-                const size_t off = ok ? ((a_base[h] + (size_t)py * p.W + px) * p.Cin + c0 + kq) : (size_t)kq;
-                float4 v = *(const float4*)(p.x + off);          // unconditional load; masked afterwards
-                if (GN) {
+                for (int h = 0; h < 2; ++h) {
+                    float4& v = h ? v1 : v0;
                     const size_t go = (size_t)a_b[h] * p.Cin + c0 + kq;
                     const float4 sc = *(const float4*)(p.gn_scale + go), sh = *(const float4*)(p.gn_shift + go);
                     v = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
@@ -203,11 +230,13 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
                         v.x = v.x / (1.f + __expf(-v.x)); v.y = v.y / (1.f + __expf(-v.y));
                         v.z = v.z / (1.f + __expf(-v.z)); v.w = v.w / (1.f + __expf(-v.w));
                     }
+                    if (!(h ? astep1 : astep0)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                ra[h] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            ra0 = v0;
+            ra1 = v1;
             c0 += BK;
-            if (c0 >= p.Cin) { c0 = 0; ++tap; }
+            if (c0 >= p.Cin) { c0 = 0; ++tap; EGR_SET_TAP(tap) }
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -227,18 +256,17 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
                 rs[i] = v;
             }
         }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (256 * h < BQ) {
-                float4 v = *(const float4*)(p.w + (size_t)kt * b_slab + b_off[h]);
-                rb4[h] = b_ok[h] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+        rb0 = *(const float4*)bptr0;
+        bptr0 += bstep0;
+        if (256 < BQ) {
+            rb1 = *(const float4*)bptr1;
+            bptr1 += bstep1;
         }
     };
     auto store_tile = [&](int buf) {
         if (VEC) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) *(float4*)&As[buf][(r0 + 64 * h) * LROW + kq] = ra[h];
+            *(float4*)&As[buf][r0 * LROW + kq] = ra0;
+            *(float4*)&As[buf][(r0 + 64) * LROW + kq] = ra1;
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -246,11 +274,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
                 As[buf][(e & (BM - 1)) * LROW + (e >> 7)] = rs[i];
             }
         }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int slot = tid + 256 * h;
-            if (slot < BQ) *(float4*)&Bs[buf][(slot >> 2) * LROW + kq] = rb4[h];
-        }
+        if (tid < BQ) *(float4*)&Bs[buf][(tid >> 2) * LROW + kq] = rb0;
+        if (tid + 256 < BQ) *(float4*)&Bs[buf][((tid + 256) >> 2) * LROW + kq] = rb1;
     };
 
     // Software pipeline (one barrier per slab, placed MID-slab):
@@ -438,6 +463,24 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmP p) {
         }
 }
 
+// per-device page of zeros the loaders read for padded / out-of-range rows
+static int zero_page(const float** out) {
+    static std::mutex mu;
+    static std::map<int, float*> pages;
+    int dev = 0;
+    EGR_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = pages.find(dev);
+    if (it == pages.end()) {
+        float* ptr = nullptr;
+        EGR_HIP(hipMalloc((void**)&ptr, 4096));
+        EGR_HIP(hipMemset(ptr, 0, 4096));
+        it = pages.emplace(dev, ptr).first;
+    }
+    *out = it->second;
+    return EGR_OK;
+}
+
 // per-device scratch for split-K partials (grown on demand; launches on one stream are ordered, so reuse is safe)
 static int splitk_workspace(size_t bytes, float** out) {
     static std::mutex mu;
@@ -534,6 +577,7 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
     p.ksplit = 1; p.kt_per = ktiles; p.ws = nullptr;
     p.zx = zx; p.zw = zw; p.zy = zy;
     p.gn_scale = gn_scale; p.gn_shift = gn_shift; p.gn_silu = gn_silu;
+    { int zrc = zero_page(&p.zeros); if (zrc) return zrc; }
     if (nz > 1) grid.z = nz;
     if (nz == 1 && tiles < 192 && ktiles >= 32) {
         int S = (768 + tiles - 1) / tiles;
