@@ -176,13 +176,16 @@ def main():
         dom_conv = max(variants, key=lambda k: variants[k][2])          # the variant with the most GPU time
         nconv, fconv, tconv = variants[dom_conv]
         conv_tfs = fconv / (tconv * 1e-3) / 1e12 if tconv > 0 else 0.0
-        row_bytes = 8.0 * SEG * C
+        # the loop runs the channels as two concurrent pipelines (one launch = C/2 channels) unless EGR_FL_STREAMS=1
+        groups = 2 if (C >= 2 and os.environ.get("EGR_FL_STREAMS", "2") != "1") else 1
+        row_bytes = 8.0 * SEG * C / groups
         dom_ms = max(kt["row_ms"], kt["col_ms"])
         dom = "k_row" if kt["row_ms"] >= kt["col_ms"] else "k_col<1>"
         hbm_ach = row_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
         try:
             traffic = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get("fatllama_c3", {}).get(dom)
+            traffic = traffic / groups if traffic else None
         except Exception:
             pass
         info = fe.plan_info(SEG, 1)
@@ -213,7 +216,9 @@ def main():
             "roofline_fatllama": {"bound": "hbm", "kernel": dom, "achieved": hbm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": hbm_ach / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": row_bytes,
                                   "avg_launch_ms": dom_ms, "k_row_ms": kt["row_ms"], "k_col_ms": kt["col_ms"],
-                                  "launches": [kt["row_launches"], kt["col_launches"]]},
+                                  "launches": [kt["row_launches"], kt["col_launches"]], "concurrent_pipelines": groups,
+                                  # all loop launches' algorithmic bytes / the stage's wall time (pipelines overlap)
+                                  "effective_gbs": (kt["row_launches"] + kt["col_launches"]) * row_bytes / (el_fl * 1e9)},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_fatllama(x_all[:, :SEG].cpu().numpy(), args.cpu_budget)

@@ -486,6 +486,9 @@ struct egr_fatllama_plan {
     unsigned* d_peaks;   // [2*C]: peak_in[C], peak_out[C]
     bool profiling;
     int threads;                  // workgroup size of the loop kernels (256 or 512)
+    int nstreams;                 // channel groups run as concurrent pipelines (1 or 2)
+    hipStream_t side;             // second pipeline's stream (forked from / joined to the caller's stream by events)
+    hipEvent_t ev_fork, ev_join;
     std::vector<hipEvent_t> ev;   // pairs (start, stop) tagged by kind
     std::vector<int> ev_kind;     // 0 = row, 1 = outer column pass, 2 = inner column pass
 };
@@ -566,6 +569,9 @@ extern "C" int egr_fatllama_plan_destroy(egr_fatllama_plan* p) {
     if (!p) return EGR_OK;
     for (void* q : p->dev_allocs) hipFree(q);
     hipFree(p->d_work); hipFree(p->d_peaks); hipFree(p->d_bhat);
+    if (p->side) hipStreamDestroy(p->side);
+    if (p->ev_fork) hipEventDestroy(p->ev_fork);
+    if (p->ev_join) hipEventDestroy(p->ev_join);
     for (auto e : p->ev) hipEventDestroy(e);
     delete p;
     return EGR_OK;
@@ -576,6 +582,9 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     egr_fatllama_plan* p = new egr_fatllama_plan();
     p->n_in = n_in; p->C = channels; p->factor = factor; p->sp = sp; p->profiling = false;
     p->bluestein = bluestein_n > 0;
+    p->nstreams = 2;
+    if (const char* e = getenv("EGR_FL_STREAMS")) { const int t = atoi(e); if (t == 1 || t == 2) p->nstreams = t; }
+    p->side = nullptr; p->ev_fork = nullptr; p->ev_join = nullptr;
     p->threads = 512;    // 16 waves per CU at 2 workgroups per CU: measured 1.4x over 256
     if (const char* e = getenv("EGR_FL_THREADS")) { const int t = atoi(e); if (t == 256 || t == 512 || t == 1024) p->threads = t; }
     p->d_bhat = nullptr;
@@ -820,29 +829,54 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         }
         hipLaunchKernelGGL((k_colz<2, 0>), gA, blk, lc, st, A, cp, P, thr, thr2, p->d_work, out, peak_out);
     } else {
-        hipLaunchKernelGGL(k_col<0>, gA, blk, lc, st, A, M, N, thr, p->d_work, out, peak_out);
-        if (three) hipLaunchKernelGGL(k_col<4>, gB, blk, lb, st, B, M, N, thr, p->d_work, out, peak_out);
-        for (int it = 0; it < max_iter; ++it) {
-            prof_begin(p, 0, st, &slot);
-            hipLaunchKernelGGL(k_row, grow, blk, lr, st, R, M, p->d_work);
-            prof_end(p, st, &slot);
-            if (three) {
-                prof_begin(p, 2, st, &slot);
-                hipLaunchKernelGGL(k_col<3>, gB, blk, lb, st, B, M, N, thr, p->d_work, out, peak_out);
-                prof_end(p, st, &slot);
-            }
-            if (it + 1 < max_iter) {
-                prof_begin(p, 1, st, &slot);
-                hipLaunchKernelGGL(k_col<1>, gA, blk, lc, st, A, M, N, thr, p->d_work, out, peak_out);
-                prof_end(p, st, &slot);
+        // The channels are independent until k_finalize.  Each loop kernel alone fills barely more than one wave of
+        // workgroups, so two channel groups run as concurrent pipelines on two streams (fork/join by events) and one
+        // group's k_row overlaps the other's k_col.
+        const int ngroups = (p->nstreams == 2 && C >= 2) ? 2 : 1;
+        if (ngroups == 2 && !p->side) {
+            EGR_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+            EGR_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+            EGR_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+        }
+        if (ngroups == 2) {
+            EGR_HIP(hipEventRecord(p->ev_fork, st));
+            EGR_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+        }
+        for (int g = 0; g < ngroups; ++g) {
+            const int c0 = g == 0 ? 0 : C / 2, cn = ngroups == 1 ? C : (g == 0 ? C / 2 : C - C / 2);
+            hipStream_t sg = g == 0 ? st : p->side;
+            cplx* wk = p->d_work + (size_t)c0 * M;
+            float* og = out + (size_t)c0 * N;
+            unsigned* pk = peak_out + c0;
+            const dim3 gAg(gA.x, cn), gBg(gB.x, cn * (three ? B.nplanes : 1)), growg(grow.x, cn);
+            hipLaunchKernelGGL(k_col<0>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
+            if (three) hipLaunchKernelGGL(k_col<4>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
+            for (int it = 0; it < max_iter; ++it) {
+                prof_begin(p, 0, sg, &slot);
+                hipLaunchKernelGGL(k_row, growg, blk, lr, sg, R, M, wk);
+                prof_end(p, sg, &slot);
                 if (three) {
-                    prof_begin(p, 2, st, &slot);
-                    hipLaunchKernelGGL(k_col<4>, gB, blk, lb, st, B, M, N, thr, p->d_work, out, peak_out);
-                    prof_end(p, st, &slot);
+                    prof_begin(p, 2, sg, &slot);
+                    hipLaunchKernelGGL(k_col<3>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
+                    prof_end(p, sg, &slot);
+                }
+                if (it + 1 < max_iter) {
+                    prof_begin(p, 1, sg, &slot);
+                    hipLaunchKernelGGL(k_col<1>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
+                    prof_end(p, sg, &slot);
+                    if (three) {
+                        prof_begin(p, 2, sg, &slot);
+                        hipLaunchKernelGGL(k_col<4>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
+                        prof_end(p, sg, &slot);
+                    }
                 }
             }
+            hipLaunchKernelGGL(k_col<2>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
         }
-        hipLaunchKernelGGL(k_col<2>, gA, blk, lc, st, A, M, N, thr, p->d_work, out, peak_out);
+        if (ngroups == 2) {
+            EGR_HIP(hipEventRecord(p->ev_join, p->side));
+            EGR_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
+        }
     }
     if (flags & (EGR_FL_NORMALIZE | EGR_FL_AUTOSCALE | EGR_FL_NODE_POST)) {
         const long long Nr = p->bluestein ? (long long)p->chirp.N : N;
