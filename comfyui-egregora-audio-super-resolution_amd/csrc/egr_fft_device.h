@@ -199,9 +199,11 @@ __device__ __forceinline__ void lds_fft(cplx*& cur, cplx*& alt, const FftDesc& d
             case 4: fft_stage<4, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
             case 5: fft_stage<5, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
             case 7: fft_stage<7, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
-#ifdef EGR_COMPOSITE_RADIX   // measured slower in round 1: one kernel holding every radix needs 190 VGPRs (occupancy 2)
+#ifdef EGR_RADIX_8_9
             case 8: fft_stage<8, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
             case 9: fft_stage<9, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+#endif
+#ifdef EGR_COMPOSITE_RADIX   // measured slower in round 1: one kernel holding every radix needs 190 VGPRs (occupancy 2)
             case 16: fft_stage<16, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
             case 25: fft_stage<25, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
 #endif

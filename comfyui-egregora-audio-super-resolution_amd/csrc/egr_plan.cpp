@@ -41,8 +41,8 @@ bool make_schedule(int L, FftDesc* d) {
         return true;
     };
     if (L < 1) return false;
-    // Composite register butterflies (16 / 8 / 25 / 9) exist in egr_fft_device.h but are compiled out by default
-    // (EGR_COMPOSITE_RADIX): fewer LDS stages, but the register cost lowered occupancy and measured slower.
+    // Radix 8 and 9 (nested 4x2 / 3x3 register butterflies, EGR_RADIX_8_9, default) cut the stage count at 105 VGPRs;
+    // the larger composites 16 / 25 (EGR_COMPOSITE_RADIX) push the all-radix kernel to 190 VGPRs and measured slower.
 #ifdef EGR_COMPOSITE_RADIX
     static const bool small_only = [] { const char* e = getenv("EGR_FFT_RADIX"); return e && e[0] == 's'; }();
 #else
@@ -52,6 +52,9 @@ bool make_schedule(int L, FftDesc* d) {
         while (n % 16 == 0) { if (!push(16)) return false; n /= 16; }
         if (n % 8 == 0) { if (!push(8)) return false; n /= 8; }
     }
+#ifdef EGR_RADIX_8_9
+    while (n % 8 == 0) { if (!push(8)) return false; n /= 8; }
+#endif
     while (n % 4 == 0) {
         if (!push(4)) return false;
         n /= 4;
@@ -64,6 +67,9 @@ bool make_schedule(int L, FftDesc* d) {
         while (n % 25 == 0) { if (!push(25)) return false; n /= 25; }
         while (n % 9 == 0) { if (!push(9)) return false; n /= 9; }
     }
+#ifdef EGR_RADIX_8_9
+    while (n % 9 == 0) { if (!push(9)) return false; n /= 9; }
+#endif
     const int odd[] = {3, 5, 7, 11, 13};
     for (int p : odd) {
         while (n % p == 0) {

@@ -8,12 +8,16 @@ import numpy as np
 
 
 def radix_schedule(L, allowed=(4, 2, 3, 5, 7, 11, 13)):
-    """Same rule as egr::make_schedule (default build): 4s, one 2, then odd primes ascending."""
+    """Same rule as egr::make_schedule (default build, EGR_RADIX_8_9): 8s, 4s, one 2, 9s, then odd primes ascending."""
     rad, n = [], L
+    while n % 8 == 0:
+        rad.append(8); n //= 8
     while n % 4 == 0:
         rad.append(4); n //= 4
     if n % 2 == 0:
         rad.append(2); n //= 2
+    while n % 9 == 0:
+        rad.append(9); n //= 9
     for p in (3, 5, 7, 11, 13):
         while n % p == 0:
             rad.append(p); n //= p
