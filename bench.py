@@ -31,6 +31,7 @@ sys.path.insert(0, str(ROOT))
 METRIC = "audio-sec/sec (xRT) FlashSR 48kHz + Fat-Llama 800-iter at 1/2/4/8 MI355X"
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+MFMA_BF16_PEAK_TFS = 2500.0  # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16)
 SR = 48000
 SEG = 60 * SR                # samples per GPU
 
@@ -171,11 +172,15 @@ def main():
 
     if rank == 0:
         audio_s = total / SR
-        variants = {k: v for k, v in prof.items() if k.startswith("k_conv_igemm")}
+        variants = {k: v for k, v in prof.items() if k.startswith("k_conv_")}
         fconv_all = sum(v[1] for v in variants.values())
         dom_conv = max(variants, key=lambda k: variants[k][2])          # the variant with the most GPU time
         nconv, fconv, tconv = variants[dom_conv]
-        conv_tfs = fconv / (tconv * 1e-3) / 1e12 if tconv > 0 else 0.0
+        conv_tfs = fconv / (tconv * 1e-3) / 1e12 if tconv > 0 else 0.0      # fp32-equivalent (algorithmic) rate
+        # k_conv_s3 executes SIX bf16 MFMA products per fp32 multiply-add: its roofline is the dense bf16 peak and
+        # `achieved` counts the executed bf16 flops (6 x algorithmic)
+        s3 = dom_conv.startswith("k_conv_s3")
+        mfma_mult, mfma_peak = (6.0, MFMA_BF16_PEAK_TFS) if s3 else (1.0, MFMA_F32_PEAK_TFS)
         # the loop runs the channels as two concurrent pipelines (one launch = C/2 channels) unless EGR_FL_STREAMS=1
         groups = 2 if (C >= 2 and os.environ.get("EGR_FL_STREAMS", "2") != "1") else 1
         row_bytes = 8.0 * SEG * C / groups
@@ -192,11 +197,16 @@ def main():
         out = {
             "metric": METRIC, "value": world * args.steps * (SEG / SR) / el, "unit": "audio-sec/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if eng.mfma == "f32" else "f32(bf16x3)",
+            "data": "synthetic",
             "config": {"workload": "chain60: per GPU 60 s stereo 48 kHz; FlashSR (5.12 s chunks, hop 4.62 s, student_ldm "
                                    "1-step + VAE + sr_vocoder, declared architecture, synthetic weights, chunk-sharded with one "
                                    "all-gather, WOLA) then Fat-Llama max_iterations=%d thr=0.6 normalize on autoscale off" % args.iters
                                    + (f" [only={args.only}]" if args.only else ""),
+                       "mfma": ("fp32 operands split exactly into three bf16 terms, six partial products on "
+                                "v_mfma_f32_32x32x16_bf16 with fp32 accumulation: error vs float64 <= the f32-MFMA kernel's "
+                                "(tests/test_gpu_flashsr.py::test_split3_conv_error_vs_float64)") if eng.mfma != "f32"
+                       else "v_mfma_f32_32x32x2_f32",
                        "arch": arch, "chunks": n_chunks, "rows_per_pass": E.ROWS_PER_PASS,
                        "fatllama_split": [info["M1"], info["M2"]]},
             "parts": {
@@ -209,8 +219,10 @@ def main():
                                       "avg_launch_ms": v[2] / max(1, v[0])} for k, v in variants.items()},
             },
             # dominant kernel of the step: the implicit-GEMM convolution (all dense contractions of FlashSR)
-            "roofline": {"bound": "mfma", "kernel": dom_conv, "achieved": conv_tfs, "peak": MFMA_F32_PEAK_TFS,
-                         "unit": "TFLOP/s", "frac": conv_tfs / MFMA_F32_PEAK_TFS, "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": dom_conv, "achieved": conv_tfs * mfma_mult, "peak": mfma_peak,
+                         "unit": "TFLOP/s", "frac": conv_tfs * mfma_mult / mfma_peak, "traffic": None,
+                         "mfma_dtype": "bf16 (6 executed products per fp32 multiply-add)" if s3 else "f32",
+                         "fp32_equivalent_tflops": conv_tfs, "vs_f32_mfma_peak": conv_tfs / MFMA_F32_PEAK_TFS,
                          "launches": nconv, "flops_total": fconv, "ms_total": tconv,
                          "avg_flops_per_launch": fconv / max(1, nconv), "avg_launch_ms": tconv / max(1, nconv)},
             "roofline_fatllama": {"bound": "hbm", "kernel": dom, "achieved": hbm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

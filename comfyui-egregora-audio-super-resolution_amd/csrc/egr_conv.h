@@ -1,0 +1,111 @@
+// Shared parameter block of the implicit-GEMM convolution kernels (egr_nn_gemm.hip: v_mfma_f32_32x32x2_f32 operands;
+// egr_nn_gemm_s3.hip: exact three-way bf16 split of the same fp32 operands on v_mfma_f32_32x32x16_bf16).
+#pragma once
+#include "egr_common.h"
+
+namespace egr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_TANH = 2, ACT_LEAKY01 = 3, ACT_LOGCLAMP = 4 };
+
+struct ConvP {
+    const float* x;        // [B][H][W][Cin]   (physical; logical input is 2H x 2W when up2 != 0)
+    const float* w;        // PACKED [ceil(K/16)][Cout][16], K = KH*KW*Cin ordered (ky, kx, ci)
+    const float* bias;     // [Cout] or null
+    const float* bias_b;   // [B][Cout] or null (time-embedding bias)
+    const float* res;      // [M][Cout] or null
+    float* y;              // [M][Cout]
+    int B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act;
+    int M, K;
+    float act_param;
+    // output placement: pixel (b, oy, ox) of the OH x OW grid is written at (b, oy*osy + ooy, ox*osx + oox) of an
+    // OHF x OWF image (identity by default); lets four 2x2 "phase" convolutions fill a 2x-upsampled output.
+    int osy, osx, ooy, oox, OHF, OWF;
+    // split-K (small-M layers): blockIdx.z owns slabs [z*kt_per, ...); raw partial tiles go to ws[z][M][Cout]
+    int ksplit, kt_per;
+    float* ws;
+    // independent problems along blockIdx.z (used when ksplit == 1): element offsets added per z
+    long long zx, zw, zy;
+    // optional fused input transform (GroupNorm of the producer): x' = x*gn_scale[b][c] + gn_shift[b][c], then SiLU;
+    // zero padding applies AFTER it (the reference pads the normalised tensor).  VEC path only.
+    const float* gn_scale;
+    const float* gn_shift;
+    int gn_silu;
+    const float* zeros;    // >= 64 zero floats: out-of-image / out-of-range rows read from here (no select needed)
+    // three-way bf16 split of w: [ceil(K/16)][3][Cout][16] bf16 (egr_split3_pack); zw counts uint4 (8 bf16) here
+    const uint4* w3;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act, float prm) {
+    switch (act) {
+        case ACT_SILU: return v / (1.0f + __expf(-v));
+        case ACT_TANH: return tanhf(v);
+        case ACT_LEAKY01: return v > 0.f ? v : 0.1f * v;
+        case ACT_LOGCLAMP: return __logf(fmaxf(v, prm));
+        default: return v;
+    }
+}
+
+// Accumulator layout of every 32x32 MFMA tile: register r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
+// Writes raw split-K partials, or bias + per-row bias + residual + activation at the (possibly strided) output place.
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0) {
+    const int lane = threadIdx.x & 63, col = lane & 31, rhalf = lane >> 5;
+    if (p.ksplit > 1) {        // raw partial sums; bias / residual / activation are applied by k_splitk_reduce
+        float* wz = p.ws + (size_t)blockIdx.z * p.M * p.Cout;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
+                if (m < p.M) {
+                    float* row = wz + (size_t)m * p.Cout + n0 + wn0 + col;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        if (n0 + wn0 + j * 32 + col < p.Cout) row[j * 32] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+    float bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + col;
+        bv[j] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+    }
+    const bool ident = (p.osy == 1 && p.osx == 1 && p.OHF == p.OH && p.OWF == p.OW);
+    const bool decode = !ident || p.bias_b;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {          // one output row (pixel) per (i, r): decode it once, then TN columns
+            const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
+            if (m < p.M) {
+                size_t mo = (size_t)m;
+                int b = 0;
+                if (decode) {
+                    const int ox = m % p.OW, t = m / p.OW, oy = t % p.OH;
+                    b = t / p.OH;
+                    if (!ident) mo = ((size_t)b * p.OHF + (size_t)oy * p.osy + p.ooy) * p.OWF + (size_t)ox * p.osx + p.oox;
+                }
+                const size_t o = mo * p.Cout + n0 + wn0 + col;
+                const float* bb = p.bias_b ? p.bias_b + (size_t)b * p.Cout + n0 + wn0 + col : nullptr;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (n0 + wn0 + j * 32 + col < p.Cout) {
+                        float v = acc[i][j][r] + bv[j];
+                        if (bb) v += bb[j * 32];
+                        if (p.res) v += p.res[o + j * 32];
+                        p.y[o + j * 32] = apply_act(v, p.act, p.act_param);
+                    }
+            }
+        }
+}
+
+// egr_nn_gemm_s3.hip: launches k_conv_s3<bm, bn> (bm = s3_bm(...), bn in {32, 64, 128}; grid.x = ceil(M / bm));
+// p.w3 must be set and Cin % 16 == 0
+int s3_bm(long long M, int Cout, int bn);
+void launch_conv_s3(int bm, int bn, dim3 grid, hipStream_t st, const ConvP& p);
+
+}  // namespace egr

@@ -13,53 +13,13 @@
 #include <map>
 #include <mutex>
 
-#include "egr_common.h"
+#include "egr_conv.h"
 
 namespace egr {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-enum { ACT_NONE = 0, ACT_SILU = 1, ACT_TANH = 2, ACT_LEAKY01 = 3, ACT_LOGCLAMP = 4 };
-
-struct ConvP {
-    const float* x;        // [B][H][W][Cin]   (physical; logical input is 2H x 2W when up2 != 0)
-    const float* w;        // PACKED [ceil(K/16)][Cout][16], K = KH*KW*Cin ordered (ky, kx, ci)
-    const float* bias;     // [Cout] or null
-    const float* bias_b;   // [B][Cout] or null (time-embedding bias)
-    const float* res;      // [M][Cout] or null
-    float* y;              // [M][Cout]
-    int B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act;
-    int M, K;
-    float act_param;
-    // output placement: pixel (b, oy, ox) of the OH x OW grid is written at (b, oy*osy + ooy, ox*osx + oox) of an
-    // OHF x OWF image (identity by default); lets four 2x2 "phase" convolutions fill a 2x-upsampled output.
-    int osy, osx, ooy, oox, OHF, OWF;
-    // split-K (small-M layers): blockIdx.z owns slabs [z*kt_per, ...); raw partial tiles go to ws[z][M][Cout]
-    int ksplit, kt_per;
-    float* ws;
-    // independent problems along blockIdx.z (used when ksplit == 1): element offsets added per z
-    long long zx, zw, zy;
-    // optional fused input transform (GroupNorm of the producer): x' = x*gn_scale[b][c] + gn_shift[b][c], then SiLU;
-    // zero padding applies AFTER it (the reference pads the normalised tensor).  VEC path only.
-    const float* gn_scale;
-    const float* gn_shift;
-    int gn_silu;
-    const float* zeros;    // >= 64 zero floats: out-of-image / out-of-range rows read from here (no select needed)
-};
 
 #define BM 128
 #define BK 16
 #define LROW (BK + 4)   // LDS row pitch in floats: 80 B keeps ds_read_b128 of 32 consecutive rows conflict-free
-
-__device__ __forceinline__ float apply_act(float v, int act, float prm) {
-    switch (act) {
-        case ACT_SILU: return v / (1.0f + __expf(-v));
-        case ACT_TANH: return tanhf(v);
-        case ACT_LEAKY01: return v > 0.f ? v : 0.1f * v;
-        case ACT_LOGCLAMP: return __logf(fmaxf(v, prm));
-        default: return v;
-    }
-}
 
 // One BK=16 slab is consumed as two half-slabs of 4 MFMA k-steps.  LDS tiles are row-major [row][k] (k contiguous):
 // lane (li = lane&31, lk = lane>>5) fetches, for half hs, the 4 k-values k = 8*lk + 4*hs .. +3 of its row with ONE
@@ -511,7 +471,7 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
                        int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t,
                        int pad_l, int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF,
                        int nz, long long zx, long long zw, long long zy, const float* gn_scale, const float* gn_shift,
-                       int gn_silu, void* stream);
+                       int gn_silu, void* stream, const void* w3 = nullptr);
 
 extern "C" int egr_conv_nhwc(const float* x, const float* w, const float* bias, const float* bias_b, const float* res,
                              float* y, int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
@@ -546,12 +506,26 @@ extern "C" int egr_gemm_zbatched(const float* x, const float* w, float* y, int n
                        1, 1, nz, zx, zw, zy, nullptr, nullptr, 0, stream);
 }
 
+// Same contraction on the bf16 matrix pipe: w3 = egr_split3_pack(w) (csrc/egr_nn_gemm_s3.hip).  nz > 1: independent
+// problems along z with element offsets zx / zy and a weight offset of zw3 16-byte units.
+extern "C" int egr_conv_s3(const float* x, const void* w3, const float* bias, const float* bias_b, const float* res, float* y,
+                           int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil,
+                           int pad_t, int pad_l, int up2, int act, float act_param, int osy, int osx, int ooy, int oox,
+                           int OHF, int OWF, int nz, int64_t zx, int64_t zw3, int64_t zy, void* stream) {
+    EGR_CHECK(w3, EGR_ERR_ARG, "null w3");
+    EGR_CHECK(nz >= 1 && nz <= 65535, EGR_ERR_ARG, "bad nz");
+    return conv_launch(x, nullptr, bias, bias_b, res, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act,
+                       act_param, osy, osx, ooy, oox, OHF, OWF, nz, zx, zw3, zy, nullptr, nullptr, 0, stream, w3);
+}
+
 static int conv_launch(const float* x, const float* w, const float* bias, const float* bias_b, const float* res, float* y,
                        int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t,
                        int pad_l, int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF,
                        int nz, long long zx, long long zw, long long zy, const float* gn_scale, const float* gn_shift,
-                       int gn_silu, void* stream) {
-    EGR_CHECK(x && w && y, EGR_ERR_ARG, "null x/w/y");
+                       int gn_silu, void* stream, const void* w3) {
+    EGR_CHECK(x && (w || w3) && y, EGR_ERR_ARG, "null x/w/y");
+    EGR_CHECK(!w3 || ((Cin % BK) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)w3) & 15) == 0 && !gn_scale), EGR_ERR_ARG,
+              "split-bf16 conv needs Cin %% 16 == 0, 16-byte aligned x / w3 and no fused input affine");
     EGR_CHECK(!gn_scale || (gn_shift && (Cin % BK) == 0 && (((uintptr_t)x) & 15) == 0), EGR_ERR_ARG,
               "fused input affine needs Cin %% 16 == 0 and a 16-byte aligned input");
     EGR_CHECK(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && OH >= 1 && OW >= 1 && Cout >= 1 && KH >= 1 && KW >= 1 &&
@@ -561,7 +535,7 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
     EGR_CHECK(M < (1LL << 31) && (long long)KH * KW * Cin < (1LL << 31), EGR_ERR_ARG, "conv too large for 32-bit indexing");
     ConvP p;
     memset(&p, 0, sizeof(p));
-    p.x = x; p.w = w; p.bias = bias; p.bias_b = bias_b; p.res = res; p.y = y;
+    p.x = x; p.w = w; p.w3 = (const uint4*)w3; p.bias = bias; p.bias_b = bias_b; p.res = res; p.y = y;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW;
     p.stride = stride; p.dil = dil; p.pad_t = pad_t; p.pad_l = pad_l; p.up2 = up2; p.act = act; p.act_param = act_param;
     p.M = (int)M; p.K = KH * KW * Cin;
@@ -570,7 +544,8 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
     p.osy = osy; p.osx = osx; p.ooy = ooy; p.oox = oox; p.OHF = OHF; p.OWF = OWF;
     const bool vec = (Cin % BK) == 0 && (((uintptr_t)x) & 15) == 0;
     const int bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
-    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((Cout + bn - 1) / bn));
+    const int bm = w3 ? s3_bm(M, Cout, bn) : BM;
+    dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)((Cout + bn - 1) / bn));
     hipStream_t st = (hipStream_t)stream;
     // split-K when the output tiles alone cannot fill the chip and the K loop is long (deep UNet / latent layers)
     const int tiles = (int)(grid.x * grid.y), ktiles = (p.K + BK - 1) / BK;
@@ -594,7 +569,8 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
         }
     }
 #define LAUNCH(BN_, V_) hipLaunchKernelGGL((k_conv_igemm<BN_, V_>), grid, dim3(256), 0, st, p)
-    if (gn_scale) {        // fused-GroupNorm loader: separate instantiations so the plain kernels pay nothing for it
+    if (w3) launch_conv_s3(bm, bn, grid, st, p);
+    else if (gn_scale) {        // fused-GroupNorm loader: separate instantiations so the plain kernels pay nothing for it
         if (bn == 128) hipLaunchKernelGGL((k_conv_igemm<128, true, true>), grid, dim3(256), 0, st, p);
         else if (bn == 64) hipLaunchKernelGGL((k_conv_igemm<64, true, true>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((k_conv_igemm<32, true, true>), grid, dim3(256), 0, st, p);

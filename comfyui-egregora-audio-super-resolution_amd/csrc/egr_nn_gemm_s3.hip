@@ -1,0 +1,309 @@
+// fp32 implicit-GEMM convolution on the bf16 matrix pipe of gfx950 — same function as k_conv_igemm, 16x the MFMA rate.
+//
+// Every fp32 operand is split exactly into three bf16 terms  x = x0 + x1 + x2  (x0 = bf16(x), x1 = bf16(x - x0),
+// x2 = bf16(x - x0 - x1); the residuals are exact in fp32).  A bf16 x bf16 product is exact in fp32 and
+// v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the six partial products
+//     a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0
+// reproduce the fp32 product up to the dropped terms a1 b2 + a2 b1 + a2 b2 < 3 * 2^-24 |a b| — the rounding an IEEE
+// fp32 multiply makes anyway.  Measured against float64 the result is MORE accurate than the fmaf chain of
+// v_mfma_f32_32x32x2_f32 (fewer roundings per accumulator: one per 16 k instead of one per k); see
+// tests/test_gpu_flashsr.py::test_split3_conv_error_vs_float64.  Six bf16 MFMAs of 32 cycles replace eight f32 MFMAs of
+// 64 cycles per 32x32x16 block: 2.67x the f32 matrix peak (2.5 PFLOP/s / 6 = 417 TFLOP/s of fp32-equivalent work).
+//
+// Weights are split once on the device (egr_split3_pack -> [slab][3][Cout][16] bf16); activations are split by the
+// loader on their way into LDS (v_cvt_pk_bf16_f32 + two subtractions per term).  LDS tiles are per plane
+// [row][2 chunks of 8 bf16] with the chunk index XOR-ed by bit 3 of the row, which makes both the loader's
+// ds_write_b128 and the MFMA operand ds_read_b128 (lane l: row l&31, k-half l>>5) conflict-free at a 32-byte pitch.
+#include <string.h>
+
+#include "egr_conv.h"
+
+namespace egr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define S3_BM 128
+#define S3_BK 16
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {        // RNE; a -> bits 0..15, b -> bits 16..31
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+// (a, b) -> packed bf16 pairs of the three split terms
+__device__ __forceinline__ void split3_pair(float a, float b, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+    p0 = pk_bf16(a, b);
+    const float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);
+    p1 = pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(p1 << 16), sb = rb - __uint_as_float(p1 & 0xffff0000u);
+    p2 = pk_bf16(sa, sb);
+}
+
+__device__ __forceinline__ void split3_x8(const float4& u, const float4& v, uint4& q0, uint4& q1, uint4& q2) {
+    split3_pair(u.x, u.y, q0.x, q1.x, q2.x);
+    split3_pair(u.z, u.w, q0.y, q1.y, q2.y);
+    split3_pair(v.x, v.y, q0.z, q1.z, q2.z);
+    split3_pair(v.z, v.w, q0.w, q1.w, q2.w);
+}
+
+__global__ __launch_bounds__(256) void k_split3_pack(const float* __restrict__ w, uint4* __restrict__ w3, long long nslabs,
+                                                     int Cout) {
+    // one thread per (slab, n, half): 8 consecutive k of one output channel
+    const long long total = nslabs * Cout * 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int half = (int)(i & 1);
+        const long long rn = i >> 1;
+        const long long slab = rn / Cout;
+        const int n = (int)(rn - slab * Cout);
+        const float4* src = (const float4*)(w + (rn * 16 + half * 8));
+        uint4 q0, q1, q2;
+        split3_x8(src[0], src[1], q0, q1, q2);
+        uint4* dst = w3 + ((slab * 3) * Cout + n) * 2 + half;
+        dst[0] = q0;
+        dst[(size_t)Cout * 2] = q1;
+        dst[(size_t)Cout * 4] = q2;
+    }
+}
+
+// <BM, BN> block tile, 4 waves.  256x128: waves 2x2, each 128x64 (TM 4, TN 2; the large-M workhorse: half the split work and
+// 0.7x the L2 traffic per MFMA of the 128x128 tile).  128xBN: small-M / thin-Cout layers and split-K.
+template <int BM, int BN> struct S3Cfg;
+template <> struct S3Cfg<256, 128> { static constexpr int WM = 2, WN = 2, TM = 4, TN = 2; };
+template <> struct S3Cfg<128, 128> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 2; };
+template <> struct S3Cfg<128, 64> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 1; };
+template <> struct S3Cfg<128, 32> { static constexpr int WM = 4, WN = 1, TM = 1, TN = 1; };
+
+__device__ __forceinline__ bf16x8 as_bf(const uint4& v) { return __builtin_bit_cast(bf16x8, v); }
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
+    typedef S3Cfg<BM, BN> TC;
+    constexpr int TM = TC::TM, TN = TC::TN;
+    constexpr int AP = BM / 128;                                  // A chunks (8 k of one row) per thread per slab
+    __shared__ uint4 As[2][3][BM * 2];
+    __shared__ uint4 Bs[2][3][BN * 2];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm0 = (wave / TC::WN) * (BM / TC::WM), wn0 = (wave % TC::WN) * (BN / TC::WN);
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int LH = p.up2 ? 2 * p.H : p.H, LW = p.up2 ? 2 * p.W : p.W;
+    if (p.ksplit <= 1 && gridDim.z > 1) {
+        p.x += (size_t)blockIdx.z * p.zx;
+        p.w3 += (size_t)blockIdx.z * p.zw;
+        p.y += (size_t)blockIdx.z * p.zy;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int ktiles_all = p.K / S3_BK;
+    const int kt_begin = p.ksplit > 1 ? blockIdx.z * p.kt_per : 0;
+    const int kt_end = p.ksplit > 1 ? min(ktiles_all, kt_begin + p.kt_per) : ktiles_all;
+
+    // ---- A: thread owns 8 consecutive k (half ah) of tile rows ar (and ar + 128 when BM = 256) ----
+    // (plain scalars on purpose: arrays captured by the lambdas below end up in scratch)
+    const int ar = tid >> 1, ah = tid & 1;
+    int a_iy0, a_ix0, a_iy1 = 0, a_ix1 = 0;
+    size_t a_base0, a_base1 = 0;
+    bool a_ok0, a_ok1 = false;
+    {
+        const int m = m0 + ar;
+        a_ok0 = m < p.M;
+        const int mm = a_ok0 ? m : 0;
+        const int ox = mm % p.OW, t = mm / p.OW, oy = t % p.OH, b = t / p.OH;
+        a_iy0 = oy * p.stride - p.pad_t;
+        a_ix0 = ox * p.stride - p.pad_l;
+        a_base0 = (size_t)b * p.H * p.W;
+    }
+    if (AP > 1) {
+        const int m = m0 + ar + 128;
+        a_ok1 = m < p.M;
+        const int mm = a_ok1 ? m : 0;
+        const int ox = mm % p.OW, t = mm / p.OW, oy = t % p.OH, b = t / p.OH;
+        a_iy1 = oy * p.stride - p.pad_t;
+        a_ix1 = ox * p.stride - p.pad_l;
+        a_base1 = (size_t)b * p.H * p.W;
+    }
+    int tap = 0, c0 = 0;
+    {
+        const int tpt = p.Cin / S3_BK;
+        tap = kt_begin / tpt;
+        c0 = (kt_begin - tap * tpt) * S3_BK;
+    }
+    const float* aptr0 = p.zeros;
+    const float* aptr1 = p.zeros;
+    int astep0 = 0, astep1 = 0;
+    auto set_tap = [&](int tp) {
+        const int ky = tp / p.KW, kx = tp - ky * p.KW;
+        {
+            const int iy = a_iy0 + ky, ix = a_ix0 + kx * p.dil;
+            const bool ok = a_ok0 && (unsigned)iy < (unsigned)LH && (unsigned)ix < (unsigned)LW;
+            const int py = p.up2 ? iy >> 1 : iy, px = p.up2 ? ix >> 1 : ix;
+            aptr0 = ok ? p.x + (a_base0 + (size_t)py * p.W + px) * p.Cin + ah * 8 : p.zeros + ah * 8;
+            astep0 = ok ? 1 : 0;
+        }
+        if (AP > 1) {
+            const int iy = a_iy1 + ky, ix = a_ix1 + kx * p.dil;
+            const bool ok = a_ok1 && (unsigned)iy < (unsigned)LH && (unsigned)ix < (unsigned)LW;
+            const int py = p.up2 ? iy >> 1 : iy, px = p.up2 ? ix >> 1 : ix;
+            aptr1 = ok ? p.x + (a_base1 + (size_t)py * p.W + px) * p.Cin + ah * 8 : p.zeros + ah * 8;
+            astep1 = ok ? 1 : 0;
+        }
+    };
+    set_tap(tap);
+    const int a_slot = ar * 2 + (ah ^ ((ar >> 3) & 1));          // row ar + 128 lands 256 slots further
+
+    // ---- B: 6*BN 16-byte chunks per slab (3 planes x BN channels x 2 halves), up to 3 per thread ----
+    constexpr int NBQ = 6 * BN;
+    const size_t b_slab = (size_t)p.Cout * 6;                    // uint4 per slab
+#define S3_BSETUP(I, PTR, STEP, SLOT)                                                                                \
+    const uint4* PTR;                                                                                                \
+    unsigned STEP;                                                                                                   \
+    int SLOT;                                                                                                        \
+    {                                                                                                                \
+        const int e = tid + 256 * (I);                                                                               \
+        const int plane = e / (2 * BN), rem = e - plane * 2 * BN, nl = rem >> 1, half = rem & 1;                     \
+        const bool ok = e < NBQ && n0 + nl < p.Cout;                                                                 \
+        SLOT = plane * (BN * 2) + nl * 2 + (half ^ ((nl >> 3) & 1));                                                 \
+        PTR = ok ? p.w3 + (size_t)kt_begin * b_slab + ((size_t)plane * p.Cout + n0 + nl) * 2 + half                  \
+                 : (const uint4*)p.zeros;                                                                            \
+        STEP = ok ? (unsigned)b_slab : 0u;                                                                                    \
+    }
+    S3_BSETUP(0, bptr0, bstep0, bslot0)
+    S3_BSETUP(1, bptr1, bstep1, bslot1)
+    S3_BSETUP(2, bptr2, bstep2, bslot2)
+#undef S3_BSETUP
+
+    float4 ra0, ra1, ra2, ra3;
+    uint4 rb0, rb1, rb2;
+    ra2 = ra3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    rb0 = rb1 = rb2 = make_uint4(0, 0, 0, 0);
+    auto load_tile = [&]() {
+#ifdef S3_ABL_NOGLOBAL
+        if (c0 > 0 || tap > 0) { c0 += S3_BK; return; }
+#endif
+        {
+            const float* s = aptr0 + astep0 * c0;
+            ra0 = *(const float4*)s;
+            ra1 = *(const float4*)(s + 4);
+        }
+        if (AP > 1) {
+            const float* s = aptr1 + astep1 * c0;
+            ra2 = *(const float4*)s;
+            ra3 = *(const float4*)(s + 4);
+        }
+        c0 += S3_BK;
+        if (c0 >= p.Cin) { c0 = 0; ++tap; set_tap(tap); }
+        rb0 = *bptr0;
+        bptr0 += bstep0;
+        if (256 < NBQ) { rb1 = *bptr1; bptr1 += bstep1; }
+        if (512 < NBQ) { rb2 = *bptr2; bptr2 += bstep2; }
+    };
+    auto store_tile = [&](int buf) {
+        uint4 q0, q1, q2;
+#ifdef S3_ABL_NOSPLIT
+        q0 = q1 = q2 = make_uint4(__float_as_uint(ra0.x), __float_as_uint(ra0.y), __float_as_uint(ra1.x), __float_as_uint(ra1.y));
+#else
+        split3_x8(ra0, ra1, q0, q1, q2);
+#endif
+#ifdef S3_ABL_NOSTORE
+        if (buf > 1)
+#endif
+        {
+            As[buf][0][a_slot] = q0;
+            As[buf][1][a_slot] = q1;
+            As[buf][2][a_slot] = q2;
+            if (AP > 1) {
+#ifndef S3_ABL_NOSPLIT
+                split3_x8(ra2, ra3, q0, q1, q2);
+#endif
+                As[buf][0][a_slot + 256] = q0;
+                As[buf][1][a_slot + 256] = q1;
+                As[buf][2][a_slot + 256] = q2;
+            }
+            if (tid < NBQ) Bs[buf][0][bslot0] = rb0;
+            if (tid + 256 < NBQ) Bs[buf][0][bslot1] = rb1;
+            if (tid + 512 < NBQ) Bs[buf][0][bslot2] = rb2;
+        }
+    };
+
+    // operand fetch: lane (li = lane&31, lk = lane>>5) reads chunk lk of row li (+32 i) — k 0..7 on lanes 0-31, 8..15 on 32-63
+    const int li = lane & 31, lk = lane >> 5;
+    const int o_slot = li * 2 + (lk ^ ((li >> 3) & 1));
+
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    if (kt_begin + 1 < kt_end) load_tile();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        uint4 b[TN][3];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) b[j][q] = Bs[cur][q][(wn0 + j * 32) * 2 + o_slot];
+        constexpr int TH = TM > 2 ? 1 : TM;                       // A sub-tiles in flight (register budget)
+#pragma unroll
+        for (int i0 = 0; i0 < TM; i0 += TH) {
+            uint4 a[TH][3];
+#pragma unroll
+            for (int i = 0; i < TH; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a[i][q] = As[cur][q][(wm0 + (i0 + i) * 32) * 2 + o_slot];
+            if (i0 == 0) {
+                if (kt + 1 < kt_end) store_tile(cur ^ 1);
+                if (kt + 2 < kt_end) load_tile();
+            }
+            // smallest terms first
+#define S3_MMA(QA, QB)                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TH; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i0 + i][j] =       \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[i][QA]), as_bf(b[j][QB]), acc[i0 + i][j], 0, 0, 0);
+            S3_MMA(2, 0)
+            S3_MMA(0, 2)
+            S3_MMA(1, 1)
+            S3_MMA(1, 0)
+            S3_MMA(0, 1)
+            S3_MMA(0, 0)
+#undef S3_MMA
+        }
+#ifndef S3_ABL_NOBARRIER
+        __syncthreads();
+#endif
+    }
+    conv_epilogue<TM, TN>(p, acc, m0, n0, wm0, wn0);
+}
+
+// block-tile height for a problem: 256 rows when that still leaves >= 2 full rounds of workgroups on the 256 CUs
+int s3_bm(long long M, int Cout, int bn) {
+    if (bn != 128) return 128;
+    const long long tiles256 = ((M + 255) / 256) * ((Cout + 127) / 128);
+    return tiles256 >= 1024 ? 256 : 128;
+}
+
+void launch_conv_s3(int bm, int bn, dim3 grid, hipStream_t st, const ConvP& p) {
+    if (bm == 256) hipLaunchKernelGGL((k_conv_s3<256, 128>), grid, dim3(256), 0, st, p);
+    else if (bn == 128) hipLaunchKernelGGL((k_conv_s3<128, 128>), grid, dim3(256), 0, st, p);
+    else if (bn == 64) hipLaunchKernelGGL((k_conv_s3<128, 64>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_conv_s3<128, 32>), grid, dim3(256), 0, st, p);
+}
+
+}  // namespace egr
+
+using namespace egr;
+
+extern "C" int egr_split3_pack(const float* w_packed, void* w3, int64_t nslabs, int Cout, void* stream) {
+    EGR_CHECK(w_packed && w3 && nslabs >= 1 && Cout >= 1, EGR_ERR_ARG, "bad split3 pack argument");
+    EGR_CHECK((((uintptr_t)w_packed) & 15) == 0 && (((uintptr_t)w3) & 15) == 0, EGR_ERR_ARG, "split3 pack needs 16-byte alignment");
+    long long nb = (nslabs * Cout * 2 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_split3_pack, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w_packed, (uint4*)w3,
+                       (long long)nslabs, Cout);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}

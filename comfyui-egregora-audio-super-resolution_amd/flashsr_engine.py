@@ -36,7 +36,9 @@ class FlashSREngine:
         self.prof = None            # when a list: (kind, flops, start_event, end_event) per MFMA kernel launch
         self.blocks = arch.unet_blocks(cfg)
         self.w: Dict[str, torch.Tensor] = {}
+        self.w3: Dict[str, torch.Tensor] = {}      # three-way bf16 splits of self.w entries (egr_split3_pack)
         self.wshape: Dict[str, tuple] = {}
+        self.mfma = self.MFMA_MODE
         self._pack(params)
         self.window = torch.hann_window(cfg.n_fft, periodic=True, dtype=torch.float32).to(self.dev)
         self.filt = torch.from_numpy(arch.kaiser_sinc_filter(cfg.aa_taps)).to(self.dev)
@@ -45,9 +47,31 @@ class FlashSREngine:
         fb = torch.zeros(self.ldm, cfg.n_mels)
         fb[:nb] = torch.from_numpy(arch.mel_filterbank(cfg)).t()
         self.w["mel_fb"] = self.pack_matrix(fb.contiguous()).to(self.dev)
+        self._split3("mel_fb")
         self.alpha, self.sigma = arch.cosine_alpha_sigma(cfg, cfg.t_steps - 1)
         self._gn_ws = None
         self._fold_time_embedding()
+
+    # Dense contractions run on the bf16 matrix pipe with fp32-grade results ("bf16x3": exact three-way split of both
+    # operands, six partial products accumulated in fp32, csrc/egr_nn_gemm_s3.hip) or on v_mfma_f32_32x32x2_f32 ("f32").
+    MFMA_MODE = os.environ.get("EGREGORA_FLASHSR_MFMA", "bf16x3")
+
+    def _split3(self, key: str):
+        """self.w3[key] = [slabs][3][Cout][16] bf16 split of the packed fp32 weight self.w[key] ([..., slabs, Cout, 16])."""
+        if self.mfma != "bf16x3":
+            return
+        wp = self.w[key]
+        Co = wp.shape[-2]
+        ns = wp.numel() // (Co * 16)
+        w3 = torch.empty(ns * 3 * Co * 16, dtype=torch.bfloat16, device=self.dev)
+        native.check(self.L.egr_split3_pack(_p(wp), _p(w3), ns, Co, self._st()), "egr_split3_pack")
+        self.w3[key] = w3
+
+    def _s3(self, key, Cin, x):
+        """The split weights for this call, or None when the bf16x3 kernel does not apply (Cin % 16, alignment, mode)."""
+        if self.mfma != "bf16x3" or key is None or Cin % 16 != 0 or x.data_ptr() % 16 != 0:
+            return None
+        return self.w3.get(key)
 
     # ------------------------------------------------------------------ weight packing
     @staticmethod
@@ -87,6 +111,8 @@ class FlashSREngine:
         Ci, Co = U.shape[2], U.shape[3]
         packed = torch.stack([self.pack_matrix(U[i, j].float().contiguous()) for i in range(4) for j in range(4)])
         self.w[key + ".wino"] = packed.contiguous().to(self.dev)        # [16][Kp/16][Co][16]
+        if Ci % 16 == 0:
+            self._split3(key + ".wino")
 
     def _conv_winograd(self, x, key, act, res, bias_t, gn=None):
         B, H, W, Cin = x.shape
@@ -101,11 +127,16 @@ class FlashSREngine:
         wt = self.w[key + ".weight.wino"]
         fl = 16 * 2.0 * P * Cin * Cout
         ev = self._prof_begin()
-        native.check(self.L.egr_gemm_zbatched(_p(V), _p(wt), _p(Mx), 16, P, Cin, Cout, P * Cin, wt[0].numel(), P * Cout,
-                                              self._st()), "egr_gemm_zbatched")
+        w3 = self._s3(key + ".weight.wino", Cin, V)
+        if w3 is not None:
+            native.check(self.L.egr_conv_s3(_p(V), _p(w3), _p(None), _p(None), _p(None), _p(Mx), P, 1, 1, Cin, 1, 1, Cout, 1, 1, 1,
+                                            1, 0, 0, 0, 0, 0.0, 1, 1, 0, 0, 1, 1, 16, P * Cin, wt[0].numel() * 3 // 8, P * Cout,
+                                            self._st()), "egr_conv_s3(winograd)")
+        else:
+            native.check(self.L.egr_gemm_zbatched(_p(V), _p(wt), _p(Mx), 16, P, Cin, Cout, P * Cin, wt[0].numel(), P * Cout,
+                                                  self._st()), "egr_gemm_zbatched")
         if ev is not None:
-            bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
-            self._prof_end(ev, f"k_conv_igemm<{bn}, true>", fl, (B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 16))
+            self._prof_end(ev, self._kind(P, Cin, Cout, w3 is not None), fl, (B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 16))
         if self.count_flops:
             self.flops += fl
         y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=self.dev)
@@ -132,6 +163,9 @@ class FlashSREngine:
             w2, shp = v.t(), (1, 1, Ci, Co)
         self.w[key] = self.pack_matrix(w2.contiguous()).to(self.dev)
         self.wshape[key] = shp
+        self.w3.pop(key, None)
+        if shp[2] % 16 == 0:
+            self._split3(key)
 
     def _pack(self, P):
         self.wshape = {}
@@ -151,22 +185,37 @@ class FlashSREngine:
         return native.stream_ptr()
 
     def conv(self, x, wkey, B, H, W, Cin, OH, OW, Cout, KH, KW, stride=1, dil=1, pad_t=0, pad_l=0, up2=0, act=ACT_NONE,
-             bias=True, bias_t=None, res=None, act_param=0.0, w=None):
+             bias=True, bias_t=None, res=None, act_param=0.0, w=None, w3key=None):
         y = torch.empty((B, OH, OW, Cout), dtype=torch.float32, device=self.dev)
         wt = w if w is not None else self.w[wkey + ".weight"]
         bt = bias_t if bias_t is not None else (self.w.get(wkey + ".bias") if bias else None)
         fl = 2.0 * B * OH * OW * Cout * KH * KW * Cin
         ev = self._prof_begin()
-        native.check(self.L.egr_conv_nhwc(_p(x), _p(wt), _p(bt), _p(None), _p(res), _p(y), B, H, W, Cin, OH, OW, Cout, KH,
-                                          KW, stride, dil, pad_t, pad_l, up2, act, float(act_param), self._st()),
-                     "egr_conv_nhwc")
-        if ev is not None:      # same variant selection as egr_conv_nhwc (csrc/egr_nn_gemm.hip)
-            bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
-            vec = "true" if (Cin % 16 == 0 and x.data_ptr() % 16 == 0) else "false"
-            self._prof_end(ev, f"k_conv_igemm<{bn}, {vec}>", fl, (B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, up2))
+        w3 = self._s3((wkey + ".weight") if w is None else w3key, Cin, x)
+        if w3 is not None:
+            native.check(self.L.egr_conv_s3(_p(x), _p(w3), _p(bt), _p(None), _p(res), _p(y), B, H, W, Cin, OH, OW, Cout, KH, KW,
+                                            stride, dil, pad_t, pad_l, up2, act, float(act_param), 1, 1, 0, 0, OH, OW, 1, 0, 0, 0,
+                                            self._st()), "egr_conv_s3")
+        else:
+            native.check(self.L.egr_conv_nhwc(_p(x), _p(wt), _p(bt), _p(None), _p(res), _p(y), B, H, W, Cin, OH, OW, Cout, KH,
+                                              KW, stride, dil, pad_t, pad_l, up2, act, float(act_param), self._st()),
+                         "egr_conv_nhwc")
+        if ev is not None:
+            vec = Cin % 16 == 0 and x.data_ptr() % 16 == 0
+            self._prof_end(ev, self._kind(B * OH * OW, Cin, Cout, w3 is not None, vec), fl,
+                           (B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, up2))
         if self.count_flops:
             self.flops += fl
         return y
+
+    @staticmethod
+    def _kind(M, Cin, Cout, s3, vec=True):
+        """Name of the kernel instantiation a contraction lands on (same selection as conv_launch, csrc/egr_nn_gemm.hip)."""
+        bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
+        if s3:
+            bm = 256 if (bn == 128 and ((M + 255) // 256) * ((Cout + 127) // 128) >= 1024) else 128
+            return f"k_conv_s3<{bm}, {bn}>"
+        return f"k_conv_igemm<{bn}, {'true' if vec else 'false'}>"
 
     def _prof_begin(self):
         if self.prof is None:
@@ -212,14 +261,19 @@ class FlashSREngine:
             for b in (0, 1):
                 fl = 2.0 * B * H * W * Cout * 4 * Cin
                 ev = self._prof_begin()
-                native.check(self.L.egr_conv_nhwc_placed(_p(x), _p(self.w[f"{key}.weight.ph{a}{b}"]), _p(bt), _p(None),
-                                                         _p(None), _p(y), B, H, W, Cin, H, W, Cout, 2, 2, 1, 1, 1 - a, 1 - b,
-                                                         0, act, 0.0, 2, 2, a, b, 2 * H, 2 * W, self._st()),
-                             "egr_conv_nhwc_placed")
+                w3 = self._s3(f"{key}.weight.ph{a}{b}", Cin, x)
+                if w3 is not None:
+                    native.check(self.L.egr_conv_s3(_p(x), _p(w3), _p(bt), _p(None), _p(None), _p(y), B, H, W, Cin, H, W, Cout, 2, 2,
+                                                    1, 1, 1 - a, 1 - b, 0, act, 0.0, 2, 2, a, b, 2 * H, 2 * W, 1, 0, 0, 0,
+                                                    self._st()), "egr_conv_s3(placed)")
+                else:
+                    native.check(self.L.egr_conv_nhwc_placed(_p(x), _p(self.w[f"{key}.weight.ph{a}{b}"]), _p(bt), _p(None),
+                                                             _p(None), _p(y), B, H, W, Cin, H, W, Cout, 2, 2, 1, 1, 1 - a, 1 - b,
+                                                             0, act, 0.0, 2, 2, a, b, 2 * H, 2 * W, self._st()),
+                                 "egr_conv_nhwc_placed")
                 if ev is not None:
-                    bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
-                    vec = "true" if Cin % 16 == 0 else "false"
-                    self._prof_end(ev, f"k_conv_igemm<{bn}, {vec}>", fl, (B, H, W, Cin, H, W, Cout, 2, 2, 1, 1, 2))
+                    self._prof_end(ev, self._kind(B * H * W, Cin, Cout, w3 is not None, Cin % 16 == 0), fl,
+                                   (B, H, W, Cin, H, W, Cout, 2, 2, 1, 1, 2))
                 if self.count_flops:
                     self.flops += fl
         return y
@@ -360,7 +414,7 @@ class FlashSREngine:
         native.check(self.L.egr_stft_frames(_p(x), B, L, cfg.n_fft, cfg.hop, rpad, cfg.n_frames, t_valid, self.ldm,
                                             _p(self.window), _p(mag), self._st()), "egr_stft_frames")
         mel = self.conv(mag, None, B * cfg.n_frames, 1, 1, self.ldm, 1, 1, cfg.n_mels, 1, 1, act=ACT_LOGCLAMP,
-                        act_param=cfg.log_floor, bias=False, w=self.w["mel_fb"])
+                        act_param=cfg.log_floor, bias=False, w=self.w["mel_fb"], w3key="mel_fb")
         return mel.view(B, cfg.n_frames, cfg.n_mels, 1)
 
     # input low-pass (lowpass_input=True): cutoff from the STFT energy, zero-phase 8th-order Chebyshev-I gain applied
@@ -515,7 +569,7 @@ class FlashSREngine:
             Bc, Lin, Ci = h.shape
             wt = self.w[f"voc.ups.{j}.weight"]
             Co = self.wshape[f"voc.ups.{j}.weight"][3] // kt
-            Y = self.conv(h, None, Bc * Lin, 1, 1, Ci, 1, 1, kt * Co, 1, 1, bias=False, w=wt)
+            Y = self.conv(h, None, Bc * Lin, 1, 1, Ci, 1, 1, kt * Co, 1, 1, bias=False, w=wt, w3key=f"voc.ups.{j}.weight")
             out = torch.empty((Bc, Lin * r, Co), dtype=torch.float32, device=self.dev)
             add = feats[n - 2 - j] if j <= n - 2 else None
             native.check(self.L.egr_col2im_convtr1d(_p(Y), _p(self.w[f"voc.ups.{j}.bias"]), _p(add), _p(out), Bc, Lin,

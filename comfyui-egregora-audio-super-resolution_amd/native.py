@@ -39,6 +39,8 @@ SIGNATURES = {
     "egr_resample_poly": (_i, [_vp, _i, _i64, _i, _i, _vp, _i, _vp, _i64, _vp]),
     "egr_conv_nhwc": (_i, [_vp] * 6 + [_i] * 15 + [_f, _vp]),
     "egr_conv_nhwc_placed": (_i, [_vp] * 6 + [_i] * 15 + [_f] + [_i] * 6 + [_vp]),
+    "egr_split3_pack": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "egr_conv_s3": (_i, [_vp] * 6 + [_i] * 15 + [_f] + [_i] * 7 + [_i64] * 3 + [_vp]),
     "egr_winograd_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "egr_groupnorm_coeff": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "egr_conv_nhwc_gn": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),

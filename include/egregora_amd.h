@@ -160,6 +160,18 @@ int egr_conv_nhwc_placed(const float* x, const float* w, const float* bias, cons
                          int pad_t, int pad_l, int up2, int act, float act_param, int osy, int osx, int ooy, int oox,
                          int OHF, int OWF, void* stream);
 
+/* The same convolution on the bf16 matrix pipe with fp32-grade results (csrc/egr_nn_gemm_s3.hip): every fp32 operand is
+ * split exactly into three bf16 terms and the six leading partial products are accumulated in fp32 by
+ * v_mfma_f32_32x32x16_bf16 (dropped terms < 3 * 2^-24 of each product; measured error vs float64 <= the f32-MFMA kernel's).
+ *   egr_split3_pack : packed fp32 weights [nslabs][Cout][16] -> w3 [nslabs][3][Cout][16] bf16 (6 * nslabs * Cout * 16 bytes)
+ *   egr_conv_s3     : egr_conv_nhwc_placed on w3; requires Cin % 16 == 0.  nz > 1 runs nz independent problems along
+ *                     blockIdx.z with offsets zx / zy (floats) and zw3 (16-byte units of w3), as egr_gemm_zbatched does. */
+int egr_split3_pack(const float* w_packed, void* w3, int64_t nslabs, int Cout, void* stream);
+int egr_conv_s3(const float* x, const void* w3, const float* bias, const float* bias_b, const float* res, float* y, int B,
+                int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t, int pad_l,
+                int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF, int nz, int64_t zx,
+                int64_t zw3, int64_t zy, void* stream);
+
 /* Winograd F(2x2,3x3) for stride-1 pad-1 3x3 convolutions with many channels (2.25x fewer multiplies):
  *   egr_winograd_input : x [B][H][W][C] -> V [16][P][C], P = B*ceil(H/2)*ceil(W/2) tiles, V[4i+j] = (B^T d B)[i][j]
  *   egr_gemm_zbatched  : M[xi] = V[xi] ([P][Cin]) x U[xi] ([Cin][Cout], each packed like egr_conv_nhwc weights), xi < nz

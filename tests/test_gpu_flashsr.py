@@ -82,6 +82,63 @@ def test_conv_nhwc_vs_torch(eng, B, H, W, Ci, Co, k, s, pad, up):
     close(nchw(got), want)
 
 
+def test_split3_conv_error_vs_float64(eng):
+    """The bf16x3 kernel (three-way exact split, six products on the bf16 MFMA, fp32 accumulate) must be at least as close
+    to float64 as the f32-MFMA kernel (an fmaf chain): max and rms error within 1.25x of it on every case, and both far
+    inside the operator tolerance.  Covers the 256x128 / 128x{128,64,32} tiles, ragged M and Cout, split-K shapes."""
+    e, cfg, P = eng
+    L = e.L
+    from egregora_amd import native
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    g = torch.Generator().manual_seed(77)
+    cases = [(2, 16, 12, 128, 128, 3), (1, 9, 7, 256, 96, 3), (3, 8, 8, 512, 40, 1), (2, 10, 6, 64, 200, 3),
+             (9, 128, 128, 32, 128, 3),      # M = 147456: 256-row tiles
+             (2, 8, 4, 640, 640, 3),         # small M, long K: split-K
+             (1, 5, 3, 16, 20, 3)]
+    for (B, H, W, Ci, Co, k) in cases:
+        x = torch.randn(B, H, W, Ci, generator=g).cuda()
+        w = (torch.randn(Co, Ci, k, k, generator=g) / math.sqrt(Ci * k * k)).cuda()
+        b = torch.randn(Co, generator=g).cuda()
+        ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=k // 2).permute(0, 2, 3, 1)
+        wp = e.pack_matrix(w.permute(2, 3, 1, 0).reshape(k * k * Ci, Co).contiguous()).cuda()
+        ns = wp.shape[0]
+        w3 = torch.empty(ns * 3 * Co * 16, dtype=torch.bfloat16, device="cuda")
+        native.check(L.egr_split3_pack(p(wp), p(w3), ns, Co, e._st()), "split3")
+        # the three planes sum back to the fp32 weights exactly
+        planes = w3.view(ns, 3, Co, 16).float().sum(1)
+        assert torch.equal(planes, wp)
+        y1 = torch.empty(B, H, W, Co, device="cuda")
+        y2 = torch.empty_like(y1)
+        native.check(L.egr_conv_nhwc(p(x), p(wp), p(b), p(None), p(None), p(y1), B, H, W, Ci, H, W, Co, k, k, 1, 1, k // 2, k // 2,
+                                     0, 0, 0.0, e._st()), "conv")
+        native.check(L.egr_conv_s3(p(x), p(w3), p(b), p(None), p(None), p(y2), B, H, W, Ci, H, W, Co, k, k, 1, 1, k // 2, k // 2,
+                                   0, 0, 0.0, 1, 1, 0, 0, H, W, 1, 0, 0, 0, e._st()), "conv_s3")
+        mx = lambda y: float((y.double() - ref).abs().max() / ref.abs().max())
+        rms = lambda y: float((y.double() - ref).norm() / ref.norm())
+        assert mx(y2) <= 1.25 * mx(y1) + 1e-8 and rms(y2) <= 1.25 * rms(y1) + 1e-8, ((B, H, W, Ci, Co, k), mx(y1), mx(y2), rms(y1), rms(y2))
+        assert mx(y2) < 2e-6, mx(y2)
+
+
+def test_f32_mfma_mode_still_matches(pack):
+    """EGREGORA_FLASHSR_MFMA=f32 keeps every contraction on v_mfma_f32_32x32x2_f32; both modes agree to fp32 round-off."""
+    from egregora_amd import flashsr_arch as A, flashsr_engine as E
+    cfg = A.tiny_config()
+    P = A.init_params(cfg, 0)
+    old = E.FlashSREngine.MFMA_MODE
+    try:
+        E.FlashSREngine.MFMA_MODE = "f32"
+        e1 = E.FlashSREngine(cfg, P)
+        E.FlashSREngine.MFMA_MODE = "bf16x3"
+        e2 = E.FlashSREngine(cfg, P)
+    finally:
+        E.FlashSREngine.MFMA_MODE = old
+    assert not e1.w3 and e2.w3
+    x = 0.3 * torch.randn(2, cfg.chunk, generator=torch.Generator().manual_seed(5)).cuda()
+    nz = e1.noise(2, None, 3)
+    y1, y2 = e1.forward_rows(x, nz), e2.forward_rows(x, nz)
+    assert rel_l2(y2, y1) < 2e-5, rel_l2(y2, y1)
+
+
 def test_winograd_conv_vs_torch(eng):
     """Winograd F(2x2,3x3) path (input transform, 16 z-batched MFMA GEMMs, output transform + epilogue)."""
     e, cfg, P = eng

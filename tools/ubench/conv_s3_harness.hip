@@ -1,0 +1,37 @@
+// Dev harness: times k_conv_s3 standalone (no torch), optionally with ablation macros (-DS3_ABL_NOGLOBAL etc.) to see what
+// bounds the kernel.  Build (from the repo root):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I comfyui-egregora-audio-super-resolution_amd/csrc [-DS3_ABL_...] \
+//         tools/ubench/conv_s3_harness.hip -o tools/ubench/conv_s3_<tag>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "egr_nn_gemm_s3.hip"
+namespace egr { void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); } }
+int main(int argc, char** argv) {
+    int B = 26, H = 128, W = 64, Ci = 512, Co = 512, k = 3, reps = 5;
+    if (argc >= 7) { B = atoi(argv[1]); H = atoi(argv[2]); W = atoi(argv[3]); Ci = atoi(argv[4]); Co = atoi(argv[5]); k = atoi(argv[6]); }
+    const long long M = (long long)B * H * W, K = (long long)k * k * Ci, ns = K / 16;
+    float *x, *wp, *y, *zeros; void* w3;
+    hipMalloc(&x, M * Ci * 4); hipMalloc(&wp, ns * Co * 16 * 4); hipMalloc(&y, M * Co * 4); hipMalloc(&w3, ns * 3 * Co * 32); hipMalloc(&zeros, 4096);
+    hipMemset(zeros, 0, 4096);
+    std::vector<float> h(M * Ci); const bool zero = getenv("S3_ZERO") != nullptr;
+    for (auto& v : h) v = zero ? 0.f : (float)rand() / RAND_MAX - 0.5f; hipMemcpy(x, h.data(), M * Ci * 4, hipMemcpyHostToDevice);
+    std::vector<float> hw(ns * Co * 16); for (auto& v : hw) v = zero ? 0.f : ((float)rand() / RAND_MAX - 0.5f) * 0.05f; hipMemcpy(wp, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+    egr_split3_pack(wp, w3, ns, Co, nullptr);
+    egr::ConvP p; memset(&p, 0, sizeof(p));
+    p.x = x; p.w3 = (const uint4*)w3; p.y = y; p.B = B; p.H = H; p.W = W; p.Cin = Ci; p.OH = H; p.OW = W; p.Cout = Co; p.KH = k; p.KW = k;
+    p.stride = 1; p.dil = 1; p.pad_t = k / 2; p.pad_l = k / 2; p.M = (int)M; p.K = (int)K; p.osy = p.osx = 1; p.OHF = H; p.OWF = W;
+    p.ksplit = 1; p.kt_per = (int)ns; p.zeros = zeros;
+    const int bn = Co > 64 ? 128 : (Co > 32 ? 64 : 32);
+    const int bm = getenv("S3_BM") ? atoi(getenv("S3_BM")) : egr::s3_bm(M, Co, bn);
+    dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)((Co + bn - 1) / bn));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    egr::launch_conv_s3(bm, bn, grid, 0, p); hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) egr::launch_conv_s3(bm, bn, grid, 0, p);
+    hipEventRecord(e1); hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("bm%d B%d %dx%d Ci%d Co%d k%d: %.3f ms  %.1f TF/s (fp32-equivalent)  err=%s\n", bm, B, H, W, Ci, Co, k, ms, 2.0 * M * Co * K / ms / 1e9,
+           hipGetErrorString(hipGetLastError()));
+    return 0;
+}

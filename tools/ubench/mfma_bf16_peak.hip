@@ -1,0 +1,64 @@
+// Dev micro-benchmark: sustained v_mfma_f32_32x32x16_bf16 rate, (0) registers only, (1) with k_conv_s3's LDS operand traffic
+// (12 ds_read_b128 per 24 MFMAs per wave), (2) = 1 + a barrier per slab.  Build: hipcc --offload-arch=gfx950 -O3 -o mfma_bf16_peak mfma_bf16_peak.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 as_bf(const uint4& v) { return __builtin_bit_cast(bf16x8, v); }
+template <int MODE>
+__global__ __launch_bounds__(256) void k(float* out, int iters, long long* cyc) {
+    __shared__ uint4 lds[2][3][256 * 2];
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 2 * 3 * 512; i += 256) ((uint4*)lds)[i] = make_uint4(0x3f803f80u, 0x3f003f00u, 0x3e803e80u, 0x3e003e00u);
+    __syncthreads();
+    const int o_slot = li * 2 + (lk ^ ((li >> 3) & 1));
+    uint4 a[2][3], b[2][3];
+    for (int i = 0; i < 2; ++i) for (int q = 0; q < 3; ++q) a[i][q] = b[i][q] = make_uint4(0x3f803f80u, 0x3f003f00u, 0x3e803e80u, 0x3e003e00u);
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+        if (MODE >= 1) {
+            const int cur = it & 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    a[i][q] = lds[cur][q][((wave >> 1) * 64 + i * 32) * 2 + o_slot];
+                    b[i][q] = lds[cur ^ 1][q][((wave & 1) * 64 + i * 32) * 2 + o_slot];
+                }
+        }
+#define MMA(QA, QB) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = \
+    __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[i][QA]), as_bf(b[j][QB]), acc[i][j], 0, 0, 0);
+        MMA(2, 0) MMA(0, 2) MMA(1, 1) MMA(1, 0) MMA(0, 1) MMA(0, 0)
+        if (MODE >= 2) __syncthreads();
+    }
+    const long long t1 = clock64();
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *cyc = t1 - t0;
+}
+template <int MODE> void run(const char* name, int blocks_per_cu) {
+    const int blocks = 256 * blocks_per_cu, iters = 20000;
+    float* out; long long* cyc;
+    (void)hipMalloc(&out, blocks * 256 * 4); (void)hipMalloc(&cyc, 8);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, 1000, cyc);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, iters, cyc);
+    (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    long long c; (void)hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+    const double flops = (double)blocks * 4 * iters * 24.0 * (2.0 * 32 * 32 * 16);
+    printf("%-34s blocks/CU=%d  %.3f ms  %.0f TF/s bf16 (%.0f fp32-equivalent)  block0 ticks=%lld -> %.1f cycles/MFMA-slot at 2.4 GHz: %.1f\n", name,
+           blocks_per_cu, ms, flops / ms / 1e9, flops / ms / 1e9 / 6, c, (double)c / (iters * 24.0 * blocks_per_cu), ms * 1e-3 * 2.4e9 / (iters * 24.0 * blocks_per_cu));
+    (void)hipFree(out); (void)hipFree(cyc);
+}
+int main() {
+    run<0>("mfma only", 1); run<0>("mfma only", 2);
+    run<1>("mfma + 12 ds_read_b128 / 24", 1); run<1>("mfma + 12 ds_read_b128 / 24", 2); run<1>("mfma + 12 ds_read_b128 / 24", 3);
+    run<2>("mfma + reads + barrier", 1); run<2>("mfma + reads + barrier", 2); run<2>("mfma + reads + barrier", 3);
+    return 0;
+}
