@@ -14,6 +14,7 @@
 // loader on their way into LDS (v_cvt_pk_bf16_f32 + two subtractions per term).  LDS tiles are per plane
 // [row][2 chunks of 8 bf16] with the chunk index XOR-ed by bit 3 of the row, which makes both the loader's
 // ds_write_b128 and the MFMA operand ds_read_b128 (lane l: row l&31, k-half l>>5) conflict-free at a 32-byte pitch.
+#include <stdlib.h>
 #include <string.h>
 
 #include "egr_conv.h"
@@ -77,7 +78,7 @@ template <> struct S3Cfg<128, 32> { static constexpr int WM = 4, WN = 1, TM = 1,
 
 __device__ __forceinline__ bf16x8 as_bf(const uint4& v) { return __builtin_bit_cast(bf16x8, v); }
 
-template <int BM, int BN>
+template <int BM, int BN, int PF>
 __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
     typedef S3Cfg<BM, BN> TC;
     constexpr int TM = TC::TM, TN = TC::TN;
@@ -180,37 +181,38 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
     S3_BSETUP(2, bptr2, bstep2, bslot2)
 #undef S3_BSETUP
 
-    float4 ra0, ra1, ra2, ra3;
-    uint4 rb0, rb1, rb2;
-    ra2 = ra3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    rb0 = rb1 = rb2 = make_uint4(0, 0, 0, 0);
-    auto load_tile = [&]() {
+    // staged tile registers: one set per slab in flight (PF = 2 sets: a load has two slab-times to land)
+    struct Stage {
+        float4 a0, a1, a2, a3;
+        uint4 b0, b1, b2;
+    };
+    auto load_tile = [&](Stage& r) {
 #ifdef S3_ABL_NOGLOBAL
         if (c0 > 0 || tap > 0) { c0 += S3_BK; return; }
 #endif
         {
             const float* s = aptr0 + astep0 * c0;
-            ra0 = *(const float4*)s;
-            ra1 = *(const float4*)(s + 4);
+            r.a0 = *(const float4*)s;
+            r.a1 = *(const float4*)(s + 4);
         }
         if (AP > 1) {
             const float* s = aptr1 + astep1 * c0;
-            ra2 = *(const float4*)s;
-            ra3 = *(const float4*)(s + 4);
+            r.a2 = *(const float4*)s;
+            r.a3 = *(const float4*)(s + 4);
         }
         c0 += S3_BK;
         if (c0 >= p.Cin) { c0 = 0; ++tap; set_tap(tap); }
-        rb0 = *bptr0;
+        r.b0 = *bptr0;
         bptr0 += bstep0;
-        if (256 < NBQ) { rb1 = *bptr1; bptr1 += bstep1; }
-        if (512 < NBQ) { rb2 = *bptr2; bptr2 += bstep2; }
+        if (256 < NBQ) { r.b1 = *bptr1; bptr1 += bstep1; }
+        if (512 < NBQ) { r.b2 = *bptr2; bptr2 += bstep2; }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](const Stage& r, int buf) {
         uint4 q0, q1, q2;
 #ifdef S3_ABL_NOSPLIT
-        q0 = q1 = q2 = make_uint4(__float_as_uint(ra0.x), __float_as_uint(ra0.y), __float_as_uint(ra1.x), __float_as_uint(ra1.y));
+        q0 = q1 = q2 = make_uint4(__float_as_uint(r.a0.x), __float_as_uint(r.a0.y), __float_as_uint(r.a1.x), __float_as_uint(r.a1.y));
 #else
-        split3_x8(ra0, ra1, q0, q1, q2);
+        split3_x8(r.a0, r.a1, q0, q1, q2);
 #endif
 #ifdef S3_ABL_NOSTORE
         if (buf > 1)
@@ -221,15 +223,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
             As[buf][2][a_slot] = q2;
             if (AP > 1) {
 #ifndef S3_ABL_NOSPLIT
-                split3_x8(ra2, ra3, q0, q1, q2);
+                split3_x8(r.a2, r.a3, q0, q1, q2);
 #endif
                 As[buf][0][a_slot + 256] = q0;
                 As[buf][1][a_slot + 256] = q1;
                 As[buf][2][a_slot + 256] = q2;
             }
-            if (tid < NBQ) Bs[buf][0][bslot0] = rb0;
-            if (tid + 256 < NBQ) Bs[buf][0][bslot1] = rb1;
-            if (tid + 512 < NBQ) Bs[buf][0][bslot2] = rb2;
+            if (tid < NBQ) Bs[buf][0][bslot0] = r.b0;
+            if (tid + 256 < NBQ) Bs[buf][0][bslot1] = r.b1;
+            if (tid + 512 < NBQ) Bs[buf][0][bslot2] = r.b2;
         }
     };
 
@@ -237,12 +239,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
     const int li = lane & 31, lk = lane >> 5;
     const int o_slot = li * 2 + (lk ^ ((li >> 3) & 1));
 
-    load_tile();
-    store_tile(0);
-    __syncthreads();
-    if (kt_begin + 1 < kt_end) load_tile();
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int cur = (kt - kt_begin) & 1;
+    // one slab: MFMAs on LDS buffer `cur`; tile kt+1 (staged in SN) -> LDS buffer cur^1; tile kt+1+PF -> SN
+    auto slab = [&](int kt, int cur, Stage& sn) {
         uint4 b[TN][3];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -257,8 +255,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) a[i][q] = As[cur][q][(wm0 + (i0 + i) * 32) * 2 + o_slot];
             if (i0 == 0) {
-                if (kt + 1 < kt_end) store_tile(cur ^ 1);
-                if (kt + 2 < kt_end) load_tile();
+                if (kt + 1 < kt_end) store_tile(sn, cur ^ 1);
+                if (kt + 1 + PF < kt_end) load_tile(sn);
             }
             // smallest terms first
 #define S3_MMA(QA, QB)                                                                                                   \
@@ -275,6 +273,26 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
 #ifndef S3_ABL_NOBARRIER
         __syncthreads();
 #endif
+    };
+
+    Stage s0, s1;
+    s0.a2 = s0.a3 = s1.a0 = s1.a1 = s1.a2 = s1.a3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    s0.b0 = s0.b1 = s0.b2 = s1.b0 = s1.b1 = s1.b2 = make_uint4(0, 0, 0, 0);
+    load_tile(s0);
+    store_tile(s0, 0);
+    __syncthreads();
+    if (PF == 1) {
+        if (kt_begin + 1 < kt_end) load_tile(s0);
+        for (int kt = kt_begin; kt < kt_end; ++kt) slab(kt, (kt - kt_begin) & 1, s0);
+    } else {
+        if (kt_begin + 1 < kt_end) load_tile(s0);
+        if (kt_begin + 2 < kt_end) load_tile(s1);
+        int kt = kt_begin;
+        for (; kt + 1 < kt_end; kt += 2) {        // buffers and stage sets alternate with the parity of kt - kt_begin
+            slab(kt, 0, s0);
+            slab(kt + 1, 1, s1);
+        }
+        if (kt < kt_end) slab(kt, 0, s0);
     }
     conv_epilogue<TM, TN>(p, acc, m0, n0, wm0, wn0);
 }
@@ -287,10 +305,11 @@ int s3_bm(long long M, int Cout, int bn) {
 }
 
 void launch_conv_s3(int bm, int bn, dim3 grid, hipStream_t st, const ConvP& p) {
-    if (bm == 256) hipLaunchKernelGGL((k_conv_s3<256, 128>), grid, dim3(256), 0, st, p);
-    else if (bn == 128) hipLaunchKernelGGL((k_conv_s3<128, 128>), grid, dim3(256), 0, st, p);
-    else if (bn == 64) hipLaunchKernelGGL((k_conv_s3<128, 64>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_conv_s3<128, 32>), grid, dim3(256), 0, st, p);
+    static const int pf = getenv("EGR_S3_PF") ? atoi(getenv("EGR_S3_PF")) : 1;
+    if (bm == 256) hipLaunchKernelGGL((k_conv_s3<256, 128, 1>), grid, dim3(256), 0, st, p);
+    else if (bn == 128) { if (pf == 2) hipLaunchKernelGGL((k_conv_s3<128, 128, 2>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((k_conv_s3<128, 128, 1>), grid, dim3(256), 0, st, p); }
+    else if (bn == 64) { if (pf == 2) hipLaunchKernelGGL((k_conv_s3<128, 64, 2>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((k_conv_s3<128, 64, 1>), grid, dim3(256), 0, st, p); }
+    else { if (pf == 2) hipLaunchKernelGGL((k_conv_s3<128, 32, 2>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((k_conv_s3<128, 32, 1>), grid, dim3(256), 0, st, p); }
 }
 
 }  // namespace egr

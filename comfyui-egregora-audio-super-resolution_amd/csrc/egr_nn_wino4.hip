@@ -1,0 +1,192 @@
+// Winograd F(4x4,3x3) transforms for the stride-1 pad-1 3x3 convolutions of the FlashSR graph (4x fewer multiplies than
+// the direct form, 36 z-batched GEMMs of [tiles][Cin] x [Cin][Cout] in between).  Both kernels are HBM-bound: the input
+// transform reads the activation once and writes 36/16 = 2.25x its size, the output transform reads 2.25x the output and
+// writes it once (F(2x2,3x3): 4x each).
+//
+// Cook-Toom points 0, +-a, +-b, inf with a = 3/4, b = 3/2 instead of the textbook 0, +-1, +-2: the error of the scheme is
+// the GEMMs' fp32 accumulation error amplified by max|M| / max|y|, and the smaller points cut that factor from ~50 to
+// ~12 (tools/probe_wino4_error.py; measured end-to-end error vs float64 in tests/test_gpu_flashsr.py).  Every constant
+// below (a^2, b^2, a^2 b^2, a b^2, a^2 b, a^3, b^3) is exact in fp32, so B^T, G and A^T agree exactly.
+//   B^T row p=0 : M0(x) = (x^2-a^2)(x^2-b^2)      rows +-a : x (x+-a)(x^2-b^2)      rows +-b : x (x+-b)(x^2-a^2)
+//   B^T row inf : x (x^2-a^2)(x^2-b^2)            (coefficients of x^0..x^5)
+//   G row p     : [1, p, p^2] / N_p,  N_0 = a^2 b^2, N_+-a = 2 a^2 (a^2-b^2), N_+-b = 2 b^2 (b^2-a^2);  G row inf : [0, 0, 1]
+//   A^T[i][p]   : p^i (i < 4), plus 1 at [3][inf]
+#include "egr_common.h"
+
+namespace egr {
+
+#define W4_A 0.75
+#define W4_B 1.5
+static constexpr float kA = (float)W4_A, kB = (float)W4_B, kA2 = kA * kA, kB2 = kB * kB, kA3 = kA2 * kA, kB3 = kB2 * kB;
+static constexpr float kC0 = kA2 * kB2, kC2 = -(kA2 + kB2);
+
+#define F4A(a, b) make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w)
+#define F4S(a, b) make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w)
+#define F4M(s, a) make_float4((s) * a.x, (s) * a.y, (s) * a.z, (s) * a.w)
+#define F4FMA(s, a, b) make_float4(fmaf((s), a.x, b.x), fmaf((s), a.y, b.y), fmaf((s), a.z, b.z), fmaf((s), a.w, b.w))
+
+// t = B^T d for one 6-vector; rows ordered 0, +a, -a, +b, -b, inf
+__device__ __forceinline__ void bt6(const float4 (&d)[6], float4 (&t)[6]) {
+    const float4 ea = F4FMA(-kB2, d[2], d[4]);              // even part of the +-a rows: d4 - b^2 d2
+    const float4 oa = F4M(kA, F4FMA(-kB2, d[1], d[3]));     // odd part: a (d3 - b^2 d1)
+    const float4 eb = F4FMA(-kA2, d[2], d[4]);              // +-b rows: d4 - a^2 d2
+    const float4 ob = F4M(kB, F4FMA(-kA2, d[1], d[3]));     //           b (d3 - a^2 d1)
+    t[0] = F4FMA(kC0, d[0], F4FMA(kC2, d[2], d[4]));
+    t[1] = F4A(ea, oa);
+    t[2] = F4S(ea, oa);
+    t[3] = F4A(eb, ob);
+    t[4] = F4S(eb, ob);
+    t[5] = F4FMA(kC0, d[1], F4FMA(kC2, d[3], d[5]));
+}
+
+// s = A^T m for one 6-vector
+__device__ __forceinline__ void at6(const float4 (&m)[6], float4 (&s)[4]) {
+    const float4 pa = F4A(m[1], m[2]), ma = F4S(m[1], m[2]), pb = F4A(m[3], m[4]), mb = F4S(m[3], m[4]);
+    s[0] = F4A(F4A(m[0], pa), pb);
+    s[1] = F4FMA(kA, ma, F4M(kB, mb));
+    s[2] = F4FMA(kA2, pa, F4M(kB2, pb));
+    s[3] = F4A(F4FMA(kA3, ma, F4M(kB3, mb)), m[5]);
+}
+
+// V[6 i + j][t][c] = (B^T d B)[i][j] of the 6x6 input tile whose origin is (4 ty - 1, 4 tx - 1); t = (b, ty, tx)
+__global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, int B, int H, int W, int C, int TH, int TW,
+                                                   const float* __restrict__ gsc, const float* __restrict__ gsh, int gsilu,
+                                                   float* __restrict__ V) {
+    const int C4 = C >> 2;
+    const long long P = (long long)B * TH * TW, total = P * C4;
+    const size_t zs = (size_t)P * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long long t = i / C4;
+        const int tx = (int)(t % TW), ty = (int)((t / TW) % TH), b = (int)(t / ((long long)TW * TH));
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gsc) {
+            sc = *(const float4*)(gsc + (size_t)b * C + 4 * c4);
+            sh = *(const float4*)(gsh + (size_t)b * C + 4 * c4);
+        }
+        float4 tt[6][6];                                  // tt[i][q] = (B^T d)[i][q]
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int ix = 4 * tx - 1 + q;
+            float4 d[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const int iy = 4 * ty - 1 + r;
+                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const size_t off = ok ? (((size_t)b * H + iy) * W + ix) * C + 4 * c4 : (size_t)(4 * c4);
+                float4 v = *(const float4*)(x + off);
+                if (gsc) {      // producer's GroupNorm (+SiLU) fused into the transform; padding stays zero
+                    v = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+                    if (gsilu) {
+                        v.x = v.x / (1.f + __expf(-v.x)); v.y = v.y / (1.f + __expf(-v.y));
+                        v.z = v.z / (1.f + __expf(-v.z)); v.w = v.w / (1.f + __expf(-v.w));
+                    }
+                }
+                d[r] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float4 col[6];
+            bt6(d, col);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) tt[r][q] = col[r];
+        }
+        float* o = V + (size_t)t * C + 4 * c4;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {                     // (.) B == B^T applied along the row
+            float4 row[6];
+            bt6(tt[r], row);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) *(float4*)(o + (size_t)(6 * r + q) * zs) = row[q];
+        }
+    }
+}
+
+// y[b][4ty+a][4tx+c][n] = act((A^T M A)[a][c] + bias[n] + res[...]),  M[6 i + j][t][n]
+__global__ __launch_bounds__(256) void k_wino4_out(const float* __restrict__ Mx, const float* __restrict__ bias,
+                                                    const float* __restrict__ res, int B, int H, int W, int N, int TH, int TW,
+                                                    int act, float* __restrict__ y) {
+    const int N4 = N >> 2;
+    const long long P = (long long)B * TH * TW, total = P * N4;
+    const size_t zs = (size_t)P * N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n4 = (int)(i % N4);
+        const long long t = i / N4;
+        const int tx = (int)(t % TW), ty = (int)((t / TW) % TH), b = (int)(t / ((long long)TW * TH));
+        const float* mi = Mx + (size_t)t * N + 4 * n4;
+        float4 s[4][6];                                   // s[a][q] = (A^T m)[a][q]
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            float4 m[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) m[r] = *(const float4*)(mi + (size_t)(6 * r + q) * zs);
+            float4 col[4];
+            at6(m, col);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) s[a][q] = col[a];
+        }
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bv = *(const float4*)(bias + 4 * n4);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float4 o[4];
+            at6(s[a], o);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const size_t off = (((size_t)b * H + 4 * ty + a) * W + 4 * tx + c) * N + 4 * n4;
+                float4 v = F4A(o[c], bv);
+                if (res) { const float4 rr = *(const float4*)(res + off); v = F4A(v, rr); }
+                if (act == 1) {
+                    v.x = v.x / (1.f + __expf(-v.x)); v.y = v.y / (1.f + __expf(-v.y));
+                    v.z = v.z / (1.f + __expf(-v.z)); v.w = v.w / (1.f + __expf(-v.w));
+                }
+                *(float4*)(y + off) = v;
+            }
+        }
+    }
+}
+
+static inline int grid1d(long long n) {
+    long long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+}  // namespace egr
+
+using namespace egr;
+
+// G (6x3, rows 0, +a, -a, +b, -b, inf) of the scheme above, in double: the host forms U = G g G^T with it
+extern "C" int egr_winograd4_g(double* g18) {
+    EGR_CHECK(g18, EGR_ERR_ARG, "null g18");
+    const double a = W4_A, b = W4_B, n0 = a * a * b * b, na = 2 * a * a * (a * a - b * b), nb = 2 * b * b * (b * b - a * a);
+    const double pts[5] = {0.0, a, -a, b, -b}, nn[5] = {n0, na, na, nb, nb};
+    for (int j = 0; j < 5; ++j) {
+        g18[3 * j + 0] = 1.0 / nn[j];
+        g18[3 * j + 1] = pts[j] / nn[j];
+        g18[3 * j + 2] = pts[j] * pts[j] / nn[j];
+    }
+    g18[15] = 0.0; g18[16] = 0.0; g18[17] = 1.0;
+    return EGR_OK;
+}
+
+extern "C" int egr_winograd4_input(const float* x, const float* gn_scale, const float* gn_shift, int gn_silu, int B, int H,
+                                   int W, int C, float* V, void* stream) {
+    EGR_CHECK(x && V && B >= 1 && H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0 && C >= 4 && C % 4 == 0 &&
+                  (!gn_scale || gn_shift), EGR_ERR_ARG, "F(4x4,3x3) input transform needs H, W, C multiples of 4");
+    const int TH = H / 4, TW = W / 4;
+    const long long n = (long long)B * TH * TW * (C / 4);
+    hipLaunchKernelGGL(k_wino4_in, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C, TH, TW, gn_scale,
+                       gn_shift, gn_silu, V);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_winograd4_output(const float* M, const float* bias, const float* res, float* y, int B, int H, int W, int N,
+                                    int act, void* stream) {
+    EGR_CHECK(M && y && B >= 1 && H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0 && N >= 4 && N % 4 == 0 &&
+                  (act == 0 || act == 1), EGR_ERR_ARG, "F(4x4,3x3) output transform needs H, W, N multiples of 4");
+    const int TH = H / 4, TW = W / 4;
+    const long long n = (long long)B * TH * TW * (N / 4);
+    hipLaunchKernelGGL(k_wino4_out, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, M, bias, res, B, H, W, N, TH, TW, act,
+                       y);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}

@@ -36,6 +36,7 @@ class FlashSREngine:
         self.prof = None            # when a list: (kind, flops, start_event, end_event) per MFMA kernel launch
         self.blocks = arch.unet_blocks(cfg)
         self.w: Dict[str, torch.Tensor] = {}
+        self.wz: Dict[str, int] = {}               # floats per component of the z-stacked Winograd packs
         self.w3: Dict[str, torch.Tensor] = {}      # three-way bf16 splits of self.w entries (egr_split3_pack)
         self.wshape: Dict[str, tuple] = {}
         self.mfma = self.MFMA_MODE
@@ -101,48 +102,69 @@ class FlashSREngine:
                                 w[:, :, i, j] += v[:, :, ky, kx]
                 self.add_weight(f"{key}.ph{a}{b}", w)
 
-    WINO_MIN_CH = int(os.environ.get("EGREGORA_FLASHSR_WINOGRAD_MIN_CH", "256"))   # 128 measured slower (transform traffic)
+    # F(2x2,3x3) paid from 256 channels (its transforms move 4x the tensor); F(4x4,3x3) moves 2.25x and pays from 128
+    WINO_MIN_CH = int(os.environ.get("EGREGORA_FLASHSR_WINOGRAD_MIN_CH", "128"))
+
+    WINO_F4 = os.environ.get("EGREGORA_FLASHSR_WINOGRAD_F4", "1") != "0"   # F(4x4,3x3) where H and W are multiples of 4
+
+    _G2 = [[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]]
+
+    def _g4(self):
+        """G of the library's F(4x4,3x3) scheme (points 0, +-3/4, +-3/2, inf; csrc/egr_nn_wino4.hip)."""
+        buf = (C.c_double * 18)()
+        native.check(self.L.egr_winograd4_g(buf), "egr_winograd4_g")
+        return [[buf[3 * j + k] for k in range(3)] for j in range(6)]
 
     def add_winograd(self, key: str, v: torch.Tensor):
-        """U = G g G^T for Winograd F(2x2,3x3): 16 [Cin][Cout] matrices, each packed slab-major (key + '.wino')."""
+        """U = G g G^T in float64 for Winograd F(2x2,3x3) (16 [Cin][Cout] matrices, key + '.wino') and, when enabled,
+        F(4x4,3x3) (36 matrices, key + '.wino4'); each matrix packed slab-major like a 1x1 conv weight."""
         v = v.detach().double()                                         # [Co,Ci,3,3]
-        G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
-        U = torch.einsum("ik,ockl,jl->ijco", G, v, G)                   # [4,4,Ci,Co]
-        Ci, Co = U.shape[2], U.shape[3]
-        packed = torch.stack([self.pack_matrix(U[i, j].float().contiguous()) for i in range(4) for j in range(4)])
-        self.w[key + ".wino"] = packed.contiguous().to(self.dev)        # [16][Kp/16][Co][16]
-        if Ci % 16 == 0:
-            self._split3(key + ".wino")
+        Ci = v.shape[1]
+        for suffix, Gm in ((".wino", self._G2),) + (((".wino4", self._g4()),) if self.WINO_F4 else ()):
+            G = torch.tensor(Gm, dtype=torch.float64)
+            U = torch.einsum("ik,ockl,jl->ijco", G, v, G)               # [n,n,Ci,Co]
+            n = U.shape[0]
+            packed = torch.stack([self.pack_matrix(U[i, j].float().contiguous()) for i in range(n) for j in range(n)])
+            self.w[key + suffix] = packed.contiguous().to(self.dev)     # [n*n][Kp/16][Co][16]
+            self.wz[key + suffix] = packed[0].numel()                   # floats per component
+            if Ci % 16 == 0:
+                self._split3(key + suffix)
+                if (key + suffix) in self.w3:                           # the fp32 pack is not needed once split
+                    self.w[key + suffix] = self.w[key + suffix][:0]
 
     def _conv_winograd(self, x, key, act, res, bias_t, gn=None):
         B, H, W, Cin = x.shape
         Cout = self.wshape[key + ".weight"][3]
-        TH, TW = (H + 1) // 2, (W + 1) // 2
+        f4 = (key + ".weight.wino4") in self.w and H % 4 == 0 and W % 4 == 0
+        wkey = key + (".weight.wino4" if f4 else ".weight.wino")
+        nz, ts = (36, 4) if f4 else (16, 2)
+        fn_in, fn_out = (self.L.egr_winograd4_input, self.L.egr_winograd4_output) if f4 else \
+            (self.L.egr_winograd_input, self.L.egr_winograd_output)
+        TH, TW = (H + ts - 1) // ts, (W + ts - 1) // ts
         P = B * TH * TW
-        V = torch.empty((16, P, Cin), dtype=torch.float32, device=self.dev)
+        V = torch.empty((nz, P, Cin), dtype=torch.float32, device=self.dev)
         gsc, gsh, gsilu = gn if gn is not None else (None, None, 0)
-        native.check(self.L.egr_winograd_input(_p(x), _p(gsc), _p(gsh), gsilu, B, H, W, Cin, _p(V), self._st()),
-                     "egr_winograd_input")
-        Mx = torch.empty((16, P, Cout), dtype=torch.float32, device=self.dev)
-        wt = self.w[key + ".weight.wino"]
-        fl = 16 * 2.0 * P * Cin * Cout
+        native.check(fn_in(_p(x), _p(gsc), _p(gsh), gsilu, B, H, W, Cin, _p(V), self._st()), "egr_winograd_input")
+        Mx = torch.empty((nz, P, Cout), dtype=torch.float32, device=self.dev)
+        zw = self.wz[wkey]
+        fl = nz * 2.0 * P * Cin * Cout
         ev = self._prof_begin()
-        w3 = self._s3(key + ".weight.wino", Cin, V)
+        w3 = self._s3(wkey, Cin, V)
         if w3 is not None:
             native.check(self.L.egr_conv_s3(_p(V), _p(w3), _p(None), _p(None), _p(None), _p(Mx), P, 1, 1, Cin, 1, 1, Cout, 1, 1, 1,
-                                            1, 0, 0, 0, 0, 0.0, 1, 1, 0, 0, 1, 1, 16, P * Cin, wt[0].numel() * 3 // 8, P * Cout,
+                                            1, 0, 0, 0, 0, 0.0, 1, 1, 0, 0, 1, 1, nz, P * Cin, zw * 3 // 8, P * Cout,
                                             self._st()), "egr_conv_s3(winograd)")
         else:
-            native.check(self.L.egr_gemm_zbatched(_p(V), _p(wt), _p(Mx), 16, P, Cin, Cout, P * Cin, wt[0].numel(), P * Cout,
+            native.check(self.L.egr_gemm_zbatched(_p(V), _p(self.w[wkey]), _p(Mx), nz, P, Cin, Cout, P * Cin, zw, P * Cout,
                                                   self._st()), "egr_gemm_zbatched")
         if ev is not None:
-            self._prof_end(ev, self._kind(P, Cin, Cout, w3 is not None), fl, (B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 16))
+            self._prof_end(ev, self._kind(P, Cin, Cout, w3 is not None), fl, (B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, nz))
         if self.count_flops:
             self.flops += fl
         y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=self.dev)
         bt = bias_t if bias_t is not None else self.w.get(key + ".bias")
-        native.check(self.L.egr_winograd_output(_p(Mx), _p(bt), _p(res), _p(y), B, H, W, Cout, 1 if act == ACT_SILU else 0,
-                                                self._st()), "egr_winograd_output")
+        native.check(fn_out(_p(Mx), _p(bt), _p(res), _p(y), B, H, W, Cout, 1 if act == ACT_SILU else 0, self._st()),
+                     "egr_winograd_output")
         return y
 
     def add_weight(self, key: str, v: torch.Tensor):

@@ -184,6 +184,18 @@ int egr_gemm_zbatched(const float* x, const float* w, float* y, int nz, int rows
 int egr_winograd_output(const float* M, const float* bias, const float* res, float* y, int B, int H, int W, int N, int act,
                         void* stream);
 
+/* Winograd F(4x4,3x3) (4x fewer multiplies; H and W multiples of 4): same three steps with 36 components,
+ *   V [36][P][C], P = B*(H/4)*(W/4) tiles, V[6i+j] = (B^T d B)[i][j] of the 6x6 input tile at (4ty-1, 4tx-1);
+ *   36 z-batched GEMMs (egr_conv_s3 / egr_gemm_zbatched with nz = 36); y = act(A^T M A + bias + res) per 4x4 output tile.
+ * Cook-Toom points 0, +-3/4, +-3/2, inf (smaller error amplification than 0, +-1, +-2; csrc/egr_nn_wino4.hip);
+ * egr_winograd4_g returns the matching G (6x3, row-major, double) and U = G g G^T (6x6 per channel pair) is prepared by
+ * the host in float64 (flashsr_engine.FlashSREngine.add_winograd). */
+int egr_winograd4_g(double* g18);
+int egr_winograd4_input(const float* x, const float* gn_scale, const float* gn_shift, int gn_silu, int B, int H, int W, int C,
+                        float* V, void* stream);
+int egr_winograd4_output(const float* M, const float* bias, const float* res, float* y, int B, int H, int W, int N, int act,
+                         void* stream);
+
 /* GroupNorm split in two: egr_groupnorm_coeff computes the statistics and the per-(b, c) scale/shift ([B][C] each);
  * egr_conv_nhwc_gn is egr_conv_nhwc (no dilation / upsample / placement) with x*scale + shift (+SiLU) applied to the
  * input while it is loaded (zero padding after it), so the normalised tensor is never materialised. */

@@ -139,11 +139,16 @@ def test_f32_mfma_mode_still_matches(pack):
     assert rel_l2(y2, y1) < 2e-5, rel_l2(y2, y1)
 
 
-def test_winograd_conv_vs_torch(eng):
-    """Winograd F(2x2,3x3) path (input transform, 16 z-batched MFMA GEMMs, output transform + epilogue)."""
+@pytest.mark.parametrize("f4", [False, True])
+def test_winograd_conv_vs_torch(eng, f4):
+    """Winograd paths (input transform, z-batched MFMA GEMMs, output transform + epilogue): F(2x2,3x3) with 16
+    components, and F(4x4,3x3) with 36 where H and W are multiples of 4 (other shapes fall back to F(2x2))."""
     e, cfg, P = eng
     g = torch.Generator().manual_seed(41)
-    for (B, H, W, Ci, Co, use_res, act) in [(2, 8, 12, 32, 48, True, 1), (1, 16, 16, 64, 128, False, 0), (3, 6, 4, 144, 80, True, 0)]:
+    oldf4 = type(e).WINO_F4
+    type(e).WINO_F4 = f4
+    for (B, H, W, Ci, Co, use_res, act) in [(2, 8, 12, 32, 48, True, 1), (1, 16, 16, 64, 128, False, 0), (3, 6, 4, 144, 80, True, 0),
+                                            (2, 4, 4, 16, 20, True, 1)]:
         x = torch.randn(B, Ci, H, W, generator=g)
         w = torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9)
         b = torch.randn(Co, generator=g)
@@ -156,9 +161,33 @@ def test_winograd_conv_vs_torch(eng):
         e.add_weight("wg.weight", w)
         e.add_winograd("wg.weight", w)
         e.w["wg.bias"] = b.cuda()
+        assert ("wg.weight.wino4" in e.w) == f4
         got = e._conv_winograd(nhwc(x).cuda(), "wg", act, nhwc(res).cuda() if use_res else None, None)
         close(nchw(got), want, 3e-5)
-    e.w.pop("wg.weight.wino")
+        e.w.pop("wg.weight.wino")
+        e.w.pop("wg.weight.wino4", None)
+    type(e).WINO_F4 = oldf4
+
+
+def test_winograd4_error_vs_float64(eng):
+    """F(4x4,3x3) in fp32 with the split-bf16 GEMMs: max error <= 1e-5 of the output maximum against a float64 direct
+    convolution at FlashSR's channel counts (the fp32 direct form sits at ~3e-7, F(2x2,3x3) at ~1e-6) --
+    half the 2e-5 single-operator tolerance of this file (measured 2e-6 .. 5e-6 with the points 0, +-3/4, +-3/2)."""
+    e, cfg, P = eng
+    g = torch.Generator().manual_seed(45)
+    for (B, H, W, Ci, Co) in [(1, 16, 16, 256, 256), (1, 8, 8, 1024, 512)]:
+        x = torch.randn(B, Ci, H, W, generator=g)
+        w = torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9)
+        b = torch.randn(Co, generator=g)
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+        e.add_weight("w4.weight", w)
+        e.add_winograd("w4.weight", w)
+        e.w["w4.bias"] = b.cuda()
+        assert "w4.weight.wino4" in e.w
+        got = nchw(e._conv_winograd(nhwc(x).cuda(), "w4", 0, None, None)).cpu().double()
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert err <= 1e-5, err
+        e.w.pop("w4.weight.wino"), e.w.pop("w4.weight.wino4")
 
 
 def test_fused_groupnorm_conv_vs_torch(eng):
@@ -185,6 +214,7 @@ def test_fused_groupnorm_conv_vs_torch(eng):
                 got = e.gn_conv3(nhwc(x).cuda(), "fg", 1e-6, "fc", res=nhwc(res).cuda())
                 close(nchw(got), want, 4e-5)
                 e.w.pop("fc.weight.wino", None)
+                e.w.pop("fc.weight.wino4", None)
     finally:
         e.cfg.gn_groups = old
         type(e).FUSE_GN = oldf

@@ -5,17 +5,22 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ bf16x8 as_bf(const uint4& v) { return __builtin_bit_cast(bf16x8, v); }
-template <int MODE>
+__device__ __forceinline__ unsigned rbf(unsigned h) {   // two random finite bf16 values of magnitude 2^-15..1
+    h = h * 2654435761u + 12345u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    const unsigned lo = (h & 0x807fu) | ((0x70u + ((h >> 8) & 0xfu)) << 7), hi = ((h >> 16) & 0x807fu) | ((0x70u + ((h >> 24) & 0xfu)) << 7);
+    return lo | (hi << 16);
+}
+template <int MODE, int RND>
 __global__ __launch_bounds__(256) void k(float* out, int iters, long long* cyc) {
     __shared__ uint4 lds[2][3][256 * 2];
     f32x16 acc[2][2];
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 2 * 3 * 512; i += 256) ((uint4*)lds)[i] = make_uint4(0x3f803f80u, 0x3f003f00u, 0x3e803e80u, 0x3e003e00u);
+    for (int i = threadIdx.x; i < 2 * 3 * 512; i += 256) ((uint4*)lds)[i] = RND ? make_uint4(rbf(i * 4 + blockIdx.x), rbf(i * 4 + 1), rbf(i * 4 + 2), rbf(i * 4 + 3)) : make_uint4(0x3f803f80u, 0x3f003f00u, 0x3e803e80u, 0x3e003e00u);
     __syncthreads();
     const int o_slot = li * 2 + (lk ^ ((li >> 3) & 1));
     uint4 a[2][3], b[2][3];
-    for (int i = 0; i < 2; ++i) for (int q = 0; q < 3; ++q) a[i][q] = b[i][q] = make_uint4(0x3f803f80u, 0x3f003f00u, 0x3e803e80u, 0x3e003e00u);
+    for (int i = 0; i < 2; ++i) for (int q = 0; q < 3; ++q) { a[i][q] = RND ? make_uint4(rbf(threadIdx.x * 64 + i * 8 + q), rbf(threadIdx.x * 64 + i * 8 + q + 3), rbf(threadIdx.x * 97 + i + q), rbf(threadIdx.x * 31 + i * 5 + q)) : make_uint4(0x3f803f80u, 0x3f003f00u, 0x3e803e80u, 0x3e003e00u); b[i][q] = a[i][q]; b[i][q].x ^= 0x00110011u * (q + 1); }
     const long long t0 = clock64();
     for (int it = 0; it < iters; ++it) {
         if (MODE >= 1) {
@@ -39,26 +44,27 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, long long* cyc) 
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) *cyc = t1 - t0;
 }
-template <int MODE> void run(const char* name, int blocks_per_cu) {
+template <int MODE, int RND> void run(const char* name, int blocks_per_cu) {
     const int blocks = 256 * blocks_per_cu, iters = 20000;
     float* out; long long* cyc;
     (void)hipMalloc(&out, blocks * 256 * 4); (void)hipMalloc(&cyc, 8);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, 1000, cyc);
+    hipLaunchKernelGGL((k<MODE, RND>), dim3(blocks), dim3(256), 0, 0, out, 1000, cyc);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, iters, cyc);
+    hipLaunchKernelGGL((k<MODE, RND>), dim3(blocks), dim3(256), 0, 0, out, iters, cyc);
     (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     long long c; (void)hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
     const double flops = (double)blocks * 4 * iters * 24.0 * (2.0 * 32 * 32 * 16);
-    printf("%-34s blocks/CU=%d  %.3f ms  %.0f TF/s bf16 (%.0f fp32-equivalent)  block0 ticks=%lld -> %.1f cycles/MFMA-slot at 2.4 GHz: %.1f\n", name,
+    printf("%-34s rnd=%d blocks/CU=%d  %.3f ms  %.0f TF/s bf16 (%.0f fp32-equivalent)  block0 ticks=%lld -> %.1f cycles/MFMA-slot at 2.4 GHz: %.1f\n", name, RND,
            blocks_per_cu, ms, flops / ms / 1e9, flops / ms / 1e9 / 6, c, (double)c / (iters * 24.0 * blocks_per_cu), ms * 1e-3 * 2.4e9 / (iters * 24.0 * blocks_per_cu));
     (void)hipFree(out); (void)hipFree(cyc);
 }
 int main() {
-    run<0>("mfma only", 1); run<0>("mfma only", 2);
-    run<1>("mfma + 12 ds_read_b128 / 24", 1); run<1>("mfma + 12 ds_read_b128 / 24", 2); run<1>("mfma + 12 ds_read_b128 / 24", 3);
-    run<2>("mfma + reads + barrier", 1); run<2>("mfma + reads + barrier", 2); run<2>("mfma + reads + barrier", 3);
+    run<0, 0>("mfma only", 2); run<0, 1>("mfma only", 2);
+    run<1, 0>("mfma + 12 ds_read_b128 / 24", 2); run<1, 1>("mfma + 12 ds_read_b128 / 24", 2);
+    run<2, 0>("mfma + reads + barrier", 2); run<2, 1>("mfma + reads + barrier", 2);
+    run<2, 1>("mfma + reads + barrier", 2); run<2, 1>("mfma + reads + barrier", 2); run<2, 0>("mfma + reads + barrier", 2);
     return 0;
 }
