@@ -8,6 +8,9 @@
 #include <mutex>
 #include <vector>
 
+#include <stdlib.h>
+#include <string.h>
+
 #include "egr_common.h"
 #include "egr_fft_device.h"
 #include "egr_plan.h"
@@ -276,6 +279,68 @@ __global__ __launch_bounds__(256) void k_snake_aa_tiled(const float* __restrict_
 #pragma unroll
         for (int k = 0; k < K; ++k) acc += f[k] * ss[2 * j + k][c];
         yb[(size_t)l * C] = acc;
+    }
+}
+
+// Register-blocked version (K = 12): a thread owns one channel and a run of J consecutive output positions.  Its x window
+// (J + 10 values, lanes run over channels so every load is a coalesced row segment) and the 2J + 10 up-rate samples it needs
+// live in registers with compile-time indices: no LDS, no barriers, (2J+10)/J sin per output (2.6 at J = 16) and 6 + ~6 FMAs
+// per up-rate sample.  Halo re-reads (10/J of the tile) hit L1/L2.  Runs at the tensor edges substitute the clamped
+// up-rate samples with predicated selects (same code path, same arithmetic).
+template <int J>
+__global__ __launch_bounds__(256) void k_snake_aa_reg(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                      const float* __restrict__ beta, const float* __restrict__ filt,
+                                                      float* __restrict__ y, int L, int C, int nruns, long long total) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int c = (int)(gid % C);
+    const long long rr = gid / C;
+    const int run = (int)(rr % nruns), b = (int)(rr / nruns);
+    const int l0 = run * J;
+    float f[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) f[k] = filt[k];
+    const float a = __expf(alpha[c]), ib = 1.0f / (__expf(beta[c]) + 1e-9f);
+    const float* xb = x + (size_t)b * L * C + c;
+    float* yb = y + (size_t)b * L * C + c;
+    const int L2 = 2 * L;
+    float xw[J + 10];                            // xw[i] = xp[l0 + i] = x[clamp(l0 - 5 + i)] (replicate padding of 5)
+#pragma unroll
+    for (int i = 0; i < J + 10; ++i) {
+        int src = l0 - 5 + i;
+        src = src < 0 ? 0 : (src > L - 1 ? L - 1 : src);
+        xw[i] = xb[(size_t)src * C];
+    }
+    float sv[2 * J + 10];                        // up-rate sample i = 2 l0 - 5 + q: taps xw[5 + (q>>1) - j] * f[(q&1) + 2j]
+#pragma unroll
+    for (int q = 0; q < 2 * J + 10; ++q) {
+        float u = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) u += xw[5 + (q >> 1) - j] * f[(q & 1) + 2 * j];
+        u *= 2.0f;
+        const float sn = __sinf(u * a);
+        sv[q] = u + ib * sn * sn;
+    }
+    const int i0 = 2 * l0 - 5;
+    if (i0 < 0 || i0 + 2 * J + 9 > L2 - 1) {     // runs at the tensor edges: up-rate indices clamp to [0, 2L-1]
+        float s_first = 0.f, s_last = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2 * J + 10; ++q) {
+            if (i0 + q == 0) s_first = sv[q];
+            if (i0 + q == L2 - 1) s_last = sv[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 2 * J + 10; ++q) {
+            if (i0 + q < 0) sv[q] = s_first;
+            if (i0 + q > L2 - 1) sv[q] = s_last;
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {             // output l0 + jj = sum_k f[k] * s[2 (l0 + jj) - 5 + k]
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc += f[k] * sv[2 * jj + k];
+        if (l0 + jj < L) yb[(size_t)(l0 + jj) * C] = acc;
     }
 }
 
@@ -677,7 +742,14 @@ extern "C" int egr_snake_aa(const float* x, const float* alpha, const float* bet
     EGR_CHECK(x && alpha && beta && filt && y && B >= 1 && B <= 65535 && L >= 1 && C >= 1 && K >= 2 && K <= 32 && K % 2 == 0,
               EGR_ERR_ARG, "bad argument");
     hipStream_t st = (hipStream_t)stream;
-    if (K == 12 && C % 64 == 0)
+    static const bool tiled = getenv("EGR_SNAKE") && !strcmp(getenv("EGR_SNAKE"), "tiled");
+    if (K == 12 && !tiled) {
+        constexpr int J = 16;
+        const int nruns = (L + J - 1) / J;
+        const long long total = (long long)B * nruns * C;
+        hipLaunchKernelGGL((k_snake_aa_reg<J>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, alpha, beta, filt, y, L, C,
+                           nruns, total);
+    } else if (K == 12 && C % 64 == 0)
         hipLaunchKernelGGL((k_snake_aa_tiled<64, 32>), dim3(C / 64, (L + 31) / 32, B), dim3(256), 0, st, x, alpha, beta, filt, y, L, C);
     else if (K == 12 && C % 32 == 0)
         hipLaunchKernelGGL((k_snake_aa_tiled<32, 64>), dim3(C / 32, (L + 63) / 64, B), dim3(256), 0, st, x, alpha, beta, filt, y, L, C);
