@@ -1,0 +1,90 @@
+"""Host-side algebra of the contraction tricks (no GPU): the library's Winograd F(4x4,3x3) scheme is an exact
+identity in float64, and the three-way bf16 split used by k_conv_s3 reproduces fp32 products to fp32 round-off.
+
+The kernels themselves are checked on the GPU (tests/test_gpu_flashsr.py); these tests pin the constants they are built
+from (csrc/egr_nn_wino4.hip: points 0, +-3/4, +-3/2, inf) and the error model quoted in DESIGN.md section 4.2a."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+A_PT, B_PT = 0.75, 1.5
+
+
+def scheme(pack):
+    from egregora_amd import native
+    buf = (C.c_double * 18)()
+    native.check(native.lib().egr_winograd4_g(buf), "egr_winograd4_g")
+    G = np.array(buf[:], dtype=np.float64).reshape(6, 3)
+    a, b = A_PT, B_PT
+    # B^T rows: coefficients (x^0..x^5) of M_p(x) = prod_{q != p} (x - q) for p in 0, +a, -a, +b, -b; last row: prod_q (x - q)
+    BT = np.array([[a * a * b * b, 0, -(a * a + b * b), 0, 1, 0],
+                   [0, -a * b * b, -b * b, a, 1, 0],
+                   [0, a * b * b, -b * b, -a, 1, 0],
+                   [0, -a * a * b, -a * a, b, 1, 0],
+                   [0, a * a * b, -a * a, -b, 1, 0],
+                   [0, a * a * b * b, 0, -(a * a + b * b), 0, 1]], dtype=np.float64)
+    pts = [0.0, a, -a, b, -b]
+    AT = np.zeros((4, 6))
+    for i in range(4):
+        for j, p in enumerate(pts):
+            AT[i, j] = p ** i
+    AT[3, 5] = 1.0
+    return G, BT, AT
+
+
+def test_g_matrix_is_the_cook_toom_g_of_the_documented_points(pack):
+    G, _, _ = scheme(pack)
+    a, b = A_PT, B_PT
+    n0, na, nb = a * a * b * b, 2 * a * a * (a * a - b * b), 2 * b * b * (b * b - a * a)
+    want = np.array([[1 / n0, 0, 0], [1 / na, a / na, a * a / na], [1 / na, -a / na, a * a / na],
+                     [1 / nb, b / nb, b * b / nb], [1 / nb, -b / nb, b * b / nb], [0, 0, 1]])
+    assert np.allclose(G, want, rtol=0, atol=1e-15)
+
+
+def test_f4x4_3x3_is_an_exact_identity_in_float64(pack):
+    G, BT, AT = scheme(pack)
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        d = rng.standard_normal((6, 6))
+        g = rng.standard_normal((3, 3))
+        y = AT @ ((G @ g @ G.T) * (BT @ d @ BT.T)) @ AT.T
+        want = np.array([[np.sum(d[i:i + 3, j:j + 3] * g) for j in range(4)] for i in range(4)])
+        assert np.abs(y - want).max() < 1e-12 * max(1.0, np.abs(want).max())
+
+
+def test_scheme_constants_are_exact_in_float32(pack):
+    """B^T, A^T entries round-trip through float32 unchanged, so the kernels' fp32 constants and the float64 G agree."""
+    _, BT, AT = scheme(pack)
+    assert np.array_equal(BT.astype(np.float32).astype(np.float64), BT)
+    assert np.array_equal(AT.astype(np.float32).astype(np.float64), AT)
+
+
+def test_three_way_bf16_split_is_exact_and_six_products_reach_fp32_roundoff():
+    g = torch.Generator().manual_seed(3)
+    K, M, N = 2304, 96, 80
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(K, N, generator=g) * 0.02
+
+    def split(x):
+        out, r = [], x.clone()
+        for _ in range(3):
+            h = r.to(torch.bfloat16).float()      # RNE, as v_cvt_pk_bf16_f32
+            out.append(h)
+            r = r - h                             # exact in fp32
+        return out
+
+    A, Bp = split(a), split(b)
+    assert torch.equal(A[0] + A[1] + A[2], a) and torch.equal(Bp[0] + Bp[1] + Bp[2], b)
+    ref = a.double() @ b.double()
+    six = sum(A[i].double() @ Bp[j].double() for i, j in ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)))
+    three = sum(A[i].double() @ Bp[j].double() for i, j in ((1, 0), (0, 1), (0, 0)))
+    e6 = float((six - ref).abs().max() / ref.abs().max())
+    e3 = float((three - ref).abs().max() / ref.abs().max())
+    chain = torch.zeros(M, N)
+    for k in range(K):                            # what v_mfma_f32_32x32x2_f32 computes: an fp32 fmaf chain
+        chain = chain + a[:, k:k + 1] * b[k:k + 1, :]
+    ec = float((chain.double() - ref).abs().max() / ref.abs().max())
+    assert e6 < 2e-8            # the dropped terms alone: far below one fp32 ulp of the result
+    assert e3 > 50 * e6         # three products (a "bf16x3" in the loose sense) would NOT be fp32-grade
+    assert e6 < 0.05 * ec       # ... while six are far inside the fp32 chain's own accumulation error
