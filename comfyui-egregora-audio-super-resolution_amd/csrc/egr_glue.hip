@@ -155,6 +155,139 @@ static int stft_tables(int n_fft, StftTables* out) {
     return EGR_OK;
 }
 
+// ---------------------------------------------------------------- evaluation metrics (egregora_audio_eval_pack.py:405-429)
+// per[f] = sqrt(mean_k (20 log10(A[f][k] + eps) - 20 log10(B[f][k] + eps))^2 + 1e-12), float32 terms like the reference,
+// the bin sum in double.  One workgroup per frame.
+__global__ __launch_bounds__(256) void k_lsd_frames(const float* __restrict__ SA, const float* __restrict__ SB, int nb,
+                                                     float* __restrict__ per) {
+    __shared__ double red[256];
+    const size_t f = blockIdx.x;
+    const float* a = SA + f * nb;
+    const float* b = SB + f * nb;
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < nb; k += 256) {
+        const float la = 20.0f * log10f(a[k] + 1e-12f), lb = 20.0f * log10f(b[k] + 1e-12f);
+        const float d = la - lb;
+        acc += (double)(d * d);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) per[f] = sqrtf((float)(red[0] / nb) + 1e-12f);
+}
+
+__global__ __launch_bounds__(256) void k_sum_f64(const float* __restrict__ v, long long n, double* __restrict__ out) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) acc += (double)v[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out, red[0]);
+}
+
+// k-th smallest (0-based) of v[0..n) for two ranks, by 4-pass radix selection on order-preserving keys.  ONE workgroup.
+__device__ __forceinline__ unsigned f2key(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+__global__ __launch_bounds__(1024) void k_order_stats2(const float* __restrict__ v, long long n, long long k0, long long k1,
+                                                        float* __restrict__ out2) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix;
+    __shared__ long long s_k;
+    for (int which = 0; which < 2; ++which) {
+        if (threadIdx.x == 0) { s_prefix = 0u; s_k = which ? k1 : k0; }
+        __syncthreads();
+        for (int pass = 3; pass >= 0; --pass) {
+            if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
+            __syncthreads();
+            const unsigned prefix = s_prefix;
+            const unsigned himask = pass == 3 ? 0u : (0xffffffffu << (8 * (pass + 1)));
+            for (long long i = threadIdx.x; i < n; i += 1024) {
+                const unsigned key = f2key(v[i]);
+                if ((key & himask) == (prefix & himask)) atomicAdd(&hist[(key >> (8 * pass)) & 255u], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                long long k = s_k;
+                int bkt = 0;
+                for (; bkt < 255; ++bkt) {
+                    if (k < (long long)hist[bkt]) break;
+                    k -= hist[bkt];
+                }
+                s_k = k;
+                s_prefix = prefix | ((unsigned)bkt << (8 * pass));
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out2[which] = key2f(s_prefix);
+        __syncthreads();
+    }
+}
+
+// SI-SDR terms on the mono downmixes (mean over channels in float32, like the reference's .mean(axis=0); sums in double):
+//   mode 0: out[0] += <s_hat, s>, out[1] += <s, s>
+//   mode 1: alpha = out[0] / (out[1] + 1e-20); out[2] += |alpha s|^2, out[3] += |s_hat - alpha s|^2
+__global__ __launch_bounds__(256) void k_sisdr(const float* __restrict__ s, int cs, long long stride_s,
+                                                const float* __restrict__ sh, int csh, long long stride_sh, long long n,
+                                                int mode, double* __restrict__ out) {
+    __shared__ double r0[256], r1[256];
+    const double alpha = mode ? out[0] / (out[1] + 1e-20) : 0.0;
+    double a0 = 0.0, a1 = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float ms = 0.f, mh = 0.f;
+        for (int c = 0; c < cs; ++c) ms += s[c * stride_s + i];
+        for (int c = 0; c < csh; ++c) mh += sh[c * stride_sh + i];
+        const double x = (double)(ms / (float)cs), y = (double)(mh / (float)csh);
+        if (mode == 0) {
+            a0 += y * x;
+            a1 += x * x;
+        } else {
+            const double t = alpha * x, e = y - t;
+            a0 += t * t;
+            a1 += e * e;
+        }
+    }
+    r0[threadIdx.x] = a0;
+    r1[threadIdx.x] = a1;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { r0[threadIdx.x] += r0[threadIdx.x + o]; r1[threadIdx.x] += r1[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(out + 2 * mode, r0[0]);
+        atomicAdd(out + 2 * mode + 1, r1[0]);
+    }
+}
+
+// np.interp(linspace(0,1,n_out,False), linspace(0,1,n_in,False), x) per row (Resample Audio (HQ) "linear" mode,
+// egregora_audio_eval_pack.py:515-519): position j*n_in/n_out in input samples, clamped to the last sample, double math.
+__global__ __launch_bounds__(256) void k_resample_linear(const float* __restrict__ x, long long n_in, long long n_out,
+                                                          float* __restrict__ y) {
+    const float* xr = x + (size_t)blockIdx.y * n_in;
+    float* yr = y + (size_t)blockIdx.y * n_out;
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < n_out; j += (long long)gridDim.x * 256) {
+        const double t = (double)j / (double)n_out;              // linspace(0, 1, n_out, endpoint=False)[j]
+        long long i = (long long)(t * (double)n_in);
+        if ((double)i / (double)n_in > t) --i;                    // largest i with t_old[i] <= t
+        if (i >= n_in - 1) { yr[j] = xr[n_in - 1]; continue; }
+        const double t0 = (double)i / (double)n_in, t1 = (double)(i + 1) / (double)n_in;
+        const double y0 = xr[i], y1 = xr[i + 1];
+        yr[j] = (float)(y0 + (t - t0) * ((y1 - y0) / (t1 - t0)));
+    }
+}
+
 static inline int grid_for(long long n) {
     long long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -240,6 +373,55 @@ extern "C" int egr_stft_mag(const float* x, int channels, int64_t n, int n_fft, 
     const size_t lds = (size_t)2 * (n_fft / 2) * sizeof(float2);
     hipLaunchKernelGGL(k_stft_mag, dim3((unsigned)frames), dim3(256), lds, (hipStream_t)stream, x, channels,
                        (long long)n, n_fft, hop, window, t.fd, t.tw, t.wsplit, out);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_lsd_frames(const float* SA, const float* SB, int64_t frames, int nb, float* per, void* stream) {
+    EGR_CHECK(SA && SB && per && frames >= 1 && frames < (1LL << 31) && nb >= 1, EGR_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_lsd_frames, dim3((unsigned)frames), dim3(256), 0, (hipStream_t)stream, SA, SB, nb, per);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_sum_f64(const float* v, int64_t n, double* out, void* stream) {
+    EGR_CHECK(v && out && n >= 1, EGR_ERR_ARG, "bad argument");
+    EGR_HIP(hipMemsetAsync(out, 0, sizeof(double), (hipStream_t)stream));
+    long long nb = (n + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_sum_f64, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, v, (long long)n, out);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_order_stats2(const float* v, int64_t n, int64_t k_lo, int64_t k_hi, float* out2, void* stream) {
+    EGR_CHECK(v && out2 && n >= 1 && k_lo >= 0 && k_lo < n && k_hi >= 0 && k_hi < n, EGR_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_order_stats2, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, (long long)n, (long long)k_lo,
+                       (long long)k_hi, out2);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_si_sdr_terms(const float* s, int cs, int64_t stride_s, const float* s_hat, int csh, int64_t stride_sh,
+                                int64_t n, double* out4, void* stream) {
+    EGR_CHECK(s && s_hat && out4 && cs >= 1 && csh >= 1 && n >= 1 && stride_s >= n && stride_sh >= n, EGR_ERR_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    EGR_HIP(hipMemsetAsync(out4, 0, 4 * sizeof(double), st));
+    long long nb = (n + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    for (int mode = 0; mode < 2; ++mode)
+        hipLaunchKernelGGL(k_sisdr, dim3((unsigned)nb), dim3(256), 0, st, s, cs, (long long)stride_s, s_hat, csh,
+                           (long long)stride_sh, (long long)n, mode, out4);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_resample_linear(const float* x, int channels, int64_t n_in, float* y, int64_t n_out, void* stream) {
+    EGR_CHECK(x && y && channels >= 1 && channels <= 65535 && n_in >= 1 && n_out >= 1, EGR_ERR_ARG, "bad argument");
+    long long nb = (n_out + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_resample_linear, dim3((unsigned)nb, channels), dim3(256), 0, (hipStream_t)stream, x, (long long)n_in,
+                       (long long)n_out, y);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }

@@ -66,3 +66,58 @@ def stft_mag(x: torch.Tensor, n_fft: int = 2048, hop: int = 512) -> torch.Tensor
     native.check(native.lib().egr_stft_mag(native.ptr(x), C, T, n_fft, hop, native.ptr(w), native.ptr(out),
                                             native.stream_ptr()), "egr_stft_mag")
     return out.t()
+
+
+def _stft_frames(x: torch.Tensor, n_fft: int, hop: int) -> torch.Tensor:
+    """[C,T] -> frame-major [frames, n_fft/2+1] magnitudes of the mono downmix."""
+    return stft_mag(x, n_fft, hop).t()
+
+
+def lsd(a: torch.Tensor, b: torch.Tensor, n_fft: int = 2048, hop: int = 512):
+    """(mean, p95) log-spectral distance in dB between two [C,T] / [T] CUDA signals of equal length, as the reference's
+    _stft_mag + _lsd (egregora_audio_eval_pack.py:389-411): everything per sample / per bin runs on the device; the host
+    only divides the frame sum and interpolates numpy's linear percentile between two order statistics."""
+    import ctypes as C
+    L = native.lib()
+    SA, SB = _stft_frames(a, n_fft, hop), _stft_frames(b, n_fft, hop)
+    frames, nb = SA.shape
+    per = torch.empty((frames,), dtype=torch.float32, device=SA.device)
+    native.check(L.egr_lsd_frames(native.ptr(SA), native.ptr(SB), frames, nb, native.ptr(per), native.stream_ptr()),
+                 "egr_lsd_frames")
+    tot = torch.empty((1,), dtype=torch.float64, device=SA.device)
+    native.check(L.egr_sum_f64(native.ptr(per), frames, native.ptr(tot), native.stream_ptr()), "egr_sum_f64")
+    pos = 0.95 * (frames - 1)                       # numpy percentile, method="linear"
+    lo = int(np.floor(pos))
+    hi = min(lo + 1, frames - 1)
+    o2 = torch.empty((2,), dtype=torch.float32, device=SA.device)
+    native.check(L.egr_order_stats2(native.ptr(per), frames, lo, hi, native.ptr(o2), native.stream_ptr()), "egr_order_stats2")
+    v_lo, v_hi = (float(v) for v in o2.cpu())
+    t = pos - lo
+    p95 = v_hi - (v_hi - v_lo) * (1.0 - t) if t >= 0.5 else v_lo + (v_hi - v_lo) * t
+    return float(np.float32(float(tot.cpu()) / frames)), float(np.float32(p95))
+
+
+def si_sdr(s: torch.Tensor, s_hat: torch.Tensor) -> float:
+    """Scale-invariant SDR in dB of the mono downmixes (reference _si_sdr, egregora_audio_eval_pack.py:414-429); the four
+    sums are formed in double on the device."""
+    if s.dim() == 1:
+        s = s[None, :]
+    if s_hat.dim() == 1:
+        s_hat = s_hat[None, :]
+    s, s_hat = s.contiguous(), s_hat.contiguous()
+    _chk(s, "si_sdr"), _chk(s_hat, "si_sdr")
+    n = min(s.shape[1], s_hat.shape[1])
+    out = torch.empty((4,), dtype=torch.float64, device=s.device)
+    native.check(native.lib().egr_si_sdr_terms(native.ptr(s), s.shape[0], s.shape[1], native.ptr(s_hat), s_hat.shape[0],
+                                                s_hat.shape[1], n, native.ptr(out), native.stream_ptr()), "egr_si_sdr_terms")
+    _, _, tt, ee = (float(v) for v in out.cpu())
+    return float(10.0 * np.log10((tt + 1e-20) / (ee + 1e-20)))
+
+
+def resample_linear(x_ct: torch.Tensor, n_out: int) -> torch.Tensor:
+    x = x_ct.contiguous()
+    _chk(x, "resample_linear")
+    y = torch.empty((x.shape[0], int(n_out)), dtype=torch.float32, device=x.device)
+    native.check(native.lib().egr_resample_linear(native.ptr(x), x.shape[0], x.shape[1], native.ptr(y), int(n_out),
+                                                   native.stream_ptr()), "egr_resample_linear")
+    return y

@@ -34,6 +34,11 @@ SIGNATURES = {
                                        C.POINTER(_i64)]),
     "egr_pcm16_roundtrip": (_i, [_vp, _vp, _i64, _f, _f, _vp]),
     "egr_stft_mag": (_i, [_vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
+    "egr_resample_linear": (_i, [_vp, _i, _i64, _vp, _i64, _vp]),
+    "egr_lsd_frames": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
+    "egr_sum_f64": (_i, [_vp, _i64, _vp, _vp]),
+    "egr_order_stats2": (_i, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "egr_si_sdr_terms": (_i, [_vp, _i, _i64, _vp, _i, _i64, _i64, _vp, _vp]),
     "egr_wola_stitch": (_i, [_vp, _i, _i, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "egr_chunk_gather": (_i, [_vp, _i, _i64, _i64, _i64, _i, _i, _vp, _vp]),
     "egr_resample_poly": (_i, [_vp, _i, _i64, _i, _i, _vp, _i, _vp, _i64, _vp]),

@@ -100,6 +100,24 @@ int egr_fatllama_kernel_times(egr_fatllama_plan* plan, double* row_ms_avg, doubl
  * Replaces the libsndfile float->PCM_16->float hops at egregora_fat_llama_gpu.py:36 and :291. */
 int egr_pcm16_roundtrip(const float* x, float* y, int64_t n, float write_scale, float read_div, void* stream);
 
+/* Linear-interpolation resampler of the "Resample Audio (HQ)" node's fallback branch: y[c][j] = np.interp at
+ * j * n_in / n_out input samples, clamped to the last sample (egregora_audio_eval_pack.py:515-519). */
+int egr_resample_linear(const float* x, int channels, int64_t n_in, float* y, int64_t n_out, void* stream);
+
+/* Evaluation metrics on the device (the parity yardstick of this pack and the reference's "Metrics (LSD + SI-SDR)" node):
+ *   egr_lsd_frames  : per[f] = sqrt(mean_k (20 log10(SA[f][k]+1e-12) - 20 log10(SB[f][k]+1e-12))^2 + 1e-12) from two
+ *                     frame-major magnitude arrays of egr_stft_mag          (_lsd, egregora_audio_eval_pack.py:405-411)
+ *   egr_sum_f64     : *out = sum v[i] in double (the mean over frames)
+ *   egr_order_stats2: out2[0..1] = the k_lo-th and k_hi-th smallest of v (0-based; radix selection) -- the two order
+ *                     statistics numpy's linear-interpolated percentile needs (p95 of the per-frame LSD)
+ *   egr_si_sdr_terms: out4 = {<s_hat,s>, <s,s>, |alpha s|^2, |s_hat - alpha s|^2} on the mono downmixes (mean over the
+ *                     cs / csh channels, rows strided by stride_*), alpha = out4[0]/(out4[1]+1e-20)   (_si_sdr, :414-429) */
+int egr_lsd_frames(const float* SA, const float* SB, int64_t frames, int nb, float* per, void* stream);
+int egr_sum_f64(const float* v, int64_t n, double* out, void* stream);
+int egr_order_stats2(const float* v, int64_t n, int64_t k_lo, int64_t k_hi, float* out2, void* stream);
+int egr_si_sdr_terms(const float* s, int cs, int64_t stride_s, const float* s_hat, int csh, int64_t stride_sh, int64_t n,
+                     double* out4, void* stream);
+
 /* STFT magnitude, Hann-windowed frames, no centring, mono downmix = mean over channels:
  *   frames = 1 + max(0,(n - n_fft)/hop); out: [frames][n_fft/2+1] float32 (frame-major; the reference's
  *   array is the transpose).  window: device float[n_fft] (caller supplies np.hanning(n_fft) so the

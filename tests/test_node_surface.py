@@ -11,8 +11,9 @@ from conftest import gjson
 
 def test_mappings_and_surface_equal_reference(pack):
     g = gjson("g8_surface")
-    assert set(pack.NODE_CLASS_MAPPINGS) == {"EgregoraAudioUpscaler", "EgregoraFatLlamaGPU", "EgregoraFatLlamaCPU"}
-    for key in pack.NODE_CLASS_MAPPINGS:
+    core = {"EgregoraAudioUpscaler", "EgregoraFatLlamaGPU", "EgregoraFatLlamaCPU"}
+    assert set(pack.NODE_CLASS_MAPPINGS) == core | {"Metrics (LSD + SI-SDR)", "Resample Audio (HQ)"}
+    for key in sorted(core):
         assert pack.NODE_DISPLAY_NAME_MAPPINGS[key] == g["display"][key]
         cls = pack.NODE_CLASS_MAPPINGS[key]
         e = g[key]
