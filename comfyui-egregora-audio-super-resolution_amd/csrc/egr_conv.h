@@ -35,6 +35,9 @@ struct ConvP {
     const float* zeros;    // >= 64 zero floats: out-of-image / out-of-range rows read from here (no select needed)
     // three-way bf16 split of w: [ceil(K/16)][3][Cout][16] bf16 (egr_split3_pack); zw counts uint4 (8 bf16) here
     const uint4* w3;
+    // z-streaming (k_conv_s3 GEMMs with nz > 1): a workgroup walks zs_nzb consecutive z problems of its (M, N) tile in one
+    // slab loop (loads of z+1 in flight while z's tile is stored); 0 = one z per workgroup (blockIdx.z)
+    int zs_nzb, nz;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float prm) {
@@ -50,7 +53,9 @@ __device__ __forceinline__ float apply_act(float v, int act, float prm) {
 // Accumulator layout of every 32x32 MFMA tile: register r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
 // Writes raw split-K partials, or bias + per-row bias + residual + activation at the (possibly strided) output place.
 template <int TM, int TN>
-__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0) {
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0,
+                                              float* yb = nullptr) {
+    float* const yout = yb ? yb : p.y;
     const int lane = threadIdx.x & 63, col = lane & 31, rhalf = lane >> 5;
     if (p.ksplit > 1) {        // raw partial sums; bias / residual / activation are applied by k_splitk_reduce
         float* wz = p.ws + (size_t)blockIdx.z * p.M * p.Cout;
@@ -97,7 +102,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                         float v = acc[i][j][r] + bv[j];
                         if (bb) v += bb[j * 32];
                         if (p.res) v += p.res[o + j * 32];
-                        p.y[o + j * 32] = apply_act(v, p.act, p.act_param);
+                        yout[o + j * 32] = apply_act(v, p.act, p.act_param);
                     }
             }
         }
@@ -106,6 +111,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
 // egr_nn_gemm_s3.hip: launches k_conv_s3<bm, bn> (bm = s3_bm(...), bn in {32, 64, 128}; grid.x = ceil(M / bm));
 // p.w3 must be set and Cin % 16 == 0
 int s3_bm(long long M, int Cout, int bn);
+int s3_zs_nzb(long long M, int Cout, int bm, int bn, int nz, int K);
 void launch_conv_s3(int bm, int bn, dim3 grid, hipStream_t st, const ConvP& p);
 
 }  // namespace egr

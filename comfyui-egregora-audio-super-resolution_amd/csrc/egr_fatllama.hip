@@ -489,6 +489,9 @@ struct egr_fatllama_plan {
     int nstreams;                 // channel groups run as concurrent pipelines (1 or 2)
     hipStream_t side;             // second pipeline's stream (forked from / joined to the caller's stream by events)
     hipEvent_t ev_fork, ev_join;
+    hipStream_t cap;              // private capture stream
+    hipGraphExec_t gexec;         // CH captured loop iterations of all pipelines (egr_fatllama_enhance)
+    const float* g_out; float g_thr; int g_groups, g_iter_odd, use_graph;
     std::vector<hipEvent_t> ev;   // pairs (start, stop) tagged by kind
     std::vector<int> ev_kind;     // 0 = row, 1 = outer column pass, 2 = inner column pass
 };
@@ -569,6 +572,8 @@ extern "C" int egr_fatllama_plan_destroy(egr_fatllama_plan* p) {
     if (!p) return EGR_OK;
     for (void* q : p->dev_allocs) hipFree(q);
     hipFree(p->d_work); hipFree(p->d_peaks); hipFree(p->d_bhat);
+    if (p->gexec) hipGraphExecDestroy(p->gexec);
+    if (p->cap) hipStreamDestroy(p->cap);
     if (p->side) hipStreamDestroy(p->side);
     if (p->ev_fork) hipEventDestroy(p->ev_fork);
     if (p->ev_join) hipEventDestroy(p->ev_join);
@@ -585,6 +590,8 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     p->nstreams = 2;
     if (const char* e = getenv("EGR_FL_STREAMS")) { const int t = atoi(e); if (t == 1 || t == 2) p->nstreams = t; }
     p->side = nullptr; p->ev_fork = nullptr; p->ev_join = nullptr;
+    p->cap = nullptr; p->gexec = nullptr; p->g_out = nullptr; p->g_thr = 0.f; p->g_groups = 0; p->g_iter_odd = 0;
+    p->use_graph = !(getenv("EGR_FL_GRAPH") && atoi(getenv("EGR_FL_GRAPH")) == 0);
     p->threads = 512;    // 16 waves per CU at 2 workgroups per CU: measured 1.4x over 256
     if (const char* e = getenv("EGR_FL_THREADS")) { const int t = atoi(e); if (t == 256 || t == 512 || t == 1024) p->threads = t; }
     p->d_bhat = nullptr;
@@ -838,45 +845,90 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
             EGR_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
             EGR_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
         }
-        if (ngroups == 2) {
-            EGR_HIP(hipEventRecord(p->ev_fork, st));
-            EGR_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
-        }
-        for (int g = 0; g < ngroups; ++g) {
+        // One group's launches for iterations [it0, it1); `first` adds the opening time-domain pass, `last` the closing one.
+        auto run_group = [&](hipStream_t s0, int g, int it0, int it1, bool first, bool last, bool prof) {
             const int c0 = g == 0 ? 0 : C / 2, cn = ngroups == 1 ? C : (g == 0 ? C / 2 : C - C / 2);
-            hipStream_t sg = g == 0 ? st : p->side;
+            hipStream_t sg = g == 0 ? s0 : p->side;
             cplx* wk = p->d_work + (size_t)c0 * M;
             float* og = out + (size_t)c0 * N;
             unsigned* pk = peak_out + c0;
             const dim3 gAg(gA.x, cn), gBg(gB.x, cn * (three ? B.nplanes : 1)), growg(grow.x, cn);
-            hipLaunchKernelGGL(k_col<0>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
-            if (three) hipLaunchKernelGGL(k_col<4>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
-            for (int it = 0; it < max_iter; ++it) {
-                prof_begin(p, 0, sg, &slot);
+            if (first) {
+                hipLaunchKernelGGL(k_col<0>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
+                if (three) hipLaunchKernelGGL(k_col<4>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
+            }
+            for (int it = it0; it < it1; ++it) {
+                if (prof) prof_begin(p, 0, sg, &slot);
                 hipLaunchKernelGGL(k_row, growg, blk, lr, sg, R, M, wk);
-                prof_end(p, sg, &slot);
+                if (prof) prof_end(p, sg, &slot);
                 if (three) {
-                    prof_begin(p, 2, sg, &slot);
+                    if (prof) prof_begin(p, 2, sg, &slot);
                     hipLaunchKernelGGL(k_col<3>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
-                    prof_end(p, sg, &slot);
+                    if (prof) prof_end(p, sg, &slot);
                 }
                 if (it + 1 < max_iter) {
-                    prof_begin(p, 1, sg, &slot);
+                    if (prof) prof_begin(p, 1, sg, &slot);
                     hipLaunchKernelGGL(k_col<1>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
-                    prof_end(p, sg, &slot);
+                    if (prof) prof_end(p, sg, &slot);
                     if (three) {
-                        prof_begin(p, 2, sg, &slot);
+                        if (prof) prof_begin(p, 2, sg, &slot);
                         hipLaunchKernelGGL(k_col<4>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
-                        prof_end(p, sg, &slot);
+                        if (prof) prof_end(p, sg, &slot);
                     }
                 }
             }
-            hipLaunchKernelGGL(k_col<2>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
+            if (last) hipLaunchKernelGGL(k_col<2>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
+        };
+        auto fork = [&](hipStream_t s0) -> int {
+            if (ngroups == 2) {
+                EGR_HIP(hipEventRecord(p->ev_fork, s0));
+                EGR_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+            }
+            return EGR_OK;
+        };
+        auto join = [&](hipStream_t s0) -> int {
+            if (ngroups == 2) {
+                EGR_HIP(hipEventRecord(p->ev_join, p->side));
+                EGR_HIP(hipStreamWaitEvent(s0, p->ev_join, 0));
+            }
+            return EGR_OK;
+        };
+        // The loop body is the same pair of launches every iteration: CH iterations of both pipelines are captured once
+        // into a hipGraph and replayed (inter-kernel gaps of ~8 us on the streams shrink to the graph's ~1 us); the
+        // executable graph is kept while (out, threshold, geometry) stay the same.  Profiling runs use plain launches.
+        constexpr int CH = 25;
+        const bool profiling = p->profiling != 0;
+        const int n_graph = (!profiling && p->use_graph && max_iter > 2 * CH) ? (max_iter - 1) / CH : 0;
+        int rc = fork(st);
+        if (rc) return rc;
+        for (int g = 0; g < ngroups; ++g) run_group(st, g, 0, 0, true, false, false);
+        if (n_graph > 0) {
+            rc = join(st);
+            if (rc) return rc;
+            if (!(p->gexec && p->g_out == out && p->g_thr == thr && p->g_groups == ngroups && p->g_iter_odd == 0)) {
+                if (p->gexec) { EGR_HIP(hipGraphExecDestroy(p->gexec)); p->gexec = nullptr; }
+                hipGraph_t graph = nullptr;
+                // captured on a private stream (the caller's may be the legacy default stream, which cannot capture)
+                if (!p->cap) EGR_HIP(hipStreamCreateWithFlags(&p->cap, hipStreamNonBlocking));
+                EGR_HIP(hipStreamBeginCapture(p->cap, hipStreamCaptureModeThreadLocal));
+                rc = fork(p->cap);
+                // iterations 0..CH-1 of a run with more than CH + 1 iterations: every one is a "middle" iteration
+                if (!rc) for (int g = 0; g < ngroups; ++g) run_group(p->cap, g, 0, CH, false, false, false);
+                if (!rc) rc = join(p->cap);
+                hipError_t ce = hipStreamEndCapture(p->cap, &graph);
+                if (rc) return rc;
+                EGR_HIP(ce);
+                EGR_HIP(hipGraphInstantiate(&p->gexec, graph, nullptr, nullptr, 0));
+                EGR_HIP(hipGraphDestroy(graph));
+                p->g_out = out; p->g_thr = thr; p->g_groups = ngroups; p->g_iter_odd = 0;
+            }
+            for (int i = 0; i < n_graph; ++i) EGR_HIP(hipGraphLaunch(p->gexec, st));
+            rc = fork(st);
+            if (rc) return rc;
         }
-        if (ngroups == 2) {
-            EGR_HIP(hipEventRecord(p->ev_join, p->side));
-            EGR_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
-        }
+        for (int g = 0; g < ngroups; ++g) run_group(st, g, n_graph * CH, max_iter, false, true, profiling);
+        rc = join(st);
+        if (rc) return rc;
     }
     if (flags & (EGR_FL_NORMALIZE | EGR_FL_AUTOSCALE | EGR_FL_NODE_POST)) {
         const long long Nr = p->bluestein ? (long long)p->chirp.N : N;

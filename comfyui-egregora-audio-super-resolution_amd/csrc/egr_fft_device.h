@@ -160,7 +160,11 @@ __device__ __forceinline__ void fft_stage(const cplx* __restrict__ in, cplx* __r
                 // ONE 16-byte load of the fp64 table entry; W^t by a depth-log2(t) product tree in fp64, rounded once
                 // to float: as accurate as reading every W^t from a float table, a third / a quarter of the loads.
                 dcplx w[R];
+#ifdef EGR_FL_ABL_NOTW
+                w[1] = make_double2(1.0 - 1e-9 * base, 1e-9 * base);   // dev ablation: no table load (wrong results)
+#else
                 w[1] = twd[base];
+#endif
 #pragma unroll
                 for (int t = 2; t < R; ++t) w[t] = dcmul(w[t >> 1], w[t - (t >> 1)]);
 #pragma unroll

@@ -544,7 +544,7 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
     p.osy = osy; p.osx = osx; p.ooy = ooy; p.oox = oox; p.OHF = OHF; p.OWF = OWF;
     const bool vec = (Cin % BK) == 0 && (((uintptr_t)x) & 15) == 0;
     const int bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
-    const int bm = w3 ? s3_bm(M, Cout, bn) : BM;
+    int bm = w3 ? s3_bm(M, Cout, bn) : BM;
     dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)((Cout + bn - 1) / bn));
     hipStream_t st = (hipStream_t)stream;
     // split-K when the output tiles alone cannot fill the chip and the K loop is long (deep UNet / latent layers)
@@ -553,7 +553,17 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
     p.zx = zx; p.zw = zw; p.zy = zy;
     p.gn_scale = gn_scale; p.gn_shift = gn_shift; p.gn_silu = gn_silu;
     { int zrc = zero_page(&p.zeros); if (zrc) return zrc; }
+    p.nz = nz; p.zs_nzb = 0;
     if (nz > 1) grid.z = nz;
+    if (w3 && nz > 1 && KH == 1 && KW == 1 && H == 1 && W == 1 && stride == 1 && zw == (long long)(p.K / BK) * Cout * 6 &&
+        !bias && !bias_b && !res && act == 0 && osy == 1 && osx == 1 && OHF == OH && OWF == OW) {
+        p.zs_nzb = s3_zs_nzb(M, Cout, 128, bn, nz, p.K);          // Winograd GEMMs: stream several z per workgroup
+        if (p.zs_nzb > 0) {                                       // (128-row tiles: the 256-row variant would spill)
+            bm = 128;
+            grid.x = (unsigned)((M + bm - 1) / bm);
+            grid.z = (nz + p.zs_nzb - 1) / p.zs_nzb;
+        }
+    }
     if (nz == 1 && tiles < 192 && ktiles >= 32) {
         int S = (768 + tiles - 1) / tiles;
         if (S > ktiles / 8) S = ktiles / 8;

@@ -78,7 +78,26 @@ template <> struct S3Cfg<128, 32> { static constexpr int WM = 4, WN = 1, TM = 1,
 
 __device__ __forceinline__ bf16x8 as_bf(const uint4& v) { return __builtin_bit_cast(bf16x8, v); }
 
-template <int BM, int BN, int PF>
+// plain tile store (z-streamed GEMMs have no bias / residual / activation / placement)
+template <int TM, int TN>
+__device__ __forceinline__ void store_tile_plain(f32x16 (&acc)[TM][TN], float* __restrict__ y, int M, int Cout, int m0, int n0,
+                                                 int wm0, int wn0) {
+    const int lane = threadIdx.x & 63, col = lane & 31, rhalf = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
+            if (m < M) {
+                float* row = y + (size_t)m * Cout + n0 + wn0 + col;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (n0 + wn0 + j * 32 + col < Cout) row[j * 32] = acc[i][j][r];
+            }
+        }
+}
+
+template <int BM, int BN, int PF, bool ZS = false>
 __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
     typedef S3Cfg<BM, BN> TC;
     constexpr int TM = TC::TM, TN = TC::TN;
@@ -89,10 +108,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
     const int wm0 = (wave / TC::WN) * (BM / TC::WM), wn0 = (wave % TC::WN) * (BN / TC::WN);
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int LH = p.up2 ? 2 * p.H : p.H, LW = p.up2 ? 2 * p.W : p.W;
-    if (p.ksplit <= 1 && gridDim.z > 1) {
-        p.x += (size_t)blockIdx.z * p.zx;
-        p.w3 += (size_t)blockIdx.z * p.zw;
-        p.y += (size_t)blockIdx.z * p.zy;
+    // z-streaming: this workgroup owns z problems [z0, z0 + nzl) of its tile; otherwise blockIdx.z is the z problem
+    const int z0 = ZS ? blockIdx.z * p.zs_nzb : blockIdx.z;
+    const int nzl = ZS ? min(p.zs_nzb, p.nz - z0) : 1;
+    if (p.ksplit <= 1 && (gridDim.z > 1 || ZS)) {
+        p.x += (size_t)z0 * p.zx;
+        p.w3 += (size_t)z0 * p.zw;
+        p.y += (size_t)z0 * p.zy;
     }
 
     f32x16 acc[TM][TN];
@@ -105,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
 
     const int ktiles_all = p.K / S3_BK;
     const int kt_begin = p.ksplit > 1 ? blockIdx.z * p.kt_per : 0;
-    const int kt_end = p.ksplit > 1 ? min(ktiles_all, kt_begin + p.kt_per) : ktiles_all;
+    const int kt_end = ZS ? nzl * ktiles_all : (p.ksplit > 1 ? min(ktiles_all, kt_begin + p.kt_per) : ktiles_all);
 
     // ---- A: thread owns 8 consecutive k (half ah) of tile rows ar (and ar + 128 when BM = 256) ----
     // (plain scalars on purpose: arrays captured by the lambdas below end up in scratch)
@@ -141,19 +163,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
     const float* aptr1 = p.zeros;
     int astep0 = 0, astep1 = 0;
     auto set_tap = [&](int tp) {
-        const int ky = tp / p.KW, kx = tp - ky * p.KW;
+        // z-streaming GEMMs (1x1 taps): the "tap" counter walks the z problems, each zx floats further
+        const int ky = ZS ? 0 : tp / p.KW, kx = ZS ? 0 : tp - ky * p.KW;
+        const size_t zoff = ZS ? (size_t)tp * p.zx : 0;
         {
             const int iy = a_iy0 + ky, ix = a_ix0 + kx * p.dil;
             const bool ok = a_ok0 && (unsigned)iy < (unsigned)LH && (unsigned)ix < (unsigned)LW;
             const int py = p.up2 ? iy >> 1 : iy, px = p.up2 ? ix >> 1 : ix;
-            aptr0 = ok ? p.x + (a_base0 + (size_t)py * p.W + px) * p.Cin + ah * 8 : p.zeros + ah * 8;
+            aptr0 = ok ? p.x + zoff + (a_base0 + (size_t)py * p.W + px) * p.Cin + ah * 8 : p.zeros + ah * 8;
             astep0 = ok ? 1 : 0;
         }
         if (AP > 1) {
             const int iy = a_iy1 + ky, ix = a_ix1 + kx * p.dil;
             const bool ok = a_ok1 && (unsigned)iy < (unsigned)LH && (unsigned)ix < (unsigned)LW;
             const int py = p.up2 ? iy >> 1 : iy, px = p.up2 ? ix >> 1 : ix;
-            aptr1 = ok ? p.x + (a_base1 + (size_t)py * p.W + px) * p.Cin + ah * 8 : p.zeros + ah * 8;
+            aptr1 = ok ? p.x + zoff + (a_base1 + (size_t)py * p.W + px) * p.Cin + ah * 8 : p.zeros + ah * 8;
             astep1 = ok ? 1 : 0;
         }
     };
@@ -270,6 +294,19 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
             S3_MMA(0, 0)
 #undef S3_MMA
         }
+        if (ZS) {                                   // last slab of a z problem: store its tile, restart the accumulators
+            const int done = kt + 1;
+            const int zl = done / ktiles_all;
+            if (done - zl * ktiles_all == 0) {
+                store_tile_plain<TM, TN>(acc, p.y + (size_t)(zl - 1) * p.zy, p.M, p.Cout, m0, n0, wm0, wn0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+        }
 #ifndef S3_ABL_NOBARRIER
         __syncthreads();
 #endif
@@ -294,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
         }
         if (kt < kt_end) slab(kt, 0, s0);
     }
-    conv_epilogue<TM, TN>(p, acc, m0, n0, wm0, wn0);
+    if (!ZS) conv_epilogue<TM, TN>(p, acc, m0, n0, wm0, wn0);
 }
 
 // block-tile height for a problem: 256 rows when that still leaves >= 2 full rounds of workgroups on the 256 CUs
@@ -304,8 +341,24 @@ int s3_bm(long long M, int Cout, int bn) {
     return tiles256 >= 1024 ? 256 : 128;
 }
 
+// z problems per workgroup for z-streamed GEMMs: as many as keeps >= ~2048 workgroups in the grid (0: no streaming)
+int s3_zs_nzb(long long M, int Cout, int bm, int bn, int nz, int K) {
+    static const bool off = getenv("EGR_S3_ZS") && atoi(getenv("EGR_S3_ZS")) == 0;
+    if (off || nz < 2 || bn != 128 || K % S3_BK) return 0;
+    const long long tiles = ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn);
+    long long groups = (2048 + tiles - 1) / tiles;
+    if (groups < 1) groups = 1;
+    if (groups > nz) groups = nz;
+    const int nzb = (int)((nz + groups - 1) / groups);
+    return nzb >= 2 ? nzb : 0;
+}
+
 void launch_conv_s3(int bm, int bn, dim3 grid, hipStream_t st, const ConvP& p) {
     static const int pf = getenv("EGR_S3_PF") ? atoi(getenv("EGR_S3_PF")) : 1;
+    if (p.zs_nzb > 0) {
+        hipLaunchKernelGGL((k_conv_s3<128, 128, 1, true>), grid, dim3(256), 0, st, p);
+        return;
+    }
     if (bm == 256) hipLaunchKernelGGL((k_conv_s3<256, 128, 1>), grid, dim3(256), 0, st, p);
     else if (bn == 128) { if (pf == 2) hipLaunchKernelGGL((k_conv_s3<128, 128, 2>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((k_conv_s3<128, 128, 1>), grid, dim3(256), 0, st, p); }
     else if (bn == 64) { if (pf == 2) hipLaunchKernelGGL((k_conv_s3<128, 64, 2>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((k_conv_s3<128, 64, 1>), grid, dim3(256), 0, st, p); }

@@ -52,6 +52,45 @@ __global__ __launch_bounds__(256) void k_gn_stats(const float* __restrict__ x, i
     }
 }
 
+// Vectorised statistics pass (C % 4 == 0, C/4 <= 256, (C/G) % 4 == 0): a thread owns 4 adjacent channels (one float4, all in
+// one group) and every NPR-th position of the block's slab; 4 independent float4 loads are in flight per thread.  Partial
+// sums are combined per group in LDS (double) and flushed with one pair of atomics per (block, group).
+__global__ __launch_bounds__(256) void k_gn_stats_v4(const float* __restrict__ x, int HW, int C, int G,
+                                                      double* __restrict__ stats /*[B][G][2]*/, int slab) {
+    __shared__ double gs[64], gss[64];
+    const int b = blockIdx.y, C4 = C >> 2, NPR = 256 / C4;
+    const int c4 = threadIdx.x % C4, pr = threadIdx.x / C4;
+    const int p0 = blockIdx.x * slab, p1 = min(HW, p0 + slab);
+    const int cpg = C / G, g = (4 * c4) / cpg;
+    if (threadIdx.x < 64) { gs[threadIdx.x] = 0.0; gss[threadIdx.x] = 0.0; }
+    __syncthreads();
+    if (pr < NPR) {
+        const float4* xb = (const float4*)(x + (size_t)b * HW * C) + c4;
+        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+        int p = p0 + pr;
+        for (; p + 3 * NPR < p1; p += 4 * NPR) {
+            const float4 v0 = xb[(size_t)p * C4], v1 = xb[(size_t)(p + NPR) * C4], v2 = xb[(size_t)(p + 2 * NPR) * C4],
+                         v3 = xb[(size_t)(p + 3 * NPR) * C4];
+            s0 += (v0.x + v0.y) + (v0.z + v0.w) + (v2.x + v2.y) + (v2.z + v2.w);
+            s1 += (v1.x + v1.y) + (v1.z + v1.w) + (v3.x + v3.y) + (v3.z + v3.w);
+            q0 += (v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w) + (v2.x * v2.x + v2.y * v2.y) + (v2.z * v2.z + v2.w * v2.w);
+            q1 += (v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w) + (v3.x * v3.x + v3.y * v3.y) + (v3.z * v3.z + v3.w * v3.w);
+        }
+        for (; p < p1; p += NPR) {
+            const float4 v = xb[(size_t)p * C4];
+            s0 += (v.x + v.y) + (v.z + v.w);
+            q0 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+        atomicAdd(&gs[g], (double)s0 + (double)s1);
+        atomicAdd(&gss[g], (double)q0 + (double)q1);
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        atomicAdd(&stats[((size_t)b * G + threadIdx.x) * 2 + 0], gs[threadIdx.x]);
+        atomicAdd(&stats[((size_t)b * G + threadIdx.x) * 2 + 1], gss[threadIdx.x]);
+    }
+}
+
 __global__ void k_gn_coeff(const double* __restrict__ stats, const float* __restrict__ gamma,
                            const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift,
                            int B, int C, int G, double count, float eps) {
@@ -657,7 +696,12 @@ extern "C" int egr_groupnorm_nhwc(const float* x, const float* gamma, const floa
     int slab = (HW + 255) / 256;
     if (slab < 16) slab = HW < 16 ? HW : 16;
     const int nslab = (HW + slab - 1) / slab;
-    hipLaunchKernelGGL(k_gn_stats, dim3(nslab, B), dim3(C < 256 ? ((C + 63) / 64) * 64 : 256), 0, st, x, HW, C, G, stats, slab);
+    if (C % 4 == 0 && C / 4 <= 256 && (C / G) % 4 == 0 && G <= 64 && (((uintptr_t)x) & 15) == 0) {
+        int slab4 = (HW + 511) / 512;                   // >= 512 workgroups per image row, >= 64 positions each
+        if (slab4 < 64) slab4 = HW < 64 ? HW : 64;
+        hipLaunchKernelGGL(k_gn_stats_v4, dim3((HW + slab4 - 1) / slab4, B), dim3(256), 0, st, x, HW, C, G, stats, slab4);
+    } else
+        hipLaunchKernelGGL(k_gn_stats, dim3(nslab, B), dim3(C < 256 ? ((C + 63) / 64) * 64 : 256), 0, st, x, HW, C, G, stats, slab);
     hipLaunchKernelGGL(k_gn_coeff, dim3((B * C + 255) / 256), dim3(256), 0, st, stats, gamma, beta, scale, shift, B, C, G,
                        (double)HW * (C / G), eps);
     const long long n4 = (long long)B * HW * C / 4;
@@ -678,7 +722,12 @@ extern "C" int egr_groupnorm_coeff(const float* x, const float* gamma, const flo
     int slab = (HW + 255) / 256;
     if (slab < 16) slab = HW < 16 ? HW : 16;
     const int nslab = (HW + slab - 1) / slab;
-    hipLaunchKernelGGL(k_gn_stats, dim3(nslab, B), dim3(C < 256 ? ((C + 63) / 64) * 64 : 256), 0, st, x, HW, C, G, stats, slab);
+    if (C % 4 == 0 && C / 4 <= 256 && (C / G) % 4 == 0 && G <= 64 && (((uintptr_t)x) & 15) == 0) {
+        int slab4 = (HW + 511) / 512;                   // >= 512 workgroups per image row, >= 64 positions each
+        if (slab4 < 64) slab4 = HW < 64 ? HW : 64;
+        hipLaunchKernelGGL(k_gn_stats_v4, dim3((HW + slab4 - 1) / slab4, B), dim3(256), 0, st, x, HW, C, G, stats, slab4);
+    } else
+        hipLaunchKernelGGL(k_gn_stats, dim3(nslab, B), dim3(C < 256 ? ((C + 63) / 64) * 64 : 256), 0, st, x, HW, C, G, stats, slab);
     hipLaunchKernelGGL(k_gn_coeff, dim3((B * C + 255) / 256), dim3(256), 0, st, stats, gamma, beta, scale, shift, B, C, G,
                        (double)HW * (C / G), eps);
     EGR_HIP(hipGetLastError());

@@ -158,7 +158,8 @@ class FlashSREngine:
             native.check(self.L.egr_gemm_zbatched(_p(V), _p(self.w[wkey]), _p(Mx), nz, P, Cin, Cout, P * Cin, zw, P * Cout,
                                                   self._st()), "egr_gemm_zbatched")
         if ev is not None:
-            self._prof_end(ev, self._kind(P, Cin, Cout, w3 is not None), fl, (B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, nz))
+            kind = "k_conv_s3<128, 128, zs>" if (w3 is not None and Cout > 64) else self._kind(P, Cin, Cout, w3 is not None)
+            self._prof_end(ev, kind, fl, (B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, nz))
         if self.count_flops:
             self.flops += fl
         y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=self.dev)

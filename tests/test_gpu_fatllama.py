@@ -52,6 +52,7 @@ CASES = [
     (1, 16000, 2, 10, 0.6),
     (2, 48000, 1, 20, 0.6),
     (1, 160000, 6, 5, 0.6),       # C1 shape (N' = 960000), fewer iterations
+    (2, 9600, 1, 77, 0.6),        # > 50 iterations: three replays of the captured 25-iteration hipGraph + a remainder
 ]
 
 
@@ -71,6 +72,18 @@ def test_loop_matches_oracle(pack, C, n, f, iters, thr):
     assert rms(got - exact) <= 2.5 * rms(want - exact) + 1e-9 * scale
     if want.shape[1] >= 4096:
         assert om.lsd_audio(want, got)[0] <= (1e-3 if f == 1 else 0.25)
+
+
+@pytest.mark.parametrize("C,n,iters", [(1, 4800, 51), (2, 9600, 77), (3, 4800, 130)])
+def test_graph_replay_equals_plain_launches(pack, C, n, iters):
+    """Above 50 iterations the loop body runs as replays of a captured 25-iteration hipGraph (one or two pipelines) plus a
+    remainder; profiling runs use plain stream launches.  Same kernels, same order per channel: bit-identical outputs."""
+    x = synth(C, n, seed=n + iters)
+    a = run_gpu(pack, x, 1, iters, 0.6)
+    b = run_gpu(pack, x, 1, iters, 0.6, profile=True)
+    a2 = run_gpu(pack, x, 1, iters, 0.6)              # cached executable graph
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, a2)
 
 
 @pytest.mark.parametrize("n,split", [(420, (6, 5, 7)), (2 * 8 * 9 * 10, (8, 9, 10)), (2 * 16 * 15 * 64, (16, 15, 64)),
