@@ -50,6 +50,71 @@ __device__ __forceinline__ float apply_act(float v, int act, float prm) {
     }
 }
 
+// Output rows of one thread: (i, r) -> pixel m.  RES is compile-time so that the residual loads of a 32-row sub-tile are
+// issued back to back before any of them is consumed (a run-time `if (p.res)` between them serialises the round trips).
+template <int I, int TM, int TN, bool RES>
+__device__ __forceinline__ void conv_epilogue_rows_i(const ConvP& p, f32x16 (&acc)[TM][TN], const float (&bv)[TN], float* yout,
+                                                     int m0, int n0, int wm0, int wn0) {
+    const int lane = threadIdx.x & 63, col = lane & 31, rhalf = lane >> 5;
+    const bool ident = (p.osy == 1 && p.osx == 1 && p.OHF == p.OH && p.OWF == p.OW);
+    const bool decode = !ident || p.bias_b;
+    const int nb = n0 + wn0 + col;
+    auto place = [&](int m, int& b) -> size_t {          // row offset (elements) of pixel m in y / res, and its batch index
+        size_t mo = (size_t)m;
+        b = 0;
+        if (decode) {
+            const int ox = m % p.OW, t = m / p.OW, oy = t % p.OH;
+            b = t / p.OH;
+            if (!ident) mo = ((size_t)b * p.OHF + (size_t)oy * p.osy + p.ooy) * p.OWF + (size_t)ox * p.osx + p.oox;
+        }
+        return mo * p.Cout + nb;
+    };
+    {
+        constexpr int i = I;                             // compile-time sub-tile row: no unrolling needed to index acc
+        float rv[16][TN];
+        if (RES) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
+                int b;
+                const size_t o = place(m < p.M ? m : 0, b);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const bool ok = m < p.M && nb + j * 32 < p.Cout;
+                    rv[r][j] = p.res[ok ? o + j * 32 : 0];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
+            if (m < p.M) {
+                int b;
+                const size_t o = place(m, b);
+                const float* bb = p.bias_b ? p.bias_b + (size_t)b * p.Cout + nb : nullptr;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (nb + j * 32 < p.Cout) {
+                        float v = acc[i][j][r] + bv[j];
+                        if (bb) v += bb[j * 32];
+                        if (RES) v += rv[r][j];
+                        yout[o + j * 32] = apply_act(v, p.act, p.act_param);
+                    }
+            }
+        }
+    }
+}
+
+template <int TM, int TN, bool RES>
+__device__ __forceinline__ void conv_epilogue_rows(const ConvP& p, f32x16 (&acc)[TM][TN], const float (&bv)[TN], float* yout,
+                                                   int m0, int n0, int wm0, int wn0) {
+    conv_epilogue_rows_i<0, TM, TN, RES>(p, acc, bv, yout, m0, n0, wm0, wn0);
+    if constexpr (TM > 1) conv_epilogue_rows_i<1, TM, TN, RES>(p, acc, bv, yout, m0, n0, wm0, wn0);
+    if constexpr (TM > 2) conv_epilogue_rows_i<2, TM, TN, RES>(p, acc, bv, yout, m0, n0, wm0, wn0);
+    if constexpr (TM > 3) conv_epilogue_rows_i<3, TM, TN, RES>(p, acc, bv, yout, m0, n0, wm0, wn0);
+    static_assert(TM <= 4, "add more rows");
+}
+
 // Accumulator layout of every 32x32 MFMA tile: register r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
 // Writes raw split-K partials, or bias + per-row bias + residual + activation at the (possibly strided) output place.
 template <int TM, int TN>
@@ -79,33 +144,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         const int n = n0 + wn0 + j * 32 + col;
         bv[j] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
     }
-    const bool ident = (p.osy == 1 && p.osx == 1 && p.OHF == p.OH && p.OWF == p.OW);
-    const bool decode = !ident || p.bias_b;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {          // one output row (pixel) per (i, r): decode it once, then TN columns
-            const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
-            if (m < p.M) {
-                size_t mo = (size_t)m;
-                int b = 0;
-                if (decode) {
-                    const int ox = m % p.OW, t = m / p.OW, oy = t % p.OH;
-                    b = t / p.OH;
-                    if (!ident) mo = ((size_t)b * p.OHF + (size_t)oy * p.osy + p.ooy) * p.OWF + (size_t)ox * p.osx + p.oox;
-                }
-                const size_t o = mo * p.Cout + n0 + wn0 + col;
-                const float* bb = p.bias_b ? p.bias_b + (size_t)b * p.Cout + n0 + wn0 + col : nullptr;
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    if (n0 + wn0 + j * 32 + col < p.Cout) {
-                        float v = acc[i][j][r] + bv[j];
-                        if (bb) v += bb[j * 32];
-                        if (p.res) v += p.res[o + j * 32];
-                        yout[o + j * 32] = apply_act(v, p.act, p.act_param);
-                    }
-            }
-        }
+    if (p.res) conv_epilogue_rows<TM, TN, true>(p, acc, bv, yout, m0, n0, wm0, wn0);
+    else conv_epilogue_rows<TM, TN, false>(p, acc, bv, yout, m0, n0, wm0, wn0);
 }
 
 // egr_nn_gemm_s3.hip: launches k_conv_s3<bm, bn> (bm = s3_bm(...), bn in {32, 64, 128}; grid.x = ceil(M / bm));

@@ -25,6 +25,17 @@ static constexpr float kC0 = kA2 * kB2, kC2 = -(kA2 + kB2);
 #define F4M(s, a) make_float4((s) * a.x, (s) * a.y, (s) * a.z, (s) * a.w)
 #define F4FMA(s, a, b) make_float4(fmaf((s), a.x, b.x), fmaf((s), a.y, b.y), fmaf((s), a.z, b.z), fmaf((s), a.w, b.w))
 
+// V / M are written once and read once by the next kernel: optionally bypass the caches on the way out (EGR_W4_NT)
+#ifdef EGR_W4_NT
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_f4(float* p, const float4& v) {
+    f4v t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, (f4v*)p);
+}
+#else
+__device__ __forceinline__ void st_f4(float* p, const float4& v) { *(float4*)p = v; }
+#endif
+
 // t = B^T d for one 6-vector; rows ordered 0, +a, -a, +b, -b, inf
 __device__ __forceinline__ void bt6(const float4 (&d)[6], float4 (&t)[6]) {
     const float4 ea = F4FMA(-kB2, d[2], d[4]);              // even part of the +-a rows: d4 - b^2 d2
@@ -48,9 +59,12 @@ __device__ __forceinline__ void at6(const float4 (&m)[6], float4 (&s)[4]) {
     s[3] = F4A(F4FMA(kA3, ma, F4M(kB3, mb)), m[5]);
 }
 
-// V[6 i + j][t][c] = (B^T d B)[i][j] of the 6x6 input tile whose origin is (4 ty - 1, 4 tx - 1); t = (b, ty, tx)
+// V[6 i + j][t][c] = (B^T d B)[i][j] of the 6x6 input tile whose origin is (4 ty - 1, 4 tx - 1); t = (b, ty, tx).
+// GN / SILU are compile-time so that the 36 tile loads are issued back to back (a run-time branch between them made the
+// compiler wait for every load separately: 36 serialized round trips per thread).
+template <bool GN, bool SILU>
 __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, int B, int H, int W, int C, int TH, int TW,
-                                                   const float* __restrict__ gsc, const float* __restrict__ gsh, int gsilu,
+                                                   const float* __restrict__ gsc, const float* __restrict__ gsh,
                                                    float* __restrict__ V) {
     const int C4 = C >> 2;
     const long long P = (long long)B * TH * TW, total = P * C4;
@@ -59,43 +73,63 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, i
         const int c4 = (int)(i % C4);
         const long long t = i / C4;
         const int tx = (int)(t % TW), ty = (int)((t / TW) % TH), b = (int)(t / ((long long)TW * TH));
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gsc) {
-            sc = *(const float4*)(gsc + (size_t)b * C + 4 * c4);
-            sh = *(const float4*)(gsh + (size_t)b * C + 4 * c4);
-        }
-        float4 tt[6][6];                                  // tt[i][q] = (B^T d)[i][q]
+        float4 d[6][6];                                   // d[r][q]: row r, column q of the tile
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const int ix = 4 * tx - 1 + q;
-            float4 d[6];
+        for (int r = 0; r < 6; ++r) {
+            const int iy = 4 * ty - 1 + r;
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                const int iy = 4 * ty - 1 + r;
+            for (int q = 0; q < 6; ++q) {
+                const int ix = 4 * tx - 1 + q;
                 const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
                 const size_t off = ok ? (((size_t)b * H + iy) * W + ix) * C + 4 * c4 : (size_t)(4 * c4);
-                float4 v = *(const float4*)(x + off);
-                if (gsc) {      // producer's GroupNorm (+SiLU) fused into the transform; padding stays zero
+                d[r][q] = *(const float4*)(x + off);
+            }
+        }
+        // interior tiles (the vast majority) need no masking; edge tiles zero their out-of-image taps after the affine
+        const bool interior = ty > 0 && tx > 0 && 4 * ty + 4 < H && 4 * tx + 4 < W;
+        if (GN) {      // producer's GroupNorm (+SiLU) fused into the transform; padding stays zero
+            const float4 sc = *(const float4*)(gsc + (size_t)b * C + 4 * c4);
+            const float4 sh = *(const float4*)(gsh + (size_t)b * C + 4 * c4);
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    float4 v = d[r][q];
                     v = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
-                    if (gsilu) {
+                    if (SILU) {
                         v.x = v.x / (1.f + __expf(-v.x)); v.y = v.y / (1.f + __expf(-v.y));
                         v.z = v.z / (1.f + __expf(-v.z)); v.w = v.w / (1.f + __expf(-v.w));
                     }
+                    d[r][q] = v;
                 }
-                d[r] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            float4 col[6];
-            bt6(d, col);
+        }
+        if (!interior) {
 #pragma unroll
-            for (int r = 0; r < 6; ++r) tt[r][q] = col[r];
+            for (int r = 0; r < 6; ++r) {
+                const int iy = 4 * ty - 1 + r;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const int ix = 4 * tx - 1 + q;
+                    if (!((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)) d[r][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {                     // B^T d : transform the columns in place
+            float4 col[6], o6[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) col[r] = d[r][q];
+            bt6(col, o6);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) d[r][q] = o6[r];
         }
         float* o = V + (size_t)t * C + 4 * c4;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {                     // (.) B == B^T applied along the row
             float4 row[6];
-            bt6(tt[r], row);
+            bt6(d[r], row);
 #pragma unroll
-            for (int q = 0; q < 6; ++q) *(float4*)(o + (size_t)(6 * r + q) * zs) = row[q];
+            for (int q = 0; q < 6; ++q) st_f4(o + (size_t)(6 * r + q) * zs, row[q]);
         }
     }
 }
@@ -173,8 +207,11 @@ extern "C" int egr_winograd4_input(const float* x, const float* gn_scale, const 
                   (!gn_scale || gn_shift), EGR_ERR_ARG, "F(4x4,3x3) input transform needs H, W, C multiples of 4");
     const int TH = H / 4, TW = W / 4;
     const long long n = (long long)B * TH * TW * (C / 4);
-    hipLaunchKernelGGL(k_wino4_in, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C, TH, TW, gn_scale,
-                       gn_shift, gn_silu, V);
+    const dim3 g(grid1d(n)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (!gn_scale) hipLaunchKernelGGL((k_wino4_in<false, false>), g, blk, 0, st, x, B, H, W, C, TH, TW, gn_scale, gn_shift, V);
+    else if (gn_silu) hipLaunchKernelGGL((k_wino4_in<true, true>), g, blk, 0, st, x, B, H, W, C, TH, TW, gn_scale, gn_shift, V);
+    else hipLaunchKernelGGL((k_wino4_in<true, false>), g, blk, 0, st, x, B, H, W, C, TH, TW, gn_scale, gn_shift, V);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }
