@@ -172,7 +172,7 @@ def main():
 
     if rank == 0:
         audio_s = total / SR
-        variants = {k: v for k, v in prof.items() if k.startswith("k_conv_")}
+        variants = {k: v for k, v in prof.items() if k.startswith("k_conv")}
         fconv_all = sum(v[1] for v in variants.values())
         dom_conv = max(variants, key=lambda k: variants[k][2])          # the variant with the most GPU time
         nconv, fconv, tconv = variants[dom_conv]

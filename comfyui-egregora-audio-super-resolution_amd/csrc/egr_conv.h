@@ -152,6 +152,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
 // p.w3 must be set and Cin % 16 == 0
 int s3_bm(long long M, int Cout, int bn);
 int s3_zs_nzb(long long M, int Cout, int bm, int bn, int nz, int K);
+// input-stationary stride-1 1-D convolution (k_conv1d_s3); returns false when the shape does not qualify
+bool launch_conv1d_s3(const ConvP& p, hipStream_t st);
 void launch_conv_s3(int bm, int bn, dim3 grid, hipStream_t st, const ConvP& p);
 
 }  // namespace egr

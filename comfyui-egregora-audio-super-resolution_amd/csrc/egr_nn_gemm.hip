@@ -579,7 +579,8 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
         }
     }
 #define LAUNCH(BN_, V_) hipLaunchKernelGGL((k_conv_igemm<BN_, V_>), grid, dim3(256), 0, st, p)
-    if (w3) launch_conv_s3(bm, bn, grid, st, p);
+    if (w3 && launch_conv1d_s3(p, st)) {}
+    else if (w3) launch_conv_s3(bm, bn, grid, st, p);
     else if (gn_scale) {        // fused-GroupNorm loader: separate instantiations so the plain kernels pay nothing for it
         if (bn == 128) hipLaunchKernelGGL((k_conv_igemm<128, true, true>), grid, dim3(256), 0, st, p);
         else if (bn == 64) hipLaunchKernelGGL((k_conv_igemm<64, true, true>), grid, dim3(256), 0, st, p);

@@ -379,3 +379,169 @@ extern "C" int egr_split3_pack(const float* w_packed, void* w3, int64_t nslabs, 
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Stride-1 1-D convolution (the vocoder's AMP blocks: k = 3 / 7 / 11, dilation 1 / 3 / 5, 16..256 channels), input-stationary:
+// the implicit-GEMM loader above re-loads and re-splits every activation once per tap; here a workgroup splits its
+// (128 + dil (k-1)) x CC halo tile ONCE into LDS and every tap reads its MFMA operands from it at a row offset, so the
+// split work and the L2 traffic drop by the tap count.  Weights stream through the same double-buffered B tiles.
+// LDS halo tile per plane: [row][CC/8 chunks of 8 bf16], chunk index XOR-ed with (row / (16 / NCH)) & (NCH - 1): conflict-free
+// ds_read_b128 for any row offset (brute-forced over all offsets for NCH = 2, 4).
+namespace egr {
+
+template <int BN, int CC>
+__global__ __launch_bounds__(256, 2) void k_conv1d_s3(ConvP p) {
+    typedef S3Cfg<128, BN> TC;
+    constexpr int TM = TC::TM, TN = TC::TN, NCH = CC / 8, NSL = CC / 16, RMAX = 128 + 50;
+    __shared__ uint4 As[3][RMAX * NCH];
+    __shared__ uint4 Bs[2][3][BN * 2];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm0 = (wave / TC::WN) * (128 / TC::WM), wn0 = (wave % TC::WN) * (BN / TC::WN);
+    const int L = p.W, b = blockIdx.z, l0 = blockIdx.x * 128, n0 = blockIdx.y * BN;
+    const int R = 128 + p.dil * (p.KW - 1), pos0 = l0 - p.pad_l;
+    const float* xb = p.x + (size_t)b * L * p.Cin;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // B tiles: 6*BN chunks per slab, up to 3 per thread (as in k_conv_s3)
+    constexpr int NBQ = 6 * BN;
+    const size_t b_slab = (size_t)p.Cout * 6;
+    const int cpt = p.Cin / 16;                  // slabs per tap in the weight pack
+#define C1_BSETUP(I, OFF, SLOT, OK)                                                                               \
+    size_t OFF;                                                                                                      \
+    int SLOT;                                                                                                        \
+    bool OK;                                                                                                         \
+    {                                                                                                                \
+        const int e = tid + 256 * (I);                                                                               \
+        const int plane = e / (2 * BN), rem = e - plane * 2 * BN, nl = rem >> 1, half = rem & 1;                     \
+        OK = e < NBQ && n0 + nl < p.Cout;                                                                            \
+        SLOT = plane * (BN * 2) + nl * 2 + (half ^ ((nl >> 3) & 1));                                                 \
+        OFF = ((size_t)plane * p.Cout + n0 + nl) * 2 + half;                                                         \
+    }
+    C1_BSETUP(0, boff0, bslot0, bok0)
+    C1_BSETUP(1, boff1, bslot1, bok1)
+    C1_BSETUP(2, boff2, bslot2, bok2)
+#undef C1_BSETUP
+    const uint4* zq = (const uint4*)p.zeros;
+    // weight tiles are prefetched FOUR slabs ahead through four register sets: at 6..24 MFMAs per slab a one-slab
+    // distance is far shorter than an L2 round trip and the thin layers ran at the latency of one load per slab
+    struct StageB { uint4 b0, b1, b2; };
+    StageB s0, s1, s2, s3;
+    s0.b0 = s0.b1 = s0.b2 = s1.b0 = s1.b1 = s1.b2 = s2.b0 = s2.b1 = s2.b2 = s3.b0 = s3.b1 = s3.b2 = make_uint4(0, 0, 0, 0);
+    const int spc = p.KW * NSL;                  // slabs per channel chunk
+    const int nchunks = p.Cin / CC, stotal = nchunks * spc;
+    auto wslab = [&](int sg) {                   // weight-pack slab of global slab sg = (chunk, tap, 16-channel sub-slab)
+        const int cc = sg / spc, s = sg - cc * spc, tap = s / NSL, cs = s - tap * NSL;
+        return (size_t)(tap * cpt + cc * NSL + cs) * b_slab;
+    };
+    auto load_b = [&](int sg, StageB& r) {
+        const uint4* base = p.w3 + wslab(sg);
+        r.b0 = bok0 ? base[boff0] : zq[0];
+        if (256 < NBQ) r.b1 = bok1 ? base[boff1] : zq[0];
+        if (512 < NBQ) r.b2 = bok2 ? base[boff2] : zq[0];
+    };
+    auto store_b = [&](int buf, const StageB& r) {
+        if (tid < NBQ) Bs[buf][0][bslot0] = r.b0;
+        if (tid + 256 < NBQ) Bs[buf][0][bslot1] = r.b1;
+        if (tid + 512 < NBQ) Bs[buf][0][bslot2] = r.b2;
+    };
+    const int li = lane & 31, lk = lane >> 5;
+    const int ob_slot = li * 2 + (lk ^ ((li >> 3) & 1));
+
+    // one slab; `nx` is the register set holding tile sg + 1 (tile T lives in set T % 4) and is refilled with tile sg + 5
+    auto slab = [&](int sg, StageB& nx) {
+        const int cur = sg & 1;
+        const int cc = sg / spc, s = sg - cc * spc, tap = s / NSL, cs = s - tap * NSL;
+        if (s == 0) {                            // new channel chunk: split its halo tile into LDS (all waves are past the
+            const int c0 = cc * CC;              // previous chunk: the barrier that ended its last slab)
+            for (int e = tid; e < R * NCH; e += 256) {
+                const int r = e / NCH, ch = e - r * NCH, pos = pos0 + r;
+                const bool ok = (unsigned)pos < (unsigned)L;
+                const float* src = ok ? xb + (size_t)pos * p.Cin + c0 + ch * 8 : p.zeros;
+                const float4 u = *(const float4*)src, v = *(const float4*)(src + 4);
+                uint4 q0, q1, q2;
+                split3_x8(u, v, q0, q1, q2);
+                const int slot = r * NCH + (ch ^ ((r / (16 / NCH)) & (NCH - 1)));
+                As[0][slot] = q0;
+                As[1][slot] = q1;
+                As[2][slot] = q2;
+            }
+        }
+        __syncthreads();                         // B tile `cur` (stored one iteration ago) and the halo tile are visible
+        uint4 bq[TN][3];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) bq[j][q] = Bs[cur][q][(wn0 + j * 32) * 2 + ob_slot];
+        uint4 aq[TM][3];
+        const int ch = cs * 2 + lk;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r = wm0 + i * 32 + li + tap * p.dil;
+            const int slot = r * NCH + (ch ^ ((r / (16 / NCH)) & (NCH - 1)));
+#pragma unroll
+            for (int q = 0; q < 3; ++q) aq[i][q] = As[q][slot];
+        }
+        if (sg + 1 < stotal) store_b(cur ^ 1, nx);   // buffer cur^1 was last read in iteration sg-1, before this barrier
+        if (sg + 5 < stotal) load_b(sg + 5, nx);
+#define C1_MMA(QA, QB)                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =            \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(aq[i][QA]), as_bf(bq[j][QB]), acc[i][j], 0, 0, 0);
+        C1_MMA(2, 0)
+        C1_MMA(0, 2)
+        C1_MMA(1, 1)
+        C1_MMA(1, 0)
+        C1_MMA(0, 1)
+        C1_MMA(0, 0)
+#undef C1_MMA
+        if (s + 1 == spc) __syncthreads();       // last slab of the chunk: everyone is done with the halo tile
+    };
+
+    load_b(0, s0);
+    store_b(0, s0);
+    if (1 < stotal) load_b(1, s1);
+    if (2 < stotal) load_b(2, s2);
+    if (3 < stotal) load_b(3, s3);
+    if (4 < stotal) load_b(4, s0);
+    int sg = 0;
+    for (; sg + 3 < stotal; sg += 4) {
+        slab(sg, s1);
+        slab(sg + 1, s2);
+        slab(sg + 2, s3);
+        slab(sg + 3, s0);
+    }
+    if (sg < stotal) slab(sg, s1);
+    if (sg + 1 < stotal) slab(sg + 1, s2);
+    if (sg + 2 < stotal) slab(sg + 2, s3);
+    conv_epilogue<TM, TN>(p, acc, b * L + l0, n0, wm0, wn0);
+}
+
+// true when the input-stationary 1-D kernel applies; launches it
+bool launch_conv1d_s3(const ConvP& p, hipStream_t st) {
+    static const bool off = getenv("EGR_S3_CONV1D") && atoi(getenv("EGR_S3_CONV1D")) == 0;
+    if (off || !p.w3 || p.H != 1 || p.KH != 1 || p.KW < 2 || p.stride != 1 || p.up2 || p.OW != p.W || (p.W % 128) != 0 ||
+        p.dil * (p.KW - 1) > 50 || 2 * p.pad_l != p.dil * (p.KW - 1) || (p.Cin % 16) != 0 || p.ksplit > 1 || p.zs_nzb > 0 ||
+        p.nz > 1 || p.osy != 1 || p.osx != 1 || p.OHF != p.OH || p.OWF != p.OW)
+        return false;
+    const int bn = p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32);
+    const dim3 grid(p.W / 128, (p.Cout + bn - 1) / bn, p.B);
+    if (p.B > 65535) return false;
+    if (p.Cin % 32 == 0) {
+        if (bn == 128) hipLaunchKernelGGL((k_conv1d_s3<128, 32>), grid, dim3(256), 0, st, p);
+        else if (bn == 64) hipLaunchKernelGGL((k_conv1d_s3<64, 32>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_conv1d_s3<32, 32>), grid, dim3(256), 0, st, p);
+    } else {
+        if (bn == 128) hipLaunchKernelGGL((k_conv1d_s3<128, 16>), grid, dim3(256), 0, st, p);
+        else if (bn == 64) hipLaunchKernelGGL((k_conv1d_s3<64, 16>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_conv1d_s3<32, 16>), grid, dim3(256), 0, st, p);
+    }
+    return true;
+}
+
+}  // namespace egr

@@ -134,10 +134,12 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, i
     }
 }
 
-// y[b][4ty+a][4tx+c][n] = act((A^T M A)[a][c] + bias[n] + res[...]),  M[6 i + j][t][n]
+// y[b][4ty+a][4tx+c][n] = act((A^T M A)[a][c] + bias[n] + res[...]),  M[6 i + j][t][n].  RES / SILU are compile-time (loads
+// of the residual are then hoisted above the arithmetic instead of being waited for one by one).
+template <bool RES, bool SILU>
 __global__ __launch_bounds__(256) void k_wino4_out(const float* __restrict__ Mx, const float* __restrict__ bias,
                                                     const float* __restrict__ res, int B, int H, int W, int N, int TH, int TW,
-                                                    int act, float* __restrict__ y) {
+                                                    float* __restrict__ y) {
     const int N4 = N >> 2;
     const long long P = (long long)B * TH * TW, total = P * N4;
     const size_t zs = (size_t)P * N;
@@ -161,18 +163,23 @@ __global__ __launch_bounds__(256) void k_wino4_out(const float* __restrict__ Mx,
         if (bias) bv = *(const float4*)(bias + 4 * n4);
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
+            const size_t off = (((size_t)b * H + 4 * ty + a) * W + 4 * tx) * N + 4 * n4;
+            float4 rr[4];
+            if (RES) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rr[c] = *(const float4*)(res + off + (size_t)c * N);
+            }
             float4 o[4];
             at6(s[a], o);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const size_t off = (((size_t)b * H + 4 * ty + a) * W + 4 * tx + c) * N + 4 * n4;
                 float4 v = F4A(o[c], bv);
-                if (res) { const float4 rr = *(const float4*)(res + off); v = F4A(v, rr); }
-                if (act == 1) {
+                if (RES) v = F4A(v, rr[c]);
+                if (SILU) {
                     v.x = v.x / (1.f + __expf(-v.x)); v.y = v.y / (1.f + __expf(-v.y));
                     v.z = v.z / (1.f + __expf(-v.z)); v.w = v.w / (1.f + __expf(-v.w));
                 }
-                *(float4*)(y + off) = v;
+                *(float4*)(y + off + (size_t)c * N) = v;
             }
         }
     }
@@ -222,8 +229,12 @@ extern "C" int egr_winograd4_output(const float* M, const float* bias, const flo
                   (act == 0 || act == 1), EGR_ERR_ARG, "F(4x4,3x3) output transform needs H, W, N multiples of 4");
     const int TH = H / 4, TW = W / 4;
     const long long n = (long long)B * TH * TW * (N / 4);
-    hipLaunchKernelGGL(k_wino4_out, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, M, bias, res, B, H, W, N, TH, TW, act,
-                       y);
+    const dim3 g(grid1d(n)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (res && act) hipLaunchKernelGGL((k_wino4_out<true, true>), g, blk, 0, st, M, bias, res, B, H, W, N, TH, TW, y);
+    else if (res) hipLaunchKernelGGL((k_wino4_out<true, false>), g, blk, 0, st, M, bias, res, B, H, W, N, TH, TW, y);
+    else if (act) hipLaunchKernelGGL((k_wino4_out<false, true>), g, blk, 0, st, M, bias, res, B, H, W, N, TH, TW, y);
+    else hipLaunchKernelGGL((k_wino4_out<false, false>), g, blk, 0, st, M, bias, res, B, H, W, N, TH, TW, y);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }

@@ -225,8 +225,11 @@ class FlashSREngine:
                          "egr_conv_nhwc")
         if ev is not None:
             vec = Cin % 16 == 0 and x.data_ptr() % 16 == 0
-            self._prof_end(ev, self._kind(B * OH * OW, Cin, Cout, w3 is not None, vec), fl,
-                           (B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, up2))
+            kind = self._kind(B * OH * OW, Cin, Cout, w3 is not None, vec)
+            if (w3 is not None and H == 1 and KH == 1 and KW >= 2 and stride == 1 and not up2 and OW == W and W % 128 == 0
+                    and dil * (KW - 1) <= 50 and 2 * pad_l == dil * (KW - 1)):       # launch_conv1d_s3's conditions
+                kind = f"k_conv1d_s3<{128 if Cout > 64 else (64 if Cout > 32 else 32)}, {32 if Cin % 32 == 0 else 16}>"
+            self._prof_end(ev, kind, fl, (B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, up2))
         if self.count_flops:
             self.flops += fl
         return y

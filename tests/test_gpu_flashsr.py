@@ -252,6 +252,26 @@ def test_conv1d_vs_torch(eng, k, dil, stride):
     close(got.permute(0, 2, 1), want)
 
 
+@pytest.mark.parametrize("Ci,Co,L,k,dil", [(16, 16, 256, 11, 5), (32, 32, 384, 7, 3), (64, 64, 128, 3, 1), (128, 128, 256, 11, 1),
+                                           (256, 256, 128, 7, 5), (48, 40, 256, 3, 3), (16, 130, 128, 11, 3)])
+def test_input_stationary_conv1d_vs_torch(eng, Ci, Co, L, k, dil):
+    """Stride-1 'same' 1-D convolutions with L % 128 == 0 take k_conv1d_s3 (halo tile split once into LDS, every tap reads
+    it at a row offset): all channel-chunk widths and tile variants, with bias + residual + leaky epilogue."""
+    e, cfg, P = eng
+    g = torch.Generator().manual_seed(Ci + k)
+    B = 3
+    x = torch.randn(B, Ci, L, generator=g)
+    w = torch.randn(Co, Ci, k, generator=g) / math.sqrt(Ci * k)
+    b = torch.randn(Co, generator=g)
+    res = torch.randn(B, Co, L, generator=g)
+    pad = dil * (k - 1) // 2
+    want = F.conv1d(x, w, b, dilation=dil, padding=pad) + res
+    e.add_weight("t1s.weight", w)
+    e.w["t1s.bias"] = b.cuda()
+    got = e.conv1d(x.permute(0, 2, 1).contiguous().cuda(), "t1s", k, dil=dil, pad=pad, res=res.permute(0, 2, 1).contiguous().cuda())
+    close(got.permute(0, 2, 1), want)
+
+
 def test_groupnorm_layernorm_softmax_geglu(eng):
     e, cfg, P = eng
     g = torch.Generator().manual_seed(3)
