@@ -1,8 +1,8 @@
 """ComfyUI custom-node pack: MI355X-native (gfx950) backend for Egregora Audio Super Resolution.
 
 Drop-in for the reference pack's three core nodes (reference __init__.py:33-43): same mapping keys, same
-display names, same INPUT_TYPES / RETURN_TYPES / FUNCTION surface -- plus the two evaluation-pack nodes that run on this
-pack's kernels (merged the way the reference merges its EVAL_MAP, __init__.py:17-23,47-53).  Compute runs in libegregora_amd.so
+display names, same INPUT_TYPES / RETURN_TYPES / FUNCTION surface -- plus the evaluation-pack nodes and the DeepFilterNet
+stage that run on this pack's kernels (merged the way the reference merges its ENHANCE_MAP / EVAL_MAP, __init__.py:9-23,47-53).  Compute runs in libegregora_amd.so
 (hand-written HIP, C ABI in include/egregora_amd.h); importing this package needs neither the library
 nor a GPU -- the nodes raise at run() time when either is missing.
 """
@@ -10,6 +10,7 @@ from .egregora_audio_super_resolution import EgregoraAudioSuperResolution
 from .egregora_fat_llama_cpu import EgregoraFatLlamaCPU
 from .egregora_fat_llama_gpu import EgregoraFatLlamaGPU
 from .egregora_audio_eval_pack import (NODE_CLASS_MAPPINGS as EVAL_MAP, NODE_DISPLAY_NAME_MAPPINGS as EVAL_NAMES)
+from .egregora_audio_enhance_extras import (NODE_CLASS_MAPPINGS as ENHANCE_MAP, NODE_DISPLAY_NAME_MAPPINGS as ENHANCE_NAMES)
 
 NODE_CLASS_MAPPINGS = {
     "EgregoraAudioUpscaler": EgregoraAudioSuperResolution,
@@ -23,7 +24,9 @@ NODE_DISPLAY_NAME_MAPPINGS = {
     "EgregoraFatLlamaCPU": "🎛️ Spectral Enhance (Fat Llama — CPU/FFTW)",
 }
 
+NODE_CLASS_MAPPINGS.update(ENHANCE_MAP)
 NODE_CLASS_MAPPINGS.update(EVAL_MAP)
+NODE_DISPLAY_NAME_MAPPINGS.update(ENHANCE_NAMES)
 NODE_DISPLAY_NAME_MAPPINGS.update(EVAL_NAMES)
 
 __all__ = ["NODE_CLASS_MAPPINGS", "NODE_DISPLAY_NAME_MAPPINGS"]

@@ -288,6 +288,104 @@ __global__ __launch_bounds__(256) void k_resample_linear(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------- DeepFilterNet stage glue (egregora_audio_enhance_extras.py:548-704)
+// rms[c][f] = sqrt(mean(x[c][480 f .. 480 f + 480)^2)) (last frame short), one wave per frame, sum in double.
+__global__ __launch_bounds__(64) void k_frame_rms(const float* __restrict__ x, long long T, long long n_frames,
+                                                   float* __restrict__ rms) {
+    const long long f = blockIdx.x;
+    const float* xc = x + (size_t)blockIdx.y * T;
+    const long long a = f * 480, b = a + 480 < T ? a + 480 : T;
+    double acc = 0.0;
+    for (long long i = a + threadIdx.x; i < b; i += 64) acc += (double)xc[i] * (double)xc[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (threadIdx.x == 0) rms[(size_t)blockIdx.y * n_frames + f] = (float)sqrt(acc / (double)(b - a));
+}
+
+// Per channel (one thread: the smoothing is a recurrence): probs = clip(rms / p95, 0, 1); one-pole smoothing; adaptive strength;
+// wet/dry gains.  Every step rounds to float32 exactly where numpy does (no fused multiply-adds), see oracle/dfn_mix.py.
+struct DfnP {
+    float alpha, oma;      // exp(-10 ms / tau) and 1 - alpha (both already rounded to float32); smooth = 0: no smoothing
+    int smooth, mode;      // mode 0 off, 1 more_on_noise, 2 more_on_speech, 3 gate_on_noise
+    float s0, a, one_m_s0, thr, s_noise, s_speech;
+    int linear;            // 0: equal power (sin / cos of pi/2 * s), 1: linear
+    double pos_frac;       // fractional part of 0.95 * (n - 1): numpy's linear percentile between the two order statistics
+};
+__global__ void k_dfn_gains(const float* __restrict__ rms, const float* __restrict__ ostat2, long long n, DfnP q,
+                            float* __restrict__ g_dry, float* __restrict__ g_wet) {
+    if (threadIdx.x != 0) return;
+    const int c = blockIdx.x;
+    const float* r = rms + (size_t)c * n;
+    const double lo = ostat2[2 * c], hi = ostat2[2 * c + 1], t = q.pos_frac;
+    // numpy _lerp: a + (b - a) t, or b - (b - a)(1 - t) for t >= 0.5 (float32 order statistics, float64 arithmetic)
+    double p95 = t >= 0.5 ? hi - (hi - lo) * (1.0 - t) : lo + (hi - lo) * t;
+    p95 = (double)(float)p95;                       // np.percentile of a float32 array returns float32
+    if (p95 == 0.0) p95 = 1e-6;
+    const float p95f = (float)p95;
+    float acc = 0.f;
+    for (long long i = 0; i < n; ++i) {
+        float v = __fdiv_rn(r[i], p95f);
+        v = fminf(fmaxf(v, 0.f), 1.f);
+        if (q.smooth) {
+            if (i == 0) acc = v;
+            acc = __fadd_rn(__fmul_rn(q.alpha, acc), __fmul_rn(q.oma, v));
+            v = fminf(fmaxf(acc, 0.f), 1.f);
+        }
+        float s;
+        if (q.mode == 1) s = __fadd_rn(q.s0, __fmul_rn(__fmul_rn(q.a, __fsub_rn(1.0f, v)), q.one_m_s0));
+        else if (q.mode == 2) s = __fadd_rn(q.s0, __fmul_rn(__fmul_rn(q.a, v), q.one_m_s0));
+        else if (q.mode == 3) s = v < q.thr ? q.s_noise : q.s_speech;
+        else s = q.s0;
+        s = fminf(fmaxf(s, 0.f), 1.f);
+        float gd, gw;
+        if (q.linear) { gw = s; gd = __fsub_rn(1.0f, s); }
+        else {
+            const float ang = __fmul_rn(1.57079637f, s);       // float32(0.5 * pi) * s
+            gw = sinf(ang);
+            gd = cosf(ang);
+        }
+        g_dry[(size_t)c * n + i] = gd;
+        g_wet[(size_t)c * n + i] = gw;
+    }
+}
+
+// y = clip(g_dry[f] * dry + g_wet[f] * wet, -1, 1) * gain, frame f = i / hop (the last gain repeats); running max |y|
+__global__ __launch_bounds__(256) void k_dfn_mix(const float* __restrict__ dry, const float* __restrict__ wet,
+                                                  const float* __restrict__ g_dry, const float* __restrict__ g_wet, long long T,
+                                                  long long n, int hop, float gain, int use_gain, float* __restrict__ y,
+                                                  unsigned* __restrict__ peak) {
+    __shared__ float red[4];
+    const size_t co = (size_t)blockIdx.y * T, go = (size_t)blockIdx.y * n;
+    float mx = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < T; i += (long long)gridDim.x * 256) {
+        long long f = i / hop;
+        if (f > n - 1) f = n - 1;
+        float v = __fadd_rn(__fmul_rn(g_dry[go + f], dry[co + i]), __fmul_rn(g_wet[go + f], wet[co + i]));
+        v = fminf(fmaxf(v, -1.f), 1.f);
+        if (use_gain) v = __fmul_rn(v, gain);
+        y[co + i] = v;
+        mx = fmaxf(mx, fabsf(v));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(peak, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+
+// limiter: if (limit && peak > ceiling && peak > 0) y *= float32(ceiling / peak); then clamp to [-1, 1]
+__global__ __launch_bounds__(256) void k_dfn_limit(float* __restrict__ y, long long n, const unsigned* __restrict__ peak,
+                                                    int limit, double ceiling) {
+    const float pk = __uint_as_float(*peak);
+    const bool scale = limit && (double)pk > ceiling && pk > 0.f;
+    const float sc = scale ? (float)(ceiling / (double)pk) : 1.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float v = y[i];
+        if (scale) v = __fmul_rn(v, sc);
+        y[i] = fminf(fmaxf(v, -1.f), 1.f);
+    }
+}
+
 static inline int grid_for(long long n) {
     long long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -422,6 +520,57 @@ extern "C" int egr_resample_linear(const float* x, int channels, int64_t n_in, f
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(k_resample_linear, dim3((unsigned)nb, channels), dim3(256), 0, (hipStream_t)stream, x, (long long)n_in,
                        (long long)n_out, y);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" size_t egr_dfn_workspace_bytes(int channels, int64_t n48) {
+    const int64_t n = (n48 + 479) / 480;
+    return (size_t)channels * n * sizeof(float) + (size_t)channels * 2 * sizeof(float) + 64;
+}
+
+extern "C" int egr_dfn_vad_gains(const float* dry48, int channels, int64_t n48, double smooth_ms, int mode, double strength,
+                                 double amount, double vad_threshold, int linear_curve, void* workspace, float* g_dry,
+                                 float* g_wet, void* stream) {
+    EGR_CHECK(dry48 && workspace && g_dry && g_wet && channels >= 1 && channels <= 65535 && n48 >= 1, EGR_ERR_ARG, "bad argument");
+    EGR_CHECK(mode >= 0 && mode <= 3 && strength >= 0.0 && strength <= 1.0, EGR_ERR_ARG, "bad mode / strength");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (n48 + 479) / 480;
+    float* rms = (float*)workspace;
+    float* ost = rms + (size_t)channels * n;
+    hipLaunchKernelGGL(k_frame_rms, dim3((unsigned)n, channels), dim3(64), 0, st, dry48, (long long)n48, (long long)n, rms);
+    const double pos = 0.95 * (double)(n - 1);
+    const int64_t lo = (int64_t)pos, hi = lo + 1 < n ? lo + 1 : n - 1;
+    for (int c = 0; c < channels; ++c)
+        hipLaunchKernelGGL(k_order_stats2, dim3(1), dim3(1024), 0, st, rms + (size_t)c * n, (long long)n, (long long)lo,
+                           (long long)hi, ost + 2 * c);
+    DfnP q;
+    const double s0 = strength, a = amount;          // Python floats in the reference: constants are formed in double
+    const double alpha = smooth_ms > 0.0 ? exp(-10.0 / fmax(1e-3, smooth_ms)) : 0.0;
+    q.alpha = (float)alpha; q.oma = (float)(1.0 - alpha); q.smooth = smooth_ms > 0.0 ? 1 : 0; q.mode = mode;
+    q.s0 = (float)s0; q.a = (float)a; q.one_m_s0 = (float)(1.0 - s0); q.thr = (float)vad_threshold;
+    q.s_noise = (float)fmin(fmax(s0 + a * (1.0 - s0), 0.0), 1.0); q.s_speech = (float)fmin(fmax(s0 * (1.0 - a), 0.0), 1.0);
+    q.linear = linear_curve ? 1 : 0; q.pos_frac = pos - (double)lo;
+    hipLaunchKernelGGL(k_dfn_gains, dim3(channels), dim3(64), 0, st, rms, ost, (long long)n, q, g_dry, g_wet);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_dfn_mix(const float* dry, const float* wet, const float* g_dry, const float* g_wet, int channels, int64_t n,
+                           int64_t n_frames, int hop, float post_gain, int use_gain, int limit, double ceiling, float* y,
+                           void* peak_ws, void* stream) {
+    EGR_CHECK(dry && wet && g_dry && g_wet && y && peak_ws && channels >= 1 && channels <= 65535 && n >= 1 && n_frames >= 1 &&
+                  hop >= 1, EGR_ERR_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    EGR_HIP(hipMemsetAsync(peak_ws, 0, sizeof(unsigned), st));
+    long long nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_dfn_mix, dim3((unsigned)nb, channels), dim3(256), 0, st, dry, wet, g_dry, g_wet, (long long)n,
+                       (long long)n_frames, hop, post_gain, use_gain, y, (unsigned*)peak_ws);
+    const long long tot = (long long)n * channels;
+    long long nb2 = (tot + 255) / 256;
+    if (nb2 > 4096) nb2 = 4096;
+    hipLaunchKernelGGL(k_dfn_limit, dim3((unsigned)nb2), dim3(256), 0, st, y, tot, (const unsigned*)peak_ws, limit, ceiling);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }

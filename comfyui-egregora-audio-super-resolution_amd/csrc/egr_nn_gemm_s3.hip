@@ -17,6 +17,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "egr_conv.h"
 
 namespace egr {
@@ -210,10 +212,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
         float4 a0, a1, a2, a3;
         uint4 b0, b1, b2;
     };
-    auto load_tile = [&](Stage& r) {
-#ifdef S3_ABL_NOGLOBAL
-        if (c0 > 0 || tap > 0) { c0 += S3_BK; return; }
-#endif
+    auto load_tile_issue = [&](Stage& r) {            // the global loads of the next tile (no control flow)
         {
             const float* s = aptr0 + astep0 * c0;
             r.a0 = *(const float4*)s;
@@ -224,12 +223,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
             r.a2 = *(const float4*)s;
             r.a3 = *(const float4*)(s + 4);
         }
+        r.b0 = *bptr0;
+        if (256 < NBQ) r.b1 = *bptr1;
+        if (512 < NBQ) r.b2 = *bptr2;
+    };
+    auto load_tile_advance = [&]() {                  // pointer bookkeeping; the tap change is the only branch
+        bptr0 += bstep0;
+        if (256 < NBQ) bptr1 += bstep1;
+        if (512 < NBQ) bptr2 += bstep2;
         c0 += S3_BK;
         if (c0 >= p.Cin) { c0 = 0; ++tap; set_tap(tap); }
-        r.b0 = *bptr0;
-        bptr0 += bstep0;
-        if (256 < NBQ) { r.b1 = *bptr1; bptr1 += bstep1; }
-        if (512 < NBQ) { r.b2 = *bptr2; bptr2 += bstep2; }
+    };
+    auto load_tile = [&](Stage& r) {
+#ifdef S3_ABL_NOGLOBAL
+        if (c0 > 0 || tap > 0) { c0 += S3_BK; return; }
+#endif
+        load_tile_issue(r);
+        load_tile_advance();
     };
     auto store_tile = [&](const Stage& r, int buf) {
         uint4 q0, q1, q2;
@@ -264,7 +274,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
     const int o_slot = li * 2 + (lk ^ ((li >> 3) & 1));
 
     // one slab: MFMAs on LDS buffer `cur`; tile kt+1 (staged in SN) -> LDS buffer cur^1; tile kt+1+PF -> SN
-    auto slab = [&](int kt, int cur, Stage& sn) {
+    // FULL: a middle slab (tile kt+1 is stored, tile kt+1+PF is loaded, unconditionally): its body up to the pointer
+    // bookkeeping is ONE basic block, which lets the scheduler interleave the split VALU / LDS stores with the MFMAs
+    auto slab = [&](int kt, int cur, Stage& sn, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         uint4 b[TN][3];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -279,8 +292,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) a[i][q] = As[cur][q][(wm0 + (i0 + i) * 32) * 2 + o_slot];
             if (i0 == 0) {
-                if (kt + 1 < kt_end) store_tile(sn, cur ^ 1);
-                if (kt + 1 + PF < kt_end) load_tile(sn);
+                if (FULL) {
+                    store_tile(sn, cur ^ 1);
+                    load_tile_issue(sn);
+                } else {
+                    if (kt + 1 < kt_end) store_tile(sn, cur ^ 1);
+                    if (kt + 1 + PF < kt_end) load_tile(sn);
+                }
             }
             // smallest terms first
 #define S3_MMA(QA, QB)                                                                                                   \
@@ -293,7 +311,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
             S3_MMA(0, 1)
             S3_MMA(0, 0)
 #undef S3_MMA
+#ifdef S3_SCHED
+            if (FULL && i0 == 0) {                  // MFMA : VALU : DS interleave for the scheduler (one MFMA, a few fillers)
+#pragma unroll
+                for (int g = 0; g < TH * TN * 6; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, S3_SCHED, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+            }
+#endif
         }
+        if (FULL) load_tile_advance();
         if (ZS) {                                   // last slab of a z problem: store its tile, restart the accumulators
             const int done = kt + 1;
             const int zl = done / ktiles_all;
@@ -318,18 +347,22 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
     load_tile(s0);
     store_tile(s0, 0);
     __syncthreads();
+    typedef std::integral_constant<bool, true> FullT;
+    typedef std::integral_constant<bool, false> TailT;
     if (PF == 1) {
         if (kt_begin + 1 < kt_end) load_tile(s0);
-        for (int kt = kt_begin; kt < kt_end; ++kt) slab(kt, (kt - kt_begin) & 1, s0);
+        int kt = kt_begin;
+        for (; kt + 2 < kt_end; ++kt) slab(kt, (kt - kt_begin) & 1, s0, FullT());
+        for (; kt < kt_end; ++kt) slab(kt, (kt - kt_begin) & 1, s0, TailT());
     } else {
         if (kt_begin + 1 < kt_end) load_tile(s0);
         if (kt_begin + 2 < kt_end) load_tile(s1);
         int kt = kt_begin;
         for (; kt + 1 < kt_end; kt += 2) {        // buffers and stage sets alternate with the parity of kt - kt_begin
-            slab(kt, 0, s0);
-            slab(kt + 1, 1, s1);
+            slab(kt, 0, s0, TailT());
+            slab(kt + 1, 1, s1, TailT());
         }
-        if (kt < kt_end) slab(kt, 0, s0);
+        if (kt < kt_end) slab(kt, 0, s0, TailT());
     }
     if (!ZS) conv_epilogue<TM, TN>(p, acc, m0, n0, wm0, wn0);
 }

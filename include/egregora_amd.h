@@ -100,6 +100,21 @@ int egr_fatllama_kernel_times(egr_fatllama_plan* plan, double* row_ms_avg, doubl
  * Replaces the libsndfile float->PCM_16->float hops at egregora_fat_llama_gpu.py:36 and :291. */
 int egr_pcm16_roundtrip(const float* x, float* y, int64_t n, float write_scale, float read_div, void* stream);
 
+/* The stage around the DeepFilterNet model of the reference's Egregora_DeepFilterNet_Denoise (the model itself is upstream's):
+ *   egr_dfn_vad_gains : 48 kHz dry signal [C][n48] -> per-10-ms-frame wet / dry gains [C][ceil(n48/480)]: frame RMS, its
+ *                       95th percentile (numpy's linear method), clip, one-pole smoothing (smooth_ms > 0), adaptive
+ *                       strength (mode 0 off, 1 more_on_noise, 2 more_on_speech, 3 gate_on_noise), equal-power or linear
+ *                       curve; float32 roundings exactly where numpy makes them   (egregora_audio_enhance_extras.py:548-606)
+ *   egr_dfn_mix       : y = clamp(limit(clip(g_dry[f] dry + g_wet[f] wet, -1, 1) * post_gain)), f = i / hop, limiter =
+ *                       ceiling / max|y| over all channels when that peak exceeds the ceiling            (:655-704)
+ * workspace: egr_dfn_workspace_bytes(C, n48) bytes; peak_ws: 4 bytes of device memory. */
+size_t egr_dfn_workspace_bytes(int channels, int64_t n48);
+int egr_dfn_vad_gains(const float* dry48, int channels, int64_t n48, double smooth_ms, int mode, double strength, double amount,
+                      double vad_threshold, int linear_curve, void* workspace, float* g_dry, float* g_wet, void* stream);
+int egr_dfn_mix(const float* dry, const float* wet, const float* g_dry, const float* g_wet, int channels, int64_t n,
+                int64_t n_frames, int hop, float post_gain, int use_gain, int limit, double ceiling, float* y, void* peak_ws,
+                void* stream);
+
 /* Linear-interpolation resampler of the "Resample Audio (HQ)" node's fallback branch: y[c][j] = np.interp at
  * j * n_in / n_out input samples, clamped to the last sample (egregora_audio_eval_pack.py:515-519). */
 int egr_resample_linear(const float* x, int channels, int64_t n_in, float* y, int64_t n_out, void* stream);
