@@ -154,6 +154,7 @@ __device__ __forceinline__ void fft_stage(const cplx* __restrict__ in, cplx* __r
             cplx x = src[(j + t * nb) * es];
             v[t] = swap_in ? make_float2(x.y, x.x) : x;
         }
+#ifndef EGR_FL_ABL_NOBFLY
         if (Ns > 1) {
             const int base = k * twstep;
             if (tw_pow) {
@@ -174,7 +175,10 @@ __device__ __forceinline__ void fft_stage(const cplx* __restrict__ in, cplx* __r
                 for (int t = 1; t < R; ++t) v[t] = cmul(v[t], tw[base * t]);
             }
         }
+#endif
+#ifndef EGR_FL_ABL_NOBFLY
         Bfly<R>::run(v);
+#endif
         cplx* dst = out + s * ss + ((j - k) * R + k) * es;
 #pragma unroll
         for (int t = 0; t < R; ++t) {
@@ -191,6 +195,9 @@ template <bool SEQFAST>
 __device__ __forceinline__ void lds_fft(cplx*& cur, cplx*& alt, const FftDesc& d, const cplx* __restrict__ tw,
                                         int nseq, int seq_log2, int es, int ss, bool inverse,
                                         const dcplx* __restrict__ twd = nullptr) {
+#ifdef EGR_FL_ABL_NOSTAGE
+    return;
+#endif
     for (int s = 0; s < d.nst; ++s) {
         const bool si = inverse && (s == 0);
         const bool so = inverse && (s == d.nst - 1);
