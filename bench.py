@@ -179,7 +179,7 @@ def main():
         conv_tfs = fconv / (tconv * 1e-3) / 1e12 if tconv > 0 else 0.0      # fp32-equivalent (algorithmic) rate
         # k_conv_s3 executes SIX bf16 MFMA products per fp32 multiply-add: its roofline is the dense bf16 peak and
         # `achieved` counts the executed bf16 flops (6 x algorithmic)
-        s3 = dom_conv.startswith("k_conv_s3")
+        s3 = dom_conv.startswith("k_conv_s3") or dom_conv.startswith("k_conv1d_s3")
         mfma_mult, mfma_peak = (6.0, MFMA_BF16_PEAK_TFS) if s3 else (1.0, MFMA_F32_PEAK_TFS)
         # the loop runs the channels as two concurrent pipelines (one launch = C/2 channels) unless EGR_FL_STREAMS=1
         groups = 2 if (C >= 2 and os.environ.get("EGR_FL_STREAMS", "2") != "1") else 1
@@ -191,6 +191,11 @@ def main():
         try:
             traffic = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get("fatllama_c3", {}).get(dom)
             traffic = traffic / groups if traffic else None
+        except Exception:
+            pass
+        conv_traffic = None
+        try:
+            conv_traffic = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get("flashsr_chain60", {}).get(dom_conv)
         except Exception:
             pass
         info = fe.plan_info(SEG, 1)
@@ -220,7 +225,7 @@ def main():
             },
             # dominant kernel of the step: the implicit-GEMM convolution (all dense contractions of FlashSR)
             "roofline": {"bound": "mfma", "kernel": dom_conv, "achieved": conv_tfs * mfma_mult, "peak": mfma_peak,
-                         "unit": "TFLOP/s", "frac": conv_tfs * mfma_mult / mfma_peak, "traffic": None,
+                         "unit": "TFLOP/s", "frac": conv_tfs * mfma_mult / mfma_peak, "traffic": conv_traffic,
                          "mfma_dtype": "bf16 (6 executed products per fp32 multiply-add)" if s3 else "f32",
                          "fp32_equivalent_tflops": conv_tfs, "vs_f32_mfma_peak": conv_tfs / MFMA_F32_PEAK_TFS,
                          "launches": nconv, "flops_total": fconv, "ms_total": tconv,

@@ -158,7 +158,12 @@ class FlashSREngine:
             native.check(self.L.egr_gemm_zbatched(_p(V), _p(self.w[wkey]), _p(Mx), nz, P, Cin, Cout, P * Cin, zw, P * Cout,
                                                   self._st()), "egr_gemm_zbatched")
         if ev is not None:
-            kind = "k_conv_s3<128, 128, zs>" if (w3 is not None and Cout > 64) else self._kind(P, Cin, Cout, w3 is not None)
+            kind = self._kind(P, Cin, Cout, w3 is not None)
+            if w3 is not None and Cout > 64:        # s3_zs_nzb (csrc/egr_nn_gemm_s3.hip): z-streamed when >= 2 z per workgroup
+                tiles = ((P + 127) // 128) * ((Cout + 127) // 128)
+                groups = min(max((2048 + tiles - 1) // tiles, 1), nz)
+                if (nz + groups - 1) // groups >= 2:
+                    kind = "k_conv_s3<128, 128, 1, true>"
             self._prof_end(ev, kind, fl, (B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, nz))
         if self.count_flops:
             self.flops += fl
@@ -240,7 +245,7 @@ class FlashSREngine:
         bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
         if s3:
             bm = 256 if (bn == 128 and ((M + 255) // 256) * ((Cout + 127) // 128) >= 1024) else 128
-            return f"k_conv_s3<{bm}, {bn}>"
+            return f"k_conv_s3<{bm}, {bn}, 1, false>"        # <BM, BN, PF, ZS> as rocprofv3 prints the instantiation
         return f"k_conv_igemm<{bn}, {'true' if vec else 'false'}>"
 
     def _prof_begin(self):
