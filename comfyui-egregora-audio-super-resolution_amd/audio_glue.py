@@ -84,3 +84,44 @@ def package(sr: int, ct: torch.Tensor) -> Dict[str, Any]:
         ct = ct[None, :]
     wf = ct.detach().to("cpu", torch.float32).unsqueeze(0).contiguous()
     return {"waveform": wf, "sample_rate": int(sr)}
+
+
+# ---------------------------------------------------------------- evaluation-pack AUDIO conventions
+# (reference egregora_audio_eval_pack.py:53-103; behaviour pinned by fixture G10)
+def eval_channels_first(arr) -> np.ndarray:
+    """[.., N] float32 with time last: size-1 axes dropped; a vector becomes one channel; a matrix is transposed when it has
+    more rows than columns; with more axes the longest one is time and the others fold into channels."""
+    a = np.squeeze(np.asarray(arr))
+    if a.ndim <= 1:
+        return a.reshape(1, -1).astype(np.float32)
+    if a.ndim == 2:
+        return (a.T if a.shape[0] > a.shape[1] else a).astype(np.float32)
+    t_axis = int(np.argmax(a.shape))
+    a = np.moveaxis(a, t_axis, -1)
+    return a.reshape(-1, a.shape[-1]).astype(np.float32)
+
+
+def eval_package(sr: int, samples, meta=None) -> Dict[str, Any]:
+    """The eval pack's AUDIO dict: both spellings of the rate, a [C,N] numpy view and a [1,C,N] tensor view, meta copied."""
+    cn = eval_channels_first(samples)
+    rate = int(sr)
+    return dict(sr=rate, sample_rate=rate, samples=cn, waveform=torch.from_numpy(cn)[None], meta=dict(meta or {}))
+
+
+def eval_audio(x: Any) -> Dict[str, Any]:
+    """ComfyUI AUDIO dict (batch element 0) or the eval pack's own dict -> eval_package(...); error text as the reference's."""
+    if isinstance(x, dict):
+        rate = x.get("sample_rate") or x.get("sr") or x.get("rate")
+        if "waveform" in x and rate is not None:
+            wf = x["waveform"]
+            wf = wf.detach().cpu().numpy() if hasattr(wf, "detach") else np.asarray(wf)
+            return eval_package(int(rate), wf[0] if wf.ndim == 3 else wf, x.get("meta", {}))
+        rate = x.get("sr") or x.get("sample_rate")
+        if "sr" in x or "sample_rate" in x:
+            for key in ("samples", "audio", "array"):
+                if x.get(key) is not None:
+                    buf = x[key]
+                    buf = buf.detach().cpu().numpy() if hasattr(buf, "detach") else np.asarray(buf)
+                    return eval_package(int(rate), buf, x.get("meta", {}))
+            raise ValueError("Audio dict missing samples/waveform")
+    raise ValueError("Unsupported AUDIO object for this node")

@@ -7,7 +7,7 @@ STFT, per-frame LSD, the percentile's order statistics, the SI-SDR sums and both
 `_normalize_CN`, `make_audio`, :60-103).  No CPU fallback: without the library or a gfx950 device `execute` raises.
 The reference's other evaluation nodes (ABX, BS.1770 loudness) are host-side bookkeeping and are not part of this pack.
 """
-from typing import Any, Dict, Optional
+from typing import Any, Dict
 
 import numpy as np
 import torch
@@ -15,55 +15,7 @@ import torch
 from . import device_ops, native, resample
 
 
-def _to_numpy(x: Any) -> np.ndarray:
-    if isinstance(x, np.ndarray):
-        return x
-    if hasattr(x, "detach") and hasattr(x, "cpu"):
-        return x.detach().cpu().numpy()
-    return np.asarray(x)
-
-
-def normalize_cn(arr) -> np.ndarray:
-    """Reference _normalize_CN (:60-74): squeeze; 1-D -> [1,N]; 2-D transposed when rows > columns; more dimensions: the
-    longest axis becomes time and the rest folds into channels.  float32."""
-    a = np.squeeze(np.asarray(arr))
-    if a.ndim == 1:
-        a = a[None, :]
-    elif a.ndim == 2:
-        if a.shape[0] > a.shape[1]:
-            a = a.T
-    else:
-        a = np.moveaxis(a, int(np.argmax(a.shape)), -1)
-        a = a.reshape(int(np.prod(a.shape[:-1])), a.shape[-1])
-    return a.astype(np.float32)
-
-
-def make_audio(sr: int, samples_cn, meta: Optional[dict] = None) -> Dict[str, Any]:
-    """Reference make_audio (:76-86): the eval pack's AUDIO dict carries both spellings of the rate and both views."""
-    s = normalize_cn(samples_cn)
-    return {"sr": int(sr), "sample_rate": int(sr), "samples": s, "waveform": torch.from_numpy(s).unsqueeze(0),
-            "meta": dict(meta or {})}
-
-
-def to_internal_audio(x: Any) -> Dict[str, Any]:
-    """Reference to_internal_audio (:89-103), including its error text."""
-    if isinstance(x, dict) and "waveform" in x and ("sample_rate" in x or "sr" in x or "rate" in x):
-        sr = int(x.get("sample_rate") or x.get("sr") or x.get("rate"))
-        wf = _to_numpy(x["waveform"])
-        if wf.ndim == 3:
-            wf = wf[0]
-        return make_audio(sr, wf, x.get("meta", {}))
-    if isinstance(x, dict) and ("sr" in x or "sample_rate" in x):
-        sr = int(x.get("sr") or x.get("sample_rate"))
-        buf = x.get("samples")
-        if buf is None:
-            buf = x.get("audio")
-        if buf is None:
-            buf = x.get("array")
-        if buf is None:
-            raise ValueError("Audio dict missing samples/waveform")
-        return make_audio(sr, _to_numpy(buf), x.get("meta", {}))
-    raise ValueError("Unsupported AUDIO object for this node")
+from .audio_glue import eval_audio as to_internal_audio, eval_channels_first as normalize_cn, eval_package as make_audio
 
 
 def _device_cn(a: Dict[str, Any]) -> torch.Tensor:
@@ -79,18 +31,10 @@ class Metrics_LSD_SISDR:
 
     @classmethod
     def INPUT_TYPES(cls):
-        return {
-            "required": {
-                "audio_ref": ("AUDIO", {}),
-                "audio_proc": ("AUDIO", {}),
-            },
-            "optional": {
-                "n_fft": ("INT", {"default": 2048, "min": 512, "max": 8192, "step": 128}),
-                "hop": ("INT", {"default": 512, "min": 64, "max": 4096, "step": 64}),
-                "compute_lsd": ("BOOLEAN", {"default": True}),
-                "compute_si_sdr": ("BOOLEAN", {"default": True}),
-            },
-        }
+        ints = dict(n_fft=(2048, 512, 8192, 128), hop=(512, 64, 4096, 64))           # widget: (default, min, max, step)
+        opt = {k: ("INT", dict(zip(("default", "min", "max", "step"), v))) for k, v in ints.items()}
+        opt.update({k: ("BOOLEAN", {"default": True}) for k in ("compute_lsd", "compute_si_sdr")})
+        return {"required": {k: ("AUDIO", {}) for k in ("audio_ref", "audio_proc")}, "optional": opt}
 
     def execute(self, audio_ref, audio_proc, n_fft=2048, hop=512, compute_lsd=True, compute_si_sdr=True):
         A = _device_cn(to_internal_audio(audio_ref))
@@ -113,19 +57,13 @@ class Resample_Audio_HQ:
     RETURN_NAMES = ("audio_out",)
     FUNCTION = "execute"
 
+    MODES = ("auto", "scipy_polyphase", "torchaudio", "linear")
+
     @classmethod
     def INPUT_TYPES(cls):
-        modes = ["auto", "scipy_polyphase", "torchaudio", "linear"]
-        return {
-            "required": {
-                "audio": ("AUDIO", {}),
-                "target_sr": ("INT", {"default": 48000, "min": 4000, "max": 384000, "step": 1}),
-            },
-            "optional": {
-                "mode": (modes, {}),
-                "kaiser_beta": ("FLOAT", {"default": 14.769, "min": 5.0, "max": 20.0, "step": 0.1}),
-            },
-        }
+        rng = lambda d, lo, hi, st: dict(zip(("default", "min", "max", "step"), (d, lo, hi, st)))
+        return {"required": {"audio": ("AUDIO", {}), "target_sr": ("INT", rng(48000, 4000, 384000, 1))},
+                "optional": {"mode": (list(cls.MODES), {}), "kaiser_beta": ("FLOAT", rng(14.769, 5.0, 20.0, 0.1))}}
 
     def execute(self, audio, target_sr=48000, mode="auto", kaiser_beta=14.769):
         a = to_internal_audio(audio)
