@@ -150,6 +150,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
 
 // egr_nn_gemm_s3.hip: launches k_conv_s3<bm, bn> (bm = s3_bm(...), bn in {32, 64, 128}; grid.x = ceil(M / bm));
 // p.w3 must be set and Cin % 16 == 0
+int s3_bn(int Cout);
 int s3_bm(long long M, int Cout, int bn);
 int s3_zs_nzb(long long M, int Cout, int bm, int bn, int nz, int K);
 // input-stationary stride-1 1-D convolution (k_conv1d_s3); returns false when the shape does not qualify

@@ -543,7 +543,7 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
               EGR_ERR_ARG, "bad output placement");
     p.osy = osy; p.osx = osx; p.ooy = ooy; p.oox = oox; p.OHF = OHF; p.OWF = OWF;
     const bool vec = (Cin % BK) == 0 && (((uintptr_t)x) & 15) == 0;
-    const int bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+    const int bn = w3 ? s3_bn(Cout) : (Cout > 64 ? 128 : (Cout > 32 ? 64 : 32));
     int bm = w3 ? s3_bm(M, Cout, bn) : BM;
     dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)((Cout + bn - 1) / bn));
     hipStream_t st = (hipStream_t)stream;

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void k_split3_pack(const float* __restrict__ w
 // 0.7x the L2 traffic per MFMA of the 128x128 tile).  128xBN: small-M / thin-Cout layers and split-K.
 template <int BM, int BN> struct S3Cfg;
 template <> struct S3Cfg<256, 128> { static constexpr int WM = 2, WN = 2, TM = 4, TN = 2; };
+template <> struct S3Cfg<128, 256> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 4; };   // Cout >= 256: half the A work per MFMA
 template <> struct S3Cfg<128, 128> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 2; };
 template <> struct S3Cfg<128, 64> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 1; };
 template <> struct S3Cfg<128, 32> { static constexpr int WM = 4, WN = 1, TM = 1, TN = 1; };
@@ -205,12 +206,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
     S3_BSETUP(0, bptr0, bstep0, bslot0)
     S3_BSETUP(1, bptr1, bstep1, bslot1)
     S3_BSETUP(2, bptr2, bstep2, bslot2)
+    S3_BSETUP(3, bptr3, bstep3, bslot3)
+    S3_BSETUP(4, bptr4, bstep4, bslot4)
+    S3_BSETUP(5, bptr5, bstep5, bslot5)
 #undef S3_BSETUP
 
     // staged tile registers: one set per slab in flight (PF = 2 sets: a load has two slab-times to land)
     struct Stage {
         float4 a0, a1, a2, a3;
-        uint4 b0, b1, b2;
+        uint4 b0, b1, b2, b3, b4, b5;
     };
     auto load_tile_issue = [&](Stage& r) {            // the global loads of the next tile (no control flow)
         {
@@ -226,11 +230,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
         r.b0 = *bptr0;
         if (256 < NBQ) r.b1 = *bptr1;
         if (512 < NBQ) r.b2 = *bptr2;
+        if (768 < NBQ) { r.b3 = *bptr3; r.b4 = *bptr4; r.b5 = *bptr5; }
     };
     auto load_tile_advance = [&]() {                  // pointer bookkeeping; the tap change is the only branch
         bptr0 += bstep0;
         if (256 < NBQ) bptr1 += bstep1;
         if (512 < NBQ) bptr2 += bstep2;
+        if (768 < NBQ) { bptr3 += bstep3; bptr4 += bstep4; bptr5 += bstep5; }
         c0 += S3_BK;
         if (c0 >= p.Cin) { c0 = 0; ++tap; set_tap(tap); }
     };
@@ -266,6 +272,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
             if (tid < NBQ) Bs[buf][0][bslot0] = r.b0;
             if (tid + 256 < NBQ) Bs[buf][0][bslot1] = r.b1;
             if (tid + 512 < NBQ) Bs[buf][0][bslot2] = r.b2;
+            if (768 < NBQ) {
+                Bs[buf][0][bslot3] = r.b3;
+                Bs[buf][0][bslot4] = r.b4;
+                Bs[buf][0][bslot5] = r.b5;
+            }
         }
     };
 
@@ -278,49 +289,43 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
     // bookkeeping is ONE basic block, which lets the scheduler interleave the split VALU / LDS stores with the MFMAs
     auto slab = [&](int kt, int cur, Stage& sn, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
-        uint4 b[TN][3];
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) b[j][q] = Bs[cur][q][(wn0 + j * 32) * 2 + o_slot];
         constexpr int TH = TM > 2 ? 1 : TM;                       // A sub-tiles in flight (register budget)
+        constexpr int TNH = TN > 2 ? 1 : TN;                      // B sub-tiles in flight
 #pragma unroll
-        for (int i0 = 0; i0 < TM; i0 += TH) {
-            uint4 a[TH][3];
+        for (int j0 = 0; j0 < TN; j0 += TNH) {
+            uint4 b[TNH][3];
 #pragma unroll
-            for (int i = 0; i < TH; ++i)
+            for (int j = 0; j < TNH; ++j)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) a[i][q] = As[cur][q][(wm0 + (i0 + i) * 32) * 2 + o_slot];
-            if (i0 == 0) {
-                if (FULL) {
-                    store_tile(sn, cur ^ 1);
-                    load_tile_issue(sn);
-                } else {
-                    if (kt + 1 < kt_end) store_tile(sn, cur ^ 1);
-                    if (kt + 1 + PF < kt_end) load_tile(sn);
+                for (int q = 0; q < 3; ++q) b[j][q] = Bs[cur][q][(wn0 + (j0 + j) * 32) * 2 + o_slot];
+#pragma unroll
+            for (int i0 = 0; i0 < TM; i0 += TH) {
+                uint4 a[TH][3];
+#pragma unroll
+                for (int i = 0; i < TH; ++i)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) a[i][q] = As[cur][q][(wm0 + (i0 + i) * 32) * 2 + o_slot];
+                if (i0 == 0 && j0 == 0) {
+                    if (FULL) {
+                        store_tile(sn, cur ^ 1);
+                        load_tile_issue(sn);
+                    } else {
+                        if (kt + 1 < kt_end) store_tile(sn, cur ^ 1);
+                        if (kt + 1 + PF < kt_end) load_tile(sn);
+                    }
                 }
-            }
-            // smallest terms first
+                // smallest terms first
 #define S3_MMA(QA, QB)                                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < TH; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i0 + i][j] =       \
-        __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[i][QA]), as_bf(b[j][QB]), acc[i0 + i][j], 0, 0, 0);
-            S3_MMA(2, 0)
-            S3_MMA(0, 2)
-            S3_MMA(1, 1)
-            S3_MMA(1, 0)
-            S3_MMA(0, 1)
-            S3_MMA(0, 0)
+    _Pragma("unroll") for (int i = 0; i < TH; ++i) _Pragma("unroll") for (int j = 0; j < TNH; ++j) acc[i0 + i][j0 + j] =  \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[i][QA]), as_bf(b[j][QB]), acc[i0 + i][j0 + j], 0, 0, 0);
+                S3_MMA(2, 0)
+                S3_MMA(0, 2)
+                S3_MMA(1, 1)
+                S3_MMA(1, 0)
+                S3_MMA(0, 1)
+                S3_MMA(0, 0)
 #undef S3_MMA
-#ifdef S3_SCHED
-            if (FULL && i0 == 0) {                  // MFMA : VALU : DS interleave for the scheduler (one MFMA, a few fillers)
-#pragma unroll
-                for (int g = 0; g < TH * TN * 6; ++g) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, S3_SCHED, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                }
             }
-#endif
         }
         if (FULL) load_tile_advance();
         if (ZS) {                                   // last slab of a z problem: store its tile, restart the accumulators
@@ -344,6 +349,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
     Stage s0, s1;
     s0.a2 = s0.a3 = s1.a0 = s1.a1 = s1.a2 = s1.a3 = make_float4(0.f, 0.f, 0.f, 0.f);
     s0.b0 = s0.b1 = s0.b2 = s1.b0 = s1.b1 = s1.b2 = make_uint4(0, 0, 0, 0);
+    s0.b3 = s0.b4 = s0.b5 = s1.b3 = s1.b4 = s1.b5 = make_uint4(0, 0, 0, 0);
     load_tile(s0);
     store_tile(s0, 0);
     __syncthreads();
@@ -368,6 +374,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
 }
 
 // block-tile height for a problem: 256 rows when that still leaves >= 2 full rounds of workgroups on the 256 CUs
+// output-channel tile: 256 wide when Cout is a multiple of 256 (half the activation loads / splits per MFMA: +20 %)
+int s3_bn(int Cout) {
+    static const bool no256 = getenv("EGR_S3_BN256") && atoi(getenv("EGR_S3_BN256")) == 0;
+    if (!no256 && Cout >= 256 && Cout % 256 == 0) return 256;
+    return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+}
+
 int s3_bm(long long M, int Cout, int bn) {
     if (bn != 128) return 128;
     const long long tiles256 = ((M + 255) / 256) * ((Cout + 127) / 128);
@@ -377,7 +390,8 @@ int s3_bm(long long M, int Cout, int bn) {
 // z problems per workgroup for z-streamed GEMMs: as many as keeps >= ~2048 workgroups in the grid (0: no streaming)
 int s3_zs_nzb(long long M, int Cout, int bm, int bn, int nz, int K) {
     static const bool off = getenv("EGR_S3_ZS") && atoi(getenv("EGR_S3_ZS")) == 0;
-    if (off || nz < 2 || bn != 128 || K % S3_BK) return 0;
+    // the 256-wide streamed variant spills a little (in-loop tile store): it pays only where the K loop is short
+    if (off || nz < 2 || bn < 128 || K % S3_BK || (bn == 256 && K > 256)) return 0;
     const long long tiles = ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn);
     long long groups = (2048 + tiles - 1) / tiles;
     if (groups < 1) groups = 1;
@@ -389,7 +403,12 @@ int s3_zs_nzb(long long M, int Cout, int bm, int bn, int nz, int K) {
 void launch_conv_s3(int bm, int bn, dim3 grid, hipStream_t st, const ConvP& p) {
     static const int pf = getenv("EGR_S3_PF") ? atoi(getenv("EGR_S3_PF")) : 1;
     if (p.zs_nzb > 0) {
-        hipLaunchKernelGGL((k_conv_s3<128, 128, 1, true>), grid, dim3(256), 0, st, p);
+        if (bn == 256) hipLaunchKernelGGL((k_conv_s3<128, 256, 1, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_conv_s3<128, 128, 1, true>), grid, dim3(256), 0, st, p);
+        return;
+    }
+    if (bn == 256) {
+        hipLaunchKernelGGL((k_conv_s3<128, 256, 1>), grid, dim3(256), 0, st, p);
         return;
     }
     if (bm == 256) hipLaunchKernelGGL((k_conv_s3<256, 128, 1>), grid, dim3(256), 0, st, p);

@@ -160,10 +160,11 @@ class FlashSREngine:
         if ev is not None:
             kind = self._kind(P, Cin, Cout, w3 is not None)
             if w3 is not None and Cout > 64:        # s3_zs_nzb (csrc/egr_nn_gemm_s3.hip): z-streamed when >= 2 z per workgroup
-                tiles = ((P + 127) // 128) * ((Cout + 127) // 128)
+                bn = 256 if (Cout >= 256 and Cout % 256 == 0) else 128
+                tiles = ((P + 127) // 128) * ((Cout + bn - 1) // bn)
                 groups = min(max((2048 + tiles - 1) // tiles, 1), nz)
-                if (nz + groups - 1) // groups >= 2:
-                    kind = "k_conv_s3<128, 128, 1, true>"
+                if (nz + groups - 1) // groups >= 2 and not (bn == 256 and Cin > 256):
+                    kind = f"k_conv_s3<128, {bn}, 1, true>"
             self._prof_end(ev, kind, fl, (B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, nz))
         if self.count_flops:
             self.flops += fl
@@ -244,6 +245,8 @@ class FlashSREngine:
         """Name of the kernel instantiation a contraction lands on (same selection as conv_launch, csrc/egr_nn_gemm.hip)."""
         bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
         if s3:
+            if Cout >= 256 and Cout % 256 == 0:         # s3_bn
+                bn = 256
             bm = 256 if (bn == 128 and ((M + 255) // 256) * ((Cout + 127) // 128) >= 1024) else 128
             return f"k_conv_s3<{bm}, {bn}, 1, false>"        # <BM, BN, PF, ZS> as rocprofv3 prints the instantiation
         return f"k_conv_igemm<{bn}, {'true' if vec else 'false'}>"

@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
     p.x = x; p.w3 = (const uint4*)w3; p.y = y; p.B = B; p.H = H; p.W = W; p.Cin = Ci; p.OH = H; p.OW = W; p.Cout = Co; p.KH = k; p.KW = k;
     p.stride = 1; p.dil = 1; p.pad_t = k / 2; p.pad_l = k / 2; p.M = (int)M; p.K = (int)K; p.osy = p.osx = 1; p.OHF = H; p.OWF = W;
     p.ksplit = 1; p.kt_per = (int)ns; p.zeros = zeros;
-    const int bn = Co > 64 ? 128 : (Co > 32 ? 64 : 32);
+    const int bn = getenv("S3_BN") ? atoi(getenv("S3_BN")) : (Co > 64 ? 128 : (Co > 32 ? 64 : 32));
     const int bm = getenv("S3_BM") ? atoi(getenv("S3_BM")) : egr::s3_bm(M, Co, bn);
     dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)((Co + bn - 1) / bn));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
