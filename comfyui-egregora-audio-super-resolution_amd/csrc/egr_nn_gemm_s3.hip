@@ -597,3 +597,137 @@ bool launch_conv1d_s3(const ConvP& p, hipStream_t st) {
 }
 
 }  // namespace egr
+
+// ------------------------------------------------------------------------------------------------------------------
+// Strided batched C[b] = alpha * A[b] (M x K) * B[b]^T (B is N x K), both operands fp32 activations (attention: Q K^T, and
+// P V with V transposed beforehand): the split-bf16 scheme with BOTH tiles split by the loader.  K % 16 == 0, rows 16-byte
+// aligned.  Same LDS layout, swizzle and MFMA schedule as k_conv_s3.
+namespace egr {
+
+struct GemmS3P {
+    const float* a; const float* b; float* c;
+    int M, N, K, lda, ldb, ldc, nb2;
+    long long sa1, sa2, sb1, sb2, sc1, sc2;
+    float alpha;
+    const float* zeros;
+};
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void k_bgemm_s3(GemmS3P p) {
+    typedef S3Cfg<128, BN> TC;
+    constexpr int TM = TC::TM, TN = TC::TN;
+    __shared__ uint4 As[2][3][128 * 2];
+    __shared__ uint4 Bs[2][3][BN * 2];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm0 = (wave / TC::WN) * (128 / TC::WM), wn0 = (wave % TC::WN) * (BN / TC::WN);
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * BN;
+    const int b1 = blockIdx.z / p.nb2, b2 = blockIdx.z - b1 * p.nb2;
+    const float* A = p.a + b1 * p.sa1 + b2 * p.sa2;
+    const float* Bm = p.b + b1 * p.sb1 + b2 * p.sb2;
+    float* Cm = p.c + b1 * p.sc1 + b2 * p.sc2;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // each thread owns one 8-float chunk of the A tile and (tid < 2 BN) one of the B tile per slab
+    const int ar = tid >> 1, ah = tid & 1;
+    const bool a_ok = m0 + ar < p.M, b_ok = tid < 2 * BN && n0 + ar < p.N;
+    const float* aptr = a_ok ? A + (size_t)(m0 + ar) * p.lda + ah * 8 : p.zeros;
+    const float* bptr = b_ok ? Bm + (size_t)(n0 + ar) * p.ldb + ah * 8 : p.zeros;
+    const int astep = a_ok ? 16 : 0, bstep = b_ok ? 16 : 0;
+    const int slot = ar * 2 + (ah ^ ((ar >> 3) & 1));
+    const int li = lane & 31, lk = lane >> 5;
+    const int o_slot = li * 2 + (lk ^ ((li >> 3) & 1));
+    const int ktiles = p.K / S3_BK;
+
+    float4 ra0, ra1, rb0, rb1;
+    auto load = [&]() {
+        ra0 = *(const float4*)aptr; ra1 = *(const float4*)(aptr + 4);
+        rb0 = *(const float4*)bptr; rb1 = *(const float4*)(bptr + 4);
+        aptr += astep; bptr += bstep;
+    };
+    auto store = [&](int buf) {
+        uint4 q0, q1, q2;
+        split3_x8(ra0, ra1, q0, q1, q2);
+        As[buf][0][slot] = q0; As[buf][1][slot] = q1; As[buf][2][slot] = q2;
+        if (tid < 2 * BN) {
+            split3_x8(rb0, rb1, q0, q1, q2);
+            Bs[buf][0][slot] = q0; Bs[buf][1][slot] = q1; Bs[buf][2][slot] = q2;
+        }
+    };
+    load();
+    store(0);
+    __syncthreads();
+    if (1 < ktiles) load();
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int cur = kt & 1;
+        uint4 a[TM][3], b[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[i][q] = As[cur][q][(wm0 + i * 32) * 2 + o_slot];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) b[j][q] = Bs[cur][q][(wn0 + j * 32) * 2 + o_slot];
+        if (kt + 1 < ktiles) store(cur ^ 1);
+        if (kt + 2 < ktiles) load();
+#define G3_MMA(QA, QB)                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =            \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[i][QA]), as_bf(b[j][QB]), acc[i][j], 0, 0, 0);
+        G3_MMA(2, 0)
+        G3_MMA(0, 2)
+        G3_MMA(1, 1)
+        G3_MMA(1, 0)
+        G3_MMA(0, 1)
+        G3_MMA(0, 0)
+#undef G3_MMA
+        __syncthreads();
+    }
+    const int col = lane & 31, rhalf = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
+            if (m < p.M) {
+                float* row = Cm + (size_t)m * p.ldc + n0 + wn0 + col;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (n0 + wn0 + j * 32 + col < p.N) row[j * 32] = p.alpha * acc[i][j][r];
+            }
+        }
+}
+
+}  // namespace egr
+
+extern "C" int egr_bgemm_nt_s3(const float* a, const float* b, float* c, int nb1, int nb2, int M, int N, int K, int lda, int ldb,
+                               int ldc, int64_t sa1, int64_t sa2, int64_t sb1, int64_t sb2, int64_t sc1, int64_t sc2, float alpha,
+                               void* stream) {
+    EGR_CHECK(a && b && c && nb1 >= 1 && nb2 >= 1 && M >= 1 && N >= 1 && K >= 16, EGR_ERR_ARG, "bad gemm argument");
+    EGR_CHECK((long long)nb1 * nb2 <= 65535, EGR_ERR_ARG, "too many batches");
+    EGR_CHECK(K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0 && sa1 % 4 == 0 &&
+                  sa2 % 4 == 0 && sb1 % 4 == 0 && sb2 % 4 == 0, EGR_ERR_UNSUPPORTED,
+              "split-bf16 batched GEMM needs K %% 16 == 0 and 16-byte aligned rows");
+    static float* zeros = nullptr;
+    if (!zeros) {
+        EGR_HIP(hipMalloc((void**)&zeros, 4096));
+        EGR_HIP(hipMemset(zeros, 0, 4096));
+    }
+    GemmS3P p;
+    p.a = a; p.b = b; p.c = c; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.nb2 = nb2;
+    p.sa1 = sa1; p.sa2 = sa2; p.sb1 = sb1; p.sb2 = sb2; p.sc1 = sc1; p.sc2 = sc2; p.alpha = alpha; p.zeros = zeros;
+    const int bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
+    dim3 grid((M + 127) / 128, (N + bn - 1) / bn, nb1 * nb2);
+    hipStream_t st = (hipStream_t)stream;
+    if (bn == 128) hipLaunchKernelGGL((k_bgemm_s3<128>), grid, dim3(256), 0, st, p);
+    else if (bn == 64) hipLaunchKernelGGL((k_bgemm_s3<64>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_bgemm_s3<32>), grid, dim3(256), 0, st, p);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}

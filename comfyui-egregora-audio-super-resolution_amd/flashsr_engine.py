@@ -400,15 +400,27 @@ class FlashSREngine:
         return y
 
     def attention(self, q, k, v, B, T, Cc, heads):
-        """q,k,v [B*T, C] -> [B*T, C]; softmax(q k^T / sqrt(d)) v per head."""
+        """q,k,v [B*T, C] -> [B*T, C]; softmax(q k^T / sqrt(d)) v per head.  bf16x3 mode: both GEMMs as A * B^T on the bf16 pipe
+        (V is transposed per row first, [B][T][C] -> [B][C][T], so that its head slices are K-contiguous)."""
         d = Cc // heads
         S = torch.empty((B, heads, T, T), dtype=torch.float32, device=self.dev)
-        native.check(self.L.egr_bgemm(_p(q), _p(k), _p(S), B, heads, T, T, d, Cc, Cc, T, T * Cc, d, T * Cc, d,
-                                      heads * T * T, T * T, 1, d ** -0.5, self._st()), "egr_bgemm(QK^T)")
+        s3 = self.mfma == "bf16x3" and d % 16 == 0 and T % 16 == 0 and Cc % 4 == 0
+        if s3:
+            native.check(self.L.egr_bgemm_nt_s3(_p(q), _p(k), _p(S), B, heads, T, T, d, Cc, Cc, T, T * Cc, d, T * Cc, d,
+                                                heads * T * T, T * T, d ** -0.5, self._st()), "egr_bgemm_nt_s3(QK^T)")
+        else:
+            native.check(self.L.egr_bgemm(_p(q), _p(k), _p(S), B, heads, T, T, d, Cc, Cc, T, T * Cc, d, T * Cc, d,
+                                          heads * T * T, T * T, 1, d ** -0.5, self._st()), "egr_bgemm(QK^T)")
         native.check(self.L.egr_softmax_rows(_p(S), B * heads * T, T, self._st()), "egr_softmax_rows")
         o = torch.empty((B * T, Cc), dtype=torch.float32, device=self.dev)
-        native.check(self.L.egr_bgemm(_p(S), _p(v), _p(o), B, heads, T, d, T, T, Cc, Cc, heads * T * T, T * T, T * Cc, d,
-                                      T * Cc, d, 0, 1.0, self._st()), "egr_bgemm(PV)")
+        if s3:
+            vt = torch.empty((B, Cc, T), dtype=torch.float32, device=self.dev)
+            native.check(self.L.egr_transpose_batched(_p(v), _p(vt), B, T, Cc, self._st()), "egr_transpose_batched")
+            native.check(self.L.egr_bgemm_nt_s3(_p(S), _p(vt), _p(o), B, heads, T, d, T, T, T, Cc, heads * T * T, T * T, Cc * T,
+                                                d * T, T * Cc, d, 1.0, self._st()), "egr_bgemm_nt_s3(PV)")
+        else:
+            native.check(self.L.egr_bgemm(_p(S), _p(v), _p(o), B, heads, T, d, T, T, Cc, Cc, heads * T * T, T * T, T * Cc, d,
+                                          T * Cc, d, 0, 1.0, self._st()), "egr_bgemm(PV)")
         if self.count_flops:
             self.flops += 4.0 * B * heads * T * T * d
         return o

@@ -217,6 +217,12 @@ int egr_gemm_zbatched(const float* x, const float* w, float* y, int nz, int rows
 int egr_winograd_output(const float* M, const float* bias, const float* res, float* y, int B, int H, int W, int N, int act,
                         void* stream);
 
+/* Strided batched C[b1][b2] = alpha * A (M x K, lda) * B^T (B is N x K, ldb) with BOTH fp32 operands split into three bf16
+ * terms by the loader (attention: Q K^T, and P V after egr_transpose_batched of V).  K % 16 == 0, 16-byte aligned rows;
+ * otherwise EGR_ERR_UNSUPPORTED (callers fall back to egr_bgemm). */
+int egr_bgemm_nt_s3(const float* a, const float* b, float* c, int nb1, int nb2, int M, int N, int K, int lda, int ldb, int ldc,
+                    int64_t sa1, int64_t sa2, int64_t sb1, int64_t sb2, int64_t sc1, int64_t sc2, float alpha, void* stream);
+
 /* Winograd F(4x4,3x3) (4x fewer multiplies; H and W multiples of 4): same three steps with 36 components,
  *   V [36][P][C], P = B*(H/4)*(W/4) tiles, V[6i+j] = (B^T d B)[i][j] of the 6x6 input tile at (4ty-1, 4tx-1);
  *   36 z-batched GEMMs (egr_conv_s3 / egr_gemm_zbatched with nz = 36); y = act(A^T M A + bias + res) per 4x4 output tile.

@@ -58,6 +58,9 @@ CONV_CASES = [
     (2, 12, 12, 32, 1, 3, 1, 1, 0),        # Cout = 1 (scalar weight path)
     (2, 9, 7, 130, 200, 1, 1, 0, 0),       # 1x1, Cin not a multiple of 16
     (1, 64, 32, 256, 256, 3, 1, 1, 0),
+    (1, 9, 7, 32, 256, 3, 1, 1, 0),        # 128x256 tile, ragged M
+    (2, 8, 8, 64, 512, 1, 1, 0, 0),        # 128x256 tile, 1x1
+    (1, 6, 10, 48, 256, 3, 1, 1, 1),       # 128x256 tile, nearest-2x input
 ]
 
 
@@ -302,7 +305,7 @@ def test_groupnorm_layernorm_softmax_geglu(eng):
     close(out, a * F.gelu(gate))
 
 
-@pytest.mark.parametrize("B,T,Cc,heads", [(2, 64, 32, 2), (1, 200, 64, 1), (2, 128, 96, 3)])
+@pytest.mark.parametrize("B,T,Cc,heads", [(2, 64, 32, 2), (1, 200, 64, 1), (2, 128, 96, 3), (1, 272, 128, 2), (2, 144, 1024, 1)])
 def test_attention_vs_torch(eng, B, T, Cc, heads):
     e, cfg, P = eng
     g = torch.Generator().manual_seed(T)
