@@ -256,7 +256,8 @@ def test_conv1d_vs_torch(eng, k, dil, stride):
 
 
 @pytest.mark.parametrize("Ci,Co,L,k,dil", [(16, 16, 256, 11, 5), (32, 32, 384, 7, 3), (64, 64, 128, 3, 1), (128, 128, 256, 11, 1),
-                                           (256, 256, 128, 7, 5), (48, 40, 256, 3, 3), (16, 130, 128, 11, 3)])
+                                           (256, 256, 128, 7, 5), (48, 40, 256, 3, 3), (16, 130, 128, 11, 3), (32, 32, 512, 11, 5),
+                                           (64, 64, 768, 7, 1), (16, 16, 1024, 3, 3)])
 def test_input_stationary_conv1d_vs_torch(eng, Ci, Co, L, k, dil):
     """Stride-1 'same' 1-D convolutions with L % 128 == 0 take k_conv1d_s3 (halo tile split once into LDS, every tap reads
     it at a row offset): all channel-chunk widths and tile variants, with bias + residual + leaky epilogue."""
