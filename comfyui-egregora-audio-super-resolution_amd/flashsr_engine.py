@@ -90,7 +90,7 @@ class FlashSREngine:
     def add_upsample_phases(self, key: str, v: torch.Tensor):
         """nearest-2x upsample followed by a 3x3 conv == four 2x2 convs on the low-res input, one per output phase
         (a, b): taps that read the same source pixel are pre-summed.  Registers key + '.ph{a}{b}'."""
-        v = v.detach().float()                                           # [Co,Ci,3,3]
+        v = v.detach().float().to(self.dev)                              # [Co,Ci,3,3]
         Co, Ci = v.shape[:2]
         for a in (0, 1):
             for b in (0, 1):
@@ -117,15 +117,16 @@ class FlashSREngine:
 
     def add_winograd(self, key: str, v: torch.Tensor):
         """U = G g G^T in float64 for Winograd F(2x2,3x3) (16 [Cin][Cout] matrices, key + '.wino') and, when enabled,
-        F(4x4,3x3) (36 matrices, key + '.wino4'); each matrix packed slab-major like a 1x1 conv weight."""
-        v = v.detach().double()                                         # [Co,Ci,3,3]
+        F(4x4,3x3) (36 matrices, key + '.wino4'); each matrix packed slab-major like a 1x1 conv weight.  Formed on the
+        device (fp64 einsum + packing): on the host this was most of the engine's 30 s start-up."""
+        v = v.detach().to(self.dev).double()                            # [Co,Ci,3,3]
         Ci = v.shape[1]
         for suffix, Gm in ((".wino", self._G2),) + (((".wino4", self._g4()),) if self.WINO_F4 else ()):
-            G = torch.tensor(Gm, dtype=torch.float64)
-            U = torch.einsum("ik,ockl,jl->ijco", G, v, G)               # [n,n,Ci,Co]
+            G = torch.tensor(Gm, dtype=torch.float64, device=self.dev)
+            U = torch.einsum("ik,ockl,jl->ijco", G, v, G).float()       # [n,n,Ci,Co]
             n = U.shape[0]
-            packed = torch.stack([self.pack_matrix(U[i, j].float().contiguous()) for i in range(n) for j in range(n)])
-            self.w[key + suffix] = packed.contiguous().to(self.dev)     # [n*n][Kp/16][Co][16]
+            packed = torch.stack([self.pack_matrix(U[i, j].contiguous()) for i in range(n) for j in range(n)])
+            self.w[key + suffix] = packed.contiguous()                  # [n*n][Kp/16][Co][16]
             self.wz[key + suffix] = packed[0].numel()                   # floats per component
             if Ci % 16 == 0:
                 self._split3(key + suffix)
@@ -177,7 +178,7 @@ class FlashSREngine:
     def add_weight(self, key: str, v: torch.Tensor):
         """Register a weight given in torch layout; self.w[key] holds the packed tensor, self.wshape[key] the
         logical (KH, KW, Cin, Cout)."""
-        v = v.detach().float()
+        v = v.detach().float().to(self.dev)                             # packed on the device
         if v.dim() == 4:                                                # conv2d [Co,Ci,kh,kw]
             Co, Ci, kh, kw = v.shape
             w2, shp = v.permute(2, 3, 1, 0).reshape(kh * kw * Ci, Co), (kh, kw, Ci, Co)
