@@ -553,3 +553,35 @@ def test_node_run_with_rate_conversion_both_sides(pack, eng, monkeypatch):
     got = res["waveform"][0].numpy()
     assert got.shape == want.shape
     assert float(np.abs(got - want).max()) <= 3e-3 * float(np.abs(want).max())
+
+
+def test_default_engine_within_north_star_lsd_of_the_strict_f32_engine(pack):
+    """Full-size FlashSR forward: the default engine (contractions as exact three-way bf16 splits on the bf16 matrix pipe,
+    Winograd F(4x4,3x3), z-streamed GEMMs, input-stationary 1-D convs) against the strict engine of the same layer table
+    (v_mfma_f32_32x32x2_f32 everywhere, no Winograd).  Bar = the north star's tolerance: LSD <= 1e-3 dB with the reference's
+    own metric (measured 2.6e-4 mean / 4.7e-4 p95), and every stage within 5e-5 relative L2 (measured <= 8.5e-6)."""
+    from egregora_amd import device_ops, flashsr_arch as A, flashsr_engine as E
+    cfg = A.FlashSRConfig()
+    P = A.init_params(cfg, 0)
+    old = (E.FlashSREngine.MFMA_MODE, E.FlashSREngine.WINO_MIN_CH)
+    try:
+        e_fast = E.FlashSREngine(cfg, P)
+        E.FlashSREngine.MFMA_MODE, E.FlashSREngine.WINO_MIN_CH = "f32", 1 << 30
+        e_ref = E.FlashSREngine(cfg, P)
+    finally:
+        E.FlashSREngine.MFMA_MODE, E.FlashSREngine.WINO_MIN_CH = old
+    assert e_fast.w3 and not e_ref.w3 and not any(k.endswith(".wino4") for k in e_ref.w)
+    rng = np.random.Generator(np.random.PCG64(202))
+    t = np.arange(cfg.chunk) / 48000.0
+    x = sum(np.sin(2 * np.pi * f * t + rng.uniform(0, 6.28)) / (k + 1) for k, f in enumerate(np.geomspace(80, 6000, 8)))
+    x = x + 0.01 * rng.standard_normal(cfg.chunk)
+    x = torch.from_numpy((0.5 * x / np.abs(x).max()).astype(np.float32))[None].repeat(2, 1).cuda()
+    nz = e_fast.noise(2, None, 7)
+    sa, sb = {}, {}
+    ya = e_fast.forward_rows(x, nz, stages=sa)
+    yb = e_ref.forward_rows(x, nz, stages=sb)
+    for k in ("mel", "z_cond", "v", "z0", "mel_hat", "y"):
+        assert rel_l2(sa[k], sb[k]) <= 5e-5, (k, rel_l2(sa[k], sb[k]))
+    mean, p95 = device_ops.lsd(ya[:1].contiguous(), yb[:1].contiguous())
+    assert mean <= 1e-3 and p95 <= 1e-3, (mean, p95)
+    assert device_ops.si_sdr(yb[:1].contiguous(), ya[:1].contiguous()) >= 90.0
