@@ -148,6 +148,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
     else conv_epilogue_rows<TM, TN, false>(p, acc, bv, yout, m0, n0, wm0, wn0);
 }
 
+// egr_nn_gemm.hip: 4 KiB of zeros on the current device (created on first use, one per device)
+int zero_page(const float** out);
+
 // egr_nn_gemm_s3.hip: launches k_conv_s3<bm, bn> (bm = s3_bm(...), bn in {32, 64, 128}; grid.x = ceil(M / bm));
 // p.w3 must be set and Cin % 16 == 0
 int s3_bn(int Cout);

@@ -423,8 +423,8 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmP p) {
         }
 }
 
-// per-device page of zeros the loaders read for padded / out-of-range rows
-static int zero_page(const float** out) {
+// per-device page of zeros the loaders read for padded / out-of-range rows (shared with egr_nn_gemm_s3.hip)
+int zero_page(const float** out) {
     static std::mutex mu;
     static std::map<int, float*> pages;
     int dev = 0;

@@ -714,11 +714,8 @@ extern "C" int egr_bgemm_nt_s3(const float* a, const float* b, float* c, int nb1
     EGR_CHECK(K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0 && sa1 % 4 == 0 &&
                   sa2 % 4 == 0 && sb1 % 4 == 0 && sb2 % 4 == 0, EGR_ERR_UNSUPPORTED,
               "split-bf16 batched GEMM needs K %% 16 == 0 and 16-byte aligned rows");
-    static float* zeros = nullptr;
-    if (!zeros) {
-        EGR_HIP(hipMalloc((void**)&zeros, 4096));
-        EGR_HIP(hipMemset(zeros, 0, 4096));
-    }
+    const float* zeros = nullptr;
+    { const int zrc = zero_page(&zeros); if (zrc) return zrc; }
     GemmS3P p;
     p.a = a; p.b = b; p.c = c; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.nb2 = nb2;
     p.sa1 = sa1; p.sa2 = sa2; p.sb1 = sb1; p.sb2 = sb2; p.sc1 = sc1; p.sc2 = sc2; p.alpha = alpha; p.zeros = zeros;
