@@ -6,14 +6,16 @@
 #include <stdlib.h>
 #include <vector>
 #include "egr_nn_gemm_s3.hip"
-namespace egr { void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); } }
+static float* g_zero_page = nullptr;
+namespace egr { int zero_page(const float** out) { *out = g_zero_page; return 0; }
+void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); } }
 int main(int argc, char** argv) {
     int B = 26, H = 128, W = 64, Ci = 512, Co = 512, k = 3, reps = 5;
     if (argc >= 7) { B = atoi(argv[1]); H = atoi(argv[2]); W = atoi(argv[3]); Ci = atoi(argv[4]); Co = atoi(argv[5]); k = atoi(argv[6]); }
     const long long M = (long long)B * H * W, K = (long long)k * k * Ci, ns = K / 16;
     float *x, *wp, *y, *zeros; void* w3;
     hipMalloc(&x, M * Ci * 4); hipMalloc(&wp, ns * Co * 16 * 4); hipMalloc(&y, M * Co * 4); hipMalloc(&w3, ns * 3 * Co * 32); hipMalloc(&zeros, 4096);
-    hipMemset(zeros, 0, 4096);
+    hipMemset(zeros, 0, 4096); g_zero_page = zeros;
     std::vector<float> h(M * Ci); const bool zero = getenv("S3_ZERO") != nullptr;
     for (auto& v : h) v = zero ? 0.f : (float)rand() / RAND_MAX - 0.5f; hipMemcpy(x, h.data(), M * Ci * 4, hipMemcpyHostToDevice);
     std::vector<float> hw(ns * Co * 16); for (auto& v : hw) v = zero ? 0.f : ((float)rand() / RAND_MAX - 0.5f) * 0.05f; hipMemcpy(wp, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
