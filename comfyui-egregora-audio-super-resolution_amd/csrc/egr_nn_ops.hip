@@ -734,6 +734,17 @@ extern "C" int egr_groupnorm_coeff(const float* x, const float* gamma, const flo
     return EGR_OK;
 }
 
+// scale / shift from statistics that already exist (stats[B][G][2] double: sum, sum of squares over HW * C/G elements)
+extern "C" int egr_groupnorm_coeff_from_stats(const double* stats, const float* gamma, const float* beta, int B, int HW, int C,
+                                              int G, float eps, float* scale, float* shift, void* stream) {
+    EGR_CHECK(stats && gamma && beta && scale && shift && B >= 1 && HW >= 1 && C >= 1 && G >= 1 && C % G == 0, EGR_ERR_ARG,
+              "bad argument");
+    hipLaunchKernelGGL(k_gn_coeff, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, gamma, beta, scale, shift,
+                       B, C, G, (double)HW * (C / G), eps);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
 extern "C" size_t egr_groupnorm_workspace_bytes(int B, int C, int G) {
     return sizeof(double) * (size_t)B * G * 2 + sizeof(float) * 2 * (size_t)B * C + 64;
 }

@@ -136,10 +136,12 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, i
 
 // y[b][4ty+a][4tx+c][n] = act((A^T M A)[a][c] + bias[n] + res[...]),  M[6 i + j][t][n].  RES / SILU are compile-time (loads
 // of the residual are then hoisted above the arithmetic instead of being waited for one by one).
-template <bool RES, bool SILU>
+// STATS: each thread also writes (sum, sum of squares) of its 64 outputs to part[t][n4] -- the GroupNorm statistics of y are
+// then a reduction over 1/32 of the tensor's bytes instead of another pass over y (egr_groupnorm_coeff_from_partials).
+template <bool RES, bool SILU, bool STATS>
 __global__ __launch_bounds__(256) void k_wino4_out(const float* __restrict__ Mx, const float* __restrict__ bias,
                                                     const float* __restrict__ res, int B, int H, int W, int N, int TH, int TW,
-                                                    float* __restrict__ y) {
+                                                    float* __restrict__ y, float2* __restrict__ part) {
     const int N4 = N >> 2;
     const long long P = (long long)B * TH * TW, total = P * N4;
     const size_t zs = (size_t)P * N;
@@ -161,6 +163,7 @@ __global__ __launch_bounds__(256) void k_wino4_out(const float* __restrict__ Mx,
         }
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (bias) bv = *(const float4*)(bias + 4 * n4);
+        float ps = 0.f, pq = 0.f;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const size_t off = (((size_t)b * H + 4 * ty + a) * W + 4 * tx) * N + 4 * n4;
@@ -180,8 +183,42 @@ __global__ __launch_bounds__(256) void k_wino4_out(const float* __restrict__ Mx,
                     v.z = v.z / (1.f + __expf(-v.z)); v.w = v.w / (1.f + __expf(-v.w));
                 }
                 *(float4*)(y + off + (size_t)c * N) = v;
+                if (STATS) {
+                    ps += (v.x + v.y) + (v.z + v.w);
+                    pq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                }
             }
         }
+        if (STATS) part[i] = make_float2(ps, pq);
+    }
+}
+
+// stats[b][g] = (sum, sum of squares) over image b's tiles and group g's channel quads of part[t][n4]; one workgroup per (g, b),
+// fixed summation order (deterministic), double accumulation.
+__global__ __launch_bounds__(256) void k_gn_from_partials(const float2* __restrict__ part, int tiles_per_image, int N4, int q4,
+                                                           double* __restrict__ stats) {
+    __shared__ double rs[256], rq[256];
+    const int g = blockIdx.x, b = blockIdx.y, G = gridDim.x;
+    const float2* pb = part + (size_t)b * tiles_per_image * N4 + (size_t)g * q4;
+    double s = 0.0, q = 0.0;
+    const long long n = (long long)tiles_per_image * q4;
+    for (long long e = threadIdx.x; e < n; e += 256) {
+        const long long t = e / q4;
+        const int j = (int)(e - t * q4);
+        const float2 v = pb[t * N4 + j];
+        s += (double)v.x;
+        q += (double)v.y;
+    }
+    rs[threadIdx.x] = s;
+    rq[threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { rs[threadIdx.x] += rs[threadIdx.x + o]; rq[threadIdx.x] += rq[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        stats[((size_t)b * G + g) * 2 + 0] = rs[0];
+        stats[((size_t)b * G + g) * 2 + 1] = rq[0];
     }
 }
 
@@ -223,18 +260,47 @@ extern "C" int egr_winograd4_input(const float* x, const float* gn_scale, const 
     return EGR_OK;
 }
 
+static int wino4_out_launch(const float* M, const float* bias, const float* res, float* y, int B, int H, int W, int N, int act,
+                            float2* part, hipStream_t st) {
+    const int TH = H / 4, TW = W / 4;
+    const long long n = (long long)B * TH * TW * (N / 4);
+    const dim3 g(grid1d(n)), blk(256);
+#define W4O(R_, S_, T_) hipLaunchKernelGGL((k_wino4_out<R_, S_, T_>), g, blk, 0, st, M, bias, res, B, H, W, N, TH, TW, y, part)
+    if (part) {
+        if (res && act) W4O(true, true, true); else if (res) W4O(true, false, true);
+        else if (act) W4O(false, true, true); else W4O(false, false, true);
+    } else {
+        if (res && act) W4O(true, true, false); else if (res) W4O(true, false, false);
+        else if (act) W4O(false, true, false); else W4O(false, false, false);
+    }
+#undef W4O
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
 extern "C" int egr_winograd4_output(const float* M, const float* bias, const float* res, float* y, int B, int H, int W, int N,
                                     int act, void* stream) {
     EGR_CHECK(M && y && B >= 1 && H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0 && N >= 4 && N % 4 == 0 &&
                   (act == 0 || act == 1), EGR_ERR_ARG, "F(4x4,3x3) output transform needs H, W, N multiples of 4");
-    const int TH = H / 4, TW = W / 4;
-    const long long n = (long long)B * TH * TW * (N / 4);
-    const dim3 g(grid1d(n)), blk(256);
-    hipStream_t st = (hipStream_t)stream;
-    if (res && act) hipLaunchKernelGGL((k_wino4_out<true, true>), g, blk, 0, st, M, bias, res, B, H, W, N, TH, TW, y);
-    else if (res) hipLaunchKernelGGL((k_wino4_out<true, false>), g, blk, 0, st, M, bias, res, B, H, W, N, TH, TW, y);
-    else if (act) hipLaunchKernelGGL((k_wino4_out<false, true>), g, blk, 0, st, M, bias, res, B, H, W, N, TH, TW, y);
-    else hipLaunchKernelGGL((k_wino4_out<false, false>), g, blk, 0, st, M, bias, res, B, H, W, N, TH, TW, y);
+    return wino4_out_launch(M, bias, res, y, B, H, W, N, act, nullptr, (hipStream_t)stream);
+}
+
+// same, and part[B*(H/4)*(W/4)][N/4] float2 receives every thread's (sum, sum of squares) of its 4 x 4 x 4 outputs
+extern "C" int egr_winograd4_output_stats(const float* M, const float* bias, const float* res, float* y, int B, int H, int W,
+                                          int N, int act, void* part, void* stream) {
+    EGR_CHECK(M && y && part && B >= 1 && H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0 && N >= 4 && N % 4 == 0 &&
+                  (act == 0 || act == 1), EGR_ERR_ARG, "F(4x4,3x3) output transform needs H, W, N multiples of 4");
+    return wino4_out_launch(M, bias, res, y, B, H, W, N, act, (float2*)part, (hipStream_t)stream);
+}
+
+// stats[B][G][2] (double: sum, sum of squares per image and group) from the partials of egr_winograd4_output_stats;
+// requires (C / G) % 4 == 0.  Feed egr_groupnorm_coeff_from_stats.
+extern "C" int egr_groupnorm_stats_from_partials(const void* part, int B, int tiles_per_image, int C, int G, double* stats,
+                                                 void* stream) {
+    EGR_CHECK(part && stats && B >= 1 && B <= 65535 && tiles_per_image >= 1 && C >= 4 && G >= 1 && C % G == 0 && (C / G) % 4 == 0,
+              EGR_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_gn_from_partials, dim3(G, B), dim3(256), 0, (hipStream_t)stream, (const float2*)part, tiles_per_image, C / 4,
+                       (C / G) / 4, stats);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }

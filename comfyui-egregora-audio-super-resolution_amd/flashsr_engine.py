@@ -171,9 +171,20 @@ class FlashSREngine:
             self.flops += fl
         y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=self.dev)
         bt = bias_t if bias_t is not None else self.w.get(key + ".bias")
-        native.check(fn_out(_p(Mx), _p(bt), _p(res), _p(y), B, H, W, Cout, 1 if act == ACT_SILU else 0, self._st()),
-                     "egr_winograd_output")
+        G = self.cfg.gn_groups
+        if f4 and self.GN_PARTIALS and Cout % G == 0 and (Cout // G) % 4 == 0:
+            # the output transform also leaves per-thread (sum, sum of squares): a GroupNorm of y then reads 1/32 of its bytes
+            part = torch.empty((P, Cout // 4, 2), dtype=torch.float32, device=self.dev)
+            native.check(self.L.egr_winograd4_output_stats(_p(Mx), _p(bt), _p(res), _p(y), B, H, W, Cout,
+                                                           1 if act == ACT_SILU else 0, _p(part), self._st()),
+                         "egr_winograd4_output_stats")
+            y._egr_gn_partials = (part, TH * TW)
+        else:
+            native.check(fn_out(_p(Mx), _p(bt), _p(res), _p(y), B, H, W, Cout, 1 if act == ACT_SILU else 0, self._st()),
+                         "egr_winograd_output")
         return y
+
+    GN_PARTIALS = os.environ.get("EGREGORA_FLASHSR_GN_PARTIALS", "1") != "0"
 
     def add_weight(self, key: str, v: torch.Tensor):
         """Register a weight given in torch layout; self.w[key] holds the packed tensor, self.wshape[key] the
@@ -356,6 +367,16 @@ class FlashSREngine:
             self._gn_ws = torch.empty(int(need) + 1024, dtype=torch.uint8, device=self.dev)
         sc = torch.empty((B, Cc), dtype=torch.float32, device=self.dev)
         sh = torch.empty((B, Cc), dtype=torch.float32, device=self.dev)
+        gp = getattr(x, "_egr_gn_partials", None)
+        if gp is not None:           # x came out of egr_winograd4_output_stats: reduce its partials instead of re-reading x
+            part, tiles = gp
+            stats = torch.empty((B, G, 2), dtype=torch.float64, device=self.dev)
+            native.check(self.L.egr_groupnorm_stats_from_partials(_p(part), B, tiles, Cc, G, _p(stats), self._st()),
+                         "egr_groupnorm_stats_from_partials")
+            native.check(self.L.egr_groupnorm_coeff_from_stats(_p(stats), _p(self.w[key + ".weight"]), _p(self.w[key + ".bias"]), B,
+                                                               HW, Cc, G, eps, _p(sc), _p(sh), self._st()),
+                         "egr_groupnorm_coeff_from_stats")
+            return sc, sh
         native.check(self.L.egr_groupnorm_coeff(_p(x), _p(self.w[key + ".weight"]), _p(self.w[key + ".bias"]), B, HW, Cc, G,
                                                 eps, _p(self._gn_ws), _p(sc), _p(sh), self._st()), "egr_groupnorm_coeff")
         return sc, sh

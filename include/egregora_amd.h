@@ -234,6 +234,15 @@ int egr_winograd4_input(const float* x, const float* gn_scale, const float* gn_s
                         float* V, void* stream);
 int egr_winograd4_output(const float* M, const float* bias, const float* res, float* y, int B, int H, int W, int N, int act,
                          void* stream);
+/* GroupNorm statistics of y without another pass over it: egr_winograd4_output_stats also writes every thread's (sum, sum of
+ * squares) over its 4x4 pixels x 4 channels to part [B*(H/4)*(W/4)][N/4] float2 (1/32 of y's bytes);
+ * egr_groupnorm_stats_from_partials reduces them to stats [B][G][2] double in a fixed order (no atomics; (N/G) % 4 == 0);
+ * egr_groupnorm_coeff_from_stats turns statistics into the per-(b, c) scale / shift the consumer applies. */
+int egr_winograd4_output_stats(const float* M, const float* bias, const float* res, float* y, int B, int H, int W, int N,
+                               int act, void* part, void* stream);
+int egr_groupnorm_stats_from_partials(const void* part, int B, int tiles_per_image, int C, int G, double* stats, void* stream);
+int egr_groupnorm_coeff_from_stats(const double* stats, const float* gamma, const float* beta, int B, int HW, int C, int G,
+                                   float eps, float* scale, float* shift, void* stream);
 
 /* GroupNorm split in two: egr_groupnorm_coeff computes the statistics and the per-(b, c) scale/shift ([B][C] each);
  * egr_conv_nhwc_gn is egr_conv_nhwc (no dilation / upsample / placement) with x*scale + shift (+SiLU) applied to the

@@ -193,6 +193,41 @@ def test_winograd4_error_vs_float64(eng):
         e.w.pop("w4.weight.wino"), e.w.pop("w4.weight.wino4")
 
 
+def test_groupnorm_statistics_from_winograd_output_partials(eng):
+    """The F(4x4) output transform leaves per-thread (sum, sum of squares); GroupNorm coefficients of its output formed from
+    those partials (no second pass over y, fixed summation order) equal the ones computed from y itself."""
+    e, cfg, P = eng
+    g = torch.Generator().manual_seed(47)
+    old = e.cfg.gn_groups
+    try:
+        for (B, H, W, Ci, Co, G, use_res, act) in [(2, 8, 12, 32, 64, 8, True, 1), (3, 16, 8, 64, 128, 32, False, 0), (1, 4, 4, 16, 48, 4, True, 0)]:
+            e.cfg.gn_groups = G
+            x = torch.randn(B, Ci, H, W, generator=g)
+            w = torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9)
+            b = torch.randn(Co, generator=g)
+            res = torch.randn(B, Co, H, W, generator=g)
+            ga, be = 1 + 0.1 * torch.randn(Co, generator=g), 0.1 * torch.randn(Co, generator=g)
+            e.add_weight("wp.weight", w)
+            e.add_winograd("wp.weight", w)
+            e.w["wp.bias"] = b.cuda()
+            e.w["gp.weight"], e.w["gp.bias"] = ga.cuda(), be.cuda()
+            y = e._conv_winograd(nhwc(x).cuda(), "wp", act, nhwc(res).cuda() if use_res else None, None)
+            assert hasattr(y, "_egr_gn_partials")
+            sc, sh = e.gn_coeff(y, "gp", 1e-6)
+            del y._egr_gn_partials
+            sc2, sh2 = e.gn_coeff(y, "gp", 1e-6)                  # statistics kernel over y itself
+            yd = nchw(y).cpu().double().view(B, G, Co // G, H * W)
+            mean, var = yd.mean(dim=(2, 3)), yd.var(dim=(2, 3), unbiased=False)
+            want_sc = (ga.double().view(1, G, -1) / (var + 1e-6).sqrt().unsqueeze(-1)).reshape(B, Co)
+            want_sh = be.double().view(1, Co) - (mean.unsqueeze(-1) * want_sc.view(B, G, -1)).reshape(B, Co)
+            for got_sc, got_sh in ((sc, sh), (sc2, sh2)):
+                assert float((got_sc.cpu().double() - want_sc).abs().max() / want_sc.abs().max()) <= 2e-6
+                assert float((got_sh.cpu().double() - want_sh).abs().max()) <= 2e-6 * float(want_sh.abs().max() + 1.0)
+            e.w.pop("wp.weight.wino"), e.w.pop("wp.weight.wino4")
+    finally:
+        e.cfg.gn_groups = old
+
+
 def test_fused_groupnorm_conv_vs_torch(eng):
     """conv3x3(silu(groupnorm(x))) with the normalisation applied in the conv loader / the Winograd input transform."""
     e, cfg, P = eng
