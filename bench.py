@@ -235,7 +235,12 @@ def main():
                                   "avg_launch_ms": dom_ms, "k_row_ms": kt["row_ms"], "k_col_ms": kt["col_ms"],
                                   "launches": [kt["row_launches"], kt["col_launches"]], "concurrent_pipelines": groups,
                                   # all loop launches' algorithmic bytes / the stage's wall time (pipelines overlap)
-                                  "effective_gbs": (kt["row_launches"] + kt["col_launches"]) * row_bytes / (el_fl * 1e9)},
+                                  "effective_gbs": (kt["row_launches"] + kt["col_launches"]) * row_bytes / (el_fl * 1e9),
+                                  # SURVEY 8(d)'s figure for UNFUSED passes (32 N bytes per iteration per channel: 4 transform
+                                  # passes each reading and writing the state) over the stage time; this design moves half of it
+                                  "survey_32N": {"bytes_total": 32.0 * SEG * C * args.iters,
+                                                 "achieved": 32.0 * SEG * C * args.iters / (el_fl * 1e9),
+                                                 "frac": 32.0 * SEG * C * args.iters / (el_fl * 1e9) / HBM_PEAK_GBS}},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_fatllama(x_all[:, :SEG].cpu().numpy(), args.cpu_budget)
