@@ -60,6 +60,7 @@ struct RowP {
     const cplx* wk;        // W_(2L)^k = W_N^(R*k), k < L
     float thr2, inv_M;
     const float* gain;     // optional [C][M+1] real gain per half-spectrum bin (replaces the threshold)
+    int phat;              // 1: the state is z = a + i b of two REAL signals; replace it by the PHAT-weighted cross-spectrum
 };
 
 __device__ __forceinline__ void atomic_max_abs(unsigned* slot, float v) {
@@ -203,6 +204,16 @@ __global__ __launch_bounds__(1024) void k_row(RowP p, long long M, cplx* __restr
         // E = (Za + conj Zb)/2 ; O = (Za - conj Zb)/(2i)
         const cplx E = make_float2(0.5f * (Za.x + Zb.x), 0.5f * (Za.y - Zb.y));
         const cplx O = make_float2(0.5f * (Za.y + Zb.y), -0.5f * (Za.x - Zb.x));
+        if (p.phat) {
+            // two-for-one: A[k] = E, B[k] = O are the spectra of a and b; R = B conj(A) / (|B conj(A)| + 1e-12) is the spectrum
+            // of the real GCC-PHAT sequence, so the new state is W[k] = R, W[M-k] = conj(R) (times 1/M for the inverse passes)
+            cplx Rk = cmulc(O, E);
+            const float inv = sc / (sqrtf(Rk.x * Rk.x + Rk.y * Rk.y) + 1e-12f);
+            Rk.x *= inv; Rk.y *= inv;
+            cur[k2] = Rk;
+            if (!same) rb[pb] = make_float2(Rk.x, -Rk.y);
+            continue;
+        }
         const cplx WO = cmul(Wk, O);
         cplx Xk = cadd(E, WO);      // X[k]
         cplx Xm = csub(E, WO);      // conj X[M-k]
@@ -983,6 +994,7 @@ extern "C" int egr_spectral_gain(egr_fatllama_plan* p, const float* x, const flo
     ColP A = p->colA, B = p->colB;
     RowP R = p->row;
     R.gain = gain;
+    R.phat = 0;
     const dim3 gA(8 * A.tiles_per_xcd, C), gB(8 * B.tiles_per_xcd, C * (three ? B.nplanes : 1)), grow(R.R / 2 + 1, C), blk(256);
     const size_t lc = p->sp.lds_col, lb = p->sp.lds_colb, lr = p->sp.lds_row;
     hipLaunchKernelGGL(k_col<0>, gA, blk, lc, st, A, M, N, -1.0f, p->d_work, const_cast<float*>(x), (unsigned*)nullptr);
@@ -990,6 +1002,89 @@ extern "C" int egr_spectral_gain(egr_fatllama_plan* p, const float* x, const flo
     hipLaunchKernelGGL(k_row, grow, blk, lr, st, R, M, p->d_work);
     if (three) hipLaunchKernelGGL(k_col<3>, gB, blk, lb, st, B, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
     hipLaunchKernelGGL(k_col<5>, gA, blk, lc, st, A, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// GCC-PHAT delay estimate on the same transform passes (reference _xcorr_delay, egregora_null_test_suite.py:213-237):
+// z = a + i b (zero-padded to n = 2^k >= len(a) + len(b)) is the packed state of a plan for N = 2n "real" samples; the row
+// pass's hook turns it into the PHAT-weighted cross-spectrum, the inverse passes return the correlation in the real parts.
+namespace egr {
+
+__global__ __launch_bounds__(256) void k_phat_pack(const float* __restrict__ a, long long na, const float* __restrict__ b,
+                                                    long long nb, long long n, float2* __restrict__ z) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        z[i] = make_float2(i < na ? a[i] : 0.f, i < nb ? b[i] : 0.f);
+}
+
+// cc_c = concat(cc[-(n/2-1):], cc[:n/2+1]), centre = n/2: cc_c[j] = cc[(j + n/2 + 1) mod n].  First maximum of
+// cc_c[centre - ms .. centre + ms]; out = {index (int bits), cc_c[idx-1], cc_c[idx], cc_c[idx+1]}.  ONE workgroup.
+__global__ __launch_bounds__(1024) void k_phat_peak(const float2* __restrict__ y, long long n, long long ms,
+                                                     float* __restrict__ out4) {
+    __shared__ float bv[1024];
+    __shared__ long long bi[1024];
+    const long long centre = n / 2, sl = centre - ms, cnt = 2 * ms + 1;
+    float best = -INFINITY;
+    long long besti = sl;
+    for (long long t = threadIdx.x; t < cnt; t += 1024) {
+        const long long j = sl + t;
+        const float v = y[(j + n / 2 + 1) % n].x;
+        if (v > best) { best = v; besti = j; }          // ascending t per thread: keeps the first maximum
+    }
+    bv[threadIdx.x] = best;
+    bi[threadIdx.x] = besti;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const float v2 = bv[threadIdx.x + o];
+            const long long i2 = bi[threadIdx.x + o];
+            if (v2 > bv[threadIdx.x] || (v2 == bv[threadIdx.x] && i2 < bi[threadIdx.x])) { bv[threadIdx.x] = v2; bi[threadIdx.x] = i2; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const long long idx = bi[0];
+        out4[0] = __int_as_float((int)(idx - centre));
+        const bool inner = idx >= 1 && idx < n - 1;
+        out4[1] = inner ? y[(idx - 1 + n / 2 + 1) % n].x : 0.f;
+        out4[2] = y[(idx + n / 2 + 1) % n].x;
+        out4[3] = inner ? y[(idx + 1 + n / 2 + 1) % n].x : 0.f;
+    }
+}
+
+}  // namespace egr
+
+using namespace egr;
+
+// plan: egr_fatllama_plan_create(&plan, 2 n, 1, 1, ...) with n = 2^k >= na + nb; work: 4 n floats of device memory
+// (z and the correlation, interleaved pairs); out4 (device, 4 floats): {peak index - n/2 as int bits, y0, y1, y2}.
+extern "C" int egr_gcc_phat(egr_fatllama_plan* p, const float* a, int64_t na, const float* b, int64_t nb, int64_t max_shift,
+                            float* work, float* out4, void* stream) {
+    EGR_CHECK(p && a && b && work && out4 && na >= 1 && nb >= 1, EGR_ERR_ARG, "null / empty argument");
+    EGR_CHECK(!p->bluestein && p->factor == 1 && p->C == 1, EGR_ERR_UNSUPPORTED, "GCC-PHAT needs a one-channel packed-real plan");
+    const long long M = p->sp.M, N = p->sp.N, n = M;
+    EGR_CHECK((n & (n - 1)) == 0 && n >= na + nb, EGR_ERR_ARG, "plan length must be 2 n with n = 2^k >= na + nb");
+    EGR_CHECK(max_shift >= 0 && max_shift < n / 2 - 1, EGR_ERR_ARG, "max_shift out of range");
+    hipStream_t st = (hipStream_t)stream;
+    const bool three = p->sp.levels == 3;
+    ColP A = p->colA, B = p->colB;
+    RowP R = p->row;
+    R.gain = nullptr;
+    R.phat = 1;
+    float* z = work;
+    float* y = work + 2 * n;
+    long long nbk = (n + 255) / 256;
+    if (nbk > 4096) nbk = 4096;
+    hipLaunchKernelGGL(k_phat_pack, dim3((unsigned)nbk), dim3(256), 0, st, a, (long long)na, b, (long long)nb, n, (float2*)z);
+    const dim3 gA(8 * A.tiles_per_xcd, 1), gB(8 * B.tiles_per_xcd, three ? B.nplanes : 1), grow(R.R / 2 + 1, 1), blk(256);
+    const size_t lc = p->sp.lds_col, lb = p->sp.lds_colb, lr = p->sp.lds_row;
+    hipLaunchKernelGGL(k_col<0>, gA, blk, lc, st, A, M, N, -1.0f, p->d_work, z, (unsigned*)nullptr);
+    if (three) hipLaunchKernelGGL(k_col<4>, gB, blk, lb, st, B, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
+    hipLaunchKernelGGL(k_row, grow, blk, lr, st, R, M, p->d_work);
+    if (three) hipLaunchKernelGGL(k_col<3>, gB, blk, lb, st, B, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
+    hipLaunchKernelGGL(k_col<5>, gA, blk, lc, st, A, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
+    hipLaunchKernelGGL(k_phat_peak, dim3(1), dim3(1024), 0, st, (const float2*)y, n, (long long)max_shift, out4);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }

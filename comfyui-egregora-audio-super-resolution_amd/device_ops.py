@@ -121,3 +121,33 @@ def resample_linear(x_ct: torch.Tensor, n_out: int) -> torch.Tensor:
     native.check(native.lib().egr_resample_linear(native.ptr(x), x.shape[0], x.shape[1], native.ptr(y), int(n_out),
                                                    native.stream_ptr()), "egr_resample_linear")
     return y
+
+
+def xcorr_delay(a: torch.Tensor, b: torch.Tensor, sr: int, max_shift_smp: int) -> float:
+    """Delay of b against a in samples by GCC-PHAT with a parabolic refinement, as the reference's _xcorr_delay
+    (egregora_null_test_suite.py:213-237) -- including its convention: the centred correlation puts lag 0 one index left of
+    the centre, so the value returned is the true lag minus one (reference quirk Q8, reproduced because callers compensate
+    with this very number).  a, b: 1-D float32 CUDA tensors; the whole-signal transforms run on the Fat-Llama passes."""
+    import ctypes as C
+    from . import fatllama_engine as fe
+    a, b = a.contiguous(), b.contiguous()
+    _chk(a, "xcorr_delay"), _chk(b, "xcorr_delay")
+    n = 1
+    while n < a.numel() + b.numel():
+        n <<= 1
+    plan = fe._plan(2 * n, 1, 1, a.device.index or 0)
+    work = torch.empty(4 * n, dtype=torch.float32, device=a.device)
+    out4 = torch.empty(4, dtype=torch.float32, device=a.device)
+    native.check(native.lib().egr_gcc_phat(C.c_void_p(plan), native.ptr(a), a.numel(), native.ptr(b), b.numel(),
+                                           int(max_shift_smp), native.ptr(work), native.ptr(out4), native.stream_ptr()),
+                 "egr_gcc_phat")
+    o = out4.cpu()
+    rel = int(o[:1].view(torch.int32)[0])
+    y0, y1, y2 = (float(v) for v in o[1:])
+    centre = n // 2
+    idx = centre + rel
+    frac = 0.0
+    if 1 <= idx < n - 1:
+        denom = 2 * (y0 - 2 * y1 + y2)
+        frac = 0.0 if abs(denom) < 1e-12 else (y0 - y2) / denom
+    return float(rel + frac)

@@ -119,6 +119,14 @@ int egr_dfn_mix(const float* dry, const float* wet, const float* g_dry, const fl
  * j * n_in / n_out input samples, clamped to the last sample (egregora_audio_eval_pack.py:515-519). */
 int egr_resample_linear(const float* x, int channels, int64_t n_in, float* y, int64_t n_out, void* stream);
 
+/* GCC-PHAT delay estimate (the null-test suite's _xcorr_delay, egregora_null_test_suite.py:213-237) on the Fat-Llama transform
+ * passes: z = a + i b zero-padded to n = 2^k >= na + nb is the packed state of a ONE-channel plan created for 2 n samples
+ * (egr_fatllama_plan_create(&plan, 2 n, 1, 1, 0, 0)); the row pass turns it into B conj(A) / (|B conj(A)| + 1e-12), the inverse
+ * passes give the correlation.  work: 4 n floats; out4 (device): {first-maximum index of the centred correlation within
+ * +-max_shift, relative to n/2, as int bits; its two neighbours and itself} for the host's parabolic refinement. */
+int egr_gcc_phat(egr_fatllama_plan* plan, const float* a, int64_t na, const float* b, int64_t nb, int64_t max_shift, float* work,
+                 float* out4, void* stream);
+
 /* Evaluation metrics on the device (the parity yardstick of this pack and the reference's "Metrics (LSD + SI-SDR)" node):
  *   egr_lsd_frames  : per[f] = sqrt(mean_k (20 log10(SA[f][k]+1e-12) - 20 log10(SB[f][k]+1e-12))^2 + 1e-12) from two
  *                     frame-major magnitude arrays of egr_stft_mag          (_lsd, egregora_audio_eval_pack.py:405-411)
