@@ -151,7 +151,7 @@ def test_winograd_conv_vs_torch(eng, f4):
     oldf4 = type(e).WINO_F4
     type(e).WINO_F4 = f4
     for (B, H, W, Ci, Co, use_res, act) in [(2, 8, 12, 32, 48, True, 1), (1, 16, 16, 64, 128, False, 0), (3, 6, 4, 144, 80, True, 0),
-                                            (2, 4, 4, 16, 20, True, 1)]:
+                                            (2, 4, 4, 16, 20, True, 1), (1, 8, 8, 24, 36, False, 1)]:     # last: Cin % 16 != 0 (f32 GEMMs)
         x = torch.randn(B, Ci, H, W, generator=g)
         w = torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9)
         b = torch.randn(Co, generator=g)
