@@ -11,6 +11,7 @@ from .egregora_fat_llama_cpu import EgregoraFatLlamaCPU
 from .egregora_fat_llama_gpu import EgregoraFatLlamaGPU
 from .egregora_audio_eval_pack import (NODE_CLASS_MAPPINGS as EVAL_MAP, NODE_DISPLAY_NAME_MAPPINGS as EVAL_NAMES)
 from .egregora_audio_enhance_extras import (NODE_CLASS_MAPPINGS as ENHANCE_MAP, NODE_DISPLAY_NAME_MAPPINGS as ENHANCE_NAMES)
+from .egregora_null_test_suite import (NODE_CLASS_MAPPINGS as NULL_MAP, NODE_DISPLAY_NAME_MAPPINGS as NULL_NAMES)
 
 NODE_CLASS_MAPPINGS = {
     "EgregoraAudioUpscaler": EgregoraAudioSuperResolution,
@@ -26,7 +27,9 @@ NODE_DISPLAY_NAME_MAPPINGS = {
 
 NODE_CLASS_MAPPINGS.update(ENHANCE_MAP)
 NODE_CLASS_MAPPINGS.update(EVAL_MAP)
+NODE_CLASS_MAPPINGS.update(NULL_MAP)
 NODE_DISPLAY_NAME_MAPPINGS.update(ENHANCE_NAMES)
 NODE_DISPLAY_NAME_MAPPINGS.update(EVAL_NAMES)
+NODE_DISPLAY_NAME_MAPPINGS.update(NULL_NAMES)
 
 __all__ = ["NODE_CLASS_MAPPINGS", "NODE_DISPLAY_NAME_MAPPINGS"]
