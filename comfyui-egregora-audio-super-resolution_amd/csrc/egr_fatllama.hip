@@ -61,6 +61,8 @@ struct RowP {
     float thr2, inv_M;
     const float* gain;     // optional [C][M+1] real gain per half-spectrum bin (replaces the threshold)
     int phat;              // 1: the state is z = a + i b of two REAL signals; replace it by the PHAT-weighted cross-spectrum
+    long long band_lo;     // > 0: keep half-spectrum bins k >= band_lo, zero the others (replaces the threshold); band = 1 selects it
+    int band;
 };
 
 __device__ __forceinline__ void atomic_max_abs(unsigned* slot, float v) {
@@ -217,7 +219,11 @@ __global__ __launch_bounds__(1024) void k_row(RowP p, long long M, cplx* __restr
         const cplx WO = cmul(Wk, O);
         cplx Xk = cadd(E, WO);      // X[k]
         cplx Xm = csub(E, WO);      // conj X[M-k]
-        if (p.gain) {
+        if (p.band) {
+            const long long k = (long long)oa + (long long)R * k2;
+            if (k < p.band_lo) Xk = make_float2(0.f, 0.f);
+            if (M - k < p.band_lo) Xm = make_float2(0.f, 0.f);
+        } else if (p.gain) {
             const long long k = (long long)oa + (long long)R * k2;
             const float* g = p.gain + (size_t)ch * (M + 1);
             const float gk = g[k], gm = g[M - k];
@@ -254,6 +260,8 @@ struct ChirpP {
     Tw2 w;                   // W_(2N)^r
     unsigned long long N;    // transform length
     float inv_N;
+    int band;                // 1: the spectrum hook keeps bins min(n, N - n) >= band_lo instead of thresholding
+    unsigned long long band_lo;
 };
 __device__ __forceinline__ cplx chirp(const ChirpP& c, unsigned long long n) {
     const unsigned long long r = (n * n) % (2ULL * c.N);
@@ -329,7 +337,9 @@ __global__ __launch_bounds__(256) void k_colz(ColP p, ChirpP cp, long long P, fl
                 const cplx cc = cur[e];
                 if (HOOK == 1) {                 // X = w c ; threshold ; a' = conj(X) w
                     cplx X = cmul(w, cc);
-                    if (!(X.x * X.x + X.y * X.y > thr2)) X = make_float2(0.f, 0.f);
+                    if (cp.band) {
+                        if ((n < N - n ? n : N - n) < cp.band_lo) X = make_float2(0.f, 0.f);
+                    } else if (!(X.x * X.x + X.y * X.y > thr2)) X = make_float2(0.f, 0.f);
                     v = cmul(make_float2(X.x, -X.y), w);
                 } else {                         // d = Re(w c)/N ; a = d w
                     const float d = (w.x * cc.x - w.y * cc.y) * cp.inv_N;
@@ -1002,6 +1012,51 @@ extern "C" int egr_spectral_gain(egr_fatllama_plan* p, const float* x, const flo
     hipLaunchKernelGGL(k_row, grow, blk, lr, st, R, M, p->d_work);
     if (three) hipLaunchKernelGGL(k_col<3>, gB, blk, lb, st, B, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
     hipLaunchKernelGGL(k_col<5>, gA, blk, lc, st, A, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+// y = irfft(rfft(x) * [k >= band_lo]) per channel: the brick-wall high band of x at ITS OWN length (any plan kind, factor 1).
+// Serves the null-test suite's _band_energy_hi_db (egregora_null_test_suite.py:192-199): by Parseval the band energies of the
+// length-N rfft follow from time-domain sums over x and y (egr_band_sums).
+extern "C" int egr_band_filter(egr_fatllama_plan* p, const float* x, int64_t band_lo, float* y, void* stream) {
+    EGR_CHECK(p && x && y && band_lo >= 0, EGR_ERR_ARG, "bad argument");
+    EGR_CHECK(p->factor == 1, EGR_ERR_UNSUPPORTED, "band filter needs a plan with factor 1");
+    hipStream_t st = (hipStream_t)stream;
+    const int C = p->C;
+    const long long M = p->sp.M, N = p->sp.N;
+    const bool three = p->sp.levels == 3;
+    ColP A = p->colA, B = p->colB;
+    RowP R = p->row;
+    R.gain = nullptr; R.phat = 0; R.band = 1; R.band_lo = band_lo;
+    const dim3 gA(8 * A.tiles_per_xcd, C), gB(8 * B.tiles_per_xcd, C * (three ? B.nplanes : 1)), blk(256);
+    const size_t lc = p->sp.lds_col, lb = p->sp.lds_colb, lr = p->sp.lds_row;
+    float* xs = const_cast<float*>(x);          // read only (MODE 0 passes)
+    if (p->bluestein) {
+        ChirpP cp = p->chirp;
+        cp.band = 1; cp.band_lo = (unsigned long long)band_lo;
+        const long long P = M;
+        const dim3 grc((R.R + 1) / 2, C);
+        unsigned* pk = p->d_peaks + C;
+        auto conv = [&]() {
+            if (three) hipLaunchKernelGGL(k_col<4>, gB, blk, lb, st, B, P, N, 0.f, p->d_work, y, pk);
+            hipLaunchKernelGGL(k_rowconv<true>, grc, blk, lr, st, R.f, R.L, R.R, R.tw, (const cplx*)p->d_bhat, 1.0f, P, p->d_work);
+            if (three) hipLaunchKernelGGL(k_col<3>, gB, blk, lb, st, B, P, N, 0.f, p->d_work, y, pk);
+        };
+        hipLaunchKernelGGL((k_colz<0, 0>), gA, blk, lc, st, A, cp, P, -1.0f, 0.f, p->d_work, xs, pk);
+        conv();
+        hipLaunchKernelGGL((k_colz<1, 1>), gA, blk, lc, st, A, cp, P, 0.f, 0.f, p->d_work, y, pk);
+        conv();
+        EGR_HIP(hipMemsetAsync(y, 0, (size_t)C * cp.N * sizeof(float), st));      // the closing pass adds d to what y holds
+        hipLaunchKernelGGL((k_colz<2, 0>), gA, blk, lc, st, A, cp, P, 0.f, 0.f, p->d_work, y, pk);
+    } else {
+        const dim3 grow(R.R / 2 + 1, C);
+        hipLaunchKernelGGL(k_col<0>, gA, blk, lc, st, A, M, N, -1.0f, p->d_work, xs, (unsigned*)nullptr);
+        if (three) hipLaunchKernelGGL(k_col<4>, gB, blk, lb, st, B, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
+        hipLaunchKernelGGL(k_row, grow, blk, lr, st, R, M, p->d_work);
+        if (three) hipLaunchKernelGGL(k_col<3>, gB, blk, lb, st, B, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
+        hipLaunchKernelGGL(k_col<5>, gA, blk, lc, st, A, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
+    }
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }

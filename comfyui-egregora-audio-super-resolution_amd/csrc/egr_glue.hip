@@ -413,6 +413,124 @@ __global__ __launch_bounds__(256) void k_shift_fir(const float* __restrict__ x, 
     }
 }
 
+// ---------------------------------------------------------------- null-test suite levels and sums (egregora_null_test_suite.py:119-165, 420-470)
+// K-weighting approximation of the suite's loudness: z = (1-k) x + k z, y = x - z (each product and sum rounded to float32 as numpy's
+// scalar loop does), then y[n] += 0.02 (y[n] - y[n-1]).  The recurrence contracts by k per sample, so a thread restarts it W samples
+// ahead of its L-sample chunk (k^W < 1e-11: below float32 resolution of the state).
+__global__ __launch_bounds__(64) void k_kweight(const float* __restrict__ x, long long n, float a1, float kf, int L, int W,
+                                                float* __restrict__ y) {
+    const long long s = ((long long)blockIdx.x * 64 + threadIdx.x) * L;
+    if (s >= n) return;
+    const float* xc = x + (size_t)blockIdx.y * n;
+    float* yc = y + (size_t)blockIdx.y * n;
+    long long i = s - W - 1;
+    if (i < 0) i = 0;
+    float z = 0.f, yp = 0.f;
+    for (; i < s; ++i) {
+        const float xv = xc[i];
+        z = __fadd_rn(__fmul_rn(a1, xv), __fmul_rn(kf, z));
+        yp = __fsub_rn(xv, z);
+    }
+    const long long e = s + L < n ? s + L : n;
+    for (; i < e; ++i) {
+        const float xv = xc[i];
+        z = __fadd_rn(__fmul_rn(a1, xv), __fmul_rn(kf, z));
+        const float yv = __fsub_rn(xv, z);
+        yc[i] = i > 0 ? __fadd_rn(yv, __fmul_rn(0.02f, __fsub_rn(yv, yp))) : yv;
+        yp = yv;
+    }
+}
+
+// mean over channels as numpy's float32 .mean(axis=0): rows added in order, one division
+__device__ __forceinline__ float mono_mean(const float* __restrict__ x, int C, long long ld, long long i) {
+    float m = x[i];
+    for (int c = 1; c < C; ++c) m = __fadd_rn(m, x[(size_t)c * ld + i]);
+    return C > 1 ? __fdiv_rn(m, (float)C) : m;
+}
+
+__global__ __launch_bounds__(256) void k_mono_mean(const float* __restrict__ x, int C, long long ld, long long n, float* __restrict__ y) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = mono_mean(x, C, ld, i);
+}
+
+// out[f] = mean(mono[f hop .. f hop + blk)^2) in double (the block is cut at n), one workgroup per block
+__global__ __launch_bounds__(256) void k_frame_meansq(const float* __restrict__ x, int C, long long n, long long blk, long long hop,
+                                                      double* __restrict__ out) {
+    __shared__ double red[256];
+    const long long a = (long long)blockIdx.x * hop, b = a + blk < n ? a + blk : n;
+    double acc = 0.0;
+    for (long long i = a + threadIdx.x; i < b; i += 256) {
+        const double m = (double)mono_mean(x, C, n, i);
+        acc += m * m;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0] / (double)(b - a);
+}
+
+template <int K>
+__device__ __forceinline__ void block_add_f64(double (&v)[K], double* __restrict__ out) {
+    __shared__ double red[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double t = v[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) atomicAdd(out + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// sums over the mono downmixes a_m, b_m (b optionally scaled by kf in float32 first): out += {sum a, sum b, sum ab, sum aa, sum bb}
+__global__ __launch_bounds__(256) void k_pair_stats(const float* __restrict__ a, int ca, long long lda, const float* __restrict__ b,
+                                                    int cb, long long ldb, long long n, float kf, int use_k, double* __restrict__ out) {
+    double v[5] = {0, 0, 0, 0, 0};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double x = (double)mono_mean(a, ca, lda, i);
+        float m = use_k ? __fmul_rn(b[i], kf) : b[i];
+        for (int c = 1; c < cb; ++c) m = __fadd_rn(m, use_k ? __fmul_rn(b[(size_t)c * ldb + i], kf) : b[(size_t)c * ldb + i]);
+        const double yv = (double)(cb > 1 ? __fdiv_rn(m, (float)cb) : m);
+        v[0] += x; v[1] += yv; v[2] += x * yv; v[3] += x * x; v[4] += yv * yv;
+    }
+    block_add_f64<5>(v, out);
+}
+
+// null[c][i] = a[c][i] + sgn * (b[c][i] * kf); out += {sum null_m^2, count(|null| > 1)}
+__global__ __launch_bounds__(256) void k_null_mix(const float* __restrict__ a, long long lda, const float* __restrict__ b, long long ldb,
+                                                  int C, long long n, float kf, int use_k, float sgn, float* __restrict__ nul,
+                                                  double* __restrict__ out) {
+    double v[2] = {0, 0};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float m = 0.f;
+        for (int c = 0; c < C; ++c) {
+            float bv = b[(size_t)c * ldb + i];
+            if (use_k) bv = __fmul_rn(bv, kf);
+            const float d = __fadd_rn(a[(size_t)c * lda + i], sgn * bv);
+            nul[(size_t)c * n + i] = d;
+            if (fabsf(d) > 1.0f) v[1] += 1.0;
+            m = c ? __fadd_rn(m, d) : d;
+        }
+        if (C > 1) m = __fdiv_rn(m, (float)C);
+        v[0] += (double)m * (double)m;
+    }
+    block_add_f64<2>(v, out);
+}
+
+// out += {sum x^2, sum x, sum (-1)^i x, sum y^2, sum y, sum (-1)^i y}: the time-domain side of Parseval for one-sided band energies
+__global__ __launch_bounds__(256) void k_band_sums(const float* __restrict__ x, const float* __restrict__ y, long long n,
+                                                   double* __restrict__ out) {
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double a = x[i], b = y[i], s = (i & 1) ? -1.0 : 1.0;
+        v[0] += a * a; v[1] += a; v[2] += s * a; v[3] += b * b; v[4] += b; v[5] += s * b;
+    }
+    block_add_f64<6>(v, out);
+}
+
 static inline int grid_for(long long n) {
     long long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -610,6 +728,66 @@ extern "C" int egr_shift_fir(const float* x, int channels, int64_t n_in, int64_t
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(k_shift_fir, dim3((unsigned)nb, channels), dim3(256), 0, (hipStream_t)stream, x, (long long)n_in,
                        (long long)shift, h, taps, (long long)n_out, y);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_kweight(const float* x, int channels, int64_t n, float one_minus_k, float k, float* y, void* stream) {
+    EGR_CHECK(x && y && channels >= 1 && channels <= 65535 && n >= 1 && k > 0.f && k < 1.f, EGR_ERR_ARG, "bad argument");
+    int W = (int)ceil(26.0 / -log((double)k));       // k^W < 6e-12
+    if (W < 64) W = 64;
+    const int L = (W + 2) / 3;
+    const long long chunks = (n + L - 1) / L;
+    hipLaunchKernelGGL(k_kweight, dim3((unsigned)((chunks + 63) / 64), channels), dim3(64), 0, (hipStream_t)stream, x, (long long)n,
+                       one_minus_k, k, L, W, y);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_mono_mean(const float* x, int channels, int64_t stride, int64_t n, float* y, void* stream) {
+    EGR_CHECK(x && y && channels >= 1 && n >= 1 && stride >= n, EGR_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_mono_mean, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, channels, (long long)stride, (long long)n, y);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_frame_meansq(const float* x, int channels, int64_t n, int64_t block, int64_t hop, int64_t frames, double* out,
+                                void* stream) {
+    EGR_CHECK(x && out && channels >= 1 && n >= 1 && block >= 1 && hop >= 1 && frames >= 1 && (frames - 1) * hop < n, EGR_ERR_ARG,
+              "bad argument");
+    hipLaunchKernelGGL(k_frame_meansq, dim3((unsigned)frames), dim3(256), 0, (hipStream_t)stream, x, channels, (long long)n,
+                       (long long)block, (long long)hop, out);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_pair_stats(const float* a, int ca, int64_t stride_a, const float* b, int cb, int64_t stride_b, int64_t n, float k,
+                              int use_k, double* out5, void* stream) {
+    EGR_CHECK(a && b && out5 && ca >= 1 && cb >= 1 && n >= 1, EGR_ERR_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    EGR_HIP(hipMemsetAsync(out5, 0, 5 * sizeof(double), st));
+    hipLaunchKernelGGL(k_pair_stats, dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(256), 0, st, a, ca, (long long)stride_a, b, cb,
+                       (long long)stride_b, (long long)n, k, use_k, out5);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_null_mix(const float* a, int64_t stride_a, const float* b, int64_t stride_b, int channels, int64_t n, float k,
+                            int use_k, int invert_b, float* null_out, double* out2, void* stream) {
+    EGR_CHECK(a && b && null_out && out2 && channels >= 1 && n >= 1, EGR_ERR_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    EGR_HIP(hipMemsetAsync(out2, 0, 2 * sizeof(double), st));
+    hipLaunchKernelGGL(k_null_mix, dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(256), 0, st, a, (long long)stride_a, b,
+                       (long long)stride_b, channels, (long long)n, k, use_k, invert_b ? -1.0f : 1.0f, null_out, out2);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_band_sums(const float* x, const float* y, int64_t n, double* out6, void* stream) {
+    EGR_CHECK(x && y && out6 && n >= 1, EGR_ERR_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    EGR_HIP(hipMemsetAsync(out6, 0, 6 * sizeof(double), st));
+    hipLaunchKernelGGL(k_band_sums, dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(256), 0, st, x, y, (long long)n, out6);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }

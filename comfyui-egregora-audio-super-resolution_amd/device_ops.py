@@ -1,4 +1,6 @@
 """Thin torch-tensor wrappers over the glue entry points of the C ABI (csrc/egr_glue.hip)."""
+import math
+
 import numpy as np
 import torch
 
@@ -151,3 +153,124 @@ def xcorr_delay(a: torch.Tensor, b: torch.Tensor, sr: int, max_shift_smp: int) -
         denom = 2 * (y0 - 2 * y1 + y2)
         frac = 0.0 if abs(denom) < 1e-12 else (y0 - y2) / denom
     return float(rel + frac)
+
+
+# ------------------------------------------------------------------ null-test suite levels and sums (egr_glue.hip, egr_fatllama.hip)
+def _rows(x: torch.Tensor, what: str) -> torch.Tensor:
+    if x.dim() == 1:
+        x = x[None, :]
+    x = x.contiguous()
+    _chk(x, what)
+    return x
+
+
+def _f64(n: int, device) -> torch.Tensor:
+    return torch.empty((n,), dtype=torch.float64, device=device)
+
+
+def mono_mean(x_ct: torch.Tensor, n: int = None) -> torch.Tensor:
+    """float32 mean over channels of the first n samples (numpy .mean(axis=0) order)."""
+    x = _rows(x_ct, "mono_mean")
+    n = x.shape[1] if n is None else int(n)
+    y = torch.empty((n,), dtype=torch.float32, device=x.device)
+    native.check(native.lib().egr_mono_mean(native.ptr(x), x.shape[0], x.shape[1], n, native.ptr(y), native.stream_ptr()), "egr_mono_mean")
+    return y
+
+
+def block_mean_squares(x_ct: torch.Tensor, block: int, hop: int) -> np.ndarray:
+    """float64 mean squares of the mono downmix over frames = 1 + max(0, (N - block) // hop) blocks (host array)."""
+    x = _rows(x_ct, "block_mean_squares")
+    frames = 1 + max(0, (x.shape[1] - block) // hop)
+    out = _f64(frames, x.device)
+    native.check(native.lib().egr_frame_meansq(native.ptr(x), x.shape[0], x.shape[1], int(block), int(hop), frames, native.ptr(out),
+                                               native.stream_ptr()), "egr_frame_meansq")
+    return out.cpu().numpy()
+
+
+def rms_db(x_ct: torch.Tensor) -> float:
+    """10 log10(mean(mono^2) + 1e-20): the reference's _rms_db on samples.mean(axis=0) (egregora_null_test_suite.py:119-122)."""
+    n = x_ct.shape[-1]
+    return 10.0 * math.log10(float(block_mean_squares(x_ct, n, n)[0]) + 1e-20)
+
+
+def k_weight(x_ct: torch.Tensor, sr: int) -> torch.Tensor:
+    x = _rows(x_ct, "k_weight")
+    k = math.exp(-2 * math.pi * (60.0 / (sr * 0.5)))
+    y = torch.empty_like(x)
+    native.check(native.lib().egr_kweight(native.ptr(x), x.shape[0], x.shape[1], float(np.float32(1 - k)), float(np.float32(k)),
+                                          native.ptr(y), native.stream_ptr()), "egr_kweight")
+    return y
+
+
+def integrated_lufs(x_ct: torch.Tensor, sr: int) -> float:
+    """The suite's gated loudness (integrated_lufs, egregora_null_test_suite.py:143-165): K-weighting and the 400 ms block
+    energies on the device, the gate over the few block values on the host in the reference's own expressions."""
+    ms = block_mean_squares(k_weight(x_ct, sr), max(1, int(round(0.400 * sr))), max(1, int(round(0.100 * sr)))) + 1e-20
+    ungated = -0.691 + 10.0 * np.log10(np.mean(ms))
+    keep = (-0.691 + 10.0 * np.log10(ms)) >= ungated - 10.0
+    if np.any(keep):
+        ms = ms[keep]
+    return float(-0.691 + 10.0 * np.log10(np.mean(ms)))
+
+
+def pair_stats(a_ct: torch.Tensor, b_ct: torch.Tensor, n: int, k: float = None):
+    """(sum a, sum b, sum ab, sum aa, sum bb) in double over the first n samples of the mono downmixes; b scaled by float32(k) first."""
+    a, b = _rows(a_ct, "pair_stats"), _rows(b_ct, "pair_stats")
+    out = _f64(5, a.device)
+    native.check(native.lib().egr_pair_stats(native.ptr(a), a.shape[0], a.shape[1], native.ptr(b), b.shape[0], b.shape[1], int(n),
+                                             float(np.float32(k if k is not None else 1.0)), int(k is not None), native.ptr(out),
+                                             native.stream_ptr()), "egr_pair_stats")
+    return tuple(float(v) for v in out.cpu())
+
+
+def null_mix(a_ct: torch.Tensor, b_ct: torch.Tensor, n: int, k: float = None, invert_b: bool = True):
+    """null = a +- float32(b * k) on [C, n]; -> (null, sum of squares of its mono downmix, number of |null| > 1)."""
+    a, b = _rows(a_ct, "null_mix"), _rows(b_ct, "null_mix")
+    if a.shape[0] != b.shape[0]:
+        raise ValueError(f"operands could not be broadcast together with shapes {tuple(a[:, :n].shape)} {tuple(b[:, :n].shape)}")
+    nul = torch.empty((a.shape[0], int(n)), dtype=torch.float32, device=a.device)
+    out = _f64(2, a.device)
+    native.check(native.lib().egr_null_mix(native.ptr(a), a.shape[1], native.ptr(b), b.shape[1], a.shape[0], int(n),
+                                           float(np.float32(k if k is not None else 1.0)), int(k is not None), int(bool(invert_b)),
+                                           native.ptr(nul), native.ptr(out), native.stream_ptr()), "egr_null_mix")
+    s, overs = (float(v) for v in out.cpu())
+    return nul, s, int(overs)
+
+
+def scale(x: torch.Tensor, gain: float) -> torch.Tensor:
+    x = x.contiguous()
+    _chk(x, "scale")
+    y = torch.empty_like(x)
+    native.check(native.lib().egr_eltwise(native.ptr(x), None, native.ptr(y), x.numel(), 3, float(np.float32(gain)), 0.0,
+                                          native.stream_ptr()), "egr_eltwise")
+    return y
+
+
+def band_energy_hi_db(x_ct: torch.Tensor, sr: int, lo_hz: float) -> float:
+    """10 log10(E_hi / E_all + 1e-20) with the one-sided energies of the length-N rfft of the mono downmix, bins f >= lo_hz on top
+    (reference _band_energy_hi_db, egregora_null_test_suite.py:192-199).  The transform runs at the signal's own length on a
+    Fat-Llama plan (packed-real, or chirp-z for lengths without one): egr_band_filter leaves the high band in the time domain and
+    Parseval turns time-domain sums into the two energies."""
+    import ctypes as C
+    from . import fatllama_engine as fe
+    mono = mono_mean(x_ct)
+    n = mono.numel()
+    step = 1.0 / (n * (1.0 / sr))                      # np.fft.rfftfreq: k * (1 / (n d))
+    lo = max(0, int(math.ceil(lo_hz / step)))
+    while lo > 0 and (lo - 1) * step >= lo_hz:
+        lo -= 1
+    while lo * step < lo_hz:
+        lo += 1
+    if lo > n // 2:
+        return 10.0 * math.log10(1e-20)
+    plan = fe._plan(n, 1, 1, mono.device.index or 0)
+    hi = torch.empty_like(mono)
+    native.check(native.lib().egr_band_filter(C.c_void_p(plan), native.ptr(mono), lo, native.ptr(hi), native.stream_ptr()),
+                 "egr_band_filter")
+    out = _f64(6, mono.device)
+    native.check(native.lib().egr_band_sums(native.ptr(mono), native.ptr(hi), n, native.ptr(out), native.stream_ptr()), "egr_band_sums")
+    xx, x0, xn, yy, y0, yn = (float(v) for v in out.cpu())
+    even = 1.0 if n % 2 == 0 else 0.0
+    e_all = 0.5 * (n * xx + x0 * x0 + even * xn * xn)
+    e_hi = 0.5 * (n * yy + y0 * y0 + even * yn * yn)
+    return 10.0 * math.log10(e_hi / (e_all + 1e-20) + 1e-20)

@@ -39,6 +39,13 @@ SIGNATURES = {
     "egr_dfn_mix": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i, _f, _i, _i, C.c_double, _vp, _vp, _vp]),
     "egr_shift_fir": (_i, [_vp, _i, _i64, _i64, _vp, _i, _vp, _i64, _vp]),
     "egr_gcc_phat": (_i, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "egr_band_filter": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "egr_kweight": (_i, [_vp, _i, _i64, _f, _f, _vp, _vp]),
+    "egr_mono_mean": (_i, [_vp, _i, _i64, _i64, _vp, _vp]),
+    "egr_frame_meansq": (_i, [_vp, _i, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "egr_pair_stats": (_i, [_vp, _i, _i64, _vp, _i, _i64, _i64, _f, _i, _vp, _vp]),
+    "egr_null_mix": (_i, [_vp, _i64, _vp, _i64, _i, _i64, _f, _i, _i, _vp, _vp, _vp]),
+    "egr_band_sums": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "egr_resample_linear": (_i, [_vp, _i, _i64, _vp, _i64, _vp]),
     "egr_lsd_frames": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     "egr_sum_f64": (_i, [_vp, _i64, _vp, _vp]),

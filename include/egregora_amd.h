@@ -127,6 +127,32 @@ int egr_resample_linear(const float* x, int channels, int64_t n_in, float* y, in
 int egr_gcc_phat(egr_fatllama_plan* plan, const float* a, int64_t na, const float* b, int64_t nb, int64_t max_shift, float* work,
                  float* out4, void* stream);
 
+/* y = irfft(rfft(x) * [k >= band_lo]) per channel at the plan's own length (packed-real or chirp-z plan, factor 1): the high band
+ * of the null-test suite's _band_energy_hi_db (egregora_null_test_suite.py:192-199); with egr_band_sums the one-sided band energies
+ * sum_{k >= band_lo} |X[k]|^2 and sum_k |X[k]|^2 of the length-n rfft follow by Parseval:
+ *   E = (n * sum v^2 + (sum v)^2 + [n even] (sum (-1)^i v)^2) / 2   for v = y (high band) and v = x (all). */
+int egr_band_filter(egr_fatllama_plan* plan, const float* x, int64_t band_lo, float* y, void* stream);
+/* out6 (device, double) = {sum x^2, sum x, sum (-1)^i x, sum y^2, sum y, sum (-1)^i y} */
+int egr_band_sums(const float* x, const float* y, int64_t n, double* out6, void* stream);
+
+/* K-weighting approximation of the suite's loudness meter (_k_weight, egregora_null_test_suite.py:125-140): one-pole high-pass
+ * z = (1-k) x + k z, y = x - z in float32 exactly as numpy's scalar loop rounds, then y[i] += 0.02 (y[i] - y[i-1]).
+ * one_minus_k and k are the float32 roundings of the reference's Python floats. */
+int egr_kweight(const float* x, int channels, int64_t n, float one_minus_k, float k, float* y, void* stream);
+/* y[i] = float32 mean over channels of x[c * stride + i] (numpy .mean(axis=0) order) */
+int egr_mono_mean(const float* x, int channels, int64_t stride, int64_t n, float* y, void* stream);
+/* out[f] (device, double) = mean over [f hop, min(f hop + block, n)) of mono(x)^2: the 400 ms / 100 ms blocks of integrated_lufs
+ * (:143-165) and, with one block of n samples, _rms_db (:119-122) */
+int egr_frame_meansq(const float* x, int channels, int64_t n, int64_t block, int64_t hop, int64_t frames, double* out, void* stream);
+/* out5 (device, double) = {sum a, sum b, sum ab, sum aa, sum bb} over the mono downmixes of a[ca][n] and b[cb][n] (b scaled by the
+ * float32 k first when use_k): least-squares scale and correlation coefficient of Audio Null Test (:431-447) */
+int egr_pair_stats(const float* a, int ca, int64_t stride_a, const float* b, int cb, int64_t stride_b, int64_t n, float k, int use_k,
+                   double* out5, void* stream);
+/* null[c][i] = a[c][i] +- fl32(b[c][i] * k) (minus when invert_b); out2 (device, double) = {sum mono(null)^2, count |null| > 1}
+ * (:437-441, 449, 463) */
+int egr_null_mix(const float* a, int64_t stride_a, const float* b, int64_t stride_b, int channels, int64_t n, float k, int use_k,
+                 int invert_b, float* null_out, double* out2, void* stream);
+
 /* Delay compensation of the null-test suite's aligner: y[c][i] = sum_k h[k] s[i + (taps-1)/2 - k] with s[i] = x[c][i - shift]
  * (zero outside [0, n_in)), i.e. an integer shift followed by np.convolve(., h, "same"); taps = 0 skips the FIR; n_out pads with
  * zeros or crops (_apply_frac_delay_CN + _pad_or_crop_CN, egregora_null_test_suite.py:203-266). */

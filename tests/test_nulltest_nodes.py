@@ -1,0 +1,172 @@
+"""`Audio Gain Match`, `Audio Null Test`, `Audio Plotter`, `Null Test (Full)` of the null-test suite
+against fixture G14, captured from the reference's nodes (tests/golden/make_golden_nulltest.py).
+
+not gpu : oracle/nulltest.py reproduces every float of the fixture exactly (levels, gains, metrics, matched and null audio); the
+          four node surfaces equal the reference's
+gpu     : kernels against the oracle (K-weighting within one ulp of the filter state, block energies 1e-12 relative, band energy at even / odd / prime
+          lengths 2e-4 dB); nodes through the C ABI against the fixture: levels and gains 2e-5 dB, audio bit-exact up to that gain
+          (1e-6 relative), metrics: dB values 2e-4, correlation 2e-6, LSD 2e-5 relative, counts exact; `Null Test (Full)` (which
+          chains the aligner, whose delay estimate moves the FIR taps) 2e-2 dB / 1e-2 of peak
+"""
+import inspect
+import json
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import gjson, gnpz
+from golden.make_golden_nulltest import FULL_CASES, GAIN_CASES, KEYS, NULL_CASES, aud, signals
+
+
+def at_rate(b, sr2, sr):
+    if sr2 == sr:
+        return b
+    C, N = b.shape
+    new = int(round(N * sr / sr2))
+    return np.stack([np.interp(np.linspace(0, 1, new, endpoint=False), np.linspace(0, 1, N, endpoint=False), b[c]) for c in range(C)]).astype(np.float32)
+
+
+def test_oracle_reproduces_fixture_exactly():
+    from oracle import nulltest as nt
+    g, z, sig = gjson("g14_nulltest"), gnpz("g14_nulltest"), signals()
+    for i, (s, kw) in enumerate(GAIN_CASES):
+        a, sr, b, sr2 = sig[s]
+        y, gd, rl, il = nt.gain_match(a, sr, at_rate(b, sr2, sr), **kw)
+        c = g["gain"][i]
+        assert (gd, rl, il) == (c["gain_db"], c["ref_level"], c["in_level"]) and np.array_equal(y[:, ::29], z[f"gain{i}"]), (s, kw)
+    for i, (s, kw) in enumerate(NULL_CASES):
+        a, sr, b, _ = sig[s]
+        nul, m = nt.null_test(a, b, sr, **kw)
+        c = g["null"][i]
+        assert m == c["metrics"] and list(m.keys()) == c["metric_order"] and np.array_equal(nul[:, ::29], z[f"null{i}"]), (s, kw)
+
+
+@pytest.mark.parametrize("key", KEYS)
+def test_surface_equals_reference(pack, key):
+    g = gjson("g14_nulltest")["surface"][key]
+    cls = pack.NODE_CLASS_MAPPINGS[key]
+    it = cls.INPUT_TYPES()
+    assert json.loads(json.dumps(it)) == g["INPUT_TYPES"]
+    assert {k: list(v.keys()) for k, v in it.items()} == g["widget_order"]
+    assert list(cls.RETURN_TYPES) == g["RETURN_TYPES"] and list(cls.RETURN_NAMES) == g["RETURN_NAMES"]
+    assert cls.FUNCTION == g["FUNCTION"] and cls.CATEGORY == g["CATEGORY"]
+    assert str(inspect.signature(cls.execute)) == g["signature"]
+    assert pack.NODE_DISPLAY_NAME_MAPPINGS[key] == g["display"]
+
+
+@pytest.mark.gpu
+def test_level_kernels_vs_oracle(pack):
+    from egregora_amd import device_ops
+    from oracle import nulltest as nt
+    rng = np.random.Generator(np.random.PCG64(41))
+    for sr, n, C in ((48000, 30000, 2), (8000, 9001, 1), (192000, 40000, 3)):
+        x = (0.3 * rng.standard_normal((C, n)) + 0.05).astype(np.float32)
+        d = torch.from_numpy(x).cuda()
+        want = nt.k_weight(sr, x)
+        got = device_ops.k_weight(d, sr).cpu().numpy()
+        # each thread restarts the float32 recurrence ahead of its chunk: states agree to the last bit or differ by one ulp of z
+        assert np.mean(got == want) > 0.8 and np.abs(got - want).max() <= 2.5e-7, (sr, np.mean(got == want), np.abs(got - want).max())
+        blk, hop = int(round(0.4 * sr)), int(round(0.1 * sr))
+        mono = x.mean(axis=0)
+        frames = 1 + max(0, (n - blk) // hop)
+        ms = np.asarray([np.mean(mono[i * hop:i * hop + blk].astype(np.float64) ** 2) for i in range(frames)])
+        assert np.allclose(device_ops.block_mean_squares(d, blk, hop), ms, rtol=1e-12, atol=0)
+        assert abs(device_ops.integrated_lufs(d, sr) - nt.integrated_lufs(sr, x)) <= 1e-6
+        assert abs(device_ops.rms_db(d) - nt.rms_db(mono)) <= 1e-9
+        assert np.array_equal(device_ops.mono_mean(d).cpu().numpy(), mono)
+
+
+@pytest.mark.gpu
+def test_band_energy_vs_oracle(pack):
+    from egregora_amd import device_ops
+    from oracle import nulltest as nt
+    rng = np.random.Generator(np.random.PCG64(42))
+    for n, sr, lo in ((24000, 48000, 8000), (24000, 48000, 0), (23999, 44100, 6000), (10007, 48000, 1000), (4096, 16000, 7999.9),
+                      (9000, 48000, 23999), (30001, 48000, 30000)):
+        t = np.arange(n) / sr
+        x = (0.2 * rng.standard_normal((2, n)) / (1 + 40 * t) + 0.3 * np.sin(2 * np.pi * 300 * t) + 0.02).astype(np.float32)
+        want = nt.band_energy_hi_db(x, sr, lo)
+        got = device_ops.band_energy_hi_db(torch.from_numpy(x).cuda(), sr, lo)
+        assert abs(got - want) <= 2e-4, (n, sr, lo, got, want)
+
+
+@pytest.mark.gpu
+def test_gain_match_node_vs_fixture(pack):
+    g, z, sig = gjson("g14_nulltest"), gnpz("g14_nulltest"), signals()
+    node = pack.NODE_CLASS_MAPPINGS["Audio Gain Match"]()
+    for i, (s, kw) in enumerate(GAIN_CASES):
+        a, sr, b, sr2 = sig[s]
+        out, gd, rl, il = node.execute(aud(a, sr), aud(b, sr2, {"tag": i}), **kw)
+        c = g["gain"][i]
+        assert max(abs(gd - c["gain_db"]), abs(rl - c["ref_level"]), abs(il - c["in_level"])) <= 2e-5, (s, kw, gd, rl, il)
+        assert list(out["waveform"].shape) == c["shape"] and out["sample_rate"] == c["sr"] and out["meta"] == c["meta"]
+        assert sorted(out.keys()) == c["keys"]
+        want = z[f"gain{i}"]
+        assert np.abs(out["samples"][:, ::29] - want).max() <= 4e-6 * np.abs(want).max(), (s, kw)
+
+
+def check_metrics(m, want, db_tol, corr_tol, lsd_rel, exact_counts=True):
+    assert list(m.keys()) == list(want.keys()) or set(m.keys()) == set(want.keys())
+    for k, v in want.items():
+        if k in ("overshoot_count",):
+            assert (m[k] == v) if exact_counts else abs(m[k] - v) <= 2 + 0.05 * v, (k, m[k], v)
+        elif k == "clipped_pct":
+            assert abs(m[k] - v) <= (1e-12 if exact_counts else 0.05 * v + 0.01), (k, m[k], v)
+        elif k == "corr_coef":
+            assert abs(m[k] - v) <= corr_tol, (k, m[k], v)
+        elif k.startswith("lsd"):
+            assert abs(m[k] - v) <= lsd_rel * abs(v), (k, m[k], v)
+        elif k == "scale_k":
+            assert abs(m[k] - v) <= 1e-9 * abs(v) + (0 if exact_counts else 1e-2), (k, m[k], v)
+        else:
+            assert abs(m[k] - v) <= db_tol, (k, m[k], v)
+
+
+@pytest.mark.gpu
+def test_null_test_node_vs_fixture(pack):
+    g, z, sig = gjson("g14_nulltest"), gnpz("g14_nulltest"), signals()
+    node = pack.NODE_CLASS_MAPPINGS["Audio Null Test"]()
+    for i, (s, kw) in enumerate(NULL_CASES):
+        a, sr, b, _ = sig[s]
+        out, m = node.execute(aud(a, sr), aud(b, sr), **kw)
+        c = g["null"][i]
+        assert list(m.keys()) == c["metric_order"]
+        check_metrics(m, c["metrics"], 2e-4, 2e-6, 2e-5)
+        assert list(out["waveform"].shape) == c["shape"] and out["sample_rate"] == c["sr"] and out["meta"] == c["meta"]
+        want = z[f"null{i}"]
+        assert np.abs(out["samples"][:, ::29] - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), (s, kw)
+    a, sr, b, _ = sig["short"]
+    with pytest.raises(ValueError, match=g["rate_mismatch_error"]):
+        node.execute(aud(a, sr), aud(b, 44100))
+
+
+@pytest.mark.gpu
+def test_full_node_vs_fixture(pack):
+    g, z, sig = gjson("g14_nulltest"), gnpz("g14_nulltest"), signals()
+    node = pack.NODE_CLASS_MAPPINGS["Null Test (Full)"]()
+    for i, (s, kw) in enumerate(FULL_CASES):
+        a, sr, b, sr2 = sig[s]
+        r = node.execute(aud(a, sr), aud(b, sr2, {"src": s}), **kw)
+        c = g["full"][i]
+        assert abs(r[2] - c["delay_ms"]) <= 2e-4 and abs(r[3] - c["gain_db"]) <= 2e-2, (r[2], r[3])
+        check_metrics(r[4], c["metrics"], 2e-2, 5e-3, 5e-3, exact_counts=False)
+        assert [list(r[0]["waveform"].shape), list(r[1]["waveform"].shape)] == c["shapes"] and [r[0]["meta"], r[1]["meta"]] == c["meta"]
+        assert [list(im.shape) for im in r[5:]] == c["images"]
+        for got, name in ((r[0], "matched"), (r[1], "null")):
+            want = z[f"full{i}_{name}"]
+            assert np.abs(got["samples"][:, ::29] - want).max() <= 1e-2 * np.abs(want).max(), (s, name)
+
+
+@pytest.mark.gpu
+def test_plotter_image_shapes(pack):
+    pytest.importorskip("matplotlib")
+    g, sig = gjson("g14_nulltest"), signals()
+    a, sr, b, _ = sig["short"]
+    nul, _ = pack.NODE_CLASS_MAPPINGS["Audio Null Test"]().execute(aud(a, sr), aud(b, sr))
+    node = pack.NODE_CLASS_MAPPINGS["Audio Plotter"]()
+    imgs = node.execute(aud(a, sr), aud(b, sr), nul)
+    assert [list(im.shape) for im in imgs] == g["plotter"]["all"]
+    assert all(im.dtype == torch.float32 and 0.0 <= float(im.min()) and float(im.max()) <= 1.0 for im in imgs)
+    assert [list(im.shape) for im in node.execute(aud(a, sr), aud(b, sr), nul, False, False, False)] == g["plotter"]["none"]
