@@ -543,7 +543,12 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
               EGR_ERR_ARG, "bad output placement");
     p.osy = osy; p.osx = osx; p.ooy = ooy; p.oox = oox; p.OHF = OHF; p.OWF = OWF;
     const bool vec = (Cin % BK) == 0 && (((uintptr_t)x) & 15) == 0;
-    const int bn = w3 ? s3_bn(Cout) : (Cout > 64 ? 128 : (Cout > 32 ? 64 : 32));
+    int bn = w3 ? s3_bn(Cout) : (Cout > 64 ? 128 : (Cout > 32 ? 64 : 32));
+    // short-K layers that cannot use split-K (the transformer blocks' linears: a few thousand rows, K <= 496): narrower column
+    // tiles until the grid covers the 256 CUs
+    static const bool narrow = !(getenv("EGR_S3_NARROW") && atoi(getenv("EGR_S3_NARROW")) == 0);
+    if (w3 && narrow && nz <= 1 && (KH * KW * Cin + BK - 1) / BK < 32)
+        while (bn > 64 && ((M + 127) / 128) * ((Cout + bn - 1) / bn) < 256) bn >>= 1;
     int bm = w3 ? s3_bm(M, Cout, bn) : BM;
     dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)((Cout + bn - 1) / bn));
     hipStream_t st = (hipStream_t)stream;

@@ -243,7 +243,7 @@ class FlashSREngine:
                          "egr_conv_nhwc")
         if ev is not None:
             vec = Cin % 16 == 0 and x.data_ptr() % 16 == 0
-            kind = self._kind(B * OH * OW, Cin, Cout, w3 is not None, vec)
+            kind = self._kind(B * OH * OW, Cin, Cout, w3 is not None, vec, KH * KW * Cin)
             if (w3 is not None and H == 1 and KH == 1 and KW >= 2 and stride == 1 and not up2 and OW == W and W % 128 == 0
                     and dil * (KW - 1) <= 50 and 2 * pad_l == dil * (KW - 1)):       # launch_conv1d_s3's conditions
                 kind = f"k_conv1d_s3<{128 if Cout > 64 else (64 if Cout > 32 else 32)}, {32 if Cin % 32 == 0 else 16}>"
@@ -253,12 +253,15 @@ class FlashSREngine:
         return y
 
     @staticmethod
-    def _kind(M, Cin, Cout, s3, vec=True):
+    def _kind(M, Cin, Cout, s3, vec=True, K=None):
         """Name of the kernel instantiation a contraction lands on (same selection as conv_launch, csrc/egr_nn_gemm.hip)."""
         bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
         if s3:
             if Cout >= 256 and Cout % 256 == 0:         # s3_bn
                 bn = 256
+            if K is not None and (K + 15) // 16 < 32:   # short-K, under-filled grid: narrower column tiles
+                while bn > 64 and ((M + 127) // 128) * ((Cout + bn - 1) // bn) < 256:
+                    bn >>= 1
             bm = 256 if (bn == 128 and ((M + 255) // 256) * ((Cout + 127) // 128) >= 1024) else 128
             return f"k_conv_s3<{bm}, {bn}, 1, false>"        # <BM, BN, PF, ZS> as rocprofv3 prints the instantiation
         return f"k_conv_igemm<{bn}, {'true' if vec else 'false'}>"
@@ -318,7 +321,7 @@ class FlashSREngine:
                                                              0, act, 0.0, 2, 2, a, b, 2 * H, 2 * W, self._st()),
                                  "egr_conv_nhwc_placed")
                 if ev is not None:
-                    self._prof_end(ev, self._kind(B * H * W, Cin, Cout, w3 is not None, Cin % 16 == 0), fl,
+                    self._prof_end(ev, self._kind(B * H * W, Cin, Cout, w3 is not None, Cin % 16 == 0, 4 * Cin), fl,
                                    (B, H, W, Cin, H, W, Cout, 2, 2, 1, 1, 2))
                 if self.count_flops:
                     self.flops += fl

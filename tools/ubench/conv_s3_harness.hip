@@ -33,6 +33,18 @@ int main(int argc, char** argv) {
     for (int i = 0; i < reps; ++i) egr::launch_conv_s3(bm, bn, grid, 0, p);
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    if (getenv("S3_CHECK")) {          // determinism: a second launch into another buffer must match bit for bit
+        float* y2; hipMalloc(&y2, M * Co * 4); hipMemset(y2, 0xff, M * Co * 4);
+        egr::ConvP q = p; q.y = y2; egr::launch_conv_s3(bm, bn, grid, 0, q); hipDeviceSynchronize();
+        std::vector<float> ha(M * Co), hb(M * Co);
+        hipMemcpy(ha.data(), y, M * Co * 4, hipMemcpyDeviceToHost); hipMemcpy(hb.data(), y2, M * Co * 4, hipMemcpyDeviceToHost);
+        long long bad = 0; for (long long i = 0; i < M * Co; ++i) bad += memcmp(&ha[i], &hb[i], 4) != 0;
+        double ref = 0; for (int kk = 0; kk < K; ++kk) ref += (double)h[(M / 2) * Ci + kk] * hw[((kk / 16) * Co + 0) * 16 + (kk % 16)];   // k = 1 only
+        printf("mismatching elements between two launches: %lld of %lld; y[M/2][0]=%.7f ref(k=1)=%.7f x0=%.6f\n", bad, M * Co, ha[(M / 2) * Co], ref, h[0]);
+    }
+    std::vector<float> hy(4096); hipMemcpy(hy.data(), y + (M / 2) * Co, 4096 * 4, hipMemcpyDeviceToHost);
+    double cs = 0; for (float v : hy) cs += (double)v * v;
+    printf("cs=%.9e ", cs);
     printf("bm%d B%d %dx%d Ci%d Co%d k%d: %.3f ms  %.1f TF/s (fp32-equivalent)  err=%s\n", bm, B, H, W, Ci, Co, k, ms, 2.0 * M * Co * K / ms / 1e9,
            hipGetErrorString(hipGetLastError()));
     return 0;
