@@ -674,6 +674,69 @@ static int frame_tables(int n_fft, FrameTables* out) {
     return EGR_OK;
 }
 
+// Thin ends of the VAE.  (1) A 3x3 convolution with very few outputs (conv_out: 128 -> 1) as a 1x1 contraction onto the kh*kw*Cout
+// per-tap partial products P[pixel][tap*Cout + co] (one ninth of the MFMA work an im2col tile with 31 idle columns needs)
+// followed by this gather: y[b,oy,ox,co] = bias[co] + sum over taps of P at the tap's source pixel (outside the image: nothing,
+// which is the zero padding).  (2) A convolution with ONE input channel (conv_in: 1 -> 128): K = kh*kw is below one MFMA slab;
+// each thread forms 4 output channels of a pixel from the kh*kw input samples on the vector ALU; the layer is bound by its
+// output write.
+__global__ __launch_bounds__(256) void k_tap_gather(const float* __restrict__ P, const float* __restrict__ bias, float* __restrict__ y,
+                                                    int B, int H, int W, int KH, int KW, int Cout, int pad_t, int pad_l) {
+    const long long total = (long long)B * H * W * Cout;
+    const int ldp = KH * KW * Cout;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int co = (int)(i % Cout);
+        const long long pix = i / Cout;
+        const int ox = (int)(pix % W), oy = (int)((pix / W) % H);
+        const long long b = pix / ((long long)W * H);
+        float acc = bias ? bias[co] : 0.f;
+        for (int ky = 0; ky < KH; ++ky) {
+            const int iy = oy + ky - pad_t;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int kx = 0; kx < KW; ++kx) {
+                const int ix = ox + kx - pad_l;
+                if ((unsigned)ix < (unsigned)W) acc += P[((b * H + iy) * W + ix) * ldp + (ky * KW + kx) * Cout + co];
+            }
+        }
+        y[i] = acc;
+    }
+}
+
+// w: the packed layout of a K = KH*KW (<= 16) weight, [Cout][16] with k contiguous.  A thread keeps ONE quad of output channels
+// (its 4 x KH*KW weights live in registers) and walks pixels; the 256 / (Cout/4) pixels of a block iteration are consecutive, the
+// lanes of a pixel read the same input samples (one transaction) and store 16 bytes each of one contiguous output row.
+template <int KK>
+__global__ __launch_bounds__(256) void k_conv_cin1(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                   float* __restrict__ y, int B, int H, int W, int Cout, int KW, int pad_t, int pad_l) {
+    const int c4n = Cout / 4, ppi = 256 / c4n;                 // pixels per block iteration
+    const int c0 = (threadIdx.x % c4n) * 4, pl = threadIdx.x / c4n;
+    float wr[KK][4];
+#pragma unroll
+    for (int k = 0; k < KK; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wr[k][j] = w[(c0 + j) * 16 + k];
+    const float4 b4 = bias ? *(const float4*)(bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned npix = (unsigned)B * H * W;                 // < 2^31 (checked by the launcher): 32-bit index math
+    for (unsigned pix = blockIdx.x * ppi + pl; pix < npix; pix += gridDim.x * ppi) {
+        const unsigned row = pix / (unsigned)W;
+        const int ox = (int)(pix - row * W), oy = (int)(row % (unsigned)H);
+        const size_t b = row / (unsigned)H;
+        float4 acc = b4;
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            const int ky = k / KW, kx = k - ky * KW;
+            const int iy = oy + ky - pad_t, ix = ox + kx - pad_l;
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const float v = ok ? x[(b * H + iy) * W + ix] : 0.f;
+            acc.x = fmaf(v, wr[k][0], acc.x);
+            acc.y = fmaf(v, wr[k][1], acc.y);
+            acc.z = fmaf(v, wr[k][2], acc.z);
+            acc.w = fmaf(v, wr[k][3], acc.w);
+        }
+        *(float4*)(y + (size_t)pix * Cout + c0) = acc;
+    }
+}
+
 static inline int grid1d(long long n) {
     long long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -777,6 +840,33 @@ extern "C" int egr_eltwise(const float* a, const float* b, float* y, int64_t n, 
 extern "C" int egr_geglu(const float* u, float* y, int64_t rows, int D, void* stream) {
     EGR_CHECK(u && y && rows >= 1 && D >= 1, EGR_ERR_ARG, "bad argument");
     hipLaunchKernelGGL(k_geglu, dim3(grid1d(rows * D)), dim3(256), 0, (hipStream_t)stream, u, y, (long long)rows, D);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_tap_gather(const float* P, const float* bias, float* y, int B, int H, int W, int KH, int KW, int Cout, int pad_t,
+                              int pad_l, void* stream) {
+    EGR_CHECK(P && y && B >= 1 && H >= 1 && W >= 1 && KH >= 1 && KW >= 1 && Cout >= 1, EGR_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_tap_gather, dim3(grid1d((long long)B * H * W * Cout)), dim3(256), 0, (hipStream_t)stream, P, bias, y, B, H, W,
+                       KH, KW, Cout, pad_t, pad_l);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_conv_cin1(const float* x, const float* w_packed, const float* bias, float* y, int B, int H, int W, int Cout, int KH,
+                             int KW, int pad_t, int pad_l, void* stream) {
+    EGR_CHECK(x && w_packed && y && B >= 1 && H >= 1 && W >= 1 && Cout >= 4 && Cout % 4 == 0 && 256 % (Cout / 4) == 0, EGR_ERR_ARG,
+              "bad argument (Cout / 4 must divide 256)");
+    EGR_CHECK((KH == 3 && KW == 3) || (KH == 1 && KW == 1), EGR_ERR_UNSUPPORTED, "one-input-channel conv: 3x3 or 1x1 only");
+    EGR_CHECK((long long)B * H * W < (1ll << 31), EGR_ERR_ARG, "image too large for 32-bit pixel indices");
+    EGR_CHECK((((uintptr_t)y) & 15) == 0 && (!bias || (((uintptr_t)bias) & 15) == 0), EGR_ERR_ARG, "y / bias need 16-byte alignment");
+    const int ppi = 256 / (Cout / 4);
+    long long nb = ((long long)B * H * W + ppi - 1) / ppi;
+    if (nb > 8192) nb = 8192;
+    if (KH == 3) hipLaunchKernelGGL((k_conv_cin1<9>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, w_packed, bias, y, B, H, W,
+                                    Cout, KW, pad_t, pad_l);
+    else hipLaunchKernelGGL((k_conv_cin1<1>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, w_packed, bias, y, B, H, W, Cout,
+                            KW, pad_t, pad_l);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }

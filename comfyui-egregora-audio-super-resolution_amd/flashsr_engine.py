@@ -40,6 +40,7 @@ class FlashSREngine:
         self.w3: Dict[str, torch.Tensor] = {}      # three-way bf16 splits of self.w entries (egr_split3_pack)
         self.wshape: Dict[str, tuple] = {}
         self.mfma = self.MFMA_MODE
+        self.thin = self.THIN_ENDS
         self._pack(params)
         self.window = torch.hann_window(cfg.n_fft, periodic=True, dtype=torch.float32).to(self.dev)
         self.filt = torch.from_numpy(arch.kaiser_sinc_filter(cfg.aa_taps)).to(self.dev)
@@ -185,6 +186,7 @@ class FlashSREngine:
         return y
 
     GN_PARTIALS = os.environ.get("EGREGORA_FLASHSR_GN_PARTIALS", "1") != "0"
+    THIN_ENDS = os.environ.get("EGREGORA_FLASHSR_THIN_ENDS", "1") != "0"     # dedicated paths for Cout*kh*kw <= 32 and Cin == 1 convs
 
     def add_weight(self, key: str, v: torch.Tensor):
         """Register a weight given in torch layout; self.w[key] holds the packed tensor, self.wshape[key] the
@@ -215,6 +217,9 @@ class FlashSREngine:
                 self.add_weight(k, v)
                 if ".upsample.conv." in k or (k.startswith("unet.") and ".up.conv." in k):
                     self.add_upsample_phases(k, v)
+                if self.thin and v.dim() == 4 and v.shape[2] * v.shape[3] * v.shape[0] <= 32 and v.shape[1] % 16 == 0:
+                    Co, Ci, kh, kw = v.shape                             # few outputs: 1x1 contraction onto per-tap products
+                    self.add_weight(k + ".taps", v.permute(2, 3, 0, 1).reshape(kh * kw * Co, Ci))
                 if v.dim() == 4 and v.shape[2] == 3 and v.shape[3] == 3 and min(v.shape[0], v.shape[1]) >= self.WINO_MIN_CH \
                         and "downsample" not in k and ".down.conv" not in k and "upsample" not in k and ".up.conv" not in k:
                     self.add_winograd(k, v)
@@ -297,6 +302,21 @@ class FlashSREngine:
         if (key + ".weight.wino") in self.w and not up2 and stride == 1 and pad == 1 and act in (ACT_NONE, ACT_SILU) \
                 and H % 2 == 0 and W % 2 == 0 and Cin % 16 == 0:
             return self._conv_winograd(x, key, act, res, bias_t)
+        plain = not up2 and stride == 1 and pad == 1 and act == ACT_NONE and res is None and bias_t is None
+        if plain and (key + ".weight.taps") in self.w and self._s3(key + ".weight.taps", Cin, x) is not None:
+            P = self.conv(x, None, B, H, W, Cin, H, W, 9 * Cout, 1, 1, bias=False, w=self.w[key + ".weight.taps"],
+                          w3key=key + ".weight.taps")
+            y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=self.dev)
+            native.check(self.L.egr_tap_gather(_p(P), _p(self.w.get(key + ".bias")), _p(y), B, H, W, 3, 3, Cout, 1, 1, self._st()),
+                         "egr_tap_gather")
+            return y
+        if plain and self.thin and Cin == 1 and Cout % 4 == 0 and 256 % (Cout // 4) == 0:
+            y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=self.dev)
+            native.check(self.L.egr_conv_cin1(_p(x), _p(self.w[key + ".weight"]), _p(self.w.get(key + ".bias")), _p(y), B, H, W, Cout,
+                                              3, 3, 1, 1, self._st()), "egr_conv_cin1")
+            if self.count_flops:
+                self.flops += 2.0 * B * H * W * Cout * 9
+            return y
         LH, LW = (2 * H, 2 * W) if up2 else (H, W)
         OH, OW = (LH // stride, LW // stride)
         return self.conv(x, key, B, H, W, Cin, OH, OW, Cout, 3, 3, stride, 1, pad, pad, up2, act, res=res, bias_t=bias_t)

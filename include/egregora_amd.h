@@ -308,6 +308,13 @@ int egr_softmax_rows(float* x, int64_t rows, int cols, void* stream);
 /* op: 0 a+b, 1 s0*a+s1*b, 2 silu(a), 3 s0*a, 4 copy */
 int egr_eltwise(const float* a, const float* b, float* y, int64_t n, int op, float s0, float s1, void* stream);
 int egr_geglu(const float* u, float* y, int64_t rows, int D, void* stream);
+/* y[b,oy,ox,co] = bias[co] + sum_{ky,kx} P[b, oy+ky-pad_t, ox+kx-pad_l][(ky*KW+kx)*Cout + co] over in-image source pixels: the second
+ * half of a kh x kw convolution with very few outputs computed as a 1x1 contraction onto per-tap partial products (VAE conv_out). */
+int egr_tap_gather(const float* P, const float* bias, float* y, int B, int H, int W, int KH, int KW, int Cout, int pad_t, int pad_l,
+                   void* stream);
+/* Stride-1 convolution of a ONE-channel image, fp32 FMAs on the vector ALU (VAE conv_in); w_packed: [Cout][16], k = ky*KW+kx first. */
+int egr_conv_cin1(const float* x, const float* w_packed, const float* bias, float* y, int B, int H, int W, int Cout, int KH, int KW,
+                  int pad_t, int pad_l, void* stream);
 int egr_concat_channels(const float* a, const float* b, float* y, int64_t M, int C1, int C2, void* stream);
 int egr_transpose_batched(const float* x, float* y, int batch, int R, int Cc, void* stream);
 /* Anti-aliased snake over [B][L][C]: 2x up (K-tap FIR, replicate pad) . x + sin^2(e^alpha x)/(e^beta+1e-9) . 2x down. */

@@ -274,6 +274,30 @@ def test_upsample_conv_as_four_phase_convs(eng):
         close(nchw(got), want)
 
 
+def test_thin_end_convs_vs_torch(eng):
+    """The VAE's thin ends: 3x3 convs with 1..3 outputs as a 1x1 contraction onto per-tap products + egr_tap_gather, and the
+    one-input-channel 3x3 conv on the vector ALU (egr_conv_cin1); borders are the zero padding."""
+    e, cfg, P = eng
+    g = torch.Generator().manual_seed(77)
+    for (B, H, W, Ci, Co) in [(2, 8, 12, 32, 1), (1, 5, 7, 128, 1), (3, 16, 4, 64, 3), (2, 9, 6, 16, 2)]:
+        x = torch.randn(B, Ci, H, W, generator=g)
+        w = torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9)
+        b = torch.randn(Co, generator=g)
+        e.add_weight("te.weight", w)
+        e.add_weight("te.weight.taps", w.permute(2, 3, 0, 1).reshape(9 * Co, Ci))
+        e.w["te.bias"] = b.cuda()
+        assert e.thin and e._s3("te.weight.taps", Ci, nhwc(x).cuda()) is not None
+        close(nchw(e.conv3(nhwc(x).cuda(), "te")), F.conv2d(x, w, b, padding=1))
+        e.w.pop("te.weight.taps"), e.w3.pop("te.weight.taps")
+    for (B, H, W, Co) in [(2, 8, 12, 32), (1, 5, 7, 128), (3, 16, 4, 4)]:
+        x = torch.randn(B, 1, H, W, generator=g)
+        w = torch.randn(Co, 1, 3, 3, generator=g) / 3.0
+        b = torch.randn(Co, generator=g)
+        e.add_weight("ti.weight", w)
+        e.w["ti.bias"] = b.cuda()
+        close(nchw(e.conv3(nhwc(x).cuda(), "ti")), F.conv2d(x, w, b, padding=1))
+
+
 @pytest.mark.parametrize("k,dil,stride", [(3, 1, 1), (7, 3, 1), (11, 5, 1), (5, 1, 2), (13, 1, 6)])
 def test_conv1d_vs_torch(eng, k, dil, stride):
     e, cfg, P = eng
@@ -592,20 +616,21 @@ def test_node_run_with_rate_conversion_both_sides(pack, eng, monkeypatch):
 
 def test_default_engine_within_north_star_lsd_of_the_strict_f32_engine(pack):
     """Full-size FlashSR forward: the default engine (contractions as exact three-way bf16 splits on the bf16 matrix pipe,
-    Winograd F(4x4,3x3), z-streamed GEMMs, input-stationary 1-D convs) against the strict engine of the same layer table
+    Winograd F(4x4,3x3), z-streamed GEMMs, input-stationary 1-D convs, per-tap conv_out, vector-ALU conv_in) against the strict engine of the same layer table
     (v_mfma_f32_32x32x2_f32 everywhere, no Winograd).  Bar = the north star's tolerance: LSD <= 1e-3 dB with the reference's
     own metric (measured 2.6e-4 mean / 4.7e-4 p95), and every stage within 5e-5 relative L2 (measured <= 8.5e-6)."""
     from egregora_amd import device_ops, flashsr_arch as A, flashsr_engine as E
     cfg = A.FlashSRConfig()
     P = A.init_params(cfg, 0)
-    old = (E.FlashSREngine.MFMA_MODE, E.FlashSREngine.WINO_MIN_CH)
+    old = (E.FlashSREngine.MFMA_MODE, E.FlashSREngine.WINO_MIN_CH, E.FlashSREngine.THIN_ENDS)
     try:
         e_fast = E.FlashSREngine(cfg, P)
-        E.FlashSREngine.MFMA_MODE, E.FlashSREngine.WINO_MIN_CH = "f32", 1 << 30
+        E.FlashSREngine.MFMA_MODE, E.FlashSREngine.WINO_MIN_CH, E.FlashSREngine.THIN_ENDS = "f32", 1 << 30, False
         e_ref = E.FlashSREngine(cfg, P)
     finally:
-        E.FlashSREngine.MFMA_MODE, E.FlashSREngine.WINO_MIN_CH = old
-    assert e_fast.w3 and not e_ref.w3 and not any(k.endswith(".wino4") for k in e_ref.w)
+        E.FlashSREngine.MFMA_MODE, E.FlashSREngine.WINO_MIN_CH, E.FlashSREngine.THIN_ENDS = old
+    assert e_fast.w3 and not e_ref.w3 and not any(k.endswith(".wino4") or k.endswith(".taps") for k in e_ref.w)
+    assert any(k.endswith(".taps") for k in e_fast.w)
     rng = np.random.Generator(np.random.PCG64(202))
     t = np.arange(cfg.chunk) / 48000.0
     x = sum(np.sin(2 * np.pi * f * t + rng.uniform(0, 6.28)) / (k + 1) for k, f in enumerate(np.geomspace(80, 6000, 8)))
