@@ -38,6 +38,9 @@ struct ConvP {
     // z-streaming (k_conv_s3 GEMMs with nz > 1): a workgroup walks zs_nzb consecutive z problems of its (M, N) tile in one
     // slab loop (loads of z+1 in flight while z's tile is stored); 0 = one z per workgroup (blockIdx.z)
     int zs_nzb, nz;
+    // k_conv_s3: 1 = walk the (row tile, column tile) space XCD-aware -- workgroup L of a z slice sits on XCD L % 8; the
+    // workgroups of one XCD take the column tiles of ONE row tile back to back, so the activation tile they share is an L2 hit
+    int xcd_remap;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float prm) {

@@ -109,7 +109,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
     __shared__ uint4 Bs[2][3][BN * 2];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm0 = (wave / TC::WN) * (BM / TC::WM), wn0 = (wave % TC::WN) * (BN / TC::WN);
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_remap) {                     // launcher guarantees gridDim.x * gridDim.y % 8 == 0 and gridDim.y > 1
+        const int lin = by * gridDim.x + bx, per = (gridDim.x * gridDim.y) >> 3;
+        const int j = (lin & 7) * per + (lin >> 3);
+        bx = j / gridDim.y;
+        by = j - bx * gridDim.y;
+    }
+    const int m0 = bx * BM, n0 = by * BN;
     const int LH = p.up2 ? 2 * p.H : p.H, LW = p.up2 ? 2 * p.W : p.W;
     // z-streaming: this workgroup owns z problems [z0, z0 + nzl) of its tile; otherwise blockIdx.z is the z problem
     const int z0 = ZS ? blockIdx.z * p.zs_nzb : blockIdx.z;
@@ -400,8 +407,11 @@ int s3_zs_nzb(long long M, int Cout, int bm, int bn, int nz, int K) {
     return nzb >= 2 ? nzb : 0;
 }
 
-void launch_conv_s3(int bm, int bn, dim3 grid, hipStream_t st, const ConvP& p) {
+void launch_conv_s3(int bm, int bn, dim3 grid, hipStream_t st, const ConvP& p_in) {
     static const int pf = getenv("EGR_S3_PF") ? atoi(getenv("EGR_S3_PF")) : 1;
+    static const bool remap = !(getenv("EGR_S3_XCD") && atoi(getenv("EGR_S3_XCD")) == 0);
+    ConvP p = p_in;
+    p.xcd_remap = (remap && grid.y > 1 && ((grid.x * grid.y) & 7) == 0) ? 1 : 0;
     if (p.zs_nzb > 0) {
         if (bn == 256) hipLaunchKernelGGL((k_conv_s3<128, 256, 1, true>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((k_conv_s3<128, 128, 1, true>), grid, dim3(256), 0, st, p);
