@@ -102,7 +102,7 @@ def main():
 
     from packload import load_pack
     load_pack()
-    from egregora_amd import (audio_glue as ag, device_ops as ops, fatllama_engine as fe, flashsr_arch as A,
+    from egregora_amd import (audio_glue as ag, fatllama_engine as fe, flashsr_arch as A,
                               flashsr_engine as E, native)
     from egregora_amd.egregora_audio_super_resolution import upscale_48k
     arch = native.require_device()

@@ -22,7 +22,7 @@ for benchmarking (BASELINE: "random-init weights of that architecture").  The sa
 roofline (FlashSREngine.flop_count walks the executed graph).
 """
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Tuple
 
 import numpy as np

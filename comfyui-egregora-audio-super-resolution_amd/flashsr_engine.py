@@ -12,7 +12,6 @@ import math
 import os
 from typing import Dict, List, Optional
 
-import numpy as np
 import torch
 
 from . import device_ops, flashsr_arch as arch, native, shard
