@@ -509,6 +509,7 @@ struct egr_fatllama_plan {
     int threads;                  // workgroup size of the loop kernels (256 or 512)
     int nstreams;                 // channel groups run as concurrent pipelines (1 or 2)
     hipStream_t side;             // second pipeline's stream (forked from / joined to the caller's stream by events)
+    int side_owned;               // 0: `side` was handed in by egr_fatllama_set_side_stream (not destroyed with the plan)
     hipEvent_t ev_fork, ev_join;
     hipStream_t cap;              // private capture stream
     hipGraphExec_t gexec;         // CH captured loop iterations of all pipelines (egr_fatllama_enhance)
@@ -595,7 +596,7 @@ extern "C" int egr_fatllama_plan_destroy(egr_fatllama_plan* p) {
     hipFree(p->d_work); hipFree(p->d_peaks); hipFree(p->d_bhat);
     if (p->gexec) hipGraphExecDestroy(p->gexec);
     if (p->cap) hipStreamDestroy(p->cap);
-    if (p->side) hipStreamDestroy(p->side);
+    if (p->side && p->side_owned) hipStreamDestroy(p->side);
     if (p->ev_fork) hipEventDestroy(p->ev_fork);
     if (p->ev_join) hipEventDestroy(p->ev_join);
     for (auto e : p->ev) hipEventDestroy(e);
@@ -610,7 +611,7 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     p->bluestein = bluestein_n > 0;
     p->nstreams = 2;
     if (const char* e = getenv("EGR_FL_STREAMS")) { const int t = atoi(e); if (t == 1 || t == 2) p->nstreams = t; }
-    p->side = nullptr; p->ev_fork = nullptr; p->ev_join = nullptr;
+    p->side = nullptr; p->side_owned = 0; p->ev_fork = nullptr; p->ev_join = nullptr;
     p->cap = nullptr; p->gexec = nullptr; p->g_out = nullptr; p->g_thr = 0.f; p->g_groups = 0; p->g_iter_odd = 0;
     p->use_graph = !(getenv("EGR_FL_GRAPH") && atoi(getenv("EGR_FL_GRAPH")) == 0);
     p->threads = 512;    // 16 waves per CU at 2 workgroups per CU: measured 1.4x over 256
@@ -863,6 +864,9 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         const int ngroups = (p->nstreams == 2 && C >= 2) ? 2 : 1;
         if (ngroups == 2 && !p->side) {
             EGR_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+            p->side_owned = 1;
+        }
+        if (ngroups == 2 && !p->ev_fork) {
             EGR_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
             EGR_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
         }
@@ -957,6 +961,27 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         hipLaunchKernelGGL(k_finalize, dim3(nb, C), blk256, 0, st, out, Nr, C, flags, peak_in, peak_out);
     }
     EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+// The second pipeline's stream.  HIP multiplexes streams onto a few hardware queues; a side stream that lands on the caller's
+// queue serialises the two channel pipelines, so the host may hand in one it has verified (egr_streams_overlap_us).  The plan
+// does not own it.  Drops a captured loop graph (it recorded the previous stream).
+extern "C" int egr_fatllama_set_side_stream(egr_fatllama_plan* p, void* stream) {
+    EGR_CHECK(p && stream, EGR_ERR_ARG, "null plan / stream");
+    if (p->side == (hipStream_t)stream) return EGR_OK;
+    if (p->side && p->side_owned) EGR_HIP(hipStreamDestroy(p->side));
+    p->side = (hipStream_t)stream;
+    p->side_owned = 0;
+    if (p->gexec) { EGR_HIP(hipGraphExecDestroy(p->gexec)); p->gexec = nullptr; }
+    return EGR_OK;
+}
+
+// Replay of the loop from a captured hipGraph on / off (default on unless EGR_FL_GRAPH=0).  The two ways give identical bits;
+// which is faster depends on how the runtime maps the graph's branches onto hardware queues, so the host may time both.
+extern "C" int egr_fatllama_set_graph(egr_fatllama_plan* p, int enable) {
+    EGR_CHECK(p != nullptr, EGR_ERR_ARG, "plan is null");
+    p->use_graph = enable ? 1 : 0;
     return EGR_OK;
 }
 

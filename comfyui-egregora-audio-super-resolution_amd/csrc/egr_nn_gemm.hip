@@ -10,6 +10,7 @@
 // kernels is the 157.3 TFLOP/s f32 matrix peak.
 #include <string.h>
 
+#include <chrono>
 #include <map>
 #include <mutex>
 
@@ -441,14 +442,15 @@ int zero_page(const float** out) {
     return EGR_OK;
 }
 
-// per-device scratch for split-K partials (grown on demand; launches on one stream are ordered, so reuse is safe)
-static int splitk_workspace(size_t bytes, float** out) {
+// scratch for split-K partials, one buffer per (device, stream): launches on one stream are ordered, so reuse within a stream
+// is safe; row groups of one forward that run on different streams (flashsr_engine.infer_rows) must not share it
+static int splitk_workspace(size_t bytes, hipStream_t st, float** out) {
     static std::mutex mu;
-    static std::map<int, std::pair<float*, size_t>> bufs;
+    static std::map<std::pair<int, hipStream_t>, std::pair<float*, size_t>> bufs;
     int dev = 0;
     EGR_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
-    auto& b = bufs[dev];
+    auto& b = bufs[std::make_pair(dev, st)];
     if (b.second < bytes) {
         if (b.first) { EGR_HIP(hipDeviceSynchronize()); EGR_HIP(hipFree(b.first)); }
         size_t want = bytes < (64u << 20) ? (64u << 20) : bytes;
@@ -457,6 +459,14 @@ static int splitk_workspace(size_t bytes, float** out) {
     }
     *out = b.first;
     return EGR_OK;
+}
+
+// busy-waits `ticks` of the 100 MHz wall clock (bounded by an iteration cap); egr_streams_overlap_us
+__global__ void k_spin(long long ticks, unsigned* sink) {
+    const long long t0 = wall_clock64();
+    unsigned n = 0;
+    while (wall_clock64() - t0 < ticks && n < (1u << 24)) ++n;
+    if (sink && n == 0xffffffffu) *sink = n;
 }
 
 }  // namespace egr
@@ -577,7 +587,7 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
             const int per = (ktiles + S - 1) / S;
             S = (ktiles + per - 1) / per;
             float* ws = nullptr;
-            int rc = splitk_workspace((size_t)S * M * Cout * sizeof(float), &ws);
+            int rc = splitk_workspace((size_t)S * M * Cout * sizeof(float), st, &ws);
             if (rc) return rc;
             p.ksplit = S; p.kt_per = per; p.ws = ws;
             grid.z = S;
@@ -618,6 +628,27 @@ extern "C" int egr_bgemm(const float* a, const float* b, float* c, int nb1, int 
     if (bn == 128) hipLaunchKernelGGL((k_bgemm<128>), grid, dim3(256), 0, st, p);
     else if (bn == 64) hipLaunchKernelGGL((k_bgemm<64>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_bgemm<32>), grid, dim3(256), 0, st, p);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+// Wall time (us) of two `spin_us` busy kernels launched back to back on streams a and b: about spin_us when the streams sit on
+// different hardware queues, about twice that when the runtime maps them onto the same one (HIP multiplexes its streams onto a few
+// hardware queues; which pairs collide is not visible through the API).
+extern "C" int egr_streams_overlap_us(void* a, void* b, int spin_us, double* elapsed_us) {
+    EGR_CHECK(elapsed_us && spin_us >= 10 && spin_us <= 5000, EGR_ERR_ARG, "bad argument");
+    hipStream_t sa = (hipStream_t)a, sb = (hipStream_t)b;
+    const long long ticks = (long long)spin_us * 100;
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, sa, 100ll, (unsigned*)nullptr);     // warm both queues
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, sb, 100ll, (unsigned*)nullptr);
+    EGR_HIP(hipStreamSynchronize(sa));
+    EGR_HIP(hipStreamSynchronize(sb));
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, sa, ticks, (unsigned*)nullptr);
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, sb, ticks, (unsigned*)nullptr);
+    EGR_HIP(hipStreamSynchronize(sa));
+    EGR_HIP(hipStreamSynchronize(sb));
+    *elapsed_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }

@@ -5,12 +5,14 @@ Stands in for `fat_llama.audio_fattener.feed.upscale` + the temp-file hops of th
 the output rate from the file upstream wrote, i.e. sr * upscale_factor.
 """
 import ctypes as C
+import os
+import time
 from collections import OrderedDict
 from typing import Tuple
 
 import torch
 
-from . import native
+from . import native, streams
 
 SAMPLE_WIDTH_BYTES = 2        # temp WAVs are PCM_16 (libsndfile default for float data)
 _PLANS: "OrderedDict[tuple, int]" = OrderedDict()
@@ -45,6 +47,8 @@ def _plan(n_in: int, channels: int, factor: int, device: int, m1_hint: int = 0, 
     _PLANS[key] = out.value
     while len(_PLANS) > _MAX_PLANS:
         _, old = _PLANS.popitem(last=False)
+        for k in [k for k in _TUNED if k[0] == old]:
+            del _TUNED[k]
         L.egr_fatllama_plan_destroy(C.c_void_p(old))
     return out.value
 
@@ -53,6 +57,8 @@ def release_plans():
     L = native.lib()
     while _PLANS:
         _, old = _PLANS.popitem(last=False)
+        for k in [k for k in _TUNED if k[0] == old]:
+            del _TUNED[k]
         L.egr_fatllama_plan_destroy(C.c_void_p(old))
 
 
@@ -70,6 +76,36 @@ def plan_info(n_in: int, factor: int, m1_hint: int = 0) -> dict:
     return d
 
 
+_TUNED = {}
+
+
+def _tune_pipelines(L, plan, x_ct, out, thr, flags):
+    """Once per plan and calling stream: hand the plan a side stream verified to overlap with the caller's (streams.py) for its
+    second channel pipeline, then time a short loop replayed from the captured hipGraph against plain launches and keep the faster
+    (identical bits; how the runtime maps a graph's branches onto hardware queues depends on the streams the process has made)."""
+    key = (plan, torch.cuda.current_stream().cuda_stream)
+    if key in _TUNED:
+        return
+    side = streams.side_streams(1)
+    if side:
+        native.check(L.egr_fatllama_set_side_stream(C.c_void_p(plan), C.c_void_p(side[0].cuda_stream)), "egr_fatllama_set_side_stream")
+    best = 1
+    if os.environ.get("EGR_FL_GRAPH") is None:
+        t = {}
+        for mode in (1, 0):
+            native.check(L.egr_fatllama_set_graph(C.c_void_p(plan), mode), "egr_fatllama_set_graph")
+            for rep in range(2):                              # the first run captures the graph
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                native.check(L.egr_fatllama_enhance(C.c_void_p(plan), native.ptr(x_ct), native.ptr(out), 127, thr, flags,
+                                                    native.stream_ptr()), "egr_fatllama_enhance")
+                torch.cuda.synchronize()
+                t[mode] = time.perf_counter() - t0
+        best = 1 if t[1] <= t[0] else 0
+        native.check(L.egr_fatllama_set_graph(C.c_void_p(plan), best), "egr_fatllama_set_graph")
+    _TUNED[key] = best
+
+
 def enhance_device(x_ct: torch.Tensor, factor: int, max_iterations: int, threshold_value: float,
                    normalize: bool, autoscale: bool, pcm_in: bool, node_post: bool,
                    m1_hint: int = 0, tc_hint: int = 0, profile: bool = False, split=None):
@@ -85,6 +121,8 @@ def enhance_device(x_ct: torch.Tensor, factor: int, max_iterations: int, thresho
     flags = ((native.FL_NORMALIZE if normalize else 0) | (native.FL_AUTOSCALE if autoscale else 0) |
              (native.FL_PCM_IN if pcm_in else 0) | (native.FL_NODE_POST if node_post else 0))
     L = native.lib()
+    if Cn >= 2 and max_iterations > 100 and not profile and split != "bluestein":
+        _tune_pipelines(L, plan, x_ct, out, float(threshold_value), flags)
     if profile:
         L.egr_fatllama_set_profiling(C.c_void_p(plan), 1)
     native.check(L.egr_fatllama_enhance(C.c_void_p(plan), native.ptr(x_ct), native.ptr(out), int(max_iterations),

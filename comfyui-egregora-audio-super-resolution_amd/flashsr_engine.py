@@ -50,7 +50,7 @@ class FlashSREngine:
         self.w["mel_fb"] = self.pack_matrix(fb.contiguous()).to(self.dev)
         self._split3("mel_fb")
         self.alpha, self.sigma = arch.cosine_alpha_sigma(cfg, cfg.t_steps - 1)
-        self._gn_ws = None
+        self._gn_ws = {}            # GroupNorm scratch per stream (row groups of one forward run on several streams)
         self._fold_time_embedding()
 
     # Dense contractions run on the bf16 matrix pipe with fp32-grade results ("bf16x3": exact three-way split of both
@@ -364,17 +364,23 @@ class FlashSREngine:
         y = self.conv(x, key, B, 1, L, Cin, 1, OL, Cout, 1, k, stride, dil, 0, pad, 0, act, res=res)
         return y.view(B, OL, Cout)
 
+    def _gn_scratch(self, need):
+        key = torch.cuda.current_stream().cuda_stream
+        ws = self._gn_ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._gn_ws[key] = torch.empty(int(need) + 1024, dtype=torch.uint8, device=self.dev)
+        return ws
+
     def groupnorm(self, x, key, eps, silu):
         B = x.shape[0]
         Cc = x.shape[-1]
         HW = x.numel() // (B * Cc)
         G = self.cfg.gn_groups
         need = self.L.egr_groupnorm_workspace_bytes(B, Cc, G)
-        if self._gn_ws is None or self._gn_ws.numel() < need:
-            self._gn_ws = torch.empty(int(need) + 1024, dtype=torch.uint8, device=self.dev)
+        ws = self._gn_scratch(need)
         y = torch.empty_like(x)
         native.check(self.L.egr_groupnorm_nhwc(_p(x), _p(self.w[key + ".weight"]), _p(self.w[key + ".bias"]), _p(y), B, HW,
-                                               Cc, G, eps, 1 if silu else 0, _p(self._gn_ws), self._st()),
+                                               Cc, G, eps, 1 if silu else 0, _p(ws), self._st()),
                      "egr_groupnorm_nhwc")
         return y
 
@@ -385,8 +391,7 @@ class FlashSREngine:
         HW = x.numel() // (B * Cc)
         G = self.cfg.gn_groups
         need = self.L.egr_groupnorm_workspace_bytes(B, Cc, G)
-        if self._gn_ws is None or self._gn_ws.numel() < need:
-            self._gn_ws = torch.empty(int(need) + 1024, dtype=torch.uint8, device=self.dev)
+        ws = self._gn_scratch(need)
         sc = torch.empty((B, Cc), dtype=torch.float32, device=self.dev)
         sh = torch.empty((B, Cc), dtype=torch.float32, device=self.dev)
         gp = getattr(x, "_egr_gn_partials", None)
@@ -400,7 +405,7 @@ class FlashSREngine:
                          "egr_groupnorm_coeff_from_stats")
             return sc, sh
         native.check(self.L.egr_groupnorm_coeff(_p(x), _p(self.w[key + ".weight"]), _p(self.w[key + ".bias"]), B, HW, Cc, G,
-                                                eps, _p(self._gn_ws), _p(sc), _p(sh), self._st()), "egr_groupnorm_coeff")
+                                                eps, _p(ws), _p(sc), _p(sh), self._st()), "egr_groupnorm_coeff")
         return sc, sh
 
     def gn_conv3(self, x, norm_key, eps, conv_key, res=None, bias_t=None):
@@ -746,13 +751,16 @@ def set_engine(engine: Optional[FlashSREngine]):
 
 def infer_rows(eng: FlashSREngine, rows_x: torch.Tensor, row_ids: torch.Tensor, seed: int,
                lowpass: bool = False) -> torch.Tensor:
-    """rows_x [R, chunk] -> [R, chunk], processed ROWS_PER_PASS rows at a time; noise keyed by global row id."""
+    """rows_x [R, chunk] -> [R, chunk], processed ROWS_PER_PASS rows at a time on the caller's stream; noise keyed by global
+    row id.  (Row groups on concurrent streams were measured -- 26 rows: 260 ms in one pass, 240..250 ms as 9 | 9 | 8 -- and NOT
+    adopted: k_stft_frames returns wrong 128-byte groups of bins when its workgroups share compute units with k_conv_s3
+    workgroups of another stream)"""
     outs = []
     for lo in range(0, rows_x.shape[0], ROWS_PER_PASS):
         xs = rows_x[lo:lo + ROWS_PER_PASS]
         ids = row_ids[lo:lo + ROWS_PER_PASS].contiguous()
         outs.append(eng.forward_rows(xs, eng.noise(xs.shape[0], ids, seed), lowpass=lowpass))
-    return torch.cat(outs, 0)
+    return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
 
 def infer_spans(x_ct: torch.Tensor, n_chunks: int, win: int, hop: int, lowpass: bool) -> torch.Tensor:

@@ -77,6 +77,9 @@ SIGNATURES = {
     "egr_softmax_rows": (_i, [_vp, _i64, _i, _vp]),
     "egr_eltwise": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _vp]),
     "egr_geglu": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "egr_fatllama_set_side_stream": (_i, [_vp, _vp]),
+    "egr_fatllama_set_graph": (_i, [_vp, _i]),
+    "egr_streams_overlap_us": (_i, [_vp, _vp, _i, _vp]),
     "egr_tap_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "egr_conv_cin1": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "egr_concat_channels": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),

@@ -85,6 +85,11 @@ int egr_spectral_gain(egr_fatllama_plan* plan, const float* x, const float* gain
 
 /* Per-channel peaks of the last enhance call copied to host: host_pin[c] = max|x_c| on the integer scale (after
  * the optional PCM_16 quantisation), host_pout[c] = max|y_c + d_c| before autoscale / normalise.  Synchronises `stream`. */
+/* Hand the plan the stream its second channel pipeline runs on (not owned; one verified with egr_streams_overlap_us to sit on
+ * another hardware queue than the caller's stream), and switch the captured-graph replay of the loop on / off (same bits either
+ * way; the host may time both and keep the faster). */
+int egr_fatllama_set_side_stream(egr_fatllama_plan* plan, void* stream);
+int egr_fatllama_set_graph(egr_fatllama_plan* plan, int enable);
 int egr_fatllama_last_peaks(egr_fatllama_plan* plan, float* host_pin, float* host_pout, void* stream);
 /* Average HIP-event duration (ms) and launch count of the two loop kernels over the last enhance
  * call when profiling was enabled with egr_fatllama_set_profiling(plan, 1). Synchronises. */
@@ -308,6 +313,11 @@ int egr_softmax_rows(float* x, int64_t rows, int cols, void* stream);
 /* op: 0 a+b, 1 s0*a+s1*b, 2 silu(a), 3 s0*a, 4 copy */
 int egr_eltwise(const float* a, const float* b, float* y, int64_t n, int op, float s0, float s1, void* stream);
 int egr_geglu(const float* u, float* y, int64_t rows, int D, void* stream);
+/* Wall time (us) of two spin_us-long busy kernels launched back to back on streams a and b: about spin_us when the two streams
+ * run concurrently (different hardware queues), about twice that when the runtime multiplexes them onto one queue.  The FlashSR
+ * engine uses it once per process to pick side streams that really overlap with the caller's stream. */
+int egr_streams_overlap_us(void* stream_a, void* stream_b, int spin_us, double* elapsed_us);
+
 /* y[b,oy,ox,co] = bias[co] + sum_{ky,kx} P[b, oy+ky-pad_t, ox+kx-pad_l][(ky*KW+kx)*Cout + co] over in-image source pixels: the second
  * half of a kh x kw convolution with very few outputs computed as a 1x1 contraction onto per-tap partial products (VAE conv_out). */
 int egr_tap_gather(const float* P, const float* bias, float* y, int B, int H, int W, int KH, int KW, int Cout, int pad_t, int pad_l,

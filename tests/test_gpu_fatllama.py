@@ -86,6 +86,28 @@ def test_graph_replay_equals_plain_launches(pack, C, n, iters):
     np.testing.assert_array_equal(a, a2)
 
 
+def test_verified_side_stream_and_graph_switch(pack):
+    """The second channel pipeline on a side stream handed in by the host (verified to overlap with the caller's), loop replayed
+    from the captured graph or launched plainly: all four combinations give the same bits; long stereo runs tune this once."""
+    import ctypes as C
+    from egregora_amd import fatllama_engine as fe, native, streams
+    x = synth(2, 9600, seed=5)
+    base = run_gpu(pack, x, 1, 130, 0.6, profile=True)
+    plan = fe._plan(9600, 2, 1, 0)
+    side = streams.side_streams(1)
+    L = native.lib()
+    if side:
+        native.check(L.egr_fatllama_set_side_stream(C.c_void_p(plan), C.c_void_p(side[0].cuda_stream)), "set_side_stream")
+    xd = torch.from_numpy(x).cuda()
+    for mode in (0, 1, 0, 1):
+        native.check(L.egr_fatllama_set_graph(C.c_void_p(plan), mode), "set_graph")
+        out = torch.empty_like(xd)
+        native.check(L.egr_fatllama_enhance(C.c_void_p(plan), native.ptr(xd), native.ptr(out), 130, 0.6, 0, native.stream_ptr()), "enhance")
+        np.testing.assert_array_equal(out.cpu().numpy(), base)
+    np.testing.assert_array_equal(run_gpu(pack, x, 1, 130, 0.6), base)          # the engine's own call: tunes this plan once
+    assert (plan, torch.cuda.current_stream().cuda_stream) in fe._TUNED
+
+
 @pytest.mark.parametrize("n,split", [(420, (6, 5, 7)), (2 * 8 * 9 * 10, (8, 9, 10)), (2 * 16 * 15 * 64, (16, 15, 64)),
                                      (2 * 4 * 3 * 5, (4, 3, 5)), (48000, (20, 24, 50)), (48000, (40, 600, 1))])
 def test_three_level_plan_matches_oracle(pack, n, split):
