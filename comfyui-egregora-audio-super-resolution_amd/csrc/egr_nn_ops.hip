@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_softmax(float* __restrict__ x, int cols
 }
 
 // ---------------------------------------------------------------- element-wise
-enum { EW_ADD = 0, EW_AXPBY = 1, EW_SILU = 2, EW_SCALE = 3, EW_COPY = 4 };
+enum { EW_ADD = 0, EW_AXPBY = 1, EW_SILU = 2, EW_SCALE = 3, EW_COPY = 4, EW_ADD_SCALE = 5 };
 __global__ __launch_bounds__(256) void k_eltwise(const float* __restrict__ a, const float* __restrict__ b,
                                                   float* __restrict__ y, long long n, int op, float s0, float s1) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256) void k_eltwise(const float* __restrict__ a, co
             case EW_AXPBY: v = s0 * a[i] + s1 * b[i]; break;
             case EW_SILU: v = a[i] / (1.f + __expf(-a[i])); break;
             case EW_SCALE: v = s0 * a[i]; break;
+            case EW_ADD_SCALE: v = s0 * __fadd_rn(a[i], b[i]); break;      // the sum rounded first, as add followed by scale
             default: v = a[i]; break;
         }
         y[i] = v;
@@ -829,8 +830,8 @@ extern "C" int egr_softmax_rows(float* x, int64_t rows, int cols, void* stream) 
 }
 
 extern "C" int egr_eltwise(const float* a, const float* b, float* y, int64_t n, int op, float s0, float s1, void* stream) {
-    EGR_CHECK(a && y && n >= 0 && op >= 0 && op <= 4, EGR_ERR_ARG, "bad argument");
-    EGR_CHECK(b || (op != EW_ADD && op != EW_AXPBY), EGR_ERR_ARG, "binary op needs b");
+    EGR_CHECK(a && y && n >= 0 && op >= 0 && op <= 5, EGR_ERR_ARG, "bad argument");
+    EGR_CHECK(b || (op != EW_ADD && op != EW_AXPBY && op != EW_ADD_SCALE), EGR_ERR_ARG, "binary op needs b");
     if (n == 0) return EGR_OK;
     hipLaunchKernelGGL(k_eltwise, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, (long long)n, op, s0, s1);
     EGR_HIP(hipGetLastError());

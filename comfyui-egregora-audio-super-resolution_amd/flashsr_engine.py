@@ -17,7 +17,7 @@ import torch
 from . import device_ops, flashsr_arch as arch, native, shard
 
 ACT_NONE, ACT_SILU, ACT_TANH, ACT_LEAKY, ACT_LOGCLAMP = 0, 1, 2, 3, 4
-EW_ADD, EW_AXPBY, EW_SILU, EW_SCALE, EW_COPY = 0, 1, 2, 3, 4
+EW_ADD, EW_AXPBY, EW_SILU, EW_SCALE, EW_COPY, EW_ADD_SCALE = 0, 1, 2, 3, 4, 5
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -646,7 +646,12 @@ class FlashSREngine:
                 xt = self.conv1d(xt, b + ".conv1", k, dil=d, pad=d * (k - 1) // 2)
                 xt = self.snake(xt, b + ".alpha2", b + ".beta2")
                 x = self.conv1d(xt, b + ".conv2", k, pad=(k - 1) // 2, res=x)
-            acc = x if acc is None else self.eltwise(acc, x, EW_ADD)
+            if acc is None:
+                acc = x
+            elif ki + 1 < len(cfg.voc_kernels):
+                acc = self.eltwise(acc, x, EW_ADD)
+            else:                                            # last branch: the mean's scale rides on the last add
+                return self.eltwise(acc, x, EW_ADD_SCALE, 1.0 / len(cfg.voc_kernels))
         return self.eltwise(acc, None, EW_SCALE, 1.0 / len(cfg.voc_kernels))
 
     def vocoder(self, mel_hat, wave):

@@ -310,7 +310,7 @@ int egr_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, fl
 int egr_layernorm_rows(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C, float eps,
                        void* stream);
 int egr_softmax_rows(float* x, int64_t rows, int cols, void* stream);
-/* op: 0 a+b, 1 s0*a+s1*b, 2 silu(a), 3 s0*a, 4 copy */
+/* op: 0 a+b, 1 s0*a+s1*b, 2 silu(a), 3 s0*a, 4 copy, 5 s0*(a+b) */
 int egr_eltwise(const float* a, const float* b, float* y, int64_t n, int op, float s0, float s1, void* stream);
 int egr_geglu(const float* u, float* y, int64_t rows, int D, void* stream);
 /* Wall time (us) of two spin_us-long busy kernels launched back to back on streams a and b: about spin_us when the two streams
