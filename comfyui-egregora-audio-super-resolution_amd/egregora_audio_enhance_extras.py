@@ -29,33 +29,30 @@ def set_enhancer(fn: Optional[Callable[[torch.Tensor, str], torch.Tensor]]):
     _ENHANCER = fn
 
 
+def _batched(wav: torch.Tensor, ranks, err: str) -> torch.Tensor:
+    """Left-pad the shape with unit axes up to [B,C,T]; ranks outside `ranks` are refused with the reference's message."""
+    if wav.dim() not in ranks:
+        raise ValueError(err)
+    return wav.reshape((1,) * (3 - wav.dim()) + tuple(wav.shape)).float()
+
+
 def _coerce_audio(x):
-    """Reference _coerce_audio (:29-52): -> (wave [B,C,T] float32, sr, meta)."""
-    if isinstance(x, dict) and "waveform" in x and "sample_rate" in x:
-        wav, sr, meta = x["waveform"], int(x["sample_rate"]), x.get("meta", {})
-        if wav.dim() == 2:
-            wav = wav.unsqueeze(0)
-        elif wav.dim() == 1:
-            wav = wav.unsqueeze(0).unsqueeze(0)
-        elif wav.dim() != 3:
-            raise ValueError("Audio waveform must be 1D, 2D or 3D [B,C,T].")
-        return wav.float(), sr, meta
-    if isinstance(x, torch.Tensor):
-        wav = x
-        if wav.dim() == 2:
-            wav = wav.unsqueeze(0)
-        elif wav.dim() != 3:
-            raise ValueError("Tensor audio must be [C,T] or [B,C,T].")
-        return wav.float(), 48000, {}
+    """-> (wave [B,C,T] float32, sr, meta).  Accepts what the reference's enhance nodes accept (:29-52): an AUDIO dict whose
+    waveform has 1-3 axes, or a bare [C,T] / [B,C,T] tensor (taken as 48 kHz); same exception types and messages."""
+    from .audio_glue import is_audio_dict
+    if is_audio_dict(x):
+        return (_batched(x["waveform"], (1, 2, 3), "Audio waveform must be 1D, 2D or 3D [B,C,T]."), int(x["sample_rate"]),
+                x.get("meta", {}))
+    if torch.is_tensor(x):
+        return _batched(x, (2, 3), "Tensor audio must be [C,T] or [B,C,T]."), 48000, {}
     raise TypeError("Unsupported audio input type.")
 
 
 def _make_audio(sr: int, wav: torch.Tensor, meta: Optional[dict] = None):
-    if wav.dim() == 2:
-        wav = wav.unsqueeze(0)
-    if wav.dim() != 3:
+    """[C,T] / [B,C,T] -> the enhance pack's AUDIO dict (waveform contiguous [B,C,T], sample_rate, meta)."""
+    if wav.dim() not in (2, 3):
         raise ValueError("samples must be 1D/2D/3D; got shape %r" % (wav.shape,))
-    return {"waveform": wav.contiguous(), "sample_rate": int(sr), "meta": meta or {}}
+    return dict(waveform=wav.reshape((1,) * (3 - wav.dim()) + tuple(wav.shape)).contiguous(), sample_rate=int(sr), meta=meta or {})
 
 
 _MODES = {"off": 0, "more_on_noise": 1, "more_on_speech": 2, "gate_on_noise": 3}

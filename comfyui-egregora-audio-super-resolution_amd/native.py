@@ -37,7 +37,6 @@ SIGNATURES = {
     "egr_dfn_workspace_bytes": (C.c_size_t, [_i, _i64]),
     "egr_dfn_vad_gains": (_i, [_vp, _i, _i64, C.c_double, _i, C.c_double, C.c_double, C.c_double, _i, _vp, _vp, _vp, _vp]),
     "egr_dfn_mix": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i, _f, _i, _i, C.c_double, _vp, _vp, _vp]),
-    "egr_shift_fir": (_i, [_vp, _i, _i64, _i64, _vp, _i, _vp, _i64, _vp]),
     "egr_gcc_phat": (_i, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
     "egr_band_filter": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "egr_kweight": (_i, [_vp, _i, _i64, _f, _f, _vp, _vp]),

@@ -158,12 +158,6 @@ int egr_pair_stats(const float* a, int ca, int64_t stride_a, const float* b, int
 int egr_null_mix(const float* a, int64_t stride_a, const float* b, int64_t stride_b, int channels, int64_t n, float k, int use_k,
                  int invert_b, float* null_out, double* out2, void* stream);
 
-/* Delay compensation of the null-test suite's aligner: y[c][i] = sum_k h[k] s[i + (taps-1)/2 - k] with s[i] = x[c][i - shift]
- * (zero outside [0, n_in)), i.e. an integer shift followed by np.convolve(., h, "same"); taps = 0 skips the FIR; n_out pads with
- * zeros or crops (_apply_frac_delay_CN + _pad_or_crop_CN, egregora_null_test_suite.py:203-266). */
-int egr_shift_fir(const float* x, int channels, int64_t n_in, int64_t shift, const float* h, int taps, float* y, int64_t n_out,
-                  void* stream);
-
 /* Evaluation metrics on the device (the parity yardstick of this pack and the reference's "Metrics (LSD + SI-SDR)" node):
  *   egr_lsd_frames  : per[f] = sqrt(mean_k (20 log10(SA[f][k]+1e-12) - 20 log10(SB[f][k]+1e-12))^2 + 1e-12) from two
  *                     frame-major magnitude arrays of egr_stft_mag          (_lsd, egregora_audio_eval_pack.py:405-411)
