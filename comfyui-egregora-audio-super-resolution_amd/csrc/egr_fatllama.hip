@@ -63,6 +63,12 @@ struct RowP {
     int phat;              // 1: the state is z = a + i b of two REAL signals; replace it by the PHAT-weighted cross-spectrum
     long long band_lo;     // > 0: keep half-spectrum bins k >= band_lo, zero the others (replaces the threshold); band = 1 selects it
     int band;
+    // threshold variants (SPEC.md section 3).  max2 != nullptr: the level is thr * sqrt(max2[ch]) with max2[ch] = max_k |X[k]|^2 of
+    // THIS iteration's spectrum (float bits, written by k_row<true>); soft: X max(0, 1 - t/|X|) instead of X [|X| > t].
+    const unsigned* max2;
+    unsigned* max2_out;    // k_row<true> only: where the maximum goes
+    float thr;
+    int soft;
 };
 
 __device__ __forceinline__ void atomic_max_abs(unsigned* slot, float v) {
@@ -88,9 +94,11 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // MODE 3: inverse (state -> twiddle^-1 -> IFFT -> state)                    [inner pass of a 3-level plan]
 // MODE 4: forward (state -> FFT -> twiddle -> state)                        [inner pass of a 3-level plan]
 // MODE 5: last, plain (state -> twiddle^-1 -> IFFT -> out = d)               [spectral-gain filter]
+// thr_rel (MODE 0 only, optional): per-channel max|y| as float bits; the time-domain level becomes thr * max|y| (SPEC.md section 3).
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_col(ColP p, long long M, long long N, float thr, cplx* __restrict__ work,
-                                              float* __restrict__ out, unsigned* __restrict__ peak_out) {
+                                              float* __restrict__ out, unsigned* __restrict__ peak_out,
+                                              const unsigned* __restrict__ thr_rel = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float red[16];
     // XCD-aware tile order: the dispatcher places block b on XCD b%8; give every XCD a contiguous run
@@ -106,6 +114,7 @@ __global__ __launch_bounds__(1024) void k_col(ColP p, long long M, long long N, 
     cplx* W = work + (size_t)ch * M + poff;
     float2* Y = (float2*)(out + (size_t)ch * N) + poff;
     const int nel = L * TC;
+    if (MODE == 0 && thr_rel) thr *= __uint_as_float(thr_rel[ch]);
 
     for (int e = threadIdx.x; e < nel; e += blockDim.x) {
         const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
@@ -165,8 +174,12 @@ __global__ __launch_bounds__(1024) void k_col(ColP p, long long M, long long N, 
 }
 
 // Row-pair kernel: outer indices oa = pair, ob = R - pair of the in-place state.
+// MAXONLY: forward transform + real split only, max_k |X[k]|^2 of the channel -> p.max2_out[ch] (nothing is written back): the
+// reduction a threshold RELATIVE to the spectrum's maximum needs before any bin can be judged.
+template <bool MAXONLY>
 __global__ __launch_bounds__(1024) void k_row(RowP p, long long M, cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float red[16];
     const int L = p.L, R = p.R;
     const int oa = blockIdx.x;
     const int ob = (R - oa) % R;
@@ -195,7 +208,14 @@ __global__ __launch_bounds__(1024) void k_row(RowP p, long long M, cplx* __restr
     if (!self) { cnt = L; boff = L - 1; rb = cur + L; }
     else if (oa == 0) { cnt = L / 2 + 1; boff = L; rb = cur; }
     else { cnt = (L + 1) / 2; boff = L - 1; rb = cur; }
-    const float thr2 = p.thr2, sc = p.inv_M;
+    const float sc = p.inv_M;
+    float thr2 = p.thr2, tlev = p.thr;
+    if (!MAXONLY && p.max2) {
+        tlev = p.thr * sqrtf(__uint_as_float(p.max2[ch]));
+        thr2 = tlev * tlev;
+    }
+    const bool variant = !MAXONLY && (p.max2 != nullptr || p.soft);
+    float mx2 = 0.f;
     for (int k2 = threadIdx.x; k2 < cnt; k2 += blockDim.x) {
         int pb = boff - k2;
         if (pb >= L) pb -= L;
@@ -219,7 +239,19 @@ __global__ __launch_bounds__(1024) void k_row(RowP p, long long M, cplx* __restr
         const cplx WO = cmul(Wk, O);
         cplx Xk = cadd(E, WO);      // X[k]
         cplx Xm = csub(E, WO);      // conj X[M-k]
-        if (p.band) {
+        if (MAXONLY) {
+            mx2 = fmaxf(mx2, fmaxf(Xk.x * Xk.x + Xk.y * Xk.y, Xm.x * Xm.x + Xm.y * Xm.y));
+            continue;
+        }
+        if (variant) {
+            const float mk = sqrtf(Xk.x * Xk.x + Xk.y * Xk.y), mm = sqrtf(Xm.x * Xm.x + Xm.y * Xm.y);
+            float gk = mk > tlev ? 1.f : 0.f, gm = mm > tlev ? 1.f : 0.f;
+            if (p.soft) {
+                if (mk > tlev) gk = 1.f - tlev / mk;
+                if (mm > tlev) gm = 1.f - tlev / mm;
+            }
+            Xk.x *= gk; Xk.y *= gk; Xm.x *= gm; Xm.y *= gm;
+        } else if (p.band) {
             const long long k = (long long)oa + (long long)R * k2;
             if (k < p.band_lo) Xk = make_float2(0.f, 0.f);
             if (M - k < p.band_lo) Xm = make_float2(0.f, 0.f);
@@ -238,6 +270,11 @@ __global__ __launch_bounds__(1024) void k_row(RowP p, long long M, cplx* __restr
         // Za' = E2 + i*O2 ; Zb' = conj(E2 - i*O2)
         cur[k2] = make_float2(sc * (E2.x - O2.y), sc * (E2.y + O2.x));
         if (!same) rb[pb] = make_float2(sc * (E2.x + O2.y), -sc * (E2.y - O2.x));
+    }
+    if (MAXONLY) {
+        mx2 = block_max(mx2, red);
+        if (threadIdx.x == 0) atomicMax(p.max2_out + ch, __float_as_uint(mx2));
+        return;
     }
     __syncthreads();
     lds_fft<false>(cur, alt, p.f, p.tw, nrows, 0, 1, L, true, p.twd);
@@ -262,6 +299,7 @@ struct ChirpP {
     float inv_N;
     int band;                // 1: the spectrum hook keeps bins min(n, N - n) >= band_lo instead of thresholding
     unsigned long long band_lo;
+    int soft;                // 1: soft shrink X max(0, 1 - thr/|X|) instead of the hard threshold
 };
 __device__ __forceinline__ cplx chirp(const ChirpP& c, unsigned long long n) {
     const unsigned long long r = (n * n) % (2ULL * c.N);
@@ -339,6 +377,10 @@ __global__ __launch_bounds__(256) void k_colz(ColP p, ChirpP cp, long long P, fl
                     cplx X = cmul(w, cc);
                     if (cp.band) {
                         if ((n < N - n ? n : N - n) < cp.band_lo) X = make_float2(0.f, 0.f);
+                    } else if (cp.soft) {
+                        const float mg = sqrtf(X.x * X.x + X.y * X.y);
+                        const float g = mg > thr ? 1.f - thr / mg : 0.f;
+                        X.x *= g; X.y *= g;
                     } else if (!(X.x * X.x + X.y * X.y > thr2)) X = make_float2(0.f, 0.f);
                     v = cmul(make_float2(X.x, -X.y), w);
                 } else {                         // d = Re(w c)/N ; a = d w
@@ -399,14 +441,16 @@ __global__ __launch_bounds__(256) void k_chirp_b(ChirpP cp, long long P, cplx* _
 }
 
 // x (optionally PCM_16-quantised) -> y = linear up-rate by f, per-channel max|x_q|.
+// zero_stuff: y[i*f] = x[i], zeros between (SPEC.md "interp").  peak_y[ch] = max|y| (what a relative time-domain threshold refers to).
 __global__ __launch_bounds__(256) void k_prepare(const float* __restrict__ x, float* __restrict__ y, long long n_in,
-                                                  int f, int pcm_in, unsigned* __restrict__ peak_in) {
+                                                  int f, int pcm_in, int zero_stuff, unsigned* __restrict__ peak_in,
+                                                  unsigned* __restrict__ peak_y) {
     __shared__ float red[8];
     const int ch = blockIdx.y;
     const float* xc = x + (size_t)ch * n_in;
     float* yc = y + (size_t)ch * n_in * f;
     const float ff = (float)f;
-    float mx = 0.f;
+    float mx = 0.f, my = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_in;
          i += (long long)gridDim.x * blockDim.x) {
         float a = xc[i];
@@ -420,25 +464,36 @@ __global__ __launch_bounds__(256) void k_prepare(const float* __restrict__ x, fl
             b = (float)qb;
         }
         mx = fmaxf(mx, fabsf(a));
-        if (i + 1 < n_in) {
+        if (zero_stuff) {
+            yc[i * f] = a;
+            for (int j = 1; j < f; ++j) yc[i * f + j] = 0.f;
+            my = fmaxf(my, fabsf(a));
+        } else if (i + 1 < n_in) {
             for (int j = 0; j < f; ++j) {
                 const float t = __fdiv_rn((float)j, ff);
                 const float u = __fsub_rn(1.0f, t);
-                yc[i * f + j] = __fadd_rn(__fmul_rn(u, a), __fmul_rn(t, b));
+                const float v = __fadd_rn(__fmul_rn(u, a), __fmul_rn(t, b));
+                yc[i * f + j] = v;
+                my = fmaxf(my, fabsf(v));
             }
         } else {
             for (int j = 0; j < f; ++j) yc[i * f + j] = 0.f;   // upstream leaves the last sample's slots zero
         }
     }
     mx = block_max(mx, red);
-    if (threadIdx.x == 0) atomic_max_abs(peak_in + ch, mx);
+    my = block_max(my, red);
+    if (threadIdx.x == 0) {
+        atomic_max_abs(peak_in + ch, mx);
+        atomic_max_abs(peak_y + ch, my);
+    }
 }
 
 // max_iter == 0 path: out = y + (|y|>thr ? y : 0), peaks
 __global__ __launch_bounds__(256) void k_noiter(float* __restrict__ y, long long N, float thr,
-                                                 unsigned* __restrict__ peak_out) {
+                                                 unsigned* __restrict__ peak_out, const unsigned* __restrict__ thr_rel) {
     __shared__ float red[8];
     const int ch = blockIdx.y;
+    if (thr_rel) thr *= __uint_as_float(thr_rel[ch]);
     float* yc = y + (size_t)ch * N;
     float mx = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N;
@@ -504,7 +559,9 @@ struct egr_fatllama_plan {
     ChirpP chirp;
     cplx* d_bhat;         // FFT_P(b) / P in the passes' transposed layout
     cplx* d_work;
-    unsigned* d_peaks;   // [2*C]: peak_in[C], peak_out[C]
+    unsigned* d_peaks;   // [3*C]: peak_in[C], peak_out[C], peak_y[C]
+    unsigned* d_max2;    // [max2_cap]: per (iteration, channel) max |X|^2 of the relative-threshold variant
+    size_t max2_cap;
     bool profiling;
     int threads;                  // workgroup size of the loop kernels (256 or 512)
     int nstreams;                 // channel groups run as concurrent pipelines (1 or 2)
@@ -593,7 +650,7 @@ extern "C" int egr_fatllama_plan_query(int64_t n_in, int factor, int m1_hint, in
 extern "C" int egr_fatllama_plan_destroy(egr_fatllama_plan* p) {
     if (!p) return EGR_OK;
     for (void* q : p->dev_allocs) hipFree(q);
-    hipFree(p->d_work); hipFree(p->d_peaks); hipFree(p->d_bhat);
+    hipFree(p->d_work); hipFree(p->d_peaks); hipFree(p->d_bhat); hipFree(p->d_max2);
     if (p->gexec) hipGraphExecDestroy(p->gexec);
     if (p->cap) hipStreamDestroy(p->cap);
     if (p->side && p->side_owned) hipStreamDestroy(p->side);
@@ -619,6 +676,7 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     p->d_bhat = nullptr;
     p->d_work = nullptr;
     p->d_peaks = nullptr;
+    p->d_max2 = nullptr; p->max2_cap = 0;
     hipGetDevice(&p->device);
     const int64_t M = sp.M, N = sp.N;
     int rc = EGR_OK;
@@ -663,7 +721,7 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     }
     r.inv_M = (float)(1.0 / (double)M);
     if (hipMalloc((void**)&p->d_work, (size_t)channels * M * sizeof(float2)) != hipSuccess ||
-        hipMalloc((void**)&p->d_peaks, 2 * channels * sizeof(unsigned)) != hipSuccess) {
+        hipMalloc((void**)&p->d_peaks, 3 * channels * sizeof(unsigned)) != hipSuccess) {
         set_error("hipMalloc of the %lld-byte loop state failed", (long long)(channels * M * 8));
         return fail(EGR_ERR_ALLOC);
     }
@@ -676,7 +734,8 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_row, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_row<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_row<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
@@ -821,13 +880,32 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
     ColP A = p->colA, B = p->colB;
     RowP R = p->row;
     R.thr2 = thr * thr;
+    R.thr = thr;
+    R.soft = (flags & EGR_FL_THR_SOFT) ? 1 : 0;
+    const bool relative = (flags & EGR_FL_THR_RELATIVE) != 0;
+    const bool no_init = (flags & EGR_FL_NO_INIT_THR) != 0;
+    EGR_CHECK(!(relative && p->bluestein), EGR_ERR_UNSUPPORTED,
+              "the relative-to-maximum threshold is built for packed-real plans only (this length takes the chirp-z path)");
     unsigned* peak_in = p->d_peaks;
     unsigned* peak_out = p->d_peaks + C;
-    EGR_HIP(hipMemsetAsync(p->d_peaks, 0, 2 * C * sizeof(unsigned), st));
+    unsigned* peak_y = p->d_peaks + 2 * C;
+    EGR_HIP(hipMemsetAsync(p->d_peaks, 0, 3 * C * sizeof(unsigned), st));
+    if (relative && max_iter > 0) {
+        const size_t need = (size_t)max_iter * C;
+        if (need > p->max2_cap) {
+            if (p->d_max2) { EGR_HIP(hipFree(p->d_max2)); p->d_max2 = nullptr; p->max2_cap = 0; }
+            EGR_HIP(hipMalloc((void**)&p->d_max2, need * sizeof(unsigned)));
+            p->max2_cap = need;
+        }
+        EGR_HIP(hipMemsetAsync(p->d_max2, 0, need * sizeof(unsigned), st));
+    }
+    // time-domain level of the opening pass: thr, thr * max|y| (relative) or none (every sample kept)
+    const float thr0 = no_init ? -1.0f : thr;
+    const unsigned* thr0_rel = (relative && !no_init) ? peak_y : nullptr;
     {
         const int nb = (int)((p->n_in + 255) / 256 < 2048 ? (p->n_in + 255) / 256 : 2048);
         hipLaunchKernelGGL(k_prepare, dim3(nb, C), dim3(256), 0, st, x, out, (long long)p->n_in, p->factor,
-                           (flags & EGR_FL_PCM_IN) ? 1 : 0, peak_in);
+                           (flags & EGR_FL_PCM_IN) ? 1 : 0, (flags & EGR_FL_ZERO_STUFF) ? 1 : 0, peak_in, peak_y);
     }
     const dim3 gA(8 * A.tiles_per_xcd, C), gB(8 * B.tiles_per_xcd, C * (three ? B.nplanes : 1)), grow(R.R / 2 + 1, C),
         blk(p->bluestein ? 256 : p->threads), blk256(256);
@@ -836,9 +914,10 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
     if (max_iter == 0) {
         const long long Nr = p->bluestein ? (long long)p->chirp.N : N;
         const int nb = (int)((Nr + 255) / 256 < 2048 ? (Nr + 255) / 256 : 2048);
-        hipLaunchKernelGGL(k_noiter, dim3(nb, C), blk256, 0, st, out, Nr, thr, peak_out);
+        hipLaunchKernelGGL(k_noiter, dim3(nb, C), blk256, 0, st, out, Nr, thr0, peak_out, thr0_rel);
     } else if (p->bluestein) {
-        const ChirpP cp = p->chirp;
+        ChirpP cp = p->chirp;
+        cp.soft = R.soft;
         const long long P = M;
         const dim3 grc((R.R + 1) / 2, C);
         const float thr2 = thr * thr;
@@ -848,7 +927,7 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
                                p->d_work);
             if (three) hipLaunchKernelGGL(k_col<3>, gB, blk, lb, st, B, P, N, thr, p->d_work, out, peak_out);
         };
-        hipLaunchKernelGGL((k_colz<0, 0>), gA, blk, lc, st, A, cp, P, thr, thr2, p->d_work, out, peak_out);
+        hipLaunchKernelGGL((k_colz<0, 0>), gA, blk, lc, st, A, cp, P, thr0, thr2, p->d_work, out, peak_out);
         for (int it = 0; it < max_iter; ++it) {
             conv();
             hipLaunchKernelGGL((k_colz<1, 1>), gA, blk, lc, st, A, cp, P, thr, thr2, p->d_work, out, peak_out);
@@ -879,12 +958,18 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
             unsigned* pk = peak_out + c0;
             const dim3 gAg(gA.x, cn), gBg(gB.x, cn * (three ? B.nplanes : 1)), growg(grow.x, cn);
             if (first) {
-                hipLaunchKernelGGL(k_col<0>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
+                hipLaunchKernelGGL(k_col<0>, gAg, blk, lc, sg, A, M, N, thr0, wk, og, pk, thr0_rel ? thr0_rel + c0 : nullptr);
                 if (three) hipLaunchKernelGGL(k_col<4>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
             }
             for (int it = it0; it < it1; ++it) {
+                RowP Rg = R;
+                if (relative) {        // this iteration's spectrum maximum first (forward row transforms + split, no write-back)
+                    Rg.max2_out = p->d_max2 + (size_t)it * C + c0;
+                    hipLaunchKernelGGL(k_row<true>, growg, blk, lr, sg, Rg, M, wk);
+                    Rg.max2 = Rg.max2_out;
+                }
                 if (prof) prof_begin(p, 0, sg, &slot);
-                hipLaunchKernelGGL(k_row, growg, blk, lr, sg, R, M, wk);
+                hipLaunchKernelGGL(k_row<false>, growg, blk, lr, sg, Rg, M, wk);
                 if (prof) prof_end(p, sg, &slot);
                 if (three) {
                     if (prof) prof_begin(p, 2, sg, &slot);
@@ -923,14 +1008,14 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         // executable graph is kept while (out, threshold, geometry) stay the same.  Profiling runs use plain launches.
         constexpr int CH = 25;
         const bool profiling = p->profiling != 0;
-        const int n_graph = (!profiling && p->use_graph && max_iter > 2 * CH) ? (max_iter - 1) / CH : 0;
+        const int n_graph = (!profiling && p->use_graph && !relative && max_iter > 2 * CH) ? (max_iter - 1) / CH : 0;
         int rc = fork(st);
         if (rc) return rc;
         for (int g = 0; g < ngroups; ++g) run_group(st, g, 0, 0, true, false, false);
         if (n_graph > 0) {
             rc = join(st);
             if (rc) return rc;
-            if (!(p->gexec && p->g_out == out && p->g_thr == thr && p->g_groups == ngroups && p->g_iter_odd == 0)) {
+            if (!(p->gexec && p->g_out == out && p->g_thr == thr && p->g_groups == ngroups && p->g_iter_odd == R.soft)) {
                 if (p->gexec) { EGR_HIP(hipGraphExecDestroy(p->gexec)); p->gexec = nullptr; }
                 hipGraph_t graph = nullptr;
                 // captured on a private stream (the caller's may be the legacy default stream, which cannot capture)
@@ -941,11 +1026,17 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
                 if (!rc) for (int g = 0; g < ngroups; ++g) run_group(p->cap, g, 0, CH, false, false, false);
                 if (!rc) rc = join(p->cap);
                 hipError_t ce = hipStreamEndCapture(p->cap, &graph);
-                if (rc) return rc;
-                EGR_HIP(ce);
-                EGR_HIP(hipGraphInstantiate(&p->gexec, graph, nullptr, nullptr, 0));
-                EGR_HIP(hipGraphDestroy(graph));
-                p->g_out = out; p->g_thr = thr; p->g_groups = ngroups; p->g_iter_odd = 0;
+                if (rc || ce != hipSuccess) {          // leave no half-captured state behind: the next call starts from scratch
+                    if (graph) hipGraphDestroy(graph);
+                    hipStreamDestroy(p->cap);
+                    p->cap = nullptr;
+                    if (rc) return rc;
+                    EGR_HIP(ce);
+                }
+                hipError_t ie = hipGraphInstantiate(&p->gexec, graph, nullptr, nullptr, 0);
+                hipGraphDestroy(graph);
+                if (ie != hipSuccess) { p->gexec = nullptr; EGR_HIP(ie); }
+                p->g_out = out; p->g_thr = thr; p->g_groups = ngroups; p->g_iter_odd = R.soft;
             }
             for (int i = 0; i < n_graph; ++i) EGR_HIP(hipGraphLaunch(p->gexec, st));
             rc = fork(st);
@@ -1034,7 +1125,7 @@ extern "C" int egr_spectral_gain(egr_fatllama_plan* p, const float* x, const flo
     const size_t lc = p->sp.lds_col, lb = p->sp.lds_colb, lr = p->sp.lds_row;
     hipLaunchKernelGGL(k_col<0>, gA, blk, lc, st, A, M, N, -1.0f, p->d_work, const_cast<float*>(x), (unsigned*)nullptr);
     if (three) hipLaunchKernelGGL(k_col<4>, gB, blk, lb, st, B, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
-    hipLaunchKernelGGL(k_row, grow, blk, lr, st, R, M, p->d_work);
+    hipLaunchKernelGGL(k_row<false>, grow, blk, lr, st, R, M, p->d_work);
     if (three) hipLaunchKernelGGL(k_col<3>, gB, blk, lb, st, B, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
     hipLaunchKernelGGL(k_col<5>, gA, blk, lc, st, A, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
     EGR_HIP(hipGetLastError());
@@ -1078,7 +1169,7 @@ extern "C" int egr_band_filter(egr_fatllama_plan* p, const float* x, int64_t ban
         const dim3 grow(R.R / 2 + 1, C);
         hipLaunchKernelGGL(k_col<0>, gA, blk, lc, st, A, M, N, -1.0f, p->d_work, xs, (unsigned*)nullptr);
         if (three) hipLaunchKernelGGL(k_col<4>, gB, blk, lb, st, B, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
-        hipLaunchKernelGGL(k_row, grow, blk, lr, st, R, M, p->d_work);
+        hipLaunchKernelGGL(k_row<false>, grow, blk, lr, st, R, M, p->d_work);
         if (three) hipLaunchKernelGGL(k_col<3>, gB, blk, lb, st, B, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
         hipLaunchKernelGGL(k_col<5>, gA, blk, lc, st, A, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
     }
@@ -1161,7 +1252,7 @@ extern "C" int egr_gcc_phat(egr_fatllama_plan* p, const float* a, int64_t na, co
     const size_t lc = p->sp.lds_col, lb = p->sp.lds_colb, lr = p->sp.lds_row;
     hipLaunchKernelGGL(k_col<0>, gA, blk, lc, st, A, M, N, -1.0f, p->d_work, z, (unsigned*)nullptr);
     if (three) hipLaunchKernelGGL(k_col<4>, gB, blk, lb, st, B, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
-    hipLaunchKernelGGL(k_row, grow, blk, lr, st, R, M, p->d_work);
+    hipLaunchKernelGGL(k_row<false>, grow, blk, lr, st, R, M, p->d_work);
     if (three) hipLaunchKernelGGL(k_col<3>, gB, blk, lb, st, B, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
     hipLaunchKernelGGL(k_col<5>, gA, blk, lc, st, A, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
     hipLaunchKernelGGL(k_phat_peak, dim3(1), dim3(1024), 0, st, (const float2*)y, n, (long long)max_shift, out4);

@@ -15,6 +15,23 @@ import torch
 from . import native, streams
 
 SAMPLE_WIDTH_BYTES = 2        # temp WAVs are PCM_16 (libsndfile default for float data)
+
+# Which reading of upstream's unverified threshold / interpolation semantics the nodes run (SPEC.md section 3): a comma list out of
+# relative, soft, no_init_thr, zero_stuff; empty = absolute level, hard threshold, time-domain pre-threshold, linear up-rating.
+VARIANT_FLAGS = {"relative": native.FL_THR_RELATIVE, "soft": native.FL_THR_SOFT, "no_init_thr": native.FL_NO_INIT_THR,
+                 "zero_stuff": native.FL_ZERO_STUFF}
+
+
+def variant_flags(names=None) -> int:
+    names = os.environ.get("EGREGORA_FATLLAMA_SPEC", "") if names is None else names
+    flags = 0
+    for tok in (t.strip() for t in str(names).split(",")):
+        if tok:
+            if tok not in VARIANT_FLAGS:
+                raise RuntimeError(f"EGREGORA_FATLLAMA_SPEC: unknown variant {tok!r} (known: {sorted(VARIANT_FLAGS)})")
+            flags |= VARIANT_FLAGS[tok]
+    return flags
+
 _PLANS: "OrderedDict[tuple, int]" = OrderedDict()
 _MAX_PLANS = 4
 
@@ -47,8 +64,7 @@ def _plan(n_in: int, channels: int, factor: int, device: int, m1_hint: int = 0, 
     _PLANS[key] = out.value
     while len(_PLANS) > _MAX_PLANS:
         _, old = _PLANS.popitem(last=False)
-        for k in [k for k in _TUNED if k[0] == old]:
-            del _TUNED[k]
+        _SIDE_SET.difference_update({k for k in _SIDE_SET if k[0] == old})
         L.egr_fatllama_plan_destroy(C.c_void_p(old))
     return out.value
 
@@ -57,8 +73,7 @@ def release_plans():
     L = native.lib()
     while _PLANS:
         _, old = _PLANS.popitem(last=False)
-        for k in [k for k in _TUNED if k[0] == old]:
-            del _TUNED[k]
+        _SIDE_SET.difference_update({k for k in _SIDE_SET if k[0] == old})
         L.egr_fatllama_plan_destroy(C.c_void_p(old))
 
 
@@ -76,40 +91,50 @@ def plan_info(n_in: int, factor: int, m1_hint: int = 0) -> dict:
     return d
 
 
-_TUNED = {}
+_TUNED = {}          # (device, caller stream) -> 1 graph replay / 0 plain launches, decided once per process
+_SIDE_SET = set()    # (plan, caller stream) pairs that already hold the verified side stream
+TUNE_ITERS = 76      # three replays of the captured 25-iteration graph + the plain remainder
+TUNE_MIN_JOB = 400   # shorter jobs keep the default (graph replay): tuning would cost as much as the job
 
 
-def _tune_pipelines(L, plan, x_ct, out, thr, flags):
-    """Once per plan and calling stream: hand the plan a side stream verified to overlap with the caller's (streams.py) for its
-    second channel pipeline, then time a short loop replayed from the captured hipGraph against plain launches and keep the faster
-    (identical bits; how the runtime maps a graph's branches onto hardware queues depends on the streams the process has made)."""
-    key = (plan, torch.cuda.current_stream().cuda_stream)
-    if key in _TUNED:
+def _tune_pipelines(L, plan, x_ct, out, thr, flags, max_iterations):
+    """Hand the plan a side stream verified to overlap with the caller's (streams.py) for its second channel pipeline, and pick
+    graph replay or plain launches for the loop (identical bits).  How the runtime maps a graph's branches onto hardware queues
+    depends on the streams the process has made, not on the signal length, so the timing runs ONCE per (device, caller stream) on
+    the first long job -- two short runs per mode into `out`, which the real call overwrites next -- and every later plan reuses it."""
+    cur = torch.cuda.current_stream()
+    skey = (plan, cur.cuda_stream)
+    if skey not in _SIDE_SET:
+        side = streams.side_streams(1)
+        if side:
+            native.check(L.egr_fatllama_set_side_stream(C.c_void_p(plan), C.c_void_p(side[0].cuda_stream)), "egr_fatllama_set_side_stream")
+        _SIDE_SET.add(skey)
+    if os.environ.get("EGR_FL_GRAPH") is not None:
         return
-    side = streams.side_streams(1)
-    if side:
-        native.check(L.egr_fatllama_set_side_stream(C.c_void_p(plan), C.c_void_p(side[0].cuda_stream)), "egr_fatllama_set_side_stream")
-    best = 1
-    if os.environ.get("EGR_FL_GRAPH") is None:
+    key = (x_ct.device.index or 0, cur.cuda_stream)
+    best = _TUNED.get(key)
+    if best is None:
+        if max_iterations < TUNE_MIN_JOB:
+            return
         t = {}
         for mode in (1, 0):
             native.check(L.egr_fatllama_set_graph(C.c_void_p(plan), mode), "egr_fatllama_set_graph")
             for rep in range(2):                              # the first run captures the graph
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                native.check(L.egr_fatllama_enhance(C.c_void_p(plan), native.ptr(x_ct), native.ptr(out), 127, thr, flags,
+                native.check(L.egr_fatllama_enhance(C.c_void_p(plan), native.ptr(x_ct), native.ptr(out), TUNE_ITERS, thr, flags,
                                                     native.stream_ptr()), "egr_fatllama_enhance")
                 torch.cuda.synchronize()
                 t[mode] = time.perf_counter() - t0
-        best = 1 if t[1] <= t[0] else 0
-        native.check(L.egr_fatllama_set_graph(C.c_void_p(plan), best), "egr_fatllama_set_graph")
-    _TUNED[key] = best
+        best = _TUNED[key] = 1 if t[1] <= t[0] else 0
+    native.check(L.egr_fatllama_set_graph(C.c_void_p(plan), best), "egr_fatllama_set_graph")
 
 
 def enhance_device(x_ct: torch.Tensor, factor: int, max_iterations: int, threshold_value: float,
                    normalize: bool, autoscale: bool, pcm_in: bool, node_post: bool,
-                   m1_hint: int = 0, tc_hint: int = 0, profile: bool = False, split=None):
-    """x_ct: [C,T] float32 CUDA tensor.  Returns [C,T*factor] float32 CUDA tensor (same stream)."""
+                   m1_hint: int = 0, tc_hint: int = 0, profile: bool = False, split=None, variant=None):
+    """x_ct: [C,T] float32 CUDA tensor.  Returns [C,T*factor] float32 CUDA tensor (same stream).
+    variant: comma list for variant_flags (None: the EGREGORA_FATLLAMA_SPEC environment variable)."""
     if not (x_ct.is_cuda and x_ct.dtype == torch.float32 and x_ct.dim() == 2):
         raise RuntimeError("enhance_device wants a [C,T] float32 tensor on the GPU")
     x_ct = x_ct.contiguous()
@@ -119,10 +144,10 @@ def enhance_device(x_ct: torch.Tensor, factor: int, max_iterations: int, thresho
     plan = _plan(T, Cn, factor, x_ct.device.index or 0, m1_hint, tc_hint, split)
     out = torch.empty((Cn, T * factor), dtype=torch.float32, device=x_ct.device)
     flags = ((native.FL_NORMALIZE if normalize else 0) | (native.FL_AUTOSCALE if autoscale else 0) |
-             (native.FL_PCM_IN if pcm_in else 0) | (native.FL_NODE_POST if node_post else 0))
+             (native.FL_PCM_IN if pcm_in else 0) | (native.FL_NODE_POST if node_post else 0) | variant_flags(variant))
     L = native.lib()
     if Cn >= 2 and max_iterations > 100 and not profile and split != "bluestein":
-        _tune_pipelines(L, plan, x_ct, out, float(threshold_value), flags)
+        _tune_pipelines(L, plan, x_ct, out, float(threshold_value), flags, int(max_iterations))
     if profile:
         L.egr_fatllama_set_profiling(C.c_void_p(plan), 1)
     native.check(L.egr_fatllama_enhance(C.c_void_p(plan), native.ptr(x_ct), native.ptr(out), int(max_iterations),

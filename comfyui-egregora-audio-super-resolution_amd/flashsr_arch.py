@@ -169,9 +169,13 @@ def _vae_attn(P, name, c, g):
     _conv(P, name + ".proj_out", c, c, 1, 1, 0.5, g)
 
 
-def init_params(cfg: FlashSRConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
-    """Seeded synthetic float32 weights for every layer of the table (torch layouts: conv [Co,Ci,kh,kw])."""
-    g = torch.Generator().manual_seed(seed)
+def init_params(cfg: FlashSRConfig, seed: int = 0, shapes_only: bool = False) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic float32 weights for every layer of the table (torch layouts: conv [Co,Ci,kh,kw]).
+    shapes_only: the same table on the meta device (names and shapes, no storage) -- what checkpoint validation compares with."""
+    if shapes_only:
+        with torch.device("meta"):
+            return init_params(cfg, seed)
+    g = torch.Generator().manual_seed(seed) if torch.empty(0).device.type != "meta" else None
     P: Dict[str, torch.Tensor] = {}
     ch, mult = cfg.vae_ch, cfg.vae_mult
     # ---- VAE encoder ----
@@ -321,25 +325,44 @@ def unet_blocks(cfg: FlashSRConfig) -> List[Tuple[str, int, int, bool]]:
 
 
 def config_from_params(P: Dict[str, torch.Tensor], base: FlashSRConfig = None) -> FlashSRConfig:
-    """Re-derive the width / depth fields of the table from the tensor shapes of a state dict that uses this
-    module's names (what `EGREGORA_FLASHSR_WEIGHTS` supplies).  Fields that shapes cannot reveal (sample rate, hop,
-    schedule length, dilations) keep the values of `base`."""
+    """Re-derive the width / depth fields of the table from the tensor shapes of a state dict in this module's names (what
+    flashsr_weights.map_checkpoints produces from the upstream files, or what `EGREGORA_FLASHSR_WEIGHTS` supplies).  Fields that
+    shapes cannot reveal (sample rate, hop, schedule length, dilation values, GroupNorm groups, attention head width) keep the
+    values of `base`; flashsr_weights then checks EVERY tensor shape of the resulting table against the checkpoint."""
     import dataclasses
     base = base or FlashSRConfig()
+    idx = lambda prefix, pos: sorted({int(k.split(".")[pos]) for k in P if k.startswith(prefix)})
     vae_ch = P["vae.encoder.conv_in.weight"].shape[0]
     z_ch = P["vae.post_quant_conv.weight"].shape[0]
-    levels = 1 + max(int(k.split(".")[3]) for k in P if k.startswith("vae.encoder.down."))
+    levels = 1 + max(idx("vae.encoder.down.", 3))
     vae_mult = tuple(P[f"vae.encoder.down.{lv}.block.0.conv1.weight"].shape[0] // vae_ch for lv in range(levels))
-    vae_res = 1 + max(int(k.split(".")[5]) for k in P if k.startswith("vae.encoder.down.0.block."))
+    vae_res = 1 + max(idx("vae.encoder.down.0.block.", 5))
+    # UNet: walk the input blocks; a `.down` entry closes a resolution level
     unet_ch = P["unet.time_embed.0.weight"].shape[1]
+    mult, attn_ds, per_level, ds, n_here = [], [], [], 1, 0
+    for i in idx("unet.in.", 2):
+        if f"unet.in.{i}.block.res.in_conv.weight" in P:
+            cout = P[f"unet.in.{i}.block.res.in_conv.weight"].shape[0]
+            n_here += 1
+            if f"unet.in.{i}.block.st.norm.weight" in P and ds not in attn_ds:
+                attn_ds.append(ds)
+            last = cout
+        elif f"unet.in.{i}.down.conv.weight" in P:
+            mult.append(last // unet_ch)
+            per_level.append(n_here)
+            n_here, ds = 0, ds * 2
+    if n_here:
+        mult.append(last // unet_ch)
+        per_level.append(n_here)
     voc_ch = P["voc.conv_pre.weight"].shape[0]
     n_mels = P["voc.conv_pre.weight"].shape[1]
-    n_up = 1 + max(int(k.split(".")[2]) for k in P if k.startswith("voc.ups."))
-    rates = []
-    for i in range(n_up):
-        kt = P[f"voc.ups.{i}.weight"].shape[2]
-        rates.append(kt // 2)                                   # kernel = 2r (+1 for odd r)
-    n_k = 1 + max(int(k.split(".")[3]) for k in P if k.startswith("voc.amp.0."))
-    kernels = tuple(P[f"voc.amp.0.{j}.0.conv1.weight"].shape[2] for j in range(n_k))
+    rates = tuple(P[f"voc.ups.{i}.weight"].shape[2] // 2 for i in idx("voc.ups.", 2))          # kernel = 2r (+1 for odd r)
+    kernels = tuple(P[f"voc.amp.0.{j}.0.conv1.weight"].shape[2] for j in idx("voc.amp.0.", 3))
+    n_dil = 1 + max(idx("voc.amp.0.0.", 4))
+    dils = base.voc_dils if len(base.voc_dils) == n_dil else tuple(2 * d + 1 for d in range(n_dil))
+    lat_down = 2 ** (levels - 1)
     return dataclasses.replace(base, vae_ch=vae_ch, z_ch=z_ch, vae_mult=vae_mult, vae_res=vae_res, unet_ch=unet_ch,
-                               voc_ch=voc_ch, n_mels=n_mels, voc_rates=tuple(rates), voc_kernels=kernels)
+                               unet_mult=tuple(mult) or base.unet_mult, unet_res=(per_level[0] if per_level else base.unet_res),
+                               unet_attn_ds=tuple(attn_ds), voc_ch=voc_ch, n_mels=n_mels, voc_rates=rates, voc_kernels=kernels,
+                               voc_dils=dils, hop=int(math.prod(rates)) if rates else base.hop,
+                               n_frames=base.n_frames if (base.n_frames % lat_down == 0) else base.n_frames)

@@ -719,32 +719,30 @@ ROWS_PER_PASS = int(os.environ.get("EGREGORA_FLASHSR_ROWS", "32"))
 SEED = int(os.environ.get("EGREGORA_FLASHSR_SEED", "0"))
 
 
-def _weights_missing_error():
-    return RuntimeError(
-        "FlashSR weights missing. Place these in models/audio/flashsr: student_ldm.pth, sr_vocoder.pth, vae.pth "
-        "(upstream checkpoints must first be converted to this pack's layer table with "
-        "EGREGORA_FLASHSR_WEIGHTS=<state_dict.pt>); set EGREGORA_FLASHSR_SYNTHETIC=1 to run the declared architecture "
-        "with seeded synthetic weights (benchmarking only).")
-
-
 def ensure_ready() -> FlashSREngine:
-    """Build the engine once per process.  Weight sources, in order: EGREGORA_FLASHSR_WEIGHTS (a torch state
-    dict using flashsr_arch names), else synthetic weights iff EGREGORA_FLASHSR_SYNTHETIC=1, else the reference's
-    'weights missing' error (reference :314-317)."""
+    """Build the engine once per process (the reference rebuilds the model on every run(), :393).  Weight sources, in order:
+      1. EGREGORA_FLASHSR_WEIGHTS -- a torch state dict already in this pack's layer-table names (flashsr_arch.py);
+      2. the three upstream checkpoints student_ldm.pth / sr_vocoder.pth / vae.pth discovered in models/audio/flashsr
+         (flashsr_weights.discover: both places the reference can mean, or EGREGORA_FLASHSR_CKPT_DIR), mapped through
+         flashsr_keymap.json and validated tensor by tensor;
+      3. otherwise the reference's "weights missing" error (:314-317).
+    The layer table always comes from the checkpoint's own tensor shapes (flashsr_arch.config_from_params).  Seeded synthetic
+    weights are for benches and tests only and are never picked up here: those callers build a FlashSREngine themselves and
+    install it with set_engine()."""
     global _ENGINE
     if _ENGINE is not None:
         return _ENGINE
     native.require_device()
-    cfg = arch.FlashSRConfig()
+    from . import flashsr_weights
     path = os.environ.get("EGREGORA_FLASHSR_WEIGHTS", "")
     if path:
         if not os.path.exists(path):
             raise RuntimeError(f"EGREGORA_FLASHSR_WEIGHTS={path} (missing).")
         params = torch.load(path, map_location="cpu", weights_only=True)
-    elif os.environ.get("EGREGORA_FLASHSR_SYNTHETIC", "") == "1":
-        params = arch.init_params(cfg, seed=0)
+        cfg = arch.config_from_params(params)
     else:
-        raise _weights_missing_error()
+        params, cfg, where = flashsr_weights.load()
+        print(f"[FlashSR] checkpoints from {where}: {len(params)} tensors, layer table {cfg}")
     _ENGINE = FlashSREngine(cfg, params)
     return _ENGINE
 

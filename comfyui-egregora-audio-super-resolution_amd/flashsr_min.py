@@ -4,8 +4,9 @@
 
 The reference file is an inert stub (it copies the input).  This one runs the real path: WAV in ->
 EgregoraAudioSuperResolution node (resample to 48 kHz, chunked FlashSR on the MI355X, WOLA, resample to --target-sr)
--> PCM_16 WAV out, then prints OK like the reference.  `--ckpt-dir` may hold `flashsr_amd_state_dict.pt` (weights in
-flashsr_arch names); without it the engine follows EGREGORA_FLASHSR_WEIGHTS / EGREGORA_FLASHSR_SYNTHETIC.
+-> PCM_16 WAV out, then prints OK like the reference.  `--ckpt-dir` is where the three upstream checkpoints are looked for first
+(student_ldm.pth, sr_vocoder.pth, vae.pth -- flashsr_weights.py); it may instead hold `flashsr_amd_state_dict.pt` (weights
+already in flashsr_arch names).
 """
 import argparse
 import importlib.util
@@ -39,6 +40,8 @@ def main(argv=None):
     ck = Path(args.ckpt_dir) / "flashsr_amd_state_dict.pt"
     if ck.exists():
         os.environ.setdefault("EGREGORA_FLASHSR_WEIGHTS", str(ck))
+    else:
+        os.environ.setdefault("EGREGORA_FLASHSR_CKPT_DIR", str(args.ckpt_dir))
     pack = sys.modules.get("egregora_amd") or _load_pack()
     from egregora_amd import wavio
     wav, sr = wavio.read_wav(args.inp)                       # [S] or [S,C], like sf.read(always_2d=False)

@@ -1,0 +1,265 @@
+"""FlashSR checkpoint discovery, loading and key mapping.
+
+Stands in for the weight half of the reference's `_FlashSRRunner` (egregora_audio_super_resolution.py:254-317, 346-359): the
+three upstream files `student_ldm.pth`, `sr_vocoder.pth`, `vae.pth` are looked for in `models/audio/flashsr/` -- BOTH places
+the reference can mean by that (quirk Q2: `_models_dir()` is `parents[2] / "models"`, one level above the `ComfyUI/models`
+its own comment, README.md:160 and install.py:10-13 name), plus `EGREGORA_FLASHSR_CKPT_DIR`.  No download is attempted (the
+north star bans the network bootstrap; SURVEY section 2 keeps "discovery + clear error text"): when files are missing the
+reference's "weights missing" sentence is raised with the directories that were searched.
+
+Upstream tensor names are turned into this pack's layer-table names (flashsr_arch.py) by a DATA-DRIVEN map,
+`flashsr_keymap.json`: per checkpoint file a list of prefixes to strip, (regex -> template) rules and ignore patterns.  The
+upstream code (`jakeoneijk/FlashSR_Inference`) is absent from the build image, so the shipped map is written from the
+published module layouts it is known to be built from (LDM `AutoencoderKL`, LDM `openaimodel.UNetModel` with
+`SpatialTransformer`, BigVGAN's generator) -- UPSTREAM-RECALL, parity unpinned.  What IS enforced: nothing is guessed
+silently.  Every upstream tensor must be mapped or explicitly ignored, every table entry must be filled, every shape must
+agree with the table derived from the checkpoint's own shapes (`flashsr_arch.config_from_params`); otherwise `load` raises
+with the full list of unmapped keys / missing entries / shape mismatches, which is what a maintainer needs to fix the JSON.
+`python -m ... flashsr_weights --shapes DIR` (or tools/compare_with_upstream.py) prints the upstream tensor-shape table.
+"""
+import json
+import os
+import re
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import flashsr_arch as arch
+
+FILES = ("student_ldm.pth", "sr_vocoder.pth", "vae.pth")          # reference :261 HF_FILES
+KEYMAP_PATH = Path(__file__).resolve().parent / "flashsr_keymap.json"
+
+
+def pack_root() -> Path:
+    return Path(__file__).resolve().parent
+
+
+def candidate_dirs() -> List[Path]:
+    """Where `models/audio/flashsr` may be, most specific first (duplicates removed, order kept)."""
+    root = pack_root()                                     # .../ComfyUI/custom_nodes/<pack>
+    env = os.environ.get("EGREGORA_FLASHSR_CKPT_DIR", "")
+    cands = [Path(env)] if env else []
+    cands.append(root.parents[1] / "models" / "audio" / "flashsr")        # README.md:160, install.py:10-13 (ComfyUI/models)
+    if len(root.parents) > 2:
+        cands.append(root.parents[2] / "models" / "audio" / "flashsr")    # reference :28-30 as written (quirk Q2)
+    out, seen = [], set()
+    for c in cands:
+        if str(c) not in seen:
+            seen.add(str(c))
+            out.append(c)
+    return out
+
+
+def missing_error(searched: List[Path], missing: Optional[Dict[str, List[str]]] = None) -> RuntimeError:
+    """The reference's sentence (:314-317) plus what was looked at."""
+    lines = [f"  {d}" + (f"  (missing: {', '.join(missing[str(d)])})" if missing and str(d) in missing else "") for d in searched]
+    return RuntimeError(
+        "FlashSR weights missing. Place these in models/audio/flashsr: student_ldm.pth, sr_vocoder.pth, vae.pth\n"
+        "Searched (this pack never downloads):\n" + "\n".join(lines) +
+        "\nSet EGREGORA_FLASHSR_CKPT_DIR to point elsewhere, or EGREGORA_FLASHSR_WEIGHTS to a state dict in this pack's own "
+        "layer-table names.")
+
+
+def discover() -> Path:
+    """The first candidate directory holding all three files; raises the 'weights missing' error otherwise."""
+    searched, missing = candidate_dirs(), {}
+    for d in searched:
+        lack = [f for f in FILES if not (d / f).is_file()]
+        if not lack:
+            return d
+        missing[str(d)] = lack
+    raise missing_error(searched, missing)
+
+
+# ------------------------------------------------------------------------------------------------ reading
+_WRAPPERS = ("state_dict", "model", "generator", "model_state_dict", "ema", "params")
+
+
+def read_state_dict(path: Path) -> Dict[str, torch.Tensor]:
+    """torch.load(weights_only=True) -> flat {name: tensor}; unwraps the usual one-level containers."""
+    obj = torch.load(str(path), map_location="cpu", weights_only=True)
+    for _ in range(3):
+        if isinstance(obj, dict) and obj and not all(torch.is_tensor(v) for v in obj.values()):
+            inner = [k for k in _WRAPPERS if k in obj and isinstance(obj[k], dict)]
+            if not inner:
+                break
+            obj = obj[inner[0]]
+    if not isinstance(obj, dict):
+        raise RuntimeError(f"{path}: expected a state dict, found {type(obj).__name__}")
+    return {str(k): v for k, v in obj.items() if torch.is_tensor(v)}
+
+
+def shape_table(sd: Dict[str, torch.Tensor]) -> List[Tuple[str, Tuple[int, ...], str]]:
+    return [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in sd.items()]
+
+
+def fold_weight_norm(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """`x.weight_g` + `x.weight_v` (torch.nn.utils.weight_norm, dim 0) and the parametrization spelling
+    `x.parametrizations.weight.original0/1` -> `x.weight` = g * v / ||v|| with the norm over every axis but 0."""
+    out = dict(sd)
+    pairs = [(k[:-len("weight_g")], k, k[:-1] + "v") for k in sd if k.endswith(".weight_g")]
+    pairs += [(k[:-len("parametrizations.weight.original0")], k, k[:-1] + "1") for k in sd
+              if k.endswith(".parametrizations.weight.original0")]
+    for base, kg, kv in pairs:
+        if kv not in sd:
+            continue
+        g, v = sd[kg].double(), sd[kv].double()
+        nrm = v.reshape(v.shape[0], -1).norm(dim=1).reshape((-1,) + (1,) * (v.dim() - 1))
+        out[base + "weight"] = (v * (g.reshape(nrm.shape) / nrm)).float()
+        del out[kg], out[kv]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ mapping
+class KeyMap:
+    """flashsr_keymap.json: {"variables": {...}, "files": {fname: {"strip": [...], "ignore": [...], "rules": [[rx, tmpl], ...],
+    "reshape": {table_key_regex: "squeeze_last" | "unsqueeze_hw"}}}}.
+    A template's {fields} are Python expressions over g1..gN (captured groups; decimal ones as ints) and the variables."""
+
+    def __init__(self, spec: dict):
+        self.spec = spec
+        self.vars = dict(spec.get("variables", {}))
+
+    @classmethod
+    def load(cls, path: Optional[Path] = None) -> "KeyMap":
+        return cls(json.loads(Path(path or KEYMAP_PATH).read_text(encoding="utf-8")))
+
+    def _expand(self, tmpl: str, m: "re.Match", extra: dict) -> str:
+        env = dict(self.vars)
+        env.update(extra)
+        for i, g in enumerate(m.groups(), 1):
+            env[f"g{i}"] = int(g) if g is not None and g.isdigit() else g
+        return re.sub(r"\{([^{}]+)\}", lambda f: str(eval(f.group(1), {"__builtins__": {}}, env)), tmpl)   # noqa: S307 (repo-owned JSON)
+
+    def map_file(self, fname: str, sd: Dict[str, torch.Tensor], extra_vars: Optional[dict] = None):
+        """-> (mapped {table_key: tensor}, unmapped upstream keys, duplicate targets)."""
+        fs = self.spec["files"][fname]
+        rules = [(re.compile(rx), t) for rx, t in fs.get("rules", [])]
+        ignore = [re.compile(rx) for rx in fs.get("ignore", [])]
+        strip = fs.get("strip", [])
+        mapped, unmapped, dup = {}, [], []
+        for k, v in fold_weight_norm(sd).items():
+            name = k
+            for pre in strip:
+                if name.startswith(pre):
+                    name = name[len(pre):]
+                    break
+            if any(rx.search(name) for rx in ignore):
+                continue
+            for rx, tmpl in rules:
+                m = rx.match(name)
+                if m:
+                    tgt = self._expand(tmpl, m, extra_vars or {})
+                    if tgt in mapped:
+                        dup.append(tgt)
+                    mapped[tgt] = v
+                    break
+            else:
+                unmapped.append(k)
+        for rx, how in fs.get("reshape", {}).items():
+            r = re.compile(rx)
+            for tk in [t for t in mapped if r.match(t)]:
+                t = mapped[tk]
+                if how == "unsqueeze_hw" and t.dim() == 2:
+                    mapped[tk] = t[:, :, None, None]
+                elif how == "squeeze_hw" and t.dim() == 4 and t.shape[2:] == (1, 1):
+                    mapped[tk] = t[:, :, 0, 0]
+                elif how == "squeeze_last" and t.dim() == 3 and t.shape[2] == 1:
+                    mapped[tk] = t[:, :, 0]
+        return mapped, unmapped, dup
+
+
+def map_checkpoints(sds: Dict[str, Dict[str, torch.Tensor]], keymap: Optional[KeyMap] = None, base: Optional[arch.FlashSRConfig] = None):
+    """{file name: upstream state dict} -> (params in flashsr_arch names, derived FlashSRConfig).  Raises RuntimeError listing
+    every unmapped upstream tensor, every unfilled table entry and every shape mismatch.  `base` supplies the fields tensor
+    shapes cannot reveal (chunk length, STFT size, GroupNorm groups, head width ...; default: the declared full-size table)."""
+    km = keymap or KeyMap.load()
+    params: Dict[str, torch.Tensor] = {}
+    problems: List[str] = []
+    for fname in FILES:
+        if fname not in sds:
+            problems.append(f"{fname}: not supplied")
+            continue
+        nk = _count_vocoder_kernels(sds[fname]) if fname == "sr_vocoder.pth" else None
+        mapped, unmapped, dup = km.map_file(fname, sds[fname], {"nk": nk} if nk else None)
+        problems += [f"{fname}: unmapped upstream tensor {k} {tuple(sds[fname][k].shape) if k in sds[fname] else ''}" for k in unmapped]
+        problems += [f"{fname}: two upstream tensors map to {t}" for t in dup]
+        params.update({k: v.detach().float().contiguous() for k, v in mapped.items()})
+    cfg = None
+    if not problems:
+        try:
+            cfg = arch.config_from_params(params, base)
+        except (KeyError, ValueError, IndexError) as e:
+            problems.append(f"layer table cannot be derived from the mapped tensors: {type(e).__name__} {e}")
+    if cfg is not None:
+        want = {k: tuple(v.shape) for k, v in arch.init_params(cfg, 0, shapes_only=True).items()}
+        for k, shp in want.items():
+            if k not in params:
+                problems.append(f"table entry {k} {shp} has no upstream tensor")
+            elif tuple(params[k].shape) != shp:
+                problems.append(f"shape mismatch at {k}: upstream {tuple(params[k].shape)} vs table {shp}")
+        problems += [f"mapped tensor {k} {tuple(params[k].shape)} is not in the layer table" for k in params if k not in want]
+    if problems:
+        head = f"FlashSR checkpoints do not fit this pack's layer table ({len(problems)} problem(s)); fix {KEYMAP_PATH.name} / flashsr_arch.py:\n  "
+        raise RuntimeError(head + "\n  ".join(problems[:200]) + ("\n  ..." if len(problems) > 200 else ""))
+    return params, cfg
+
+
+def _count_vocoder_kernels(sd: Dict[str, torch.Tensor]) -> Optional[int]:
+    """BigVGAN numbers its AMP blocks `resblocks.{stage * n_kernels + j}`: n_kernels = blocks / up stages."""
+    blocks = {int(m.group(1)) for k in sd for m in [re.search(r"resblocks\.(\d+)\.", k)] if m}
+    ups = {int(m.group(1)) for k in sd for m in [re.search(r"(?:^|\.)ups\.(\d+)\.", k)] if m}
+    if blocks and ups and len(blocks) % len(ups) == 0:
+        return len(blocks) // len(ups)
+    return None
+
+
+def load(ckpt_dir: Optional[Path] = None, keymap: Optional[KeyMap] = None, base: Optional[arch.FlashSRConfig] = None):
+    """Discover (or take) the checkpoint directory, read the three files, map them.  -> (params, cfg, directory)."""
+    d = Path(ckpt_dir) if ckpt_dir else discover()
+    lack = [f for f in FILES if not (d / f).is_file()]
+    if lack:
+        raise missing_error([d], {str(d): lack})
+    params, cfg = map_checkpoints({f: read_state_dict(d / f) for f in FILES}, keymap, base)
+    return params, cfg, d
+
+
+def export_upstream_named(params: Dict[str, torch.Tensor], keymap: Optional[KeyMap] = None) -> Dict[str, Dict[str, torch.Tensor]]:
+    """Inverse direction for tests and tooling: this pack's params -> three state dicts in the upstream spelling the shipped key
+    map understands (module prefixes, BigVGAN block numbering, weight-normalised convolutions as weight_g / weight_v)."""
+    km = keymap or KeyMap.load()
+    inv = km.spec["export"]
+    out = {f: {} for f in FILES}
+    nk = 1 + max(int(k.split(".")[3]) for k in params if k.startswith("voc.amp.0."))
+    for k, v in params.items():
+        for fname, rules in inv.items():
+            done = False
+            for rx, tmpl in rules["rules"]:
+                m = re.match(rx, k)
+                if m:
+                    name = rules.get("prefix", "") + km._expand(tmpl, m, {"nk": nk})
+                    if rules.get("weight_norm") and name.endswith(".weight") and v.dim() == 3:
+                        nrm = v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, 1, 1)
+                        out[fname][name + "_g"], out[fname][name + "_v"] = nrm.clone(), v.clone()
+                    else:
+                        out[fname][name] = v.clone()
+                    done = True
+                    break
+            if done:
+                break
+        else:
+            raise RuntimeError(f"export: no rule for {k}")
+    return out
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser(description="print the tensor-shape table of the upstream FlashSR checkpoints")
+    ap.add_argument("--shapes", default="", help="checkpoint directory (default: discovery)")
+    a = ap.parse_args()
+    d = Path(a.shapes) if a.shapes else discover()
+    for f in FILES:
+        print(f"# {d / f}")
+        for name, shp, dt in shape_table(read_state_dict(d / f)):
+            print(f"{name}\t{list(shp)}\t{dt}")

@@ -12,6 +12,7 @@ LIB_PATH = Path(__file__).resolve().parent / "libegregora_amd.so"
 
 EGR_OK = 0
 FL_NORMALIZE, FL_AUTOSCALE, FL_PCM_IN, FL_NODE_POST = 0x1, 0x2, 0x4, 0x8
+FL_THR_RELATIVE, FL_THR_SOFT, FL_NO_INIT_THR, FL_ZERO_STUFF = 0x10, 0x20, 0x40, 0x80      # SPEC.md section 3
 FL_INFO_LEN = 40
 
 # name -> (restype, argtypes); must list every symbol of include/egregora_amd.h

@@ -53,6 +53,11 @@ typedef struct egr_fatllama_plan egr_fatllama_plan;
 #define EGR_FL_AUTOSCALE 0x2u  /* upstream toggle_autoscale: per channel out *= max|in| / max|out| */
 #define EGR_FL_PCM_IN    0x4u  /* x is unit-scale float; quantise like the temp-WAV write (PCM_16)  */
 #define EGR_FL_NODE_POST 0x8u  /* apply write patch (/32768 iff max>1) + PCM_16 write + float read  */
+/* Threshold semantics of the loop -- upstream's are unverified (SPEC.md section 3 names each variant); default = none set */
+#define EGR_FL_THR_RELATIVE 0x10u /* level = threshold * max|.| of the array judged (per channel, every iteration)  */
+#define EGR_FL_THR_SOFT     0x20u /* spectrum: X max(0, 1 - level/|X|) instead of X [|X| > level]                   */
+#define EGR_FL_NO_INIT_THR  0x40u /* d0 = y (no time-domain threshold before the first transform)                  */
+#define EGR_FL_ZERO_STUFF   0x80u /* up-rate by zero insertion (y[i*f] = x[i]) instead of linear interpolation      */
 
 /* Host-only planning query (no GPU needed): fills info[] =
  *   {supported (1 = packed real plan, 2 = Bluestein over M = P complex points), N, M, M1, M2, TC, nst1, nst2,
@@ -75,7 +80,9 @@ int egr_fatllama_plan_destroy(egr_fatllama_plan* plan);
  * Runs: (PCM_IN quantise) -> linear up-rate by `factor` -> d0 = |y|>thr ? y : 0 ->
  *       max_iter x { X = rfft(d); X = |X|>thr ? X : 0; d = irfft(X) } -> out = y + d ->
  *       (autoscale) -> (normalise) -> (NODE_POST).
- * All max_iter iterations are executed (no fixed-point early exit). */
+ * All max_iter iterations are executed (no fixed-point early exit).  The EGR_FL_THR_* / NO_INIT_THR / ZERO_STUFF flags select
+ * the other readings of upstream's threshold and interpolation (SPEC.md section 3; oracle: FatLlamaSpec fields of the same
+ * names); EGR_FL_THR_RELATIVE adds one reduction pass per iteration and is refused (EGR_ERR_UNSUPPORTED) on chirp-z plans. */
 int egr_fatllama_enhance(egr_fatllama_plan* plan, const float* x, float* out, int max_iter, float threshold,
                          unsigned flags, void* stream);
 

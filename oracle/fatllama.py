@@ -34,8 +34,14 @@ class FatLlamaSpec:
     # ---- upstream feed.upscale ----
     factor_rounding: str = "round"       # upscale_factor = round(target_bps / source_bps), min 1
     interp: str = "linear"               # y[i*f+j] = (1-j/f) x[i] + (j/f) x[i+1], i < n-1; tail zero
+                                         # "zero_stuff": y[i*f] = x[i], zeros between (spectral-sparsity interpolation)
     normalize_scope: str = "joint"       # out / max|out| over all channels
     autoscale: str = "match_peak"        # per channel: out *= max|in| / max|out|
+    # ---- threshold semantics of the IST loop (SPEC.md section 3; every combination runs on the device) ----
+    threshold_ref: str = "absolute"      # "absolute": t = threshold_value; "relative_to_max": t = threshold_value * max|.| of
+                                         #   the array being thresholded (per channel, recomputed every iteration)
+    threshold_kind: str = "hard"         # "hard": X [|X| > t]; "soft": X max(0, 1 - t/|X|) (complex soft shrink)
+    init_threshold: str = "same"         # "same": d0 = hard-threshold of y with the same reference rule; "none": d0 = y
     use_rfft: bool = False               # oracle default: full complex FFT like upstream
 
 
@@ -61,11 +67,14 @@ def upscale_factor(sr, channels, target_bitrate_kbps, spec=DEFAULT_SPEC):
     return max(1, f)
 
 
-def interpolate(x, f):
-    """Linear up-rate by integer factor; the last input sample's f slots stay zero."""
+def interpolate(x, f, spec=DEFAULT_SPEC):
+    """Up-rate by integer factor.  linear: the last input sample's f slots stay zero; zero_stuff: y[::f] = x."""
     x = np.asarray(x, np.float32)
     n = x.shape[0]
     y = np.zeros(n * f, np.float32)
+    if spec.interp == "zero_stuff":
+        y[::f] = x
+        return y
     if n > 1:
         t = (np.arange(f, dtype=np.float32) / np.float32(f))[None, :]
         a = x[:-1, None]
@@ -74,28 +83,43 @@ def interpolate(x, f):
     return y
 
 
+def _level(mag, thr, spec):
+    """The threshold level for an array of magnitudes under spec.threshold_ref (same dtype as `mag`)."""
+    t = mag.dtype.type(thr)
+    if spec.threshold_ref == "relative_to_max":
+        t = t * (np.max(mag) if mag.size else mag.dtype.type(0))
+    return t
+
+
+def _shrink(X, thr, spec):
+    """Threshold a (complex or real) array under spec.threshold_ref / spec.threshold_kind; dtype preserved."""
+    mag = np.abs(X)
+    t = _level(mag, thr, spec)
+    if spec.threshold_kind == "soft":
+        one = mag.dtype.type(1)
+        g = np.where(mag > t, one - t / np.where(mag > t, mag, one), mag.dtype.type(0))
+        return (X * g).astype(X.dtype)
+    return np.where(mag > t, X, 0).astype(X.dtype)
+
+
 def ist_loop(y, max_iter, thr, spec=DEFAULT_SPEC, trace=None, exact=False):
-    """d0 = where(|y|>thr, y, 0); repeat: X=fft(d); X=where(|X|>thr, X, 0); d=ifft(X).real.
+    """d0 = where(|y|>t0, y, 0); repeat: X=fft(d); X=shrink(X, t); d=ifft(X).real, t per SPEC.md section 3.
     exact=True runs the same loop in float64/complex128 (a yardstick for float32 round-off, not upstream)."""
-    if exact:
-        y = np.asarray(y, np.float64)
-        d = np.where(np.abs(y) > thr, y, 0.0)
-        for it in range(int(max_iter)):
-            X = np.fft.fft(d)
-            X = np.where(np.abs(X) > thr, X, 0)
-            d = np.fft.ifft(X).real
-        return d
-    thr = np.float32(thr)
-    d = np.where(np.abs(y) > thr, y, np.float32(0)).astype(np.float32)
+    rt = np.float64 if exact else np.float32
+    ct = np.complex128 if exact else np.complex64
+    y = np.asarray(y, rt)
+    if spec.init_threshold == "none":
+        d = y.copy()
+    else:
+        mag = np.abs(y)
+        d = np.where(mag > _level(mag, thr, spec), y, rt(0)).astype(rt)
     for it in range(int(max_iter)):
-        if spec.use_rfft:
-            X = _fft.rfft(d)
-            X = np.where(np.abs(X) > thr, X, 0).astype(np.complex64)
-            d = _fft.irfft(X, n=d.shape[0]).astype(np.float32)
+        if exact:
+            d = np.fft.ifft(_shrink(np.fft.fft(d), thr, spec)).real
+        elif spec.use_rfft:
+            d = _fft.irfft(_shrink(_fft.rfft(d).astype(ct), thr, spec), n=d.shape[0]).astype(rt)
         else:
-            X = _fft.fft(d.astype(np.complex64))
-            X = np.where(np.abs(X) > thr, X, 0).astype(np.complex64)
-            d = _fft.ifft(X).real.astype(np.float32)
+            d = _fft.ifft(_shrink(_fft.fft(d.astype(ct)).astype(ct), thr, spec)).real.astype(rt)
         if trace is not None:
             trace.append(d.copy())
     return d
@@ -108,7 +132,7 @@ def enhance_channels(x_ci, factor, max_iter, thr, normalize=True, autoscale=True
     x_ci = np.asarray(x_ci, np.float32)
     outs = []
     for c in range(x_ci.shape[0]):
-        y = interpolate(x_ci[c], factor)
+        y = interpolate(x_ci[c], factor, spec)
         d = ist_loop(y, max_iter, thr, spec, exact=exact)
         outs.append(y.astype(np.float64) + d if exact else (y + d).astype(np.float32))
     out = np.stack(outs, 0)

@@ -66,7 +66,7 @@ def lowpass_ref(x, cfg, pct=0.985, order=8, ripple_db=0.05):
                          torch.cosh(order * torch.acosh(torch.clamp(xw, min=1.0))))
         g = 1.0 / (1.0 + eps2 * tn * tn)
         g = torch.where(f < 0.4999 * cfg.sr, g, torch.zeros_like(g))
-        ys.append(torch.fft.irfft(torch.fft.rfft(x[b].double()) * g, n=L).float())
+        ys.append(torch.fft.irfft(torch.fft.rfft(x[b].double()) * g, n=L).to(x.dtype))
     return torch.stack(ys), cuts
 
 
@@ -124,10 +124,10 @@ def vae_decode(z, P, cfg):
 
 
 # ------------------------------------------------------------------ UNet
-def timestep_embedding(t, dim, device):
+def timestep_embedding(t, dim, device, dtype=torch.float32):
     half = dim // 2
-    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=device) / half)
-    args = torch.tensor([float(t)], device=device)[:, None] * freqs[None]
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=dtype, device=device) / half)
+    args = torch.tensor([float(t)], device=device, dtype=dtype)[:, None] * freqs[None]
     return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)      # [1,dim]
 
 
@@ -170,7 +170,7 @@ def _unet_block(x, temb_act, P, base, cfg, has_attn):
 
 
 def unet(x, t, P, cfg, blocks):
-    temb = timestep_embedding(t, cfg.unet_ch, x.device)
+    temb = timestep_embedding(t, cfg.unet_ch, x.device, x.dtype)
     temb = F.linear(temb, P["unet.time_embed.0.weight"], P["unet.time_embed.0.bias"])
     temb = F.linear(F.silu(temb), P["unet.time_embed.2.weight"], P["unet.time_embed.2.bias"])
     temb_act = F.silu(temb)
@@ -253,8 +253,15 @@ def vocoder(mel, wave, P, cfg, filt):
 
 
 # ------------------------------------------------------------------ whole model
+def to_float64(P):
+    """The same parameters as float64 tensors: flashsr_forward then runs every op in double precision -- the yardstick
+    that separates the fp32 round-off of EITHER implementation from a real disagreement (tests/test_gpu_flashsr.py)."""
+    return {k: v.double() for k, v in P.items()}
+
+
 def flashsr_forward(x, noise, P, cfg, blocks, mel_fb, filt, stages=None):
-    """x [B,chunk] float32, noise [B,z_ch,h,w] -> y [B,chunk].  `stages` (dict) receives the intermediates."""
+    """x [B,chunk], noise [B,z_ch,h,w] -> y [B,chunk], in the dtype of the arguments (float32: the oracle; float64: the
+    yardstick).  `stages` (dict) receives the intermediates."""
     mel = log_mel(x, cfg, mel_fb)
     z_c = vae_encode(mel, P, cfg)
     t = cfg.t_steps - 1

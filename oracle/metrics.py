@@ -38,6 +38,27 @@ def lsd_audio(a, b, n_fft=2048, hop=512):
     return lsd(stft_mag(a[..., :n], n_fft, hop), stft_mag(b[..., :n], n_fft, hop))
 
 
+def lsd_masked(a, b, floor_db=None, n_fft=2048, hop=512, f32_run=None, margin_db=80.0):
+    """Mean over frames of the log-spectral distance between `a` (the trusted float64 run) and `b`, restricted to the STFT bins
+    where a float32 implementation CAN hold the north star's 1e-3 dB.  Test-only companion of `lsd`; not a reference function.
+
+    A float32 transform chain leaves a round-off floor e in every bin; a bin of magnitude S then moves by 8.7 e/S dB, so 1e-3 dB
+    needs S >= 8700 e whatever the implementation (upstream's included).  The floor is MEASURED, not assumed: e = rms over all
+    bins of |STFT(f32_run)| - |STFT(a)|, where f32_run is the float32 ORACLE's output for the same input (never the device's), and
+    the bins kept are those with S >= e * 10^(margin_db/20) (80 dB: the float32 oracle itself sits at 1e-4 relative there).
+    Alternatively floor_db keeps the bins within floor_db of the largest magnitude.  Returns (lsd_db, fraction of bins kept)."""
+    n = min(a.shape[-1], b.shape[-1])
+    SA, SB = stft_mag(a[..., :n], n_fft, hop).astype(np.float64), stft_mag(b[..., :n], n_fft, hop).astype(np.float64)
+    if f32_run is not None:
+        SO = stft_mag(f32_run[..., :n], n_fft, hop).astype(np.float64)
+        keep = SA >= np.sqrt(np.mean((SO - SA) ** 2)) * 10.0 ** (margin_db / 20.0)
+    else:
+        keep = SA > SA.max() * 10.0 ** (-float(floor_db) / 20.0)
+    d = (20 * np.log10(SA + 1e-12) - 20 * np.log10(SB + 1e-12)) ** 2
+    per = np.sqrt((d * keep).sum(axis=0) / np.maximum(keep.sum(axis=0), 1) + 1e-12)
+    return float(np.mean(per)), float(keep.mean())
+
+
 def si_sdr(s, s_hat):
     """Scale-invariant SDR in dB on the mono downmix, float64.  :414-429."""
     s = np.asarray(s, np.float64)

@@ -5,9 +5,11 @@ Tolerances (floating point; stated per north_star "within 1e-3 LSD"):
     the GPU's error against the float64 run of the same loop is <= 3x the float32 oracle's own error
   * LSD(gpu, oracle) <= 1e-3 dB with the reference's own metric (oracle.metrics.lsd_audio) on full-band
     material.  Where the spectrum has nulls > 100 dB below the peak (linear up-rating puts sinc^2 zeros at
-    multiples of the source rate) float32 round-off of EITHER implementation decides those bins, so the gate
-    there is on the error itself: rms(gpu - f64) <= 2.5 * rms(oracle_f32 - f64), and LSD <= 0.25 dB as a
-    sanity bound (measured: 0.03-0.08 dB, against 0.008-0.02 dB for the float32 oracle vs float64).
+    multiples of the source rate) float32 round-off of EITHER implementation decides those bins: there the
+    gate is the LSD of the device against the FLOAT64 run of the same loop over the bins a float32 transform can
+    resolve to 1e-3 dB at all -- magnitude >= 80 dB above the float32 ORACLE's measured round-off floor
+    (oracle.metrics.lsd_masked; the kept fraction is printed and bounded) -- <= 1e-3 dB, plus
+    rms(gpu - f64) <= 2.5 * rms(oracle_f32 - f64) over everything.
   * after the PCM_16 hop (node output): values are k/32768 and the quantiser turns a 3e-7 relative error
     into a +-1 LSB flip wherever x*32767 lands within ~0.01 of a rounding boundary (~2% of samples for ANY
     two float32 pipelines): require |diff| <= 1 LSB everywhere and <= 5% of samples differing.
@@ -20,6 +22,10 @@ from oracle import fatllama as ofl
 from oracle import metrics as om
 
 pytestmark = pytest.mark.gpu
+
+# Where the factor > 1 LSD gate applies: bins at least this far above the float32 round-off floor (measured from the float32
+# oracle vs float64).  At the margin a float32 result sits 1e-4 relative = 8.7e-4 dB from float64 -- the north star's bar.
+F32_MARGIN_DB = 80.0
 
 
 def synth(C, n, seed, scale=8000.0, integer=True):
@@ -71,7 +77,14 @@ def test_loop_matches_oracle(pack, C, n, f, iters, thr):
     rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
     assert rms(got - exact) <= 2.5 * rms(want - exact) + 1e-9 * scale
     if want.shape[1] >= 4096:
-        assert om.lsd_audio(want, got)[0] <= (1e-3 if f == 1 else 0.25)
+        if f == 1:
+            assert om.lsd_audio(want, got)[0] <= 1e-3
+        else:
+            lg, kept = om.lsd_masked(exact, got, f32_run=want, margin_db=F32_MARGIN_DB)
+            lo, _ = om.lsd_masked(exact, want, f32_run=want, margin_db=F32_MARGIN_DB)
+            print(f"\nfactor {f}: LSD over the {kept:.1%} of bins >= {F32_MARGIN_DB:.0f} dB above the float32 floor: device {lg:.2e} dB, float32 oracle "
+                  f"{lo:.2e} dB; within 100 dB of the peak: {om.lsd_masked(exact, got, 100.0)[0]:.2e} / {om.lsd_masked(exact, want, 100.0)[0]:.2e}")
+            assert lg <= 1e-3 and kept >= 0.5, (lg, lo, kept)
 
 
 @pytest.mark.parametrize("C,n,iters", [(1, 4800, 51), (2, 9600, 77), (3, 4800, 130)])
@@ -105,7 +118,7 @@ def test_verified_side_stream_and_graph_switch(pack):
         native.check(L.egr_fatllama_enhance(C.c_void_p(plan), native.ptr(xd), native.ptr(out), 130, 0.6, 0, native.stream_ptr()), "enhance")
         np.testing.assert_array_equal(out.cpu().numpy(), base)
     np.testing.assert_array_equal(run_gpu(pack, x, 1, 130, 0.6), base)          # the engine's own call: tunes this plan once
-    assert (plan, torch.cuda.current_stream().cuda_stream) in fe._TUNED
+    assert (plan, torch.cuda.current_stream().cuda_stream) in fe._SIDE_SET
 
 
 @pytest.mark.parametrize("n,split", [(420, (6, 5, 7)), (2 * 8 * 9 * 10, (8, 9, 10)), (2 * 16 * 15 * 64, (16, 15, 64)),
@@ -224,3 +237,96 @@ def test_full_size_properties_c3_shape(pack):
     k = run_gpu(pack, x, 1, 2, 0.0)
     y = x.copy(); y[:, -1] = 0.0
     assert float(np.max(np.abs(k - 2.0 * y))) <= 3e-5 * s
+
+
+def c1_signal():
+    """BASELINE configs[0] input (SURVEY 8(d) recipe): 10 s mono 16 kHz, 8 log-spaced sines 80 Hz..6 kHz (1/k) + noise, peak 0.5."""
+    n, sr = 160000, 16000
+    rng = np.random.Generator(np.random.PCG64(101))
+    t = np.arange(n) / sr
+    x = sum(np.sin(2 * np.pi * f * t) / (k + 1) for k, f in enumerate(np.geomspace(80.0, 6000.0, 8))) + 0.01 * rng.standard_normal(n)
+    return (0.5 * x / np.max(np.abs(x))).astype(np.float32)[None], sr
+
+
+def test_c1_exactly_as_baseline_states_it_through_the_cpu_node(pack):
+    """BASELINE configs[0]: 160 000 samples mono @16 kHz, max_iterations = 50, 1411 kbps (factor 6, N' = 960 000), through
+    EgregoraFatLlamaCPU().run (reference egregora_fat_llama_cpu.py:126-134,147: 7 kwargs, upstream's default toggles) against
+    oracle.node_run on the same input: PCM_16 output within 1 LSB everywhere, <= 5 % of samples differing; and the raw loop on
+    the same data against the float64 yardstick (LSD over the bins float32 can resolve <= 1e-3 dB, see the module docstring; the
+    input is eight tones over a -40 dB noise floor up-rated six-fold, so most bins are images far below the tones)."""
+    cs, sr = c1_signal()
+    node = pack.NODE_CLASS_MAPPINGS["EgregoraFatLlamaCPU"]()
+    (res,) = node.run("wav", 50, 0.6, 1411, AUDIO={"waveform": torch.from_numpy(cs)[None], "sample_rate": sr})
+    want, sr_out = ofl.node_run(cs, sr, 50, 0.6, 1411, True, True)
+    got = res["waveform"][0].numpy()
+    assert res["sample_rate"] == sr_out == 96000 and got.shape == want.shape == (1, 960000)
+    lsb = np.abs(got - want) * 32768.0
+    assert float(lsb.max()) <= 1.0 + 1e-6 and float(np.mean(lsb > 0.5)) <= 5e-2, (float(lsb.max()), float(np.mean(lsb > 0.5)))
+    xi = ofl.pcm16_write(cs).astype(np.float32)
+    raw = run_gpu(pack, xi, 6, 50, 0.6)
+    exact = ofl.enhance_channels(xi, 6, 50, 0.6, normalize=False, autoscale=False, exact=True)
+    oracle32 = ofl.enhance_channels(xi, 6, 50, 0.6, normalize=False, autoscale=False)
+    rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
+    lg, kept = om.lsd_masked(exact, raw, f32_run=oracle32, margin_db=F32_MARGIN_DB)
+    lo, _ = om.lsd_masked(exact, oracle32, f32_run=oracle32, margin_db=F32_MARGIN_DB)
+    print(f"\nC1 raw loop: rms err device {rms(raw - exact):.3e} / oracle32 {rms(oracle32 - exact):.3e}; LSD over the {kept:.1%} of bins >= "
+          f"{F32_MARGIN_DB:.0f} dB above the float32 floor: device {lg:.2e} dB, float32 oracle {lo:.2e} dB; PCM_16 samples differing "
+          f"{float(np.mean(lsb > 0.5)):.4f}")
+    assert rms(raw - exact) <= 2.5 * rms(oracle32 - exact)
+    assert lg <= 1e-3 and kept >= 0.15, (lg, kept)
+
+
+def test_800_iterations_against_the_oracle(pack):
+    """The headline iteration count on 1 s of stereo 48 kHz (N = 48 000 per channel): all 800 iterations on both sides.  The loop is
+    a projection, so round-off does not compound: same gates as the short runs."""
+    x = synth(2, 48000, seed=800)
+    want = ofl.enhance_channels(x, 1, 800, 0.6, normalize=False, autoscale=False)
+    exact = ofl.enhance_channels(x, 1, 800, 0.6, normalize=False, autoscale=False, exact=True)
+    got = run_gpu(pack, x, 1, 800, 0.6)
+    scale = float(np.max(np.abs(want)))
+    rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
+    print(f"\n800 iterations: max err device {float(np.max(np.abs(got - exact))):.3e} oracle32 {float(np.max(np.abs(want - exact))):.3e} "
+          f"(peak {scale:.0f}); rms {rms(got - exact):.3e} / {rms(want - exact):.3e}; LSD(device, oracle32) {om.lsd_audio(want, got)[0]:.2e} dB")
+    assert float(np.max(np.abs(got - want))) <= 2e-5 * scale
+    assert rms(got - exact) <= 2.5 * rms(want - exact) + 1e-9 * scale
+    assert om.lsd_audio(want, got)[0] <= 1e-3 and om.lsd_audio(exact, got)[0] <= 1e-3
+
+
+VARIANTS = [  # (variant list for the device, FatLlamaSpec overrides, threshold, data scale)
+    ("", {}, 50.0, 100.0),
+    ("soft", {"threshold_kind": "soft"}, 50.0, 100.0),
+    ("relative", {"threshold_ref": "relative_to_max"}, 0.02, 8000.0),
+    ("relative,soft", {"threshold_ref": "relative_to_max", "threshold_kind": "soft"}, 0.02, 8000.0),
+    ("relative,no_init_thr", {"threshold_ref": "relative_to_max", "init_threshold": "none"}, 0.3, 8000.0),
+    ("relative,soft,zero_stuff", {"threshold_ref": "relative_to_max", "threshold_kind": "soft", "interp": "zero_stuff"}, 0.05, 8000.0),
+    ("zero_stuff,no_init_thr", {"interp": "zero_stuff", "init_threshold": "none"}, 400.0, 100.0),
+]
+
+
+@pytest.mark.parametrize("variant,over,thr,scale", VARIANTS)
+@pytest.mark.parametrize("C,n,f,iters", [(2, 4800, 1, 4), (1, 3000, 3, 6), (2, 48000, 2, 60)])
+def test_threshold_and_interpolation_variants_match_the_oracle(pack, variant, over, thr, scale, C, n, f, iters):
+    """SPEC.md section 3: absolute / relative-to-maximum level x hard / soft shrink, with or without the time-domain pre-threshold,
+    linear or zero-insertion up-rating -- each against the oracle run with the matching FatLlamaSpec, at thresholds that really
+    gate bins.  A hard threshold may flip a borderline bin, so the bar is energy-relative (1e-6 of the output energy, as in
+    test_large_threshold_actually_gates_bins); the soft shrink is continuous and is also held to 2e-5 of the peak."""
+    import dataclasses
+    spec = dataclasses.replace(ofl.DEFAULT_SPEC, **over)
+    x = synth(C, n, seed=n + f + len(variant), scale=scale)
+    want = ofl.enhance_channels(x, f, iters, thr, normalize=False, autoscale=False, spec=spec)
+    got = run_gpu(pack, x, f, iters, thr, variant=variant)
+    assert got.shape == want.shape
+    y = np.stack([ofl.interpolate(x[c], f, spec) for c in range(C)])
+    d_want, d_got = want - y, got - y
+    kept = float(np.sum(d_want.astype(np.float64) ** 2) / max(float(np.sum(y.astype(np.float64) ** 2)), 1e-30))
+    assert 1e-4 < kept < 0.9999 or variant == "", (variant, kept)      # the threshold removes a real share of the energy
+    num = float(np.sum((got - want).astype(np.float64) ** 2)); den = float(np.sum(want.astype(np.float64) ** 2)) + 1e-30
+    assert num / den < 1e-6, (variant, num / den)
+    if "soft" in variant:
+        assert float(np.max(np.abs(got - want))) <= 2e-5 * float(np.max(np.abs(want))), variant
+
+
+def test_relative_threshold_on_a_chirp_z_length_is_refused_loudly(pack):
+    from egregora_amd import fatllama_engine as fe
+    with pytest.raises(RuntimeError, match="relative"):
+        fe.enhance_device(torch.zeros(1, 101, device="cuda"), 1, 2, 0.5, False, False, False, False, variant="relative")

@@ -521,23 +521,47 @@ def test_node_end_to_end_with_synthetic_engine(pack, eng):
 
 
 def test_full_size_engine_vs_torch_reference_one_row(pack):
-    """The declared full-size architecture (Winograd / phase-conv / split-K paths active) against the PyTorch fp32
-    graph on the host CPU, one row, stage by stage.  Tolerance: relative L2 <= 5e-4 per stage, 2e-3 on the waveform
-    (thousands of fp32 layers with different summation orders on both sides)."""
+    """The declared full-size architecture (Winograd / phase-conv / split-K paths active, contractions on the bf16 pipe as exact
+    three-way splits) against the PyTorch graph on the host CPU, one row, stage by stage, with a FLOAT64 run of the same graph as
+    the yardstick -- the pattern of tests/test_gpu_fatllama.py.  Gates:
+      * waveform: LSD(HIP, f64) with the reference's metric (2048/512) <= 1e-3 dB mean AND p95 -- the north star's tolerance, against
+        the float64 truth rather than against another fp32 run (measured 1.6e-4 / 2.8e-4 dB; torch fp32 itself: 0.8e-4 / 1.3e-4);
+      * every stage: rms(HIP - f64) <= 3 x rms(torch fp32 - f64) and <= 1e-5 of the stage's rms.  Measured ratios: mel 1.06,
+        z_cond 1.56, v / z0 1.46, mel_hat 2.46, y 2.10 -- the VAE decoder's Winograd F(4x4,3x3) layers amplify the GEMMs' fp32
+        accumulation error by max|M| / max|y| ~ 12 where torch's direct convolutions do not; the absolute
+        errors stay at 4e-7 .. 5e-6 of the signal;
+      * the previous relative-L2 gates vs torch fp32 (5e-4 per stage, 2e-3 waveform) stay as a coarse net."""
     from egregora_amd import flashsr_arch as A, flashsr_engine as E
-    from oracle import flashsr_torch as R
+    from oracle import flashsr_torch as R, metrics as om
     cfg = A.FlashSRConfig()
     P = A.init_params(cfg, 0)
     e = E.FlashSREngine(cfg, P)
     x = 0.2 * torch.randn(1, cfg.chunk, generator=torch.Generator().manual_seed(5))
     nz = e.noise(1, torch.zeros(1, dtype=torch.int64, device="cuda"), 0)
-    got_st, want_st = {}, {}
+    got_st, want_st, ex_st = {}, {}, {}
     y = e.forward_rows(x.cuda(), nz, got_st)
     torch.cuda.synchronize()
     torch.set_num_threads(max(1, min(64, torch.get_num_threads())))
+    fb, filt = torch.from_numpy(A.mel_filterbank(cfg)), torch.from_numpy(A.kaiser_sinc_filter(cfg.aa_taps))
     with torch.no_grad():
-        want = R.flashsr_forward(x, nchw(nz.cpu()), P, cfg, A.unet_blocks(cfg), torch.from_numpy(A.mel_filterbank(cfg)),
-                                 torch.from_numpy(A.kaiser_sinc_filter(cfg.aa_taps)), want_st)
+        want = R.flashsr_forward(x, nchw(nz.cpu()), P, cfg, A.unet_blocks(cfg), fb, filt, want_st)
+        exact = R.flashsr_forward(x.double(), nchw(nz.cpu()).double(), R.to_float64(P), cfg, A.unet_blocks(cfg), fb.double(),
+                                  filt.double(), ex_st)
+    rms = lambda a: float(a.double().pow(2).mean().sqrt())
+    report = {}
+    for k in ("mel", "z_cond", "v", "z0", "mel_hat", "y"):
+        gt = got_st[k].permute(0, 3, 1, 2).cpu() if got_st[k].dim() == 4 else got_st[k].cpu()
+        eg, eo = rms(gt.double() - ex_st[k]), rms(want_st[k].double() - ex_st[k])
+        report[k] = (eg, eo, eg / max(eo, 1e-300), rms(ex_st[k]))
+    lsd_g = om.lsd_audio(exact.numpy(), y.cpu().numpy())
+    lsd_o = om.lsd_audio(exact.numpy(), want.numpy())
+    print("\nfull-size row vs float64: stage -> (rms err HIP, rms err torch32, ratio, rms of the stage)")
+    for k, v in report.items():
+        print(f"  {k:8s} {v[0]:.3e} {v[1]:.3e} ratio {v[2]:.2f}  (signal rms {v[3]:.3e})")
+    print(f"  LSD(HIP, f64) mean/p95 = {lsd_g[0]:.3e} / {lsd_g[1]:.3e} dB ; LSD(torch32, f64) = {lsd_o[0]:.3e} / {lsd_o[1]:.3e} dB")
+    for k, v in report.items():
+        assert v[0] <= 3.0 * v[1] + 1e-9 * v[3] and v[0] <= 1e-5 * v[3], (k, v)
+    assert lsd_g[0] <= 1e-3 and lsd_g[1] <= 1e-3, (lsd_g, lsd_o)
     for k in ("mel", "z_cond", "v", "z0", "mel_hat"):
         gt = got_st[k].permute(0, 3, 1, 2)
         assert rel_l2(gt, want_st[k]) <= 5e-4, (k, rel_l2(gt, want_st[k]))
