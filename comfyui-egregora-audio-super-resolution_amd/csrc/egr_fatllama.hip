@@ -29,14 +29,22 @@
 namespace egr {
 
 // Twiddle W_T^r for r < T as a product of two table entries: thi[r >> sh] * tlo[r & (2^sh - 1)]
-// (tables of ~sqrt(T) entries each, generated in long double and rounded once).
+// (tables of ~sqrt(T) entries each, generated in long double).  The tables and the product are DOUBLE precision and the
+// result is rounded to float once: every loop iteration multiplies element e by the same W on the way in and conj(W) on
+// the way out, so |W|^2 - 1 is a per-element gain that compounds over the iterations -- (1 + eps)^800.  A product of two
+// float-rounded factors leaves eps ~ 1.2e-7, the single rounding ~ 4e-8 (what any float32 twiddle table has); measured
+// on 800 iterations: rms error vs float64 2.9x -> 1.xx the pocketfft oracle's (tests/test_gpu_fatllama.py).
 struct Tw2 {
-    const cplx* hi;
-    const cplx* lo;
+    const dcplx* hi;
+    const dcplx* lo;
     int sh;
 };
+__device__ __forceinline__ dcplx tw2d(const Tw2& t, unsigned r) {
+    return dcmul(t.hi[r >> t.sh], t.lo[r & ((1u << t.sh) - 1u)]);
+}
 __device__ __forceinline__ cplx tw2(const Tw2& t, unsigned r) {
-    return cmul(t.hi[r >> t.sh], t.lo[r & ((1u << t.sh) - 1u)]);
+    const dcplx w = tw2d(t, r);
+    return make_float2((float)w.x, (float)w.y);
 }
 
 // One strided ("column") pass: `nplanes` matrices [L][ncols] (row-major), transform along L for a tile of TC
@@ -57,8 +65,10 @@ struct RowP {
     const cplx* tw;        // W_L stage table
     const dcplx* twd;      // the same table in double precision (power-twiddle path)
     Tw2 wo;                // W_N^o, o < R
-    const cplx* wk;        // W_(2L)^k = W_N^(R*k), k < L
+    const dcplx* wk;       // W_(2L)^k = W_N^(R*k), k < L (double: multiplied with W_N^o in double, rounded once)
     float thr2, inv_M;
+    double inv_M_d;        // 1/M in double: the loop's scaling is applied in double and rounded once (a float 1/M is off by up to
+                           // 6e-8 relative, the SAME way every iteration -- 5e-5 after 800)
     const float* gain;     // optional [C][M+1] real gain per half-spectrum bin (replaces the threshold)
     int phat;              // 1: the state is z = a + i b of two REAL signals; replace it by the PHAT-weighted cross-spectrum
     long long band_lo;     // > 0: keep half-spectrum bins k >= band_lo, zero the others (replaces the threshold); band = 1 selects it
@@ -202,13 +212,14 @@ __global__ __launch_bounds__(1024) void k_row(RowP p, long long M, cplx* __restr
     lds_fft<false>(cur, alt, p.f, p.tw, nrows, 0, 1, L, false, p.twd);
 
     // real-split, threshold, un-split on the (k, M-k) pairs; Z[o + R*k] sits at row(o)[k]
-    const cplx wa = tw2(p.wo, (unsigned)oa);
+    const dcplx wa = tw2d(p.wo, (unsigned)oa);
     int cnt, boff;          // partner of row-a element k is row-b element (boff - k) mod L
     cplx* rb;
     if (!self) { cnt = L; boff = L - 1; rb = cur + L; }
     else if (oa == 0) { cnt = L / 2 + 1; boff = L; rb = cur; }
     else { cnt = (L + 1) / 2; boff = L - 1; rb = cur; }
     const float sc = p.inv_M;
+    const double scd = p.inv_M_d;
     float thr2 = p.thr2, tlev = p.thr;
     if (!MAXONLY && p.max2) {
         tlev = p.thr * sqrtf(__uint_as_float(p.max2[ch]));
@@ -222,7 +233,8 @@ __global__ __launch_bounds__(1024) void k_row(RowP p, long long M, cplx* __restr
         const bool same = self && (pb == k2);
         const cplx Za = cur[k2];
         const cplx Zb = rb[pb];
-        const cplx Wk = cmul(wa, p.wk[k2]);
+        const dcplx Wkd = dcmul(wa, p.wk[k2]);
+        const cplx Wk = make_float2((float)Wkd.x, (float)Wkd.y);
         // E = (Za + conj Zb)/2 ; O = (Za - conj Zb)/(2i)
         const cplx E = make_float2(0.5f * (Za.x + Zb.x), 0.5f * (Za.y - Zb.y));
         const cplx O = make_float2(0.5f * (Za.y + Zb.y), -0.5f * (Za.x - Zb.x));
@@ -268,8 +280,8 @@ __global__ __launch_bounds__(1024) void k_row(RowP p, long long M, cplx* __restr
         const cplx H = make_float2(0.5f * (Xk.x - Xm.x), 0.5f * (Xk.y - Xm.y));
         const cplx O2 = cmulc(H, Wk);
         // Za' = E2 + i*O2 ; Zb' = conj(E2 - i*O2)
-        cur[k2] = make_float2(sc * (E2.x - O2.y), sc * (E2.y + O2.x));
-        if (!same) rb[pb] = make_float2(sc * (E2.x + O2.y), -sc * (E2.y - O2.x));
+        cur[k2] = make_float2((float)(scd * (double)(E2.x - O2.y)), (float)(scd * (double)(E2.y + O2.x)));
+        if (!same) rb[pb] = make_float2((float)(scd * (double)(E2.x + O2.y)), -(float)(scd * (double)(E2.y - O2.x)));
     }
     if (MAXONLY) {
         mx2 = block_max(mx2, red);
@@ -595,16 +607,25 @@ static int upload_d(egr_fatllama_plan* p, int L, const dcplx** d) {
     return EGR_OK;
 }
 
+// exp(-2 pi i j num / den), j < count, as a double-precision device table
+static int upload_dtab(egr_fatllama_plan* p, int64_t count, int64_t num, int64_t den, const dcplx** d) {
+    std::vector<double2> h;
+    make_twiddles_d(h, count, num, den);
+    void* ptr = nullptr;
+    EGR_HIP(hipMalloc(&ptr, h.size() * sizeof(double2)));
+    p->dev_allocs.push_back(ptr);
+    EGR_HIP(hipMemcpy(ptr, h.data(), h.size() * sizeof(double2), hipMemcpyHostToDevice));
+    *d = (const dcplx*)ptr;
+    return EGR_OK;
+}
+
 // tables for W_T^r, r < T
 static int make_tw2(egr_fatllama_plan* p, int64_t T, Tw2* out) {
     int sh = 0;
     while ((1LL << (2 * sh)) < T) ++sh;          // 2^sh >= sqrt(T)
-    std::vector<float2> h;
     int rc;
-    make_twiddles(h, (T >> sh) + 1, 1LL << sh, T);
-    if ((rc = upload(p, h, &out->hi))) return rc;
-    make_twiddles(h, 1LL << sh, 1, T);
-    if ((rc = upload(p, h, &out->lo))) return rc;
+    if ((rc = upload_dtab(p, (T >> sh) + 1, 1LL << sh, T, &out->hi))) return rc;
+    if ((rc = upload_dtab(p, 1LL << sh, 1, T, &out->lo))) return rc;
     out->sh = sh;
     return EGR_OK;
 }
@@ -708,18 +729,16 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     make_twiddles(h, r.L, 1, r.L);
     if ((rc = upload(p, h, &r.tw))) return fail(rc);
     if ((rc = upload_d(p, r.L, &r.twd))) return fail(rc);
-    make_twiddles(h, r.L, 1, 2 * (int64_t)r.L);
-    if ((rc = upload(p, h, &r.wk))) return fail(rc);
+    if ((rc = upload_dtab(p, r.L, 1, 2 * (int64_t)r.L, &r.wk))) return fail(rc);
     {   // W_N^o for o < R, as hi/lo tables over the range [0, R)
         int sh = 0;
         while ((1LL << (2 * sh)) < r.R) ++sh;
-        make_twiddles(h, ((int64_t)r.R >> sh) + 1, 1LL << sh, N);
-        if ((rc = upload(p, h, &r.wo.hi))) return fail(rc);
-        make_twiddles(h, 1LL << sh, 1, N);
-        if ((rc = upload(p, h, &r.wo.lo))) return fail(rc);
+        if ((rc = upload_dtab(p, ((int64_t)r.R >> sh) + 1, 1LL << sh, N, &r.wo.hi))) return fail(rc);
+        if ((rc = upload_dtab(p, 1LL << sh, 1, N, &r.wo.lo))) return fail(rc);
         r.wo.sh = sh;
     }
     r.inv_M = (float)(1.0 / (double)M);
+    r.inv_M_d = 1.0 / (double)M;
     if (hipMalloc((void**)&p->d_work, (size_t)channels * M * sizeof(float2)) != hipSuccess ||
         hipMalloc((void**)&p->d_peaks, 3 * channels * sizeof(unsigned)) != hipSuccess) {
         set_error("hipMalloc of the %lld-byte loop state failed", (long long)(channels * M * 8));

@@ -1,0 +1,1205 @@
+// FlashSR model handle behind the C ABI:
+//   egr_flashsr_create / egr_flashsr_infer / egr_flashsr_destroy stand in for the upstream calls
+//   `FlashSR(student_ldm.pth, sr_vocoder.pth, vae.pth)` + `.eval().to(dev)` and `model(x[C,245760], lowpass_input)` that the
+//   reference makes at egregora_audio_super_resolution.py:346-359 and :361-369.
+// The whole graph walk lives here: layer table (egr_flashsr_config = flashsr_arch.FlashSRConfig) -> weight repacking -> kernel
+// launches of the operators in egr_nn_*.hip, with a stream-ordered scratch arena instead of one allocation per operator.
+// The host (Python or C) only supplies named fp32 tensors in torch layouts and calls infer on device pointers.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "egr_common.h"
+
+extern "C" {
+int egr_pack_weight(const float* src, float* dst, int layout, int K, int N, int Ci, int Co, int KH, int KW, void* stream);
+int egr_phase_weights(const float* w_oihw, float* dst4, int Co, int Ci, void* stream);
+int egr_winograd_pack_u(const float* w_oihw, float* dst, const double* G_dev, int np, int Co, int Ci, void* stream);
+}
+
+namespace {
+
+using egr::set_error;
+
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_TANH = 2, ACT_LEAKY = 3, ACT_LOGCLAMP = 4 };
+enum { EW_ADD = 0, EW_AXPBY = 1, EW_SILU = 2, EW_SCALE = 3, EW_COPY = 4, EW_ADD_SCALE = 5 };
+
+#define OKR(call)                 \
+    do {                          \
+        int rc__ = (call);        \
+        if (rc__ != EGR_OK) return rc__; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ scratch arena
+// Exact-size free lists over hipMalloc'ed blocks.  Everything runs on ONE stream, so a block may be handed out again as soon as
+// the host has enqueued its last consumer (stream order does the rest).  Layer shapes repeat, so after the first forward of a
+// given row count no allocation reaches the runtime.
+struct Arena {
+    std::unordered_map<size_t, std::vector<void*>> free_;
+    std::vector<void*> all_;
+    size_t total = 0;
+    void* get(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes == 0) bytes = 256;
+        auto& v = free_[bytes];
+        if (!v.empty()) { void* p = v.back(); v.pop_back(); return p; }
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { set_error("FlashSR scratch arena: hipMalloc(%zu) failed (%zu bytes held)", bytes, total); return nullptr; }
+        all_.push_back(p);
+        total += bytes;
+        return p;
+    }
+    void put(void* p, size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes == 0) bytes = 256;
+        free_[bytes].push_back(p);
+    }
+    ~Arena() { for (void* p : all_) hipFree(p); }
+};
+
+struct Ten {                       // an fp32 activation owned by the arena (move-only)
+    Arena* a = nullptr;
+    float* p = nullptr;
+    size_t bytes = 0;
+    int nd = 0;
+    int64_t d[4] = {0, 0, 0, 0};
+    std::shared_ptr<Ten> part;     // GroupNorm partial sums left by the F(4x4) output transform (egr_winograd4_output_stats)
+    int part_tiles = 0;
+    Ten() {}
+    Ten(const Ten&) = delete;
+    Ten& operator=(const Ten&) = delete;
+    Ten(Ten&& o) noexcept { *this = std::move(o); }
+    Ten& operator=(Ten&& o) noexcept {
+        if (this != &o) {
+            release();
+            a = o.a; p = o.p; bytes = o.bytes; nd = o.nd; memcpy(d, o.d, sizeof(d)); part = std::move(o.part); part_tiles = o.part_tiles;
+            o.a = nullptr; o.p = nullptr; o.bytes = 0;
+        }
+        return *this;
+    }
+    ~Ten() { release(); }
+    void release() { if (a && p) a->put(p, bytes); p = nullptr; a = nullptr; part.reset(); }
+    int64_t numel() const { int64_t n = 1; for (int i = 0; i < nd; ++i) n *= d[i]; return n; }
+    void view(std::initializer_list<int64_t> s) { nd = 0; for (int64_t v : s) d[nd++] = v; }
+};
+
+struct Wt {                        // one entry of the weight store
+    float* w = nullptr;            // raw tensor (norms, biases, snake parameters) or fp32 slab-major pack
+    void* w3 = nullptr;            // three-way bf16 split of the pack (egr_split3_pack)
+    int KH = 0, KW = 0, Cin = 0, Cout = 0;   // logical shape of a packed contraction (Cout = GEMM N)
+    int64_t zfloats = 0;           // floats per component of a z-stacked Winograd pack
+    int64_t numel = 0;
+};
+
+struct ProfRec { std::string kind; double flops; hipEvent_t a, b; };
+
+}  // namespace
+
+struct egr_flashsr {
+    egr_flashsr_config cfg;
+    unsigned flags = 0;
+    int device = 0;
+    Arena arena;
+    std::vector<void*> owned;                         // weight allocations
+    std::unordered_map<std::string, Wt> W;
+    std::vector<std::string> blk_name;                // UNet block table (flashsr_arch.unet_blocks)
+    std::vector<int> blk_cin, blk_cout, blk_attn;
+    float* window = nullptr; float* filt = nullptr;
+    int ldm = 0, lat_h = 0, lat_w = 0;
+    float alpha = 0.f, sigma = 0.f;
+    int rows_per_pass = 32;
+    int wino_min_ch = 128;
+    double flops = 0.0; bool count_flops = false;
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+    std::map<int, egr_fatllama_plan*> lp_plans;       // input low-pass: spectral-gain plans per row count
+    void* gn_ws = nullptr; size_t gn_ws_bytes = 0;
+    hipStream_t st = nullptr;                         // stream of the call in flight
+
+    bool f32_mfma() const { return (flags & EGR_FSR_F32_MFMA) != 0; }
+    bool has(const std::string& k) const { return W.find(k) != W.end(); }
+    const Wt* get(const std::string& k) const { auto it = W.find(k); return it == W.end() ? nullptr : &it->second; }
+    float* ptr(const std::string& k) const { auto it = W.find(k); return it == W.end() ? nullptr : it->second.w; }
+};
+
+namespace {
+
+typedef egr_flashsr M;
+
+int dev_alloc(M* m, size_t bytes, void** out) {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 16;
+    if (hipMalloc(&p, bytes) != hipSuccess) { set_error("FlashSR weights: hipMalloc(%zu) failed", bytes); return EGR_ERR_ALLOC; }
+    m->owned.push_back(p);
+    *out = p;
+    return EGR_OK;
+}
+
+int new_ten(M* m, Ten& t, std::initializer_list<int64_t> shape) {
+    t.release();
+    t.view(shape);
+    t.bytes = (size_t)t.numel() * sizeof(float);
+    t.p = (float*)m->arena.get(t.bytes);
+    if (!t.p) return EGR_ERR_ALLOC;
+    t.a = &m->arena;
+    return EGR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ layer table
+void build_blocks(M* m) {
+    const egr_flashsr_config& c = m->cfg;
+    auto is_attn = [&](int ds) { for (int i = 0; i < c.unet_n_attn; ++i) if (c.unet_attn_ds[i] == ds) return 1; return 0; };
+    auto add = [&](const std::string& n, int ci, int co, int at) { m->blk_name.push_back(n); m->blk_cin.push_back(ci); m->blk_cout.push_back(co); m->blk_attn.push_back(at); };
+    const int mc = c.unet_ch;
+    add("in.0.conv_in", 2 * c.z_ch, mc, 0);
+    std::vector<int> skip{mc};
+    int ch = mc, ds = 1, idx = 1;
+    for (int lv = 0; lv < c.unet_levels; ++lv) {
+        for (int r = 0; r < c.unet_res; ++r) {
+            add("in." + std::to_string(idx) + ".block", ch, mc * c.unet_mult[lv], is_attn(ds));
+            ch = mc * c.unet_mult[lv];
+            skip.push_back(ch);
+            ++idx;
+        }
+        if (lv != c.unet_levels - 1) {
+            add("in." + std::to_string(idx) + ".down", ch, ch, 0);
+            skip.push_back(ch);
+            ds *= 2;
+            ++idx;
+        }
+    }
+    add("mid.0.block", ch, ch, 1);
+    add("mid.1.block", ch, ch, 0);
+    idx = 0;
+    for (int lv = c.unet_levels - 1; lv >= 0; --lv) {
+        for (int i = 0; i <= c.unet_res; ++i) {
+            const int sc = skip.back(); skip.pop_back();
+            add("out." + std::to_string(idx) + ".block", ch + sc, mc * c.unet_mult[lv], is_attn(ds));
+            ch = mc * c.unet_mult[lv];
+            if (lv != 0 && i == c.unet_res) { add("out." + std::to_string(idx) + ".up", ch, ch, 0); ds /= 2; }
+            ++idx;
+        }
+    }
+}
+
+int up_kernel(int r) { return 2 * r + (r % 2); }
+
+// ------------------------------------------------------------------------------------------------ weight packing
+int split3(M* m, Wt& w) {
+    if (m->f32_mfma() || !w.w) return EGR_OK;
+    const int64_t ns = w.numel / ((int64_t)w.Cout * 16);
+    void* p3 = nullptr;
+    OKR(dev_alloc(m, (size_t)ns * 3 * w.Cout * 16 * 2, &p3));
+    OKR(egr_split3_pack(w.w, p3, ns, w.Cout, m->st));
+    w.w3 = p3;
+    return EGR_OK;
+}
+
+// src in torch layout on the device; layout as in egr_pack_weight; registers key with logical (KH, KW, Cin, N)
+int add_packed(M* m, const std::string& key, const float* src, int layout, int K, int N, int Ci, int Co, int KH, int KW, int logical_kh,
+               int logical_kw, int logical_cin) {
+    Wt w;
+    const int64_t slabs = (K + 15) / 16;
+    w.numel = slabs * N * 16;
+    void* p = nullptr;
+    OKR(dev_alloc(m, (size_t)w.numel * sizeof(float), &p));
+    w.w = (float*)p;
+    OKR(egr_pack_weight(src, w.w, layout, K, N, Ci, Co, KH, KW, m->st));
+    w.KH = logical_kh; w.KW = logical_kw; w.Cin = logical_cin; w.Cout = N;
+    if (logical_cin % 16 == 0) OKR(split3(m, w));
+    m->W[key] = w;
+    return EGR_OK;
+}
+
+int add_weight(M* m, const std::string& key, const egr_tensor_desc& t) {
+    const int64_t* s = t.shape;
+    if (t.ndim == 4) return add_packed(m, key, t.data, 0, (int)(s[2] * s[3] * s[1]), (int)s[0], (int)s[1], (int)s[0], (int)s[2], (int)s[3], (int)s[2], (int)s[3], (int)s[1]);
+    if (key.rfind("voc.ups.", 0) == 0 && t.ndim == 3)       // ConvTranspose1d [Ci][Co][k] -> GEMM [Ci][k*Co]
+        return add_packed(m, key, t.data, 1, (int)s[0], (int)(s[2] * s[1]), (int)s[0], (int)s[1], 1, (int)s[2], 1, 1, (int)s[0]);
+    if (t.ndim == 3) return add_packed(m, key, t.data, 0, (int)(s[2] * s[1]), (int)s[0], (int)s[1], (int)s[0], 1, (int)s[2], 1, (int)s[2], (int)s[1]);
+    return add_packed(m, key, t.data, 0, (int)s[1], (int)s[0], (int)s[1], (int)s[0], 1, 1, 1, 1, (int)s[1]);
+}
+
+int add_phases(M* m, const std::string& key, const egr_tensor_desc& t) {
+    const int Co = (int)t.shape[0], Ci = (int)t.shape[1];
+    float* tmp = nullptr;
+    const size_t n = (size_t)4 * Co * Ci * 4;
+    if (hipMalloc((void**)&tmp, n * sizeof(float)) != hipSuccess) { set_error("hipMalloc(phase weights) failed"); return EGR_ERR_ALLOC; }
+    int rc = egr_phase_weights(t.data, tmp, Co, Ci, m->st);
+    for (int a = 0; a < 2 && rc == EGR_OK; ++a)
+        for (int b = 0; b < 2 && rc == EGR_OK; ++b)
+            rc = add_packed(m, key + ".ph" + std::to_string(a) + std::to_string(b), tmp + (size_t)(2 * a + b) * Co * Ci * 4, 0, 4 * Ci, Co, Ci, Co, 2, 2, 2, 2, Ci);
+    hipStreamSynchronize(m->st);
+    hipFree(tmp);
+    return rc;
+}
+
+const double kG2[12] = {1.0, 0.0, 0.0, 0.5, 0.5, 0.5, 0.5, -0.5, 0.5, 0.0, 0.0, 1.0};
+
+int add_winograd(M* m, const std::string& key, const egr_tensor_desc& t, const double* G2_dev, const double* G4_dev) {
+    const int Co = (int)t.shape[0], Ci = (int)t.shape[1];
+    const int64_t zf = (int64_t)((Ci + 15) / 16) * Co * 16;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && (m->flags & EGR_FSR_NO_WINO_F4)) break;
+        const int np = pass == 0 ? 4 : 6;
+        Wt w;
+        w.numel = (int64_t)np * np * zf;
+        w.zfloats = zf;
+        w.KH = w.KW = 1; w.Cin = Ci; w.Cout = Co;
+        float* pk = nullptr;
+        if (hipMalloc((void**)&pk, (size_t)w.numel * sizeof(float)) != hipSuccess) { set_error("hipMalloc(Winograd U) failed"); return EGR_ERR_ALLOC; }
+        int rc = egr_winograd_pack_u(t.data, pk, pass == 0 ? G2_dev : G4_dev, np, Co, Ci, m->st);
+        w.w = pk;
+        if (rc == EGR_OK && Ci % 16 == 0) rc = split3(m, w);
+        if (rc == EGR_OK && w.w3) {                         // the fp32 pack is not needed once split
+            hipStreamSynchronize(m->st);
+            hipFree(pk);
+            w.w = nullptr;
+        } else if (rc == EGR_OK) {
+            m->owned.push_back(pk);
+        } else {
+            hipFree(pk);
+            return rc;
+        }
+        m->W[key + (pass == 0 ? ".wino" : ".wino4")] = w;
+    }
+    return EGR_OK;
+}
+
+bool contains(const std::string& s, const char* sub) { return s.find(sub) != std::string::npos; }
+bool ends_with(const std::string& s, const char* suf) { const size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; }
+
+int pack_all(M* m, const egr_tensor_desc* ts, int n) {
+    double g4[18];
+    OKR(egr_winograd4_g(g4));
+    double* Gd = nullptr;
+    OKR(dev_alloc(m, 30 * sizeof(double), (void**)&Gd));
+    EGR_HIP(hipMemcpyAsync(Gd, kG2, 12 * sizeof(double), hipMemcpyHostToDevice, m->st));
+    EGR_HIP(hipMemcpyAsync(Gd + 12, g4, 18 * sizeof(double), hipMemcpyHostToDevice, m->st));
+    const bool thin = !(m->flags & EGR_FSR_NO_THIN_ENDS);
+    for (int i = 0; i < n; ++i) {
+        const egr_tensor_desc& t = ts[i];
+        EGR_CHECK(t.name && t.data && t.ndim >= 0 && t.ndim <= 4, EGR_ERR_ARG, "tensor %d: bad descriptor", i);
+        const std::string k = t.name;
+        if (k.rfind("const.", 0) == 0) continue;
+        if (ends_with(k, ".weight") && t.ndim >= 2) {
+            OKR(add_weight(m, k, t));
+            const int64_t* s = t.shape;
+            if (contains(k, ".upsample.conv.") || (k.rfind("unet.", 0) == 0 && contains(k, ".up.conv."))) OKR(add_phases(m, k, t));
+            if (thin && t.ndim == 4 && s[2] * s[3] * s[0] <= 32 && s[1] % 16 == 0)       // few outputs: 1x1 contraction onto per-tap products
+                OKR(add_packed(m, k + ".taps", t.data, 2, (int)s[1], (int)(s[2] * s[3] * s[0]), (int)s[1], (int)s[0], (int)s[2], (int)s[3], 1, 1, (int)s[1]));
+            if (!(m->flags & EGR_FSR_NO_WINOGRAD) && t.ndim == 4 && s[2] == 3 && s[3] == 3 && std::min(s[0], s[1]) >= m->wino_min_ch &&
+                !contains(k, "downsample") && !contains(k, ".down.conv") && !contains(k, "upsample") && !contains(k, ".up.conv"))
+                OKR(add_winograd(m, k, t, Gd, Gd + 12));
+        } else {
+            Wt w;
+            int64_t ne = 1;
+            for (int d = 0; d < t.ndim; ++d) ne *= t.shape[d];
+            w.numel = ne;
+            void* p = nullptr;
+            OKR(dev_alloc(m, (size_t)ne * sizeof(float), &p));
+            EGR_HIP(hipMemcpyAsync(p, t.data, (size_t)ne * sizeof(float), hipMemcpyDeviceToDevice, m->st));
+            w.w = (float*)p;
+            m->W[k] = w;
+        }
+    }
+    return EGR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ profiling helpers
+std::string kind_of(long long Mrows, int Cin, int Cout, bool s3, bool vec = true, long long K = -1) {
+    int bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+    char buf[96];
+    if (s3) {
+        if (Cout >= 256 && Cout % 256 == 0) bn = 256;
+        if (K >= 0 && (K + 15) / 16 < 32)
+            while (bn > 64 && ((Mrows + 127) / 128) * ((Cout + bn - 1) / bn) < 256) bn >>= 1;
+        const int bm = (bn == 128 && ((Mrows + 255) / 256) * ((Cout + 127) / 128) >= 1024) ? 256 : 128;
+        snprintf(buf, sizeof(buf), "k_conv_s3<%d, %d, 1, false>", bm, bn);
+    } else {
+        snprintf(buf, sizeof(buf), "k_conv_igemm<%d, %s>", bn, vec ? "true" : "false");
+    }
+    return buf;
+}
+
+struct ProfScope {
+    M* m; bool on; hipEvent_t a = nullptr, b = nullptr;
+    explicit ProfScope(M* mm) : m(mm), on(mm->profiling) {
+        if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, m->st); }
+    }
+    void end(const std::string& kind, double flops) {
+        if (!on) return;
+        hipEventRecord(b, m->st);
+        m->prof.push_back(ProfRec{kind, flops, a, b});
+        on = false;
+    }
+    ~ProfScope() { if (on) { hipEventDestroy(a); hipEventDestroy(b); } }
+};
+
+// ------------------------------------------------------------------------------------------------ operators
+const void* s3_of(const M* m, const Wt* w, int Cin, const float* x) {
+    if (m->f32_mfma() || !w || Cin % 16 != 0 || (((uintptr_t)x) & 15) != 0) return nullptr;
+    return w->w3;
+}
+
+// general convolution: weights by key (key + ".weight", bias key + ".bias") or explicit entry `wk`
+int conv(M* m, Ten& y, const Ten& x, const std::string& wkey, int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
+         int stride = 1, int dil = 1, int pad_t = 0, int pad_l = 0, int up2 = 0, int act = ACT_NONE, bool bias = true,
+         const float* bias_t = nullptr, const float* res = nullptr, float act_param = 0.f, const Wt* wk = nullptr) {
+    OKR(new_ten(m, y, {B, OH, OW, Cout}));
+    const Wt* w = wk ? wk : m->get(wkey + ".weight");
+    EGR_CHECK(w != nullptr, EGR_ERR_ARG, "FlashSR: weight %s.weight missing", wkey.c_str());
+    const float* bt = bias_t ? bias_t : (bias && !wk ? m->ptr(wkey + ".bias") : nullptr);
+    const double fl = 2.0 * B * OH * OW * Cout * KH * KW * Cin;
+    ProfScope ps(m);
+    const void* w3 = s3_of(m, w, Cin, x.p);
+    if (w3) {
+        OKR(egr_conv_s3(x.p, w3, bt, nullptr, res, y.p, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act, act_param, 1, 1,
+                        0, 0, OH, OW, 1, 0, 0, 0, m->st));
+    } else {
+        EGR_CHECK(w->w != nullptr, EGR_ERR_ARG, "FlashSR: no fp32 pack for %s", wkey.c_str());
+        OKR(egr_conv_nhwc(x.p, w->w, bt, nullptr, res, y.p, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act, act_param,
+                          m->st));
+    }
+    if (ps.on) {
+        const bool vec = Cin % 16 == 0 && (((uintptr_t)x.p) & 15) == 0;
+        std::string kind = kind_of((long long)B * OH * OW, Cin, Cout, w3 != nullptr, vec, (long long)KH * KW * Cin);
+        if (w3 && H == 1 && KH == 1 && KW >= 2 && stride == 1 && !up2 && OW == W && W % 128 == 0 && dil * (KW - 1) <= 50 &&
+            2 * pad_l == dil * (KW - 1)) {                        // launch_conv1d_s3's conditions
+            char buf[64];
+            snprintf(buf, sizeof(buf), "k_conv1d_s3<%d, %d>", Cout > 64 ? 128 : (Cout > 32 ? 64 : 32), Cin % 32 == 0 ? 32 : 16);
+            kind = buf;
+        }
+        ps.end(kind, fl);
+    }
+    if (m->count_flops) m->flops += fl;
+    return EGR_OK;
+}
+
+int gn_scratch(M* m, size_t need) {
+    if (m->gn_ws_bytes < need) {
+        if (m->gn_ws) { hipStreamSynchronize(m->st); hipFree(m->gn_ws); m->gn_ws = nullptr; m->gn_ws_bytes = 0; }
+        if (hipMalloc(&m->gn_ws, need + 1024) != hipSuccess) { set_error("hipMalloc(GroupNorm workspace) failed"); return EGR_ERR_ALLOC; }
+        m->gn_ws_bytes = need + 1024;
+    }
+    return EGR_OK;
+}
+
+int groupnorm(M* m, Ten& y, const Ten& x, const std::string& key, float eps, bool silu) {
+    const int B = (int)x.d[0], Cc = (int)x.d[x.nd - 1];
+    const int HW = (int)(x.numel() / ((int64_t)B * Cc));
+    const int G = m->cfg.gn_groups;
+    OKR(gn_scratch(m, egr_groupnorm_workspace_bytes(B, Cc, G)));
+    y.release();
+    y.nd = x.nd; memcpy(y.d, x.d, sizeof(y.d));
+    y.bytes = (size_t)y.numel() * 4;
+    y.p = (float*)m->arena.get(y.bytes);
+    if (!y.p) return EGR_ERR_ALLOC;
+    y.a = &m->arena;
+    return egr_groupnorm_nhwc(x.p, m->ptr(key + ".weight"), m->ptr(key + ".bias"), y.p, B, HW, Cc, G, eps, silu ? 1 : 0, m->gn_ws, m->st);
+}
+
+int gn_coeff(M* m, Ten& sc, Ten& sh, const Ten& x, const std::string& key, float eps) {
+    const int B = (int)x.d[0], Cc = (int)x.d[x.nd - 1];
+    const int HW = (int)(x.numel() / ((int64_t)B * Cc));
+    const int G = m->cfg.gn_groups;
+    OKR(gn_scratch(m, egr_groupnorm_workspace_bytes(B, Cc, G)));
+    OKR(new_ten(m, sc, {B, Cc}));
+    OKR(new_ten(m, sh, {B, Cc}));
+    if (x.part) {        // x came out of egr_winograd4_output_stats: reduce its partials instead of re-reading x
+        Ten stats;
+        OKR(new_ten(m, stats, {B, G, 4}));            // [B][G][2] doubles
+        OKR(egr_groupnorm_stats_from_partials(x.part->p, B, x.part_tiles, Cc, G, (double*)stats.p, m->st));
+        return egr_groupnorm_coeff_from_stats((const double*)stats.p, m->ptr(key + ".weight"), m->ptr(key + ".bias"), B, HW, Cc, G, eps, sc.p, sh.p, m->st);
+    }
+    return egr_groupnorm_coeff(x.p, m->ptr(key + ".weight"), m->ptr(key + ".bias"), B, HW, Cc, G, eps, m->gn_ws, sc.p, sh.p, m->st);
+}
+
+int conv_winograd(M* m, Ten& y, const Ten& x, const std::string& key, int act, const float* res, const float* bias_t, const float* gsc = nullptr,
+                  const float* gsh = nullptr, int gsilu = 0) {
+    const int B = (int)x.d[0], H = (int)x.d[1], W = (int)x.d[2], Cin = (int)x.d[3];
+    const Wt* wb = m->get(key + ".weight");
+    const int Cout = wb->Cout;
+    const bool f4 = m->has(key + ".weight.wino4") && H % 4 == 0 && W % 4 == 0;
+    const Wt* wz = m->get(key + (f4 ? ".weight.wino4" : ".weight.wino"));
+    const int nz = f4 ? 36 : 16, ts = f4 ? 4 : 2;
+    const int TH = (H + ts - 1) / ts, TW = (W + ts - 1) / ts;
+    const int64_t P = (int64_t)B * TH * TW;
+    Ten V, Mx;
+    OKR(new_ten(m, V, {nz, P, Cin}));
+    if (f4) OKR(egr_winograd4_input(x.p, gsc, gsh, gsilu, B, H, W, Cin, V.p, m->st));
+    else OKR(egr_winograd_input(x.p, gsc, gsh, gsilu, B, H, W, Cin, V.p, m->st));
+    OKR(new_ten(m, Mx, {nz, P, Cout}));
+    const double fl = nz * 2.0 * (double)P * Cin * Cout;
+    {
+        ProfScope ps(m);
+        const void* w3 = s3_of(m, wz, Cin, V.p);
+        if (w3) {
+            OKR(egr_conv_s3(V.p, w3, nullptr, nullptr, nullptr, Mx.p, (int)P, 1, 1, Cin, 1, 1, Cout, 1, 1, 1, 1, 0, 0, 0, 0, 0.0f, 1, 1, 0, 0, 1, 1, nz,
+                            P * Cin, wz->zfloats * 3 / 8, P * Cout, m->st));
+        } else {
+            EGR_CHECK(wz->w != nullptr, EGR_ERR_ARG, "FlashSR: no fp32 Winograd pack for %s", key.c_str());
+            OKR(egr_gemm_zbatched(V.p, wz->w, Mx.p, nz, (int)P, Cin, Cout, P * Cin, wz->zfloats, P * Cout, m->st));
+        }
+        if (ps.on) {
+            std::string kind = kind_of(P, Cin, Cout, w3 != nullptr);
+            if (w3 && Cout > 64) {          // s3_zs_nzb (csrc/egr_nn_gemm_s3.hip): z-streamed when >= 2 z per workgroup
+                const int bn = (Cout >= 256 && Cout % 256 == 0) ? 256 : 128;
+                const long long tiles = ((P + 127) / 128) * ((Cout + bn - 1) / bn);
+                const long long groups = std::min<long long>(std::max<long long>((2048 + tiles - 1) / tiles, 1), nz);
+                if ((nz + groups - 1) / groups >= 2 && !(bn == 256 && Cin > 256)) {
+                    char buf[64];
+                    snprintf(buf, sizeof(buf), "k_conv_s3<128, %d, 1, true>", bn);
+                    kind = buf;
+                }
+            }
+            ps.end(kind, fl);
+        }
+    }
+    if (m->count_flops) m->flops += fl;
+    V.release();
+    OKR(new_ten(m, y, {B, H, W, Cout}));
+    const float* bt = bias_t ? bias_t : m->ptr(key + ".bias");
+    const int G = m->cfg.gn_groups;
+    const int silu = act == ACT_SILU ? 1 : 0;
+    if (f4 && !(m->flags & EGR_FSR_NO_GN_PARTIALS) && Cout % G == 0 && (Cout / G) % 4 == 0) {
+        auto part = std::make_shared<Ten>();
+        OKR(new_ten(m, *part, {P, Cout / 4, 2}));
+        OKR(egr_winograd4_output_stats(Mx.p, bt, res, y.p, B, H, W, Cout, silu, part->p, m->st));
+        y.part = part;
+        y.part_tiles = TH * TW;
+    } else if (f4) {
+        OKR(egr_winograd4_output(Mx.p, bt, res, y.p, B, H, W, Cout, silu, m->st));
+    } else {
+        OKR(egr_winograd_output(Mx.p, bt, res, y.p, B, H, W, Cout, silu, m->st));
+    }
+    return EGR_OK;
+}
+
+int conv_up2_phases(M* m, Ten& y, const Ten& x, const std::string& key, int act) {
+    const int B = (int)x.d[0], H = (int)x.d[1], W = (int)x.d[2], Cin = (int)x.d[3];
+    const int Cout = m->get(key + ".weight")->Cout;
+    OKR(new_ten(m, y, {B, 2 * H, 2 * W, Cout}));
+    const float* bt = m->ptr(key + ".bias");
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            const Wt* w = m->get(key + ".weight.ph" + std::to_string(a) + std::to_string(b));
+            const double fl = 2.0 * B * H * W * Cout * 4 * Cin;
+            ProfScope ps(m);
+            const void* w3 = s3_of(m, w, Cin, x.p);
+            if (w3)
+                OKR(egr_conv_s3(x.p, w3, bt, nullptr, nullptr, y.p, B, H, W, Cin, H, W, Cout, 2, 2, 1, 1, 1 - a, 1 - b, 0, act, 0.0f, 2, 2, a, b,
+                                2 * H, 2 * W, 1, 0, 0, 0, m->st));
+            else
+                OKR(egr_conv_nhwc_placed(x.p, w->w, bt, nullptr, nullptr, y.p, B, H, W, Cin, H, W, Cout, 2, 2, 1, 1, 1 - a, 1 - b, 0, act, 0.0f, 2, 2,
+                                         a, b, 2 * H, 2 * W, m->st));
+            if (ps.on) ps.end(kind_of((long long)B * H * W, Cin, Cout, w3 != nullptr, Cin % 16 == 0, 4LL * Cin), fl);
+            if (m->count_flops) m->flops += fl;
+        }
+    return EGR_OK;
+}
+
+int conv3(M* m, Ten& y, const Ten& x, const std::string& key, int stride = 1, int up2 = 0, int act = ACT_NONE, const float* res = nullptr,
+          int pad = 1, const float* bias_t = nullptr) {
+    const int B = (int)x.d[0], H = (int)x.d[1], W = (int)x.d[2], Cin = (int)x.d[3];
+    const Wt* wb = m->get(key + ".weight");
+    EGR_CHECK(wb != nullptr, EGR_ERR_ARG, "FlashSR: weight %s.weight missing", key.c_str());
+    const int Cout = wb->Cout;
+    if (up2 && m->has(key + ".weight.ph00") && stride == 1 && pad == 1 && !res && !bias_t) return conv_up2_phases(m, y, x, key, act);
+    if (m->has(key + ".weight.wino") && !up2 && stride == 1 && pad == 1 && (act == ACT_NONE || act == ACT_SILU) && H % 2 == 0 && W % 2 == 0 &&
+        Cin % 16 == 0)
+        return conv_winograd(m, y, x, key, act, res, bias_t);
+    const bool plain = !up2 && stride == 1 && pad == 1 && act == ACT_NONE && !res && !bias_t;
+    const bool thin = !(m->flags & EGR_FSR_NO_THIN_ENDS);
+    const Wt* taps = m->get(key + ".weight.taps");
+    if (plain && taps && s3_of(m, taps, Cin, x.p)) {
+        Ten P;
+        OKR(conv(m, P, x, key, B, H, W, Cin, H, W, 9 * Cout, 1, 1, 1, 1, 0, 0, 0, ACT_NONE, false, nullptr, nullptr, 0.f, taps));
+        OKR(new_ten(m, y, {B, H, W, Cout}));
+        return egr_tap_gather(P.p, m->ptr(key + ".bias"), y.p, B, H, W, 3, 3, Cout, 1, 1, m->st);
+    }
+    if (plain && thin && Cin == 1 && Cout % 4 == 0 && 256 % (Cout / 4) == 0) {
+        OKR(new_ten(m, y, {B, H, W, Cout}));
+        OKR(egr_conv_cin1(x.p, wb->w, m->ptr(key + ".bias"), y.p, B, H, W, Cout, 3, 3, 1, 1, m->st));
+        if (m->count_flops) m->flops += 2.0 * B * H * W * Cout * 9;
+        return EGR_OK;
+    }
+    const int LH = up2 ? 2 * H : H, LW = up2 ? 2 * W : W;
+    return conv(m, y, x, key, B, H, W, Cin, LH / stride, LW / stride, Cout, 3, 3, stride, 1, pad, pad, up2, act, true, bias_t, res);
+}
+
+int conv1x1(M* m, Ten& y, const Ten& x, const std::string& key, const float* res = nullptr, int act = ACT_NONE) {
+    const int B = (int)x.d[0], H = (int)x.d[1], W = (int)x.d[2], Cin = (int)x.d[3];
+    return conv(m, y, x, key, B, H, W, Cin, H, W, m->get(key + ".weight")->Cout, 1, 1, 1, 1, 0, 0, 0, act, true, nullptr, res);
+}
+
+int linear(M* m, Ten& y, const Ten& x2, const std::string& key, const float* res = nullptr, int act = ACT_NONE, bool bias = true) {
+    const int rows = (int)x2.d[0], Cin = (int)x2.d[1];
+    const Wt* w = m->get(key + ".weight");
+    EGR_CHECK(w != nullptr, EGR_ERR_ARG, "FlashSR: weight %s.weight missing", key.c_str());
+    OKR(conv(m, y, x2, key, rows, 1, 1, Cin, 1, 1, w->Cout, 1, 1, 1, 1, 0, 0, 0, act, bias, nullptr, res));
+    y.view({rows, w->Cout});
+    return EGR_OK;
+}
+
+int conv1d(M* m, Ten& y, const Ten& x, const std::string& key, int k, int stride = 1, int dil = 1, int pad = 0, int act = ACT_NONE,
+           const float* res = nullptr) {
+    const int B = (int)x.d[0], L = (int)x.d[1], Cin = (int)x.d[2];
+    const int Cout = m->get(key + ".weight")->Cout;
+    const int OL = (L + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+    OKR(conv(m, y, x, key, B, 1, L, Cin, 1, OL, Cout, 1, k, stride, dil, 0, pad, 0, act, true, nullptr, res));
+    y.view({B, OL, Cout});
+    return EGR_OK;
+}
+
+// conv3x3(silu(groupnorm(x))) with the normalisation fused into the Winograd input transform when the layer takes that path
+int gn_conv3(M* m, Ten& y, const Ten& x, const std::string& norm_key, float eps, const std::string& conv_key, const float* res = nullptr,
+             const float* bias_t = nullptr) {
+    const int H = (int)x.d[1], W = (int)x.d[2], Cin = (int)x.d[3];
+    const bool wino = m->has(conv_key + ".weight.wino") && H % 2 == 0 && W % 2 == 0;
+    const bool fused_ok = !(m->flags & EGR_FSR_NO_FUSE_GN) && Cin % 16 == 0 && Cin % m->cfg.gn_groups == 0 && wino;
+    if (!fused_ok) {
+        Ten h;
+        OKR(groupnorm(m, h, x, norm_key, eps, true));
+        return conv3(m, y, h, conv_key, 1, 0, ACT_NONE, res, 1, bias_t);
+    }
+    Ten sc, sh;
+    OKR(gn_coeff(m, sc, sh, x, norm_key, eps));
+    return conv_winograd(m, y, x, conv_key, ACT_NONE, res, bias_t, sc.p, sh.p, 1);
+}
+
+int layernorm(M* m, Ten& y, const Ten& x2, const std::string& key) {
+    OKR(new_ten(m, y, {x2.d[0], x2.d[1]}));
+    return egr_layernorm_rows(x2.p, m->ptr(key + ".weight"), m->ptr(key + ".bias"), y.p, x2.d[0], (int)x2.d[1], 1e-5f, m->st);
+}
+
+int eltwise(M* m, Ten& y, const Ten& a, const float* b, int op, float s0 = 0.f, float s1 = 0.f) {
+    y.release();
+    y.nd = a.nd; memcpy(y.d, a.d, sizeof(y.d));
+    y.bytes = (size_t)y.numel() * 4;
+    y.p = (float*)m->arena.get(y.bytes);
+    if (!y.p) return EGR_ERR_ALLOC;
+    y.a = &m->arena;
+    return egr_eltwise(a.p, b, y.p, a.numel(), op, s0, s1, m->st);
+}
+
+// q, k, v [B*T][C] -> [B*T][C]: softmax(q k^T / sqrt(d)) v per head
+int attention(M* m, Ten& o, const Ten& q, const Ten& k, const Ten& v, int B, int T, int Cc, int heads) {
+    const int d = Cc / heads;
+    Ten S;
+    OKR(new_ten(m, S, {B, heads, T, T}));
+    const bool s3 = !m->f32_mfma() && d % 16 == 0 && T % 16 == 0 && Cc % 4 == 0;
+    const float scale = 1.0f / sqrtf((float)d);
+    const float sc = (float)pow((double)d, -0.5);
+    (void)scale;
+    if (s3)
+        OKR(egr_bgemm_nt_s3(q.p, k.p, S.p, B, heads, T, T, d, Cc, Cc, T, (int64_t)T * Cc, d, (int64_t)T * Cc, d, (int64_t)heads * T * T,
+                            (int64_t)T * T, sc, m->st));
+    else
+        OKR(egr_bgemm(q.p, k.p, S.p, B, heads, T, T, d, Cc, Cc, T, (int64_t)T * Cc, d, (int64_t)T * Cc, d, (int64_t)heads * T * T, (int64_t)T * T, 1,
+                      sc, m->st));
+    OKR(egr_softmax_rows(S.p, (int64_t)B * heads * T, T, m->st));
+    OKR(new_ten(m, o, {(int64_t)B * T, Cc}));
+    if (s3) {
+        Ten vt;
+        OKR(new_ten(m, vt, {B, Cc, T}));
+        OKR(egr_transpose_batched(v.p, vt.p, B, T, Cc, m->st));
+        OKR(egr_bgemm_nt_s3(S.p, vt.p, o.p, B, heads, T, d, T, T, T, Cc, (int64_t)heads * T * T, (int64_t)T * T, (int64_t)Cc * T, (int64_t)d * T,
+                            (int64_t)T * Cc, d, 1.0f, m->st));
+    } else {
+        OKR(egr_bgemm(S.p, v.p, o.p, B, heads, T, d, T, T, Cc, Cc, (int64_t)heads * T * T, (int64_t)T * T, (int64_t)T * Cc, d, (int64_t)T * Cc, d, 0,
+                      1.0f, m->st));
+    }
+    if (m->count_flops) m->flops += 4.0 * B * heads * (double)T * T * d;
+    return EGR_OK;
+}
+
+int snake(M* m, Ten& y, const Ten& x, const std::string& akey, const std::string& bkey) {
+    OKR(new_ten(m, y, {x.d[0], x.d[1], x.d[2]}));
+    return egr_snake_aa(x.p, m->ptr(akey), m->ptr(bkey), m->filt, y.p, (int)x.d[0], (int)x.d[1], (int)x.d[2], m->cfg.aa_taps, m->st);
+}
+
+int concat(M* m, Ten& y, const Ten& a, const Ten& b) {
+    const int64_t rows = a.d[0] * a.d[1] * a.d[2];
+    OKR(new_ten(m, y, {a.d[0], a.d[1], a.d[2], a.d[3] + b.d[3]}));
+    return egr_concat_channels(a.p, b.p, y.p, rows, (int)a.d[3], (int)b.d[3], m->st);
+}
+
+// ------------------------------------------------------------------------------------------------ constant sub-graph
+// time embedding at t = T-1: silu(MLP(emb)) is shared by all res-blocks; each block's projection is folded into its conv bias
+int fold_time_embedding(M* m, const float* emb_dev) {
+    const egr_flashsr_config& c = m->cfg;
+    Ten emb, t1, t2;
+    OKR(new_ten(m, emb, {1, c.unet_ch}));
+    EGR_HIP(hipMemcpyAsync(emb.p, emb_dev, (size_t)c.unet_ch * 4, hipMemcpyDeviceToDevice, m->st));
+    OKR(linear(m, t1, emb, "unet.time_embed.0", nullptr, ACT_SILU));
+    OKR(linear(m, t2, t1, "unet.time_embed.2", nullptr, ACT_SILU));
+    for (size_t i = 0; i < m->blk_name.size(); ++i) {
+        const std::string& name = m->blk_name[i];
+        if (!ends_with(name, ".block")) continue;
+        const std::string base = "unet." + name;
+        Ten e;
+        OKR(linear(m, e, t2, base + ".res.emb"));
+        const Wt* b = m->get(base + ".res.in_conv.bias");
+        EGR_CHECK(b != nullptr, EGR_ERR_ARG, "FlashSR: %s.res.in_conv.bias missing", base.c_str());
+        Wt bt;
+        bt.numel = b->numel;
+        void* p = nullptr;
+        OKR(dev_alloc(m, (size_t)b->numel * 4, &p));
+        bt.w = (float*)p;
+        OKR(egr_eltwise(b->w, e.p, bt.w, b->numel, EW_ADD, 0.f, 0.f, m->st));
+        m->W[base + ".res.in_conv.bias_t"] = bt;
+    }
+    EGR_HIP(hipStreamSynchronize(m->st));
+    return EGR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ stages
+int log_mel(M* m, Ten& mel, const float* x, int B, int L) {
+    const egr_flashsr_config& c = m->cfg;
+    const int rpad = (c.n_fft - c.hop) / 2;
+    const int t_valid = std::min(c.n_frames, (L + 2 * rpad - c.n_fft) / c.hop + 1);
+    Ten mag;
+    OKR(new_ten(m, mag, {B, c.n_frames, m->ldm}));
+    OKR(egr_stft_frames(x, B, L, c.n_fft, c.hop, rpad, c.n_frames, t_valid, m->ldm, m->window, mag.p, m->st));
+    mag.view({(int64_t)B * c.n_frames, 1, 1, m->ldm});
+    OKR(conv(m, mel, mag, "mel_fb", B * c.n_frames, 1, 1, m->ldm, 1, 1, c.n_mels, 1, 1, 1, 1, 0, 0, 0, ACT_LOGCLAMP, false, nullptr, nullptr,
+             c.log_floor, m->get("mel_fb")));
+    mel.view({B, c.n_frames, c.n_mels, 1});
+    return EGR_OK;
+}
+
+// lowpass_input=True: cutoff from the STFT energy, zero-phase 8th-order Chebyshev-I gain applied on the Fat-Llama transform passes
+int lowpass(M* m, Ten& y, const float* x, int B, int L) {
+    const egr_flashsr_config& c = m->cfg;
+    const int rpad = (c.n_fft - c.hop) / 2;
+    const int T = (L + 2 * rpad - c.n_fft) / c.hop + 1;
+    const int nb = c.n_fft / 2 + 1;
+    Ten mag, cut, gain;
+    OKR(new_ten(m, mag, {B, T, m->ldm}));
+    OKR(egr_stft_frames(x, B, L, c.n_fft, c.hop, rpad, T, T, m->ldm, m->window, mag.p, m->st));
+    OKR(new_ten(m, cut, {B}));
+    const int64_t nbins = L / 2 + 1;
+    OKR(new_ten(m, gain, {B, nbins}));
+    OKR(egr_lowpass_gain(mag.p, B, T, m->ldm, nb, 0.985f, (float)c.sr, 8, 0.05f, nbins, (int*)cut.p, gain.p, m->st));
+    egr_fatllama_plan*& plan = m->lp_plans[B];
+    if (!plan) OKR(egr_fatllama_plan_create(&plan, L, B, 1, 0, 0));
+    OKR(new_ten(m, y, {B, L}));
+    return egr_spectral_gain(plan, x, gain.p, y.p, m->st);
+}
+
+int vae_res(M* m, Ten& y, const Ten& x, const std::string& name) {
+    Ten h, sc;
+    OKR(gn_conv3(m, h, x, name + ".norm1", 1e-6f, name + ".conv1"));
+    const float* scp = x.p;
+    if (m->has(name + ".nin_shortcut.weight")) { OKR(conv1x1(m, sc, x, name + ".nin_shortcut")); scp = sc.p; }
+    return gn_conv3(m, y, h, name + ".norm2", 1e-6f, name + ".conv2", scp);
+}
+
+int vae_attn(M* m, Ten& y, const Ten& x, const std::string& name) {
+    const int B = (int)x.d[0], H = (int)x.d[1], W = (int)x.d[2], Cc = (int)x.d[3];
+    Ten h, q, k, v, o;
+    OKR(groupnorm(m, h, x, name + ".norm", 1e-6f, false));
+    OKR(conv1x1(m, q, h, name + ".q"));
+    OKR(conv1x1(m, k, h, name + ".k"));
+    OKR(conv1x1(m, v, h, name + ".v"));
+    OKR(attention(m, o, q, k, v, B, H * W, Cc, 1));
+    o.view({B, H, W, Cc});
+    return conv1x1(m, y, o, name + ".proj_out", x.p);
+}
+
+int vae_encode(M* m, Ten& z, const Ten& mel) {
+    const egr_flashsr_config& c = m->cfg;
+    Ten h, t;
+    OKR(conv3(m, h, mel, "vae.encoder.conv_in"));
+    for (int lv = 0; lv < c.vae_levels; ++lv) {
+        for (int b = 0; b < c.vae_res; ++b) {
+            OKR(vae_res(m, t, h, "vae.encoder.down." + std::to_string(lv) + ".block." + std::to_string(b)));
+            h = std::move(t);
+        }
+        if (lv != c.vae_levels - 1) {
+            OKR(conv3(m, t, h, "vae.encoder.down." + std::to_string(lv) + ".downsample.conv", 2, 0, ACT_NONE, nullptr, 0));
+            h = std::move(t);
+        }
+    }
+    OKR(vae_res(m, t, h, "vae.encoder.mid.block_1")); h = std::move(t);
+    OKR(vae_attn(m, t, h, "vae.encoder.mid.attn_1")); h = std::move(t);
+    OKR(vae_res(m, t, h, "vae.encoder.mid.block_2")); h = std::move(t);
+    OKR(groupnorm(m, t, h, "vae.encoder.norm_out", 1e-6f, true));
+    OKR(conv3(m, h, t, "vae.encoder.conv_out"));
+    Ten mom;
+    OKR(conv1x1(m, mom, h, "vae.quant_conv"));
+    // the mean half of the moments: channels [0, z_ch) of 2 z_ch
+    const int64_t rows = mom.d[0] * mom.d[1] * mom.d[2];
+    OKR(new_ten(m, z, {mom.d[0], mom.d[1], mom.d[2], c.z_ch}));
+    EGR_HIP(hipMemcpy2DAsync(z.p, (size_t)c.z_ch * 4, mom.p, (size_t)2 * c.z_ch * 4, (size_t)c.z_ch * 4, (size_t)rows, hipMemcpyDeviceToDevice, m->st));
+    return EGR_OK;
+}
+
+int vae_decode(M* m, Ten& y, const Ten& z) {
+    const egr_flashsr_config& c = m->cfg;
+    Ten h, t;
+    OKR(conv1x1(m, t, z, "vae.post_quant_conv"));
+    OKR(conv3(m, h, t, "vae.decoder.conv_in"));
+    OKR(vae_res(m, t, h, "vae.decoder.mid.block_1")); h = std::move(t);
+    OKR(vae_attn(m, t, h, "vae.decoder.mid.attn_1")); h = std::move(t);
+    OKR(vae_res(m, t, h, "vae.decoder.mid.block_2")); h = std::move(t);
+    for (int lv = c.vae_levels - 1; lv >= 0; --lv) {
+        for (int b = 0; b <= c.vae_res; ++b) {
+            OKR(vae_res(m, t, h, "vae.decoder.up." + std::to_string(lv) + ".block." + std::to_string(b)));
+            h = std::move(t);
+        }
+        if (lv != 0) {
+            OKR(conv3(m, t, h, "vae.decoder.up." + std::to_string(lv) + ".upsample.conv", 1, 1));
+            h = std::move(t);
+        }
+    }
+    OKR(groupnorm(m, t, h, "vae.decoder.norm_out", 1e-6f, true));
+    return conv3(m, y, t, "vae.decoder.conv_out");
+}
+
+int unet_block(M* m, Ten& y, const Ten& x, const std::string& base, bool has_attn) {
+    const egr_flashsr_config& c = m->cfg;
+    Ten h, sc, r;
+    OKR(gn_conv3(m, h, x, base + ".res.in_norm", 1e-5f, base + ".res.in_conv", nullptr, m->ptr(base + ".res.in_conv.bias_t")));
+    const float* scp = x.p;
+    if (m->has(base + ".res.skip.weight")) { OKR(conv1x1(m, sc, x, base + ".res.skip")); scp = sc.p; }
+    OKR(gn_conv3(m, r, h, base + ".res.out_norm", 1e-5f, base + ".res.out_conv", scp));
+    h.release(); sc.release();
+    if (!has_attn) { y = std::move(r); return EGR_OK; }
+    const int B = (int)r.d[0], H = (int)r.d[1], W = (int)r.d[2], Cc = (int)r.d[3];
+    const int T = H * W, heads = Cc / c.head_dim;
+    Ten g0, t;
+    OKR(groupnorm(m, g0, r, base + ".st.norm", 1e-6f, false));
+    OKR(conv1x1(m, t, g0, base + ".st.proj_in"));
+    g0.release();
+    t.view({(int64_t)B * T, Cc});
+    for (int a = 1; a <= 2; ++a) {
+        const std::string an = base + ".st.attn" + std::to_string(a);
+        Ten n_, q, k, v, o, t2;
+        OKR(layernorm(m, n_, t, an + "_ln"));
+        OKR(linear(m, q, n_, an + ".to_q", nullptr, ACT_NONE, false));
+        OKR(linear(m, k, n_, an + ".to_k", nullptr, ACT_NONE, false));
+        OKR(linear(m, v, n_, an + ".to_v", nullptr, ACT_NONE, false));
+        OKR(attention(m, o, q, k, v, B, T, Cc, heads));
+        OKR(linear(m, t2, o, an + ".to_out", t.p));
+        t = std::move(t2);
+    }
+    Ten ln, u, g, t3;
+    OKR(layernorm(m, ln, t, base + ".st.ff_ln"));
+    OKR(linear(m, u, ln, base + ".st.ff.geglu"));
+    OKR(new_ten(m, g, {(int64_t)B * T, 4 * Cc}));
+    OKR(egr_geglu(u.p, g.p, (int64_t)B * T, 4 * Cc, m->st));
+    OKR(linear(m, t3, g, base + ".st.ff.out", t.p));
+    t3.view({B, H, W, Cc});
+    return conv1x1(m, y, t3, base + ".st.proj_out", r.p);
+}
+
+int unet(M* m, Ten& out, Ten&& x0) {
+    std::vector<Ten> skips;
+    Ten h = std::move(x0), t;
+    for (size_t i = 0; i < m->blk_name.size(); ++i) {
+        const std::string& name = m->blk_name[i];
+        const std::string base = "unet." + name;
+        const std::string part = name.substr(0, name.find('.'));
+        const std::string kind = name.substr(name.rfind('.') + 1);
+        if (kind == "conv_in") {
+            OKR(conv3(m, t, h, base));
+            h = std::move(t);
+            Ten cp; cp.nd = h.nd; memcpy(cp.d, h.d, sizeof(cp.d)); cp.p = h.p;      // non-owning alias: the skip stack owns, h aliases
+            skips.push_back(std::move(h));
+            h = std::move(cp);
+        } else if (kind == "down") {
+            OKR(conv3(m, t, h, base + ".conv", 2, 0, ACT_NONE, nullptr, 1));
+            Ten cp; cp.nd = t.nd; memcpy(cp.d, t.d, sizeof(cp.d)); cp.p = t.p;
+            skips.push_back(std::move(t));
+            h = std::move(cp);
+        } else if (kind == "up") {
+            OKR(conv3(m, t, h, base + ".conv", 1, 1));
+            h = std::move(t);
+        } else {
+            if (part == "out") {
+                Ten cat;
+                OKR(concat(m, cat, h, skips.back()));
+                skips.pop_back();
+                h = std::move(cat);
+            }
+            OKR(unet_block(m, t, h, base, m->blk_attn[i] != 0));
+            if (part == "in") {
+                Ten cp; cp.nd = t.nd; memcpy(cp.d, t.d, sizeof(cp.d)); cp.p = t.p;
+                skips.push_back(std::move(t));
+                h = std::move(cp);
+            } else {
+                h = std::move(t);
+            }
+        }
+    }
+    OKR(groupnorm(m, t, h, "unet.out_norm", 1e-5f, true));
+    return conv3(m, out, t, "unet.out_conv");
+}
+
+int amp(M* m, Ten& y, Ten&& h, int j) {
+    const egr_flashsr_config& c = m->cfg;
+    Ten acc;
+    for (int ki = 0; ki < c.voc_n_kernels; ++ki) {
+        const int k = c.voc_kernels[ki];
+        Ten x;                                   // aliases h on the first dilation
+        const Ten* cur = &h;
+        for (int di = 0; di < c.voc_n_dils; ++di) {
+            const int d = c.voc_dils[di];
+            const std::string b = "voc.amp." + std::to_string(j) + "." + std::to_string(ki) + "." + std::to_string(di);
+            Ten xt, xc, xs, xn;
+            OKR(snake(m, xt, *cur, b + ".alpha1", b + ".beta1"));
+            OKR(conv1d(m, xc, xt, b + ".conv1", k, 1, d, d * (k - 1) / 2));
+            xt.release();
+            OKR(snake(m, xs, xc, b + ".alpha2", b + ".beta2"));
+            xc.release();
+            OKR(conv1d(m, xn, xs, b + ".conv2", k, 1, 1, (k - 1) / 2, ACT_NONE, cur->p));
+            x = std::move(xn);
+            cur = &x;
+        }
+        if (ki == 0) {
+            acc = std::move(x);
+        } else if (ki + 1 < c.voc_n_kernels) {
+            Ten s;
+            OKR(eltwise(m, s, acc, x.p, EW_ADD));
+            acc = std::move(s);
+        } else {                                   // last branch: the mean's scale rides on the last add
+            return eltwise(m, y, acc, x.p, EW_ADD_SCALE, 1.0f / c.voc_n_kernels);
+        }
+    }
+    return eltwise(m, y, acc, nullptr, EW_SCALE, 1.0f / c.voc_n_kernels);
+}
+
+int vocoder(M* m, Ten& y, const Ten& mel_hat, const float* wave, int B) {
+    const egr_flashsr_config& c = m->cfg;
+    const int T = (int)mel_hat.d[1], Fm = (int)mel_hat.d[2];
+    const int n = c.voc_n_rates;
+    std::vector<Ten> feats(n);
+    {
+        Ten e0;                                     // non-owning view of the input rows
+        e0.view({B, c.chunk, 1});
+        e0.p = const_cast<float*>(wave);
+        const Ten* e = &e0;
+        for (int i = 0; i < n; ++i) {
+            const int r = c.voc_rates[n - 1 - i];
+            OKR(conv1d(m, feats[i], *e, "voc.wave_enc." + std::to_string(i), 2 * r + 1, r, 1, r, ACT_LEAKY));
+            e = &feats[i];
+        }
+    }
+    Ten mh;                                        // [B][T][Fm] view of mel_hat
+    mh.view({B, T, Fm});
+    mh.p = mel_hat.p;
+    Ten h;
+    OKR(conv1d(m, h, mh, "voc.conv_pre", 7, 1, 1, 3, ACT_NONE, feats[n - 1].p));
+    feats[n - 1].release();
+    for (int j = 0; j < n; ++j) {
+        const int r = c.voc_rates[j];
+        const int kt = up_kernel(r);
+        const int Bc = (int)h.d[0], Lin = (int)h.d[1], Ci = (int)h.d[2];
+        const Wt* wt = m->get("voc.ups." + std::to_string(j) + ".weight");
+        const int Co = wt->Cout / kt;
+        Ten Y, out, hx;
+        hx.view({(int64_t)Bc * Lin, 1, 1, Ci});
+        hx.p = h.p;
+        OKR(conv(m, Y, hx, "voc.ups." + std::to_string(j), Bc * Lin, 1, 1, Ci, 1, 1, kt * Co, 1, 1, 1, 1, 0, 0, 0, ACT_NONE, false, nullptr, nullptr, 0.f, wt));
+        OKR(new_ten(m, out, {Bc, (int64_t)Lin * r, Co}));
+        const float* add = (j <= n - 2) ? feats[n - 2 - j].p : nullptr;
+        OKR(egr_col2im_convtr1d(Y.p, m->ptr("voc.ups." + std::to_string(j) + ".bias"), add, out.p, Bc, Lin, Lin * r, Co, kt, r, (kt - r) / 2, m->st));
+        Y.release();
+        if (j <= n - 2) feats[n - 2 - j].release();
+        Ten nx;
+        OKR(amp(m, nx, std::move(out), j));
+        h = std::move(nx);
+    }
+    Ten s;
+    OKR(snake(m, s, h, "voc.post.alpha", "voc.post.beta"));
+    OKR(conv1d(m, y, s, "voc.conv_post", 7, 1, 1, 3, ACT_TANH));
+    y.view({B, y.d[1]});
+    return EGR_OK;
+}
+
+int copy_out(M* m, float* dst, const Ten& t) {
+    if (!dst) return EGR_OK;
+    EGR_HIP(hipMemcpyAsync(dst, t.p, (size_t)t.numel() * 4, hipMemcpyDeviceToDevice, m->st));
+    return EGR_OK;
+}
+
+// x [R][chunk], noise [R][h][w][z] (channels-last) -> y [R][chunk]; stages (optional): mel, z_cond, v, z0, mel_hat, y_full
+int forward(M* m, const float* x_in, const float* noise, int R, int lowpass_on, float* y_out, float* const* stages) {
+    const egr_flashsr_config& c = m->cfg;
+    const float* x = x_in;
+    Ten xl;
+    if (lowpass_on) { OKR(lowpass(m, xl, x_in, R, c.chunk)); x = xl.p; }
+    Ten mel, z_c, v, z0, mel_hat, y;
+    OKR(log_mel(m, mel, x, R, c.chunk));
+    OKR(vae_encode(m, z_c, mel));
+    {
+        Ten nz, cat;                               // non-owning view of the caller's noise
+        nz.view({R, m->lat_h, m->lat_w, c.z_ch});
+        nz.p = const_cast<float*>(noise);
+        OKR(concat(m, cat, nz, z_c));
+        OKR(unet(m, v, std::move(cat)));
+        OKR(eltwise(m, z0, nz, v.p, EW_AXPBY, m->alpha, -m->sigma));
+    }
+    OKR(vae_decode(m, mel_hat, z0));
+    OKR(vocoder(m, y, mel_hat, x, R));
+    if (stages) {
+        OKR(copy_out(m, stages[0], mel)); OKR(copy_out(m, stages[1], z_c)); OKR(copy_out(m, stages[2], v));
+        OKR(copy_out(m, stages[3], z0)); OKR(copy_out(m, stages[4], mel_hat)); OKR(copy_out(m, stages[5], y));
+    }
+    const int64_t Ly = y.d[1];
+    EGR_CHECK(Ly >= c.chunk, EGR_ERR_UNSUPPORTED, "FlashSR: vocoder output %lld shorter than the chunk %d", (long long)Ly, c.chunk);
+    EGR_HIP(hipMemcpy2DAsync(y_out, (size_t)c.chunk * 4, y.p, (size_t)Ly * 4, (size_t)c.chunk * 4, (size_t)R, hipMemcpyDeviceToDevice, m->st));
+    return EGR_OK;
+}
+
+const egr_tensor_desc* find(const egr_tensor_desc* ts, int n, const char* name) {
+    for (int i = 0; i < n; ++i) if (ts[i].name && strcmp(ts[i].name, name) == 0) return &ts[i];
+    return nullptr;
+}
+
+}  // namespace
+
+// ==================================================================================================== C ABI
+extern "C" int egr_flashsr_default_config(egr_flashsr_config* c) {
+    EGR_CHECK(c != nullptr, EGR_ERR_ARG, "config is null");
+    memset(c, 0, sizeof(*c));
+    c->struct_bytes = (int)sizeof(*c);
+    c->sr = 48000; c->chunk = 245760; c->n_fft = 2048; c->hop = 480; c->n_mels = 256; c->n_frames = 512;
+    c->fmin = 20.f; c->fmax = 24000.f; c->log_floor = 1e-5f;
+    c->vae_ch = 128; c->vae_levels = 4; c->vae_mult[0] = 1; c->vae_mult[1] = 2; c->vae_mult[2] = 4; c->vae_mult[3] = 8; c->vae_res = 2;
+    c->z_ch = 16; c->gn_groups = 32;
+    c->unet_ch = 128; c->unet_levels = 4; c->unet_mult[0] = 1; c->unet_mult[1] = 2; c->unet_mult[2] = 3; c->unet_mult[3] = 5; c->unet_res = 2;
+    c->unet_n_attn = 3; c->unet_attn_ds[0] = 2; c->unet_attn_ds[1] = 4; c->unet_attn_ds[2] = 8; c->head_dim = 32; c->t_steps = 1000;
+    c->voc_ch = 512; c->voc_n_rates = 5; const int r[5] = {6, 5, 4, 2, 2}; memcpy(c->voc_rates, r, sizeof(r));
+    c->voc_n_kernels = 3; c->voc_kernels[0] = 3; c->voc_kernels[1] = 7; c->voc_kernels[2] = 11;
+    c->voc_n_dils = 3; c->voc_dils[0] = 1; c->voc_dils[1] = 3; c->voc_dils[2] = 5; c->aa_taps = 12;
+    return EGR_OK;
+}
+
+extern "C" int egr_flashsr_destroy(egr_flashsr* m) {
+    if (!m) return EGR_OK;
+    hipDeviceSynchronize();
+    for (void* p : m->owned) hipFree(p);
+    for (auto& kv : m->lp_plans) egr_fatllama_plan_destroy(kv.second);
+    for (auto& r : m->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    if (m->gn_ws) hipFree(m->gn_ws);
+    delete m;
+    return EGR_OK;
+}
+
+extern "C" int egr_flashsr_create(egr_flashsr** out, const egr_flashsr_config* cfg, const egr_tensor_desc* tensors, int n_tensors,
+                                  unsigned flags, void* stream) {
+    EGR_CHECK(out && cfg && tensors && n_tensors > 0, EGR_ERR_ARG, "egr_flashsr_create: null argument");
+    *out = nullptr;
+    EGR_CHECK(cfg->struct_bytes == (int)sizeof(egr_flashsr_config), EGR_ERR_ARG, "egr_flashsr_config size %d != %d (ABI mismatch)",
+              cfg->struct_bytes, (int)sizeof(egr_flashsr_config));
+    EGR_CHECK(cfg->vae_levels >= 1 && cfg->vae_levels <= EGR_FSR_MAX && cfg->unet_levels >= 1 && cfg->unet_levels <= EGR_FSR_MAX &&
+              cfg->voc_n_rates >= 1 && cfg->voc_n_rates <= EGR_FSR_MAX && cfg->voc_n_kernels >= 1 && cfg->voc_n_kernels <= EGR_FSR_MAX &&
+              cfg->voc_n_dils >= 1 && cfg->voc_n_dils <= EGR_FSR_MAX && cfg->unet_n_attn >= 0 && cfg->unet_n_attn <= EGR_FSR_MAX,
+              EGR_ERR_ARG, "egr_flashsr_config: level / rate counts out of range");
+    egr_flashsr* m = new egr_flashsr();
+    m->cfg = *cfg;
+    m->flags = flags;
+    m->st = (hipStream_t)stream;
+    hipGetDevice(&m->device);
+    if (const char* e = getenv("EGREGORA_FLASHSR_WINOGRAD_MIN_CH")) m->wino_min_ch = atoi(e);
+    if (const char* e = getenv("EGREGORA_FLASHSR_ROWS")) { const int r = atoi(e); if (r >= 1) m->rows_per_pass = r; }
+    build_blocks(m);
+    const int down = 1 << (cfg->vae_levels - 1);
+    m->lat_h = cfg->n_frames / down; m->lat_w = cfg->n_mels / down;
+    const int nb = cfg->n_fft / 2 + 1;
+    m->ldm = ((nb + 15) / 16) * 16;
+    auto fail = [&](int rc) { egr_flashsr_destroy(m); return rc; };
+    int rc = pack_all(m, tensors, n_tensors);
+    if (rc) return fail(rc);
+    // derived constants travel with the weights (the host computes them exactly as the oracle does): Hann window, mel filterbank,
+    // anti-alias FIR, sinusoidal embedding of t = T-1
+    const egr_tensor_desc* tw = find(tensors, n_tensors, "const.window");
+    const egr_tensor_desc* tf = find(tensors, n_tensors, "const.aa_filter");
+    const egr_tensor_desc* tm = find(tensors, n_tensors, "const.mel_fb");
+    const egr_tensor_desc* te = find(tensors, n_tensors, "const.time_emb");
+    if (!(tw && tf && tm && te)) { set_error("egr_flashsr_create: const.window / const.aa_filter / const.mel_fb / const.time_emb must accompany the weights"); return fail(EGR_ERR_ARG); }
+    if (tw->shape[0] != cfg->n_fft || tf->shape[0] != cfg->aa_taps || tm->ndim != 2 || tm->shape[0] != cfg->n_mels || tm->shape[1] != nb ||
+        te->shape[te->ndim - 1] != cfg->unet_ch) { set_error("egr_flashsr_create: constant tensor shapes do not match the config"); return fail(EGR_ERR_ARG); }
+    void* p = nullptr;
+    if ((rc = dev_alloc(m, (size_t)cfg->n_fft * 4, &p))) return fail(rc);
+    m->window = (float*)p;
+    hipMemcpyAsync(m->window, tw->data, (size_t)cfg->n_fft * 4, hipMemcpyDeviceToDevice, m->st);
+    if ((rc = dev_alloc(m, (size_t)cfg->aa_taps * 4, &p))) return fail(rc);
+    m->filt = (float*)p;
+    hipMemcpyAsync(m->filt, tf->data, (size_t)cfg->aa_taps * 4, hipMemcpyDeviceToDevice, m->st);
+    // mel filterbank [n_mels][nb] as a contraction weight: K = nb (padded to ldm), N = n_mels
+    if ((rc = add_packed(m, "mel_fb", tm->data, 0, nb, cfg->n_mels, nb, cfg->n_mels, 1, 1, 1, 1, m->ldm))) return fail(rc);
+    {   // cosine schedule at t = T-1 (Nichol & Dhariwal), alpha^2 + sigma^2 = 1
+        const double s = 0.008, T = (double)cfg->t_steps, t = T - 1.0;
+        auto f = [&](double u) { const double cc = cos((u / T + s) / (1 + s) * M_PI / 2); return cc * cc; };
+        double abar = f(t + 1) / f(0);
+        abar = abar < 1e-5 ? 1e-5 : (abar > 0.99999 ? 0.99999 : abar);
+        m->alpha = (float)sqrt(abar); m->sigma = (float)sqrt(1.0 - abar);
+    }
+    if ((rc = fold_time_embedding(m, te->data))) return fail(rc);
+    if (hipStreamSynchronize(m->st) != hipSuccess || hipGetLastError() != hipSuccess) { set_error("egr_flashsr_create: device work failed"); return fail(EGR_ERR_HIP); }
+    *out = m;
+    return EGR_OK;
+}
+
+extern "C" int egr_flashsr_set_rows_per_pass(egr_flashsr* m, int rows) {
+    EGR_CHECK(m && rows >= 1, EGR_ERR_ARG, "bad argument");
+    m->rows_per_pass = rows;
+    return EGR_OK;
+}
+
+extern "C" int egr_flashsr_forward(egr_flashsr* m, const float* x, const float* noise, int rows, int lowpass, float* y, float* const* stages,
+                                   void* stream) {
+    EGR_CHECK(m && x && noise && y && rows >= 1, EGR_ERR_ARG, "egr_flashsr_forward: null / empty argument");
+    m->st = (hipStream_t)stream;
+    return forward(m, x, noise, rows, lowpass, y, stages);
+}
+
+// x [rows][chunk] -> y [rows][chunk]; rows = chunks x channels ride the batch dimension (reference :366-368) and are processed
+// rows_per_pass at a time; the noise of row r is a function of (seed, row_ids[r] or r) only, so results do not depend on how the
+// rows are spread over passes or ranks.
+extern "C" int egr_flashsr_infer(egr_flashsr* m, const float* x, int rows, int lowpass, uint64_t seed, const int64_t* row_ids, float* y,
+                                 void* stream) {
+    EGR_CHECK(m && x && y && rows >= 1, EGR_ERR_ARG, "egr_flashsr_infer: null / empty argument");
+    m->st = (hipStream_t)stream;
+    const egr_flashsr_config& c = m->cfg;
+    const int64_t per_row = (int64_t)m->lat_h * m->lat_w * c.z_ch;
+    for (int lo = 0; lo < rows; lo += m->rows_per_pass) {
+        const int n = std::min(m->rows_per_pass, rows - lo);
+        Ten nz, ids;
+        OKR(new_ten(m, nz, {n, per_row}));
+        const int64_t* idp = row_ids ? row_ids + lo : nullptr;
+        if (!row_ids && lo > 0) {                 // implicit ids continue across passes
+            std::vector<int64_t> h(n);
+            for (int i = 0; i < n; ++i) h[i] = lo + i;
+            OKR(new_ten(m, ids, {2 * (int64_t)n}));
+            EGR_HIP(hipMemcpyAsync(ids.p, h.data(), (size_t)n * 8, hipMemcpyHostToDevice, m->st));
+            EGR_HIP(hipStreamSynchronize(m->st));
+            idp = (const int64_t*)ids.p;
+        }
+        OKR(egr_randn(nz.p, per_row, n, seed, idp, m->st));
+        OKR(forward(m, x + (size_t)lo * c.chunk, nz.p, n, lowpass, y + (size_t)lo * c.chunk, nullptr));
+    }
+    return EGR_OK;
+}
+
+extern "C" int egr_flashsr_set_profiling(egr_flashsr* m, int enable) {
+    EGR_CHECK(m != nullptr, EGR_ERR_ARG, "handle is null");
+    for (auto& r : m->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    m->prof.clear();
+    m->profiling = enable != 0;
+    return EGR_OK;
+}
+
+// Aggregated HIP-event timing of the MFMA contraction launches since profiling was switched on: entry i of the distinct kernel
+// instantiations -> name, launches, flops, milliseconds.  Returns the number of distinct kinds through *count when kind_buf is null.
+extern "C" int egr_flashsr_profile(egr_flashsr* m, int index, char* kind_buf, size_t buflen, int64_t* launches, double* flops, double* ms,
+                                   int* count) {
+    EGR_CHECK(m != nullptr, EGR_ERR_ARG, "handle is null");
+    EGR_HIP(hipDeviceSynchronize());
+    std::map<std::string, std::tuple<int64_t, double, double>> agg;
+    for (auto& r : m->prof) {
+        float t = 0.f;
+        hipEventElapsedTime(&t, r.a, r.b);
+        auto& e = agg[r.kind];
+        std::get<0>(e) += 1; std::get<1>(e) += r.flops; std::get<2>(e) += t;
+    }
+    if (count) *count = (int)agg.size();
+    if (!kind_buf) return EGR_OK;
+    EGR_CHECK(index >= 0 && index < (int)agg.size(), EGR_ERR_ARG, "profile index out of range");
+    auto it = agg.begin();
+    std::advance(it, index);
+    snprintf(kind_buf, buflen, "%s", it->first.c_str());
+    if (launches) *launches = std::get<0>(it->second);
+    if (flops) *flops = std::get<1>(it->second);
+    if (ms) *ms = std::get<2>(it->second);
+    return EGR_OK;
+}
+
+// Dense-contraction flops of one forward over `rows` rows (dry run with counting on; 2 Cin Cout Kh Kw Hout Wout per conv as executed).
+extern "C" int egr_flashsr_flop_count(egr_flashsr* m, int rows, double* flops, void* stream) {
+    EGR_CHECK(m && flops && rows >= 1, EGR_ERR_ARG, "bad argument");
+    m->st = (hipStream_t)stream;
+    const egr_flashsr_config& c = m->cfg;
+    Ten x, nz, y;
+    OKR(new_ten(m, x, {rows, c.chunk}));
+    OKR(new_ten(m, nz, {rows, (int64_t)m->lat_h * m->lat_w * c.z_ch}));
+    OKR(new_ten(m, y, {rows, c.chunk}));
+    EGR_HIP(hipMemsetAsync(x.p, 0, x.bytes, m->st));
+    OKR(egr_randn(nz.p, (int64_t)m->lat_h * m->lat_w * c.z_ch, rows, 0, nullptr, m->st));
+    m->count_flops = true; m->flops = 0.0;
+    const int rc = forward(m, x.p, nz.p, rows, 0, y.p, nullptr);
+    m->count_flops = false;
+    EGR_HIP(hipStreamSynchronize(m->st));
+    *flops = m->flops;
+    return rc;
+}
+
+extern "C" int64_t egr_flashsr_scratch_bytes(egr_flashsr* m) { return m ? (int64_t)m->arena.total : 0; }
+
+// ---------------------------------------------------------------------------------------------------- weight blob files
+// "EGRW" container: what `egr_flashsr_create` takes, on disk -- written once by the host that owns checkpoint I/O
+// (flashsr_weights.write_blob) and loadable from plain C:
+//   char magic[8] = "EGRW0001"; int32 config_bytes; egr_flashsr_config; int32 n_tensors;
+//   n x { int32 name_len; char name[name_len]; int32 ndim; int64 shape[4]; int64 offset (bytes from file start); }
+//   ... fp32 data, each tensor 64-byte aligned
+extern "C" int egr_flashsr_create_from_file(egr_flashsr** out, const char* path, unsigned flags, void* stream) {
+    EGR_CHECK(out && path, EGR_ERR_ARG, "null argument");
+    *out = nullptr;
+    FILE* f = fopen(path, "rb");
+    EGR_CHECK(f != nullptr, EGR_ERR_ARG, "cannot open %s", path);
+    std::vector<char> buf;
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    buf.resize((size_t)sz);
+    const size_t got = fread(buf.data(), 1, (size_t)sz, f);
+    fclose(f);
+    EGR_CHECK(got == (size_t)sz && sz > 16 && memcmp(buf.data(), "EGRW0001", 8) == 0, EGR_ERR_ARG, "%s is not an EGRW0001 weight blob", path);
+    size_t pos = 8;
+    auto rd = [&](void* dst, size_t n) -> bool { if (pos + n > buf.size()) return false; memcpy(dst, buf.data() + pos, n); pos += n; return true; };
+    int32_t cb = 0, nt = 0;
+    egr_flashsr_config cfg;
+    bool ok = rd(&cb, 4) && cb == (int32_t)sizeof(cfg) && rd(&cfg, sizeof(cfg)) && rd(&nt, 4) && nt > 0;
+    EGR_CHECK(ok, EGR_ERR_ARG, "%s: header does not match this library's egr_flashsr_config (%d bytes)", path, (int)sizeof(cfg));
+    std::vector<std::string> names(nt);
+    std::vector<egr_tensor_desc> ds(nt);
+    std::vector<int64_t> offs(nt);
+    size_t total = 0;
+    for (int i = 0; i < nt && ok; ++i) {
+        int32_t nl = 0, nd = 0;
+        ok = rd(&nl, 4) && nl > 0 && nl < 512;
+        if (ok) { names[i].resize(nl); ok = rd(&names[i][0], nl); }
+        ok = ok && rd(&nd, 4) && nd >= 0 && nd <= 4 && rd(ds[i].shape, 32) && rd(&offs[i], 8);
+        ds[i].ndim = nd;
+        int64_t ne = 1;
+        for (int d = 0; d < nd; ++d) ne *= ds[i].shape[d];
+        ok = ok && offs[i] >= 0 && (size_t)offs[i] + (size_t)ne * 4 <= buf.size();
+        total += ((size_t)ne * 4 + 255) & ~(size_t)255;
+    }
+    EGR_CHECK(ok, EGR_ERR_ARG, "%s: corrupt tensor index", path);
+    char* dev = nullptr;
+    EGR_HIP(hipMalloc((void**)&dev, total + 256));
+    size_t dpos = 0;
+    for (int i = 0; i < nt; ++i) {
+        int64_t ne = 1;
+        for (int d = 0; d < ds[i].ndim; ++d) ne *= ds[i].shape[d];
+        hipMemcpy(dev + dpos, buf.data() + offs[i], (size_t)ne * 4, hipMemcpyHostToDevice);
+        ds[i].name = names[i].c_str();
+        ds[i].data = (const float*)(dev + dpos);
+        dpos += ((size_t)ne * 4 + 255) & ~(size_t)255;
+    }
+    const int rc = egr_flashsr_create(out, &cfg, ds.data(), nt, flags, stream);
+    hipFree(dev);
+    return rc;
+}

@@ -1,11 +1,17 @@
-"""FlashSR on the MI355X: executes the layer table of flashsr_arch.py with the HIP operators of
-libegregora_amd.so (csrc/egr_nn_gemm.hip, csrc/egr_nn_ops.hip).  Stands in for the reference's
-`_FlashSRRunner` (egregora_audio_super_resolution.py:254-369): build once per process (the reference rebuilds per
-call, :393), `infer` on [rows, 245760] where rows = chunks x channels ride the batch dimension (:366-368).
+"""FlashSR on the MI355X.  Stands in for the reference's `_FlashSRRunner` (egregora_audio_super_resolution.py:254-369): built
+once per process (the reference rebuilds per call, :393), inference on [rows, 245760] where rows = chunks x channels ride the
+batch dimension (:366-368).
 
-Activations are channels-last ([B][H][W][C] / [B][L][C]) float32; every dense contraction runs on
-v_mfma_f32_32x32x2_f32 through egr_conv_nhwc / egr_bgemm; torch only owns the buffers.
-PARITY UNPINNED vs upstream (see flashsr_arch.py); checked against oracle/flashsr_torch.py (same table, torch fp32).
+PRODUCT PATH: the C-ABI model handle -- `egr_flashsr_create` / `egr_flashsr_infer` (include/egregora_amd.h, csrc/egr_flashsr.cpp):
+the graph walk, weight repacking and scratch arena live in the library; this module only hands it the named weight tensors
+(`FlashSREngine.handle`, `infer_rows`).
+`FlashSREngine.forward_rows` below is the same graph driven operator by operator from Python (hundreds of ctypes calls per
+pass, torch owning the buffers): kept as the introspection / ablation executor the tests use -- per-stage taps, the strict
+f32-MFMA and no-Winograd modes -- and pinned bit-for-bit against the handle (tests/test_gpu_flashsr_capi.py); both share the
+packing kernels of csrc/egr_flashsr_pack.hip, so they hold identical operands.
+
+Activations are channels-last ([B][H][W][C] / [B][L][C]) float32.
+PARITY UNPINNED vs upstream (see flashsr_arch.py); checked against oracle/flashsr_torch.py (same table, torch fp32 / fp64).
 """
 import ctypes as C
 import math
@@ -40,14 +46,16 @@ class FlashSREngine:
         self.wshape: Dict[str, tuple] = {}
         self.mfma = self.MFMA_MODE
         self.thin = self.THIN_ENDS
+        self._handle = None
+        self._params = {k: v.detach().float().contiguous() for k, v in params.items()}     # torch layouts, for the C-ABI handle
+        self._g_dev = {}
         self._pack(params)
         self.window = torch.hann_window(cfg.n_fft, periodic=True, dtype=torch.float32).to(self.dev)
         self.filt = torch.from_numpy(arch.kaiser_sinc_filter(cfg.aa_taps)).to(self.dev)
         nb = cfg.n_fft // 2 + 1
         self.ldm = ((nb + 15) // 16) * 16
-        fb = torch.zeros(self.ldm, cfg.n_mels)
-        fb[:nb] = torch.from_numpy(arch.mel_filterbank(cfg)).t()
-        self.w["mel_fb"] = self.pack_matrix(fb.contiguous()).to(self.dev)
+        self.mel_fb = torch.from_numpy(arch.mel_filterbank(cfg)).contiguous().to(self.dev)       # [n_mels][nb]
+        self.w["mel_fb"] = self._pack_dev(self.mel_fb, 0, nb, cfg.n_mels, nb, cfg.n_mels, 1, 1)
         self._split3("mel_fb")
         self.alpha, self.sigma = arch.cosine_alpha_sigma(cfg, cfg.t_steps - 1)
         self._gn_ws = {}            # GroupNorm scratch per stream (row groups of one forward run on several streams)
@@ -74,33 +82,136 @@ class FlashSREngine:
             return None
         return self.w3.get(key)
 
-    # ------------------------------------------------------------------ weight packing
+    # ------------------------------------------------------------------ the C-ABI model handle (product path)
+    def time_embedding_input(self) -> torch.Tensor:
+        """Sinusoidal embedding of the fixed step t = T-1, [1, unet_ch] float32 (the input of unet.time_embed)."""
+        half = self.cfg.unet_ch // 2
+        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+        args = float(self.cfg.t_steps - 1) * freqs
+        return torch.cat([torch.cos(args), torch.sin(args)])[None].contiguous().to(self.dev)
+
+    def named_tensors(self) -> Dict[str, torch.Tensor]:
+        """What egr_flashsr_create takes: the layer table's parameters in torch layouts + the four derived constants."""
+        t = {k: v.to(self.dev) for k, v in self._params.items()}
+        t["const.window"] = self.window
+        t["const.mel_fb"] = self.mel_fb
+        t["const.aa_filter"] = self.filt
+        t["const.time_emb"] = self.time_embedding_input()
+        return t
+
+    def handle_flags(self) -> int:
+        f = native.FSR_F32_MFMA if self.mfma != "bf16x3" else 0
+        f |= native.FSR_NO_WINOGRAD if self.WINO_MIN_CH >= (1 << 20) else 0
+        f |= 0 if self.WINO_F4 else native.FSR_NO_WINO_F4
+        f |= 0 if self.GN_PARTIALS else native.FSR_NO_GN_PARTIALS
+        f |= 0 if self.thin else native.FSR_NO_THIN_ENDS
+        f |= native.FSR_NO_FUSE_GN if self.FUSE_GN == "0" else 0
+        return f
+
+    @property
+    def handle(self) -> int:
+        """egr_flashsr handle built from this engine's parameters (once)."""
+        if self._handle is None:
+            named = self.named_tensors()
+            descs = (native.TensorDescC * len(named))()
+            keep = []
+            for d, (k, v) in zip(descs, named.items()):
+                v = v.contiguous()
+                keep.append(v)
+                d.name, d.data, d.ndim = k.encode(), v.data_ptr(), v.dim()
+                for i, n in enumerate(v.shape):
+                    d.shape[i] = n
+            cc = native.flashsr_config_c(self.cfg)
+            out = C.c_void_p()
+            native.check(self.L.egr_flashsr_create(C.byref(out), C.byref(cc), descs, len(named), self.handle_flags(), self._st()),
+                         "egr_flashsr_create")
+            self._handle = out.value
+            native.check(self.L.egr_flashsr_set_rows_per_pass(C.c_void_p(self._handle), ROWS_PER_PASS), "egr_flashsr_set_rows_per_pass")
+        return self._handle
+
+    def close(self):
+        if self._handle is not None:
+            self.L.egr_flashsr_destroy(C.c_void_p(self._handle))
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def c_forward(self, x: torch.Tensor, noise: torch.Tensor, stages: Optional[dict] = None, lowpass: bool = False) -> torch.Tensor:
+        """egr_flashsr_forward: one pass through the library's graph walk; same arguments and results as forward_rows."""
+        x = x.contiguous()
+        R = x.shape[0]
+        cfg = self.cfg
+        y = torch.empty((R, cfg.chunk), dtype=torch.float32, device=self.dev)
+        ptrs = None
+        if stages is not None:
+            h, w = cfg.lat_hw
+            bufs = dict(mel=torch.empty((R, cfg.n_frames, cfg.n_mels, 1), dtype=torch.float32, device=self.dev),
+                        z_cond=torch.empty((R, h, w, cfg.z_ch), dtype=torch.float32, device=self.dev),
+                        v=torch.empty((R, h, w, cfg.z_ch), dtype=torch.float32, device=self.dev),
+                        z0=torch.empty((R, h, w, cfg.z_ch), dtype=torch.float32, device=self.dev),
+                        mel_hat=torch.empty((R, cfg.n_frames, cfg.n_mels, 1), dtype=torch.float32, device=self.dev),
+                        y=torch.empty((R, cfg.n_frames * cfg.hop), dtype=torch.float32, device=self.dev))
+            ptrs = (C.c_void_p * 6)(*[bufs[k].data_ptr() for k in ("mel", "z_cond", "v", "z0", "mel_hat", "y")])
+            stages.update(bufs)
+        native.check(self.L.egr_flashsr_forward(C.c_void_p(self.handle), _p(x), _p(noise.contiguous()), R, 1 if lowpass else 0, _p(y), ptrs,
+                                                self._st()), "egr_flashsr_forward")
+        return y
+
+    def c_infer(self, x: torch.Tensor, row_ids: Optional[torch.Tensor], seed: int, lowpass: bool = False) -> torch.Tensor:
+        """egr_flashsr_infer: [R, chunk] -> [R, chunk], noise keyed by (seed, global row id), rows-per-pass handled in the library."""
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        native.check(self.L.egr_flashsr_set_rows_per_pass(C.c_void_p(self.handle), ROWS_PER_PASS), "egr_flashsr_set_rows_per_pass")
+        native.check(self.L.egr_flashsr_infer(C.c_void_p(self.handle), _p(x), x.shape[0], 1 if lowpass else 0, int(seed) & (2 ** 64 - 1),
+                                              _p(row_ids.contiguous()) if row_ids is not None else None, _p(y), self._st()),
+                     "egr_flashsr_infer")
+        return y
+
+    def c_profile(self, fn) -> dict:
+        """{kernel instantiation: (launches, flops, ms)} of the MFMA contraction launches the handle made while fn() ran."""
+        h = C.c_void_p(self.handle)
+        native.check(self.L.egr_flashsr_set_profiling(h, 1), "egr_flashsr_set_profiling")
+        fn()
+        n = C.c_int()
+        native.check(self.L.egr_flashsr_profile(h, 0, None, 0, None, None, None, C.byref(n)), "egr_flashsr_profile")
+        out = {}
+        for i in range(n.value):
+            buf, la, fl, ms = C.create_string_buffer(128), C.c_int64(), C.c_double(), C.c_double()
+            native.check(self.L.egr_flashsr_profile(h, i, buf, 128, C.byref(la), C.byref(fl), C.byref(ms), None), "egr_flashsr_profile")
+            out[buf.value.decode()] = (la.value, fl.value, ms.value)
+        native.check(self.L.egr_flashsr_set_profiling(h, 0), "egr_flashsr_set_profiling")
+        return out
+
+    # ------------------------------------------------------------------ weight packing (kernels shared with the C-ABI handle)
     @staticmethod
     def pack_matrix(w2: torch.Tensor) -> torch.Tensor:
-        """[K][Cout] -> the kernel's slab-major layout [ceil(K/16)][Cout][16] (k contiguous, zero padded)."""
+        """[K][Cout] -> the kernels' slab-major layout [ceil(K/16)][Cout][16] in plain torch (tests build operands with it)."""
         K, Co = w2.shape
         Kp = ((K + 15) // 16) * 16
         if Kp != K:
             w2 = torch.cat([w2, w2.new_zeros(Kp - K, Co)], 0)
         return w2.reshape(Kp // 16, 16, Co).permute(0, 2, 1).contiguous()
 
-    # rows of the 3x3 kernel that collapse onto each of the two source rows, per output phase (a = 0, 1)
-    _PHASE_TAPS = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+    def _pack_dev(self, src: torch.Tensor, layout: int, K: int, N: int, Ci: int, Co: int, KH: int, KW: int) -> torch.Tensor:
+        """egr_pack_weight: torch layout -> the kernels' slab-major [ceil(K/16)][N][16] (k contiguous, zero padded)."""
+        dst = torch.empty(((K + 15) // 16, N, 16), dtype=torch.float32, device=self.dev)
+        native.check(self.L.egr_pack_weight(_p(src), _p(dst), layout, K, N, Ci, Co, KH, KW, self._st()), "egr_pack_weight")
+        return dst
 
     def add_upsample_phases(self, key: str, v: torch.Tensor):
         """nearest-2x upsample followed by a 3x3 conv == four 2x2 convs on the low-res input, one per output phase
-        (a, b): taps that read the same source pixel are pre-summed.  Registers key + '.ph{a}{b}'."""
-        v = v.detach().float().to(self.dev)                              # [Co,Ci,3,3]
+        (a, b): taps that read the same source pixel are pre-summed (egr_phase_weights).  Registers key + '.ph{a}{b}'."""
+        v = v.detach().float().contiguous().to(self.dev)                 # [Co,Ci,3,3]
         Co, Ci = v.shape[:2]
+        ph = torch.empty((4, Co, Ci, 2, 2), dtype=torch.float32, device=self.dev)
+        native.check(self.L.egr_phase_weights(_p(v), _p(ph), Co, Ci, self._st()), "egr_phase_weights")
         for a in (0, 1):
             for b in (0, 1):
-                w = v.new_zeros(Co, Ci, 2, 2)
-                for i, kys in enumerate(self._PHASE_TAPS[a]):
-                    for j, kxs in enumerate(self._PHASE_TAPS[b]):
-                        for ky in kys:
-                            for kx in kxs:
-                                w[:, :, i, j] += v[:, :, ky, kx]
-                self.add_weight(f"{key}.ph{a}{b}", w)
+                self.add_weight(f"{key}.ph{a}{b}", ph[2 * a + b])
 
     # F(2x2,3x3) paid from 256 channels (its transforms move 4x the tensor); F(4x4,3x3) moves 2.25x and pays from 128
     WINO_MIN_CH = int(os.environ.get("EGREGORA_FLASHSR_WINOGRAD_MIN_CH", "128"))
@@ -117,17 +228,18 @@ class FlashSREngine:
 
     def add_winograd(self, key: str, v: torch.Tensor):
         """U = G g G^T in float64 for Winograd F(2x2,3x3) (16 [Cin][Cout] matrices, key + '.wino') and, when enabled,
-        F(4x4,3x3) (36 matrices, key + '.wino4'); each matrix packed slab-major like a 1x1 conv weight.  Formed on the
-        device (fp64 einsum + packing): on the host this was most of the engine's 30 s start-up."""
-        v = v.detach().to(self.dev).double()                            # [Co,Ci,3,3]
-        Ci = v.shape[1]
+        F(4x4,3x3) (36 matrices, key + '.wino4'), each matrix packed slab-major like a 1x1 conv weight (egr_winograd_pack_u)."""
+        v = v.detach().float().contiguous().to(self.dev)                # [Co,Ci,3,3]
+        Co, Ci = v.shape[:2]
         for suffix, Gm in ((".wino", self._G2),) + (((".wino4", self._g4()),) if self.WINO_F4 else ()):
-            G = torch.tensor(Gm, dtype=torch.float64, device=self.dev)
-            U = torch.einsum("ik,ockl,jl->ijco", G, v, G).float()       # [n,n,Ci,Co]
-            n = U.shape[0]
-            packed = torch.stack([self.pack_matrix(U[i, j].contiguous()) for i in range(n) for j in range(n)])
-            self.w[key + suffix] = packed.contiguous()                  # [n*n][Kp/16][Co][16]
-            self.wz[key + suffix] = packed[0].numel()                   # floats per component
+            n = len(Gm)
+            if n not in self._g_dev:
+                self._g_dev[n] = torch.tensor(Gm, dtype=torch.float64, device=self.dev).contiguous()
+            zf = ((Ci + 15) // 16) * Co * 16
+            packed = torch.empty((n * n, zf), dtype=torch.float32, device=self.dev)
+            native.check(self.L.egr_winograd_pack_u(_p(v), _p(packed), _p(self._g_dev[n]), n, Co, Ci, self._st()), "egr_winograd_pack_u")
+            self.w[key + suffix] = packed.view(n * n, (Ci + 15) // 16, Co, 16)   # [n*n][Kp/16][Co][16]
+            self.wz[key + suffix] = zf                                  # floats per component
             if Ci % 16 == 0:
                 self._split3(key + suffix)
                 if (key + suffix) in self.w3:                           # the fp32 pack is not needed once split
@@ -190,20 +302,20 @@ class FlashSREngine:
     def add_weight(self, key: str, v: torch.Tensor):
         """Register a weight given in torch layout; self.w[key] holds the packed tensor, self.wshape[key] the
         logical (KH, KW, Cin, Cout)."""
-        v = v.detach().float().to(self.dev)                             # packed on the device
+        v = v.detach().float().contiguous().to(self.dev)                # packed on the device
         if v.dim() == 4:                                                # conv2d [Co,Ci,kh,kw]
             Co, Ci, kh, kw = v.shape
-            w2, shp = v.permute(2, 3, 1, 0).reshape(kh * kw * Ci, Co), (kh, kw, Ci, Co)
+            pk, shp = self._pack_dev(v, 0, kh * kw * Ci, Co, Ci, Co, kh, kw), (kh, kw, Ci, Co)
         elif key.startswith("voc.ups."):                                # convT1d [Ci,Co,k] -> GEMM [Ci][k*Co]
             Ci, Co, k = v.shape
-            w2, shp = v.permute(0, 2, 1).reshape(Ci, k * Co), (1, 1, Ci, k * Co)
+            pk, shp = self._pack_dev(v, 1, Ci, k * Co, Ci, Co, 1, k), (1, 1, Ci, k * Co)
         elif v.dim() == 3:                                              # conv1d [Co,Ci,k]
             Co, Ci, k = v.shape
-            w2, shp = v.permute(2, 1, 0).reshape(k * Ci, Co), (1, k, Ci, Co)
+            pk, shp = self._pack_dev(v, 0, k * Ci, Co, Ci, Co, 1, k), (1, k, Ci, Co)
         else:                                                           # linear [Co,Ci]
             Co, Ci = v.shape
-            w2, shp = v.t(), (1, 1, Ci, Co)
-        self.w[key] = self.pack_matrix(w2.contiguous()).to(self.dev)
+            pk, shp = self._pack_dev(v, 0, Ci, Co, Ci, Co, 1, 1), (1, 1, Ci, Co)
+        self.w[key] = pk
         self.wshape[key] = shp
         self.w3.pop(key, None)
         if shp[2] % 16 == 0:
@@ -483,11 +595,7 @@ class FlashSREngine:
 
     # ------------------------------------------------------------------ constant sub-graph: time embedding at t = T-1
     def _fold_time_embedding(self):
-        cfg = self.cfg
-        half = cfg.unet_ch // 2
-        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
-        args = float(cfg.t_steps - 1) * freqs
-        emb = torch.cat([torch.cos(args), torch.sin(args)])[None].contiguous().to(self.dev)
+        emb = self.time_embedding_input()
         t = self.linear(emb, "unet.time_embed.0", act=ACT_SILU)
         t = self.linear(t, "unet.time_embed.2", act=ACT_SILU)            # silu(temb), shared by all res-blocks
         for name, cin, cout, attn in self.blocks:
@@ -717,6 +825,7 @@ class FlashSREngine:
 _ENGINE: Optional[FlashSREngine] = None
 ROWS_PER_PASS = int(os.environ.get("EGREGORA_FLASHSR_ROWS", "32"))
 SEED = int(os.environ.get("EGREGORA_FLASHSR_SEED", "0"))
+EXECUTOR = os.environ.get("EGREGORA_FLASHSR_EXECUTOR", "capi")      # "capi": egr_flashsr_infer (product); "python": forward_rows
 
 
 def ensure_ready() -> FlashSREngine:
@@ -754,10 +863,11 @@ def set_engine(engine: Optional[FlashSREngine]):
 
 def infer_rows(eng: FlashSREngine, rows_x: torch.Tensor, row_ids: torch.Tensor, seed: int,
                lowpass: bool = False) -> torch.Tensor:
-    """rows_x [R, chunk] -> [R, chunk], processed ROWS_PER_PASS rows at a time on the caller's stream; noise keyed by global
-    row id.  (Row groups on concurrent streams were measured -- 26 rows: 260 ms in one pass, 240..250 ms as 9 | 9 | 8 -- and NOT
-    adopted: k_stft_frames returns wrong 128-byte groups of bins when its workgroups share compute units with k_conv_s3
-    workgroups of another stream)"""
+    """rows_x [R, chunk] -> [R, chunk] through the C-ABI handle (egr_flashsr_infer: ROWS_PER_PASS rows at a time on the caller's
+    stream, noise keyed by global row id).  EGREGORA_FLASHSR_EXECUTOR=python routes through the operator-by-operator driver
+    instead (bit-identical; dev only).  One stream only: row groups on concurrent streams are not used."""
+    if EXECUTOR != "python":
+        return eng.c_infer(rows_x, row_ids, seed, lowpass)
     outs = []
     for lo in range(0, rows_x.shape[0], ROWS_PER_PASS):
         xs = rows_x[lo:lo + ROWS_PER_PASS]

@@ -253,6 +253,31 @@ def export_upstream_named(params: Dict[str, torch.Tensor], keymap: Optional[KeyM
     return out
 
 
+def write_blob(path, cfg: arch.FlashSRConfig, named: Dict[str, torch.Tensor]):
+    """The "EGRW0001" container egr_flashsr_create_from_file reads (csrc/egr_flashsr.cpp): config struct + named fp32 tensors.
+    `named` = FlashSREngine.named_tensors() (layer-table parameters in torch layouts + the const.* tables)."""
+    import ctypes as C
+    import struct
+    from . import native
+    cc = native.flashsr_config_c(cfg)
+    items = [(k, v.detach().to("cpu", torch.float32).contiguous()) for k, v in named.items()]
+    head = b"EGRW0001" + struct.pack("<i", C.sizeof(cc)) + bytes(cc) + struct.pack("<i", len(items))
+    index_len = sum(4 + len(k.encode()) + 4 + 32 + 8 for k, _ in items)
+    off = (len(head) + index_len + 63) // 64 * 64
+    index, offs = b"", []
+    for k, v in items:
+        shp = list(v.shape) + [0] * (4 - v.dim())
+        index += struct.pack("<i", len(k.encode())) + k.encode() + struct.pack("<i4qq", v.dim(), *shp, off)
+        offs.append(off)
+        off = (off + v.numel() * 4 + 63) // 64 * 64
+    with open(path, "wb") as f:
+        f.write(head + index)
+        for (k, v), o in zip(items, offs):
+            f.seek(o)
+            f.write(v.numpy().tobytes())
+        f.truncate(off)
+
+
 if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser(description="print the tensor-shape table of the upstream FlashSR checkpoints")

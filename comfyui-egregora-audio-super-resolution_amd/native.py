@@ -89,7 +89,61 @@ SIGNATURES = {
     "egr_stft_frames": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "egr_lowpass_gain": (_i, [_vp, _i, _i, _i, _i, _f, _f, _i, _f, _i64, _vp, _vp, _vp]),
     "egr_randn": (_i, [_vp, _i64, _i, C.c_uint64, _vp, _vp]),
+    "egr_flashsr_default_config": (_i, [_vp]),
+    "egr_flashsr_create": (_i, [C.POINTER(_vp), _vp, _vp, _i, _u, _vp]),
+    "egr_flashsr_create_from_file": (_i, [C.POINTER(_vp), C.c_char_p, _u, _vp]),
+    "egr_flashsr_destroy": (_i, [_vp]),
+    "egr_flashsr_infer": (_i, [_vp, _vp, _i, _i, C.c_uint64, _vp, _vp, _vp]),
+    "egr_flashsr_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "egr_flashsr_set_rows_per_pass": (_i, [_vp, _i]),
+    "egr_flashsr_set_profiling": (_i, [_vp, _i]),
+    "egr_flashsr_profile": (_i, [_vp, _i, C.c_char_p, C.c_size_t, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                 C.POINTER(_i)]),
+    "egr_flashsr_flop_count": (_i, [_vp, _i, C.POINTER(C.c_double), _vp]),
+    "egr_flashsr_scratch_bytes": (_i64, [_vp]),
+    "egr_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "egr_phase_weights": (_i, [_vp, _vp, _i, _i, _vp]),
+    "egr_winograd_pack_u": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
 }
+
+FSR_MAX = 8
+FSR_F32_MFMA, FSR_NO_WINOGRAD, FSR_NO_WINO_F4, FSR_NO_GN_PARTIALS, FSR_NO_THIN_ENDS, FSR_NO_FUSE_GN = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
+
+
+class FlashSRConfigC(C.Structure):
+    """egr_flashsr_config (include/egregora_amd.h)."""
+    _A = _i * FSR_MAX
+    _fields_ = [("struct_bytes", _i), ("sr", _i), ("chunk", _i), ("n_fft", _i), ("hop", _i), ("n_mels", _i), ("n_frames", _i),
+                ("fmin", _f), ("fmax", _f), ("log_floor", _f),
+                ("vae_ch", _i), ("vae_levels", _i), ("vae_mult", _A), ("vae_res", _i), ("z_ch", _i), ("gn_groups", _i),
+                ("unet_ch", _i), ("unet_levels", _i), ("unet_mult", _A), ("unet_res", _i), ("unet_n_attn", _i), ("unet_attn_ds", _A),
+                ("head_dim", _i), ("t_steps", _i),
+                ("voc_ch", _i), ("voc_n_rates", _i), ("voc_rates", _A), ("voc_n_kernels", _i), ("voc_kernels", _A),
+                ("voc_n_dils", _i), ("voc_dils", _A), ("aa_taps", _i)]
+
+
+class TensorDescC(C.Structure):
+    """egr_tensor_desc."""
+    _fields_ = [("name", C.c_char_p), ("data", _vp), ("ndim", _i), ("shape", _i64 * 4)]
+
+
+def flashsr_config_c(cfg) -> FlashSRConfigC:
+    """flashsr_arch.FlashSRConfig -> egr_flashsr_config."""
+    c = FlashSRConfigC()
+    c.struct_bytes = C.sizeof(FlashSRConfigC)
+    for f in ("sr", "chunk", "n_fft", "hop", "n_mels", "n_frames", "fmin", "fmax", "log_floor", "vae_ch", "vae_res", "z_ch", "gn_groups",
+              "unet_ch", "unet_res", "head_dim", "t_steps", "voc_ch", "aa_taps"):
+        setattr(c, f, getattr(cfg, f))
+    for name, n_name, vals in (("vae_mult", "vae_levels", cfg.vae_mult), ("unet_mult", "unet_levels", cfg.unet_mult),
+                               ("unet_attn_ds", "unet_n_attn", cfg.unet_attn_ds), ("voc_rates", "voc_n_rates", cfg.voc_rates),
+                               ("voc_kernels", "voc_n_kernels", cfg.voc_kernels), ("voc_dils", "voc_n_dils", cfg.voc_dils)):
+        if len(vals) > FSR_MAX:
+            raise RuntimeError(f"FlashSRConfig.{name} has {len(vals)} entries; the C ABI holds {FSR_MAX}")
+        setattr(c, n_name, len(vals))
+        arr = getattr(c, name)
+        for i, v in enumerate(vals):
+            arr[i] = int(v)
+    return c
 
 
 def lib():

@@ -345,6 +345,74 @@ int egr_lowpass_gain(const float* mag, int B, int T, int ldm, int nb, float pct,
 /* Standard normals: element e of row r is a function of (seed, row_ids[r] or r, e) only (Philox4x32-10). */
 int egr_randn(float* out, int64_t per_row, int rows, uint64_t seed, const int64_t* row_ids, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * FlashSR model handle -- the inner boundary of SURVEY.md section 8(b).
+ * Replaces the two upstream calls the reference makes:
+ *   egr_flashsr_create  <->  FlashSR(student_ldm.pth, sr_vocoder.pth, vae.pth); model.eval(); model.to(dev)
+ *                            (egregora_audio_super_resolution.py:346-359; built once, not on every run() as at :393)
+ *   egr_flashsr_infer   <->  model(x[C, 245760] on the device, lowpass_input=bool) under torch.inference_mode()  (:361-369)
+ * The graph walk (layer table -> operator launches) and its scratch memory live in the library (csrc/egr_flashsr.cpp); the host
+ * keeps checkpoint I/O: it hands over named fp32 tensors in torch layouts, using the layer-table names of flashsr_arch.py
+ * (conv weights [Co][Ci][kh][kw], ConvTranspose1d [Ci][Co][k], linear [Co][Ci], ...) plus four derived constants
+ * "const.window" [n_fft], "const.mel_fb" [n_mels][n_fft/2+1], "const.aa_filter" [aa_taps], "const.time_emb" [unet_ch].
+ * Handles are not thread-safe; one per device.  All work is enqueued on the stream given to each call.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct egr_flashsr egr_flashsr;
+#define EGR_FSR_MAX 8
+typedef struct egr_flashsr_config {          /* mirrors flashsr_arch.FlashSRConfig field by field */
+    int struct_bytes;                        /* sizeof(egr_flashsr_config): ABI check */
+    int sr, chunk, n_fft, hop, n_mels, n_frames;
+    float fmin, fmax, log_floor;
+    int vae_ch, vae_levels, vae_mult[EGR_FSR_MAX], vae_res, z_ch, gn_groups;
+    int unet_ch, unet_levels, unet_mult[EGR_FSR_MAX], unet_res, unet_n_attn, unet_attn_ds[EGR_FSR_MAX], head_dim, t_steps;
+    int voc_ch, voc_n_rates, voc_rates[EGR_FSR_MAX], voc_n_kernels, voc_kernels[EGR_FSR_MAX], voc_n_dils, voc_dils[EGR_FSR_MAX], aa_taps;
+} egr_flashsr_config;
+typedef struct egr_tensor_desc {
+    const char* name;
+    const float* data;                       /* DEVICE pointer, fp32, contiguous */
+    int ndim;                                /* 0..4 */
+    int64_t shape[4];
+} egr_tensor_desc;
+/* create flags (default 0 = the shipped configuration) */
+#define EGR_FSR_F32_MFMA       0x01u /* every contraction on v_mfma_f32_32x32x2_f32 instead of the exact 3-way bf16 split */
+#define EGR_FSR_NO_WINOGRAD    0x02u
+#define EGR_FSR_NO_WINO_F4     0x04u
+#define EGR_FSR_NO_GN_PARTIALS 0x08u
+#define EGR_FSR_NO_THIN_ENDS   0x10u
+#define EGR_FSR_NO_FUSE_GN     0x20u
+int egr_flashsr_default_config(egr_flashsr_config* cfg);       /* the declared full-size table */
+int egr_flashsr_create(egr_flashsr** out, const egr_flashsr_config* cfg, const egr_tensor_desc* tensors, int n_tensors,
+                       unsigned flags, void* stream);           /* repacks on `stream`, synchronises before returning */
+/* The same from an "EGRW0001" weight-blob file (config + named tensors; written by flashsr_weights.write_blob from the three
+ * upstream checkpoints): the form a host without Python links against. */
+int egr_flashsr_create_from_file(egr_flashsr** out, const char* path, unsigned flags, void* stream);
+int egr_flashsr_destroy(egr_flashsr* h);
+/* x, y: [rows][chunk] fp32 device; rows = chunks x channels ride the batch dimension (reference :366-368) and are processed
+ * rows-per-pass at a time.  The 1-step diffusion noise of row r depends only on (seed, row_ids[r]) -- row_ids: device int64[rows],
+ * or NULL for 0..rows-1 -- so the result is independent of pass and rank boundaries (the reference never seeds). */
+int egr_flashsr_infer(egr_flashsr* h, const float* x, int rows, int lowpass_input, uint64_t seed, const int64_t* row_ids, float* y,
+                      void* stream);
+/* One pass with caller-supplied noise [rows][lat_h][lat_w][z_ch] (channels-last); stages: NULL or 6 device pointers (each may be
+ * NULL) receiving mel [R][T][n_mels], z_cond, v, z0 [R][h][w][z], mel_hat [R][T][n_mels], and the vocoder's full output. */
+int egr_flashsr_forward(egr_flashsr* h, const float* x, const float* noise, int rows, int lowpass_input, float* y, float* const* stages,
+                        void* stream);
+int egr_flashsr_set_rows_per_pass(egr_flashsr* h, int rows);
+/* HIP-event timing of the MFMA contraction launches, aggregated per kernel instantiation (bench.py's roofline): switch on, run,
+ * then read entry `index` (kind_buf NULL: only *count).  egr_flashsr_flop_count: executed dense flops of one pass over `rows`. */
+int egr_flashsr_set_profiling(egr_flashsr* h, int enable);
+int egr_flashsr_profile(egr_flashsr* h, int index, char* kind_buf, size_t buflen, int64_t* launches, double* flops, double* ms, int* count);
+int egr_flashsr_flop_count(egr_flashsr* h, int rows, double* flops, void* stream);
+int64_t egr_flashsr_scratch_bytes(egr_flashsr* h);
+/* Weight repacking shared by the handle and the Python graph driver (csrc/egr_flashsr_pack.hip):
+ *   egr_pack_weight     : torch layout -> slab-major [ceil(K/16)][N][16]; layout 0 conv/linear [N][Ci][KH][KW] (k = (ky KW + kx) Ci + ci),
+ *                         1 ConvTranspose1d [K=Ci][Co][KW] (n = kk Co + co), 2 per-tap products [Co][K=Ci][KH][KW] (n = tap Co + co)
+ *   egr_phase_weights   : [Co][Ci][3][3] -> four [Co][Ci][2][2] phase kernels of "nearest-2x then 3x3" (dst [4][Co][Ci][2][2])
+ *   egr_winograd_pack_u : U = G g G^T in double per (co, ci), np = 4 (F(2x2,3x3)) or 6 (F(4x4,3x3)); G_dev: np x 3 doubles on the
+ *                         device; dst [np*np][ceil(Ci/16)][Co][16] */
+int egr_pack_weight(const float* src, float* dst, int layout, int K, int N, int Ci, int Co, int KH, int KW, void* stream);
+int egr_phase_weights(const float* w_oihw, float* dst4, int Co, int Ci, void* stream);
+int egr_winograd_pack_u(const float* w_oihw, float* dst, const double* G_dev, int np, int Co, int Ci, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -277,19 +277,29 @@ def test_c1_exactly_as_baseline_states_it_through_the_cpu_node(pack):
 
 
 def test_800_iterations_against_the_oracle(pack):
-    """The headline iteration count on 1 s of stereo 48 kHz (N = 48 000 per channel): all 800 iterations on both sides.  The loop is
-    a projection, so round-off does not compound: same gates as the short runs."""
+    """The headline iteration count on 1 s of stereo 48 kHz (N = 48 000 per channel): all 800 iterations on both sides, float64 run
+    as the yardstick.  Float32 round-off DOES build up over the iterations in any implementation: with a 0.6 threshold on PCM-scale
+    data each iteration is FFT -> IFFT, and element e meets the same rounded twiddle (|W|^2 - 1 ~ 4e-8) every time, a gain that
+    compounds to (1 + eps)^800 ~ 3e-5 -- the pocketfft oracle itself ends 2.4e-5 of the peak away from float64.  Gates: the
+    device's error against float64 is within 2x (max) / 2.5x (rms) of the float32 oracle's (measured 1.3x / 1.8x, after moving the
+    composite twiddles and the 1/M scaling to double precision: before that 2.0x / 2.9x), and the LSD against float64 over the
+    bins a float32 transform can resolve (module docstring) is <= 1e-3 dB."""
     x = synth(2, 48000, seed=800)
     want = ofl.enhance_channels(x, 1, 800, 0.6, normalize=False, autoscale=False)
     exact = ofl.enhance_channels(x, 1, 800, 0.6, normalize=False, autoscale=False, exact=True)
     got = run_gpu(pack, x, 1, 800, 0.6)
     scale = float(np.max(np.abs(want)))
     rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
-    print(f"\n800 iterations: max err device {float(np.max(np.abs(got - exact))):.3e} oracle32 {float(np.max(np.abs(want - exact))):.3e} "
-          f"(peak {scale:.0f}); rms {rms(got - exact):.3e} / {rms(want - exact):.3e}; LSD(device, oracle32) {om.lsd_audio(want, got)[0]:.2e} dB")
-    assert float(np.max(np.abs(got - want))) <= 2e-5 * scale
+    mg, mo = float(np.max(np.abs(got - exact))), float(np.max(np.abs(want - exact)))
+    lg, kept = om.lsd_masked(exact, got, f32_run=want, margin_db=F32_MARGIN_DB)
+    lo, _ = om.lsd_masked(exact, want, f32_run=want, margin_db=F32_MARGIN_DB)
+    print(f"\n800 iterations: max err device {mg:.3e} oracle32 {mo:.3e} (peak {scale:.0f}); rms {rms(got - exact):.3e} / {rms(want - exact):.3e}; "
+          f"LSD vs float64 over the {kept:.1%} of bins >= {F32_MARGIN_DB:.0f} dB above the float32 floor: device {lg:.2e} dB, oracle32 {lo:.2e} dB; "
+          f"plain LSD(device, oracle32) {om.lsd_audio(want, got)[0]:.2e} dB")
+    assert np.isfinite(got).all()
+    assert mg <= 2.0 * mo and mg <= 1e-4 * scale
     assert rms(got - exact) <= 2.5 * rms(want - exact) + 1e-9 * scale
-    assert om.lsd_audio(want, got)[0] <= 1e-3 and om.lsd_audio(exact, got)[0] <= 1e-3
+    assert lg <= 1e-3 and kept >= 0.3, (lg, lo, kept)
 
 
 VARIANTS = [  # (variant list for the device, FatLlamaSpec overrides, threshold, data scale)

@@ -539,7 +539,7 @@ def test_full_size_engine_vs_torch_reference_one_row(pack):
     x = 0.2 * torch.randn(1, cfg.chunk, generator=torch.Generator().manual_seed(5))
     nz = e.noise(1, torch.zeros(1, dtype=torch.int64, device="cuda"), 0)
     got_st, want_st, ex_st = {}, {}, {}
-    y = e.forward_rows(x.cuda(), nz, got_st)
+    y = e.c_forward(x.cuda(), nz, got_st)                     # through the C ABI (egr_flashsr_forward)
     torch.cuda.synchronize()
     torch.set_num_threads(max(1, min(64, torch.get_num_threads())))
     fb, filt = torch.from_numpy(A.mel_filterbank(cfg)), torch.from_numpy(A.kaiser_sinc_filter(cfg.aa_taps))

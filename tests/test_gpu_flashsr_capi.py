@@ -1,0 +1,169 @@
+"""The FlashSR inner boundary of SURVEY.md section 8(b) through ctypes: egr_flashsr_create / egr_flashsr_infer / egr_flashsr_forward /
+egr_flashsr_create_from_file / egr_flashsr_destroy (include/egregora_amd.h, csrc/egr_flashsr.cpp) stand in for the reference's
+`FlashSR(s, v, vae)` + `model(x, lowpass_input=...)` (egregora_audio_super_resolution.py:346-369).
+
+The library's graph walk must equal the operator-by-operator Python driver (`FlashSREngine.forward_rows`, itself pinned against
+oracle/flashsr_torch.py in tests/test_gpu_flashsr.py) BIT FOR BIT: same kernels, same order, same operands (both pack weights with
+csrc/egr_flashsr_pack.hip) -- at the toy size with every stage tapped, at full size, with the input low-pass, in the strict
+f32-MFMA / no-Winograd configuration, across pass boundaries, and from a weight-blob file."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+STAGES = ("mel", "z_cond", "v", "z0", "mel_hat", "y")
+
+
+@pytest.fixture(scope="module")
+def tiny(pack):
+    from egregora_amd import flashsr_arch as A, flashsr_engine as E
+    cfg = A.tiny_config()
+    P = A.init_params(cfg, 0)
+    e = E.FlashSREngine(cfg, P)
+    yield e, cfg, P
+    e.close()
+
+
+def rows(cfg, n, seed):
+    return (0.3 * torch.randn(n, cfg.chunk, generator=torch.Generator().manual_seed(seed))).cuda()
+
+
+@pytest.mark.parametrize("lowpass", [False, True])
+def test_library_graph_walk_equals_python_driver_bit_for_bit(pack, tiny, lowpass):
+    e, cfg, _ = tiny
+    x = rows(cfg, 3, 1)
+    nz = e.noise(3, torch.tensor([5, 0, 9], dtype=torch.int64, device="cuda"), 11)
+    sa, sb = {}, {}
+    ya = e.forward_rows(x, nz, stages=sa, lowpass=lowpass)
+    yb = e.c_forward(x, nz, stages=sb, lowpass=lowpass)
+    torch.cuda.synchronize()
+    for k in STAGES:
+        assert torch.equal(sa[k].reshape(-1), sb[k].reshape(-1)), k
+    assert torch.equal(ya, yb) and bool(torch.isfinite(yb).all())
+    assert torch.equal(e.c_forward(x, nz, lowpass=lowpass), yb)           # arena reuse on the second call: same bits
+
+
+def test_infer_keys_noise_by_row_id_and_is_independent_of_pass_boundaries(pack, tiny, monkeypatch):
+    from egregora_amd import flashsr_engine as E
+    e, cfg, _ = tiny
+    x = rows(cfg, 7, 2)
+    ids = torch.tensor([3, 1, 4, 1, 5, 9, 2], dtype=torch.int64, device="cuda")
+    monkeypatch.setattr(E, "ROWS_PER_PASS", 32)
+    one = E.infer_rows(e, x, ids, 42)
+    monkeypatch.setattr(E, "ROWS_PER_PASS", 3)                              # passes of 3 + 3 + 1 rows
+    split = E.infer_rows(e, x, ids, 42)
+    monkeypatch.setattr(E, "EXECUTOR", "python")
+    py = E.infer_rows(e, x, ids, 42)
+    torch.cuda.synchronize()
+    assert torch.equal(split, py)
+    # rows are independent; tile choices follow the row count of a pass, so 7-row and 3-row passes agree to fp32 round-off only
+    assert float((one - split).abs().max()) <= 2e-4 * float(one.abs().max())
+    assert torch.equal(one[1], one[3]) is False                             # same id 1, different input rows
+    same_in = torch.cat([x[:1], x[:1]])
+    y2 = e.c_infer(same_in, torch.tensor([8, 8], dtype=torch.int64, device="cuda"), 42)
+    assert torch.equal(y2[0], y2[1])                                         # same input + same id -> same noise -> same output
+    y3 = e.c_infer(same_in, torch.tensor([8, 9], dtype=torch.int64, device="cuda"), 42)
+    assert not torch.equal(y3[0], y3[1])
+    # implicit ids 0..R-1 continue across passes
+    assert torch.equal(e.c_infer(x, None, 7), e.c_infer(x, torch.arange(7, dtype=torch.int64, device="cuda"), 7))
+
+
+def test_raw_ctypes_call_sequence_like_the_reference_runner(pack, tiny):
+    """create -> infer -> destroy with nothing but ctypes and device pointers (what INTEGRATION.md section 2b shows in C)."""
+    from egregora_amd import native
+    e, cfg, _ = tiny
+    L = native.lib()
+    named = e.named_tensors()
+    descs = (native.TensorDescC * len(named))()
+    for d, (k, v) in zip(descs, named.items()):
+        d.name, d.data, d.ndim = k.encode(), v.data_ptr(), v.dim()
+        for i, n in enumerate(v.shape):
+            d.shape[i] = n
+    cc = native.flashsr_config_c(cfg)
+    h = C.c_void_p()
+    assert L.egr_flashsr_create(C.byref(h), C.byref(cc), descs, len(named), 0, None) == 0, native.last_error()
+    x = rows(cfg, 2, 3)
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()
+    assert L.egr_flashsr_infer(h, C.c_void_p(x.data_ptr()), 2, 0, 123, None, C.c_void_p(y.data_ptr()), None) == 0, native.last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(y, e.c_infer(x, None, 123))
+    assert L.egr_flashsr_scratch_bytes(h) > 0
+    assert L.egr_flashsr_destroy(h) == 0
+    bad = native.flashsr_config_c(cfg)
+    bad.struct_bytes = 12
+    assert L.egr_flashsr_create(C.byref(h), C.byref(bad), descs, len(named), 0, None) != 0 and "ABI" in native.last_error()
+    assert L.egr_flashsr_create(C.byref(h), C.byref(cc), descs, 5, 0, None) != 0          # tensors missing: loud, no partial handle
+
+
+def test_weight_blob_file_round_trip(pack, tiny, tmp_path):
+    from egregora_amd import flashsr_weights as W, native
+    e, cfg, _ = tiny
+    path = tmp_path / "flashsr_tiny.egrw"
+    W.write_blob(str(path), cfg, e.named_tensors())
+    L = native.lib()
+    h = C.c_void_p()
+    assert L.egr_flashsr_create_from_file(C.byref(h), str(path).encode(), 0, None) == 0, native.last_error()
+    x = rows(cfg, 2, 4)
+    nz = e.noise(2, None, 1)
+    y = torch.empty_like(x)
+    assert L.egr_flashsr_forward(h, C.c_void_p(x.data_ptr()), C.c_void_p(nz.data_ptr()), 2, 0, C.c_void_p(y.data_ptr()), None, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y, e.c_forward(x, nz))
+    L.egr_flashsr_destroy(h)
+    (tmp_path / "junk.egrw").write_bytes(b"not a blob at all, just bytes")
+    assert L.egr_flashsr_create_from_file(C.byref(h), str(tmp_path / "junk.egrw").encode(), 0, None) != 0
+    assert "EGRW0001" in native.last_error()
+
+
+def test_strict_configuration_flags(pack):
+    """f32 MFMA everywhere, no Winograd, no thin-end kernels: the handle built with the matching flags equals the Python driver."""
+    from egregora_amd import flashsr_arch as A, flashsr_engine as E
+    cfg = A.tiny_config()
+    P = A.init_params(cfg, 1)
+    old = (E.FlashSREngine.MFMA_MODE, E.FlashSREngine.WINO_MIN_CH, E.FlashSREngine.THIN_ENDS)
+    try:
+        E.FlashSREngine.MFMA_MODE, E.FlashSREngine.WINO_MIN_CH, E.FlashSREngine.THIN_ENDS = "f32", 1 << 30, False
+        e = E.FlashSREngine(cfg, P)
+    finally:
+        E.FlashSREngine.MFMA_MODE, E.FlashSREngine.WINO_MIN_CH, E.FlashSREngine.THIN_ENDS = old
+    x = rows(cfg, 2, 6)
+    nz = e.noise(2, None, 3)
+    assert torch.equal(e.forward_rows(x, nz), e.c_forward(x, nz))
+    e.close()
+
+
+def test_profile_and_flop_count_agree_with_the_python_driver(pack, tiny):
+    from egregora_amd import native
+    e, cfg, _ = tiny
+    x = rows(cfg, 2, 7)
+    nz = e.noise(2, None, 0)
+    e.prof = []
+    e.forward_rows(x, nz)
+    py = e.prof_summary()
+    e.prof = None
+    c = e.c_profile(lambda: e.c_forward(x, nz))
+    assert set(c) == set(py)
+    for k in py:
+        assert c[k][0] == py[k][0] and c[k][1] == pytest.approx(py[k][1]) and c[k][2] > 0
+    fl = C.c_double()
+    native.check(native.lib().egr_flashsr_flop_count(C.c_void_p(e.handle), 2, C.byref(fl), None), "egr_flashsr_flop_count")
+    assert fl.value == pytest.approx(e.flop_count(2))
+
+
+def test_full_size_handle_equals_python_driver_bit_for_bit(pack):
+    from egregora_amd import flashsr_arch as A, flashsr_engine as E
+    cfg = A.FlashSRConfig()
+    e = E.FlashSREngine(cfg, A.init_params(cfg, 0))
+    x = 0.2 * torch.randn(2, cfg.chunk, generator=torch.Generator().manual_seed(5))
+    nz = e.noise(2, None, 0)
+    sa, sb = {}, {}
+    ya = e.forward_rows(x.cuda(), nz, stages=sa)
+    yb = e.c_forward(x.cuda(), nz, stages=sb)
+    torch.cuda.synchronize()
+    for k in STAGES:
+        assert torch.equal(sa[k].reshape(-1), sb[k].reshape(-1)), k
+    assert torch.equal(ya, yb)
+    e.close()
