@@ -86,6 +86,10 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--rows", type=int, default=0, help="FlashSR rows per pass (default: engine setting)")
     ap.add_argument("--only", default="", help="'flashsr' or 'fatllama': time one stage only (dev)")
+    ap.add_argument("--workload", default="chain60", choices=["chain60", "c4"],
+                    help="chain60 (default, weak scaling: 60 s per GPU through FlashSR + Fat-Llama) or c4 = BASELINE configs[3]: "
+                         "FlashSR long-form, ONE 10-minute stereo file chunk-sharded over the N GPUs with one all-gather + WOLA "
+                         "(strong scaling: north_star's '>= 6x chunk-parallel speed-up at 8 GPUs')")
     ap.add_argument("--lean", action="store_true", help="skip the untimed extras (parts); used under rocprofv3 so the "
                                                         "per-kernel averages cover the timed workload only")
     args = ap.parse_args()
@@ -113,7 +117,10 @@ def main():
     eng = E.FlashSREngine(cfg, A.init_params(cfg, seed=0))
     E.set_engine(eng)
 
-    total = world * SEG
+    c4 = args.workload == "c4"
+    if c4:
+        args.only = "flashsr"
+    total = 600 * SR if c4 else world * SEG
     x_all = torch.from_numpy(synth(404, total)).cuda()          # the whole file is replicated on every rank
     C = x_all.shape[0]
     n_chunks = len(ag.spans(total))
@@ -157,17 +164,24 @@ def main():
 
     # ---- untimed extras: per-stage times, configs[1], per-kernel HIP-event timing for the rooflines ----
     el_fs, y48 = timed(stage_flashsr, 1)
-    el_fl, _ = timed(lambda: stage_fatllama(y48), 1)
+    el_fl, y_fl = timed(lambda: stage_fatllama(y48), 1)
+    # sanity outside the timed region: every sample finite, and all `iters` iterations land where ONE iteration lands (the loop is
+    # a projection; a drift between the two would mean the long run is not doing the arithmetic the metric names)
+    from egregora_amd import device_ops
+    seg48 = y48[:, rank * SEG:(rank + 1) * SEG].contiguous() if not c4 else y48[:, :SEG].contiguous()
+    y_one = fe.enhance_device(seg48, 1, 1, 0.6, **fl_flags)
+    if c4:
+        y_fl = fe.enhance_device(seg48, 1, args.iters, 0.6, **fl_flags)
+    assert bool(torch.isfinite(y48).all()) and bool(torch.isfinite(y_fl).all()), "non-finite output"
+    lsd_iters = device_ops.lsd(y_one[:, :20 * SR].contiguous(), y_fl[:, :20 * SR].contiguous())
+    assert lsd_iters[0] < 0.05, lsd_iters
     el_c2 = None
     if not args.lean:
         x_c2 = x_all[:, :cfg.chunk].contiguous()
         upscale_48k(x_c2, False)
         el_c2, _ = timed(lambda: upscale_48k(x_c2, False), 3)
-    eng.prof = []
-    stage_flashsr()
-    prof = eng.prof_summary()
-    eng.prof = None
-    fe.enhance_device(y48[:, rank * SEG:(rank + 1) * SEG].contiguous(), 1, args.iters, 0.6, profile=True, **fl_flags)
+    prof = eng.c_profile(stage_flashsr)           # HIP events around every MFMA contraction launch of the library's graph walk
+    fe.enhance_device(seg48, 1, args.iters, 0.6, profile=True, **fl_flags)
     kt = fe.kernel_times(SEG, C, 1, local_rank)
 
     if rank == 0:
@@ -200,14 +214,21 @@ def main():
             pass
         info = fe.plan_info(SEG, 1)
         out = {
-            "metric": METRIC, "value": world * args.steps * (SEG / SR) / el, "unit": "audio-sec/sec", "n_gpus": world,
+            "metric": METRIC, "value": args.steps * audio_s / el, "unit": "audio-sec/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if eng.mfma == "f32" else "f32(bf16x3)",
+            "scaling": "strong" if c4 else "weak", "vs_baseline": None, "dtype": "f32" if eng.mfma == "f32" else "f32(bf16x3)",
             "data": "synthetic",
-            "config": {"workload": "chain60: per GPU 60 s stereo 48 kHz; FlashSR (5.12 s chunks, hop 4.62 s, student_ldm "
-                                   "1-step + VAE + sr_vocoder, declared architecture, synthetic weights, chunk-sharded with one "
-                                   "all-gather, WOLA) then Fat-Llama max_iterations=%d thr=0.6 normalize on autoscale off" % args.iters
-                                   + (f" [only={args.only}]" if args.only else ""),
+            "config": {"workload": ("c4: BASELINE configs[3], ONE 10 min stereo 48 kHz file, FlashSR (5.12 s chunks, hop 4.62 s, "
+                                    "student_ldm 1-step + VAE + sr_vocoder, declared architecture, synthetic weights) chunk-sharded over "
+                                    "the GPUs with one all-gather, WOLA on every rank; total work fixed as N grows" if c4 else
+                                    "chain60: per GPU 60 s stereo 48 kHz; FlashSR (5.12 s chunks, hop 4.62 s, student_ldm "
+                                    "1-step + VAE + sr_vocoder, declared architecture, synthetic weights, chunk-sharded with one "
+                                    "all-gather, WOLA) then Fat-Llama max_iterations=%d thr=0.6 normalize on autoscale off, "
+                                    "threshold variant '%s' (SPEC.md section 3: absolute level, hard threshold, time-domain "
+                                    "pre-threshold, linear up-rating unless listed)" % (args.iters, os.environ.get("EGREGORA_FATLLAMA_SPEC", "") or "default"))
+                                   + (f" [only={args.only}]" if args.only and not c4 else ""),
+                       "flashsr_executor": "egr_flashsr_infer (C ABI, csrc/egr_flashsr.cpp)" if E.EXECUTOR != "python" else "python driver",
+                       "lsd_800_vs_1_iteration_db": lsd_iters[0],
                        "mfma": ("fp32 operands split exactly into three bf16 terms, six partial products on "
                                 "v_mfma_f32_32x32x16_bf16 with fp32 accumulation: error vs float64 <= the f32-MFMA kernel's "
                                 "(tests/test_gpu_flashsr.py::test_split3_conv_error_vs_float64)") if eng.mfma != "f32"
@@ -220,6 +241,7 @@ def main():
                 "configs1_flashsr_single_chunk_stereo_xrt": (3 * 5.12 / el_c2) if el_c2 else None,
                 "configs1_ms": (1e3 * el_c2 / 3) if el_c2 else None,
                 "flashsr_flops_per_row": fconv_all / max(1, (len(ag.spans(total)) + world - 1) // world * C),
+                "flashsr_scratch_arena_gb": native.lib().egr_flashsr_scratch_bytes(eng.handle) / 1e9,
                 "conv_variants": {k: {"launches": v[0], "tflops": v[1] / 1e12, "ms": v[2],
                                       "avg_launch_ms": v[2] / max(1, v[0])} for k, v in variants.items()},
             },

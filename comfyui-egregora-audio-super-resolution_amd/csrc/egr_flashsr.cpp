@@ -87,6 +87,8 @@ struct Ten {                       // an fp32 activation owned by the arena (mov
     ~Ten() { release(); }
     void release() { if (a && p) a->put(p, bytes); p = nullptr; a = nullptr; part.reset(); }
     int64_t numel() const { int64_t n = 1; for (int i = 0; i < nd; ++i) n *= d[i]; return n; }
+    // non-owning view of the same storage (the owner must outlive it); keeps the GroupNorm partials the owner carries
+    Ten alias() const { Ten v; v.nd = nd; memcpy(v.d, d, sizeof(d)); v.p = p; v.part = part; v.part_tiles = part_tiles; return v; }
     void view(std::initializer_list<int64_t> s) { nd = 0; for (int64_t v : s) d[nd++] = v; }
 };
 
@@ -812,13 +814,12 @@ int unet(M* m, Ten& out, Ten&& x0) {
         const std::string kind = name.substr(name.rfind('.') + 1);
         if (kind == "conv_in") {
             OKR(conv3(m, t, h, base));
-            h = std::move(t);
-            Ten cp; cp.nd = h.nd; memcpy(cp.d, h.d, sizeof(cp.d)); cp.p = h.p;      // non-owning alias: the skip stack owns, h aliases
-            skips.push_back(std::move(h));
+            Ten cp = t.alias();                        // the skip stack owns the tensor, h views it
+            skips.push_back(std::move(t));
             h = std::move(cp);
         } else if (kind == "down") {
             OKR(conv3(m, t, h, base + ".conv", 2, 0, ACT_NONE, nullptr, 1));
-            Ten cp; cp.nd = t.nd; memcpy(cp.d, t.d, sizeof(cp.d)); cp.p = t.p;
+            Ten cp = t.alias();
             skips.push_back(std::move(t));
             h = std::move(cp);
         } else if (kind == "up") {
@@ -833,7 +834,7 @@ int unet(M* m, Ten& out, Ten&& x0) {
             }
             OKR(unet_block(m, t, h, base, m->blk_attn[i] != 0));
             if (part == "in") {
-                Ten cp; cp.nd = t.nd; memcpy(cp.d, t.d, sizeof(cp.d)); cp.p = t.p;
+                Ten cp = t.alias();
                 skips.push_back(std::move(t));
                 h = std::move(cp);
             } else {
