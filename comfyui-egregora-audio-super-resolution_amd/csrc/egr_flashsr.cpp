@@ -12,6 +12,7 @@
 
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -962,6 +963,34 @@ int forward(M* m, const float* x_in, const float* noise, int R, int lowpass_on, 
     return EGR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ one forward at a time per device
+// Open erratum: k_stft_frames returns 16 wrong bins per affected wave whenever its workgroups share compute
+// units with k_conv_s3 workgroups of ANOTHER stream (39-40 of 40 runs; not with the f32-MFMA kernel, not with torch kernels, not
+// among k_stft_frames launches; independent of the foreign kernel's LDS footprint -- tools/probe_coresidency_lds.py).  Until the
+// cause is known the library forbids the co-schedule: forwards issued on different streams of one device are chained by an event,
+// so the GPU never runs two of them at once, whatever streams the host (ComfyUI nodes, threads) uses.  Within one forward everything
+// is on one stream.  EGR_FSR_NO_STREAM_GUARD=1 removes the chain (probe / reproducer only).
+struct ForwardGuard {
+    static std::mutex& mu() { static std::mutex m; return m; }
+    static std::map<int, std::pair<hipStream_t, hipEvent_t>>& last() { static std::map<int, std::pair<hipStream_t, hipEvent_t>> l; return l; }
+    std::unique_lock<std::mutex> lk;
+    int dev; hipStream_t st; bool on;
+    ForwardGuard(int device, hipStream_t s) : lk(mu()), dev(device), st(s) {
+        static const bool off = getenv("EGR_FSR_NO_STREAM_GUARD") && atoi(getenv("EGR_FSR_NO_STREAM_GUARD")) != 0;
+        on = !off;
+        if (!on) return;
+        auto it = last().find(dev);
+        if (it != last().end() && it->second.second && it->second.first != st) hipStreamWaitEvent(st, it->second.second, 0);
+    }
+    ~ForwardGuard() {
+        if (!on) return;
+        auto& e = last()[dev];
+        if (!e.second) hipEventCreateWithFlags(&e.second, hipEventDisableTiming);
+        hipEventRecord(e.second, st);
+        e.first = st;
+    }
+};
+
 const egr_tensor_desc* find(const egr_tensor_desc* ts, int n, const char* name) {
     for (int i = 0; i < n; ++i) if (ts[i].name && strcmp(ts[i].name, name) == 0) return &ts[i];
     return nullptr;
@@ -1063,6 +1092,7 @@ extern "C" int egr_flashsr_forward(egr_flashsr* m, const float* x, const float* 
                                    void* stream) {
     EGR_CHECK(m && x && noise && y && rows >= 1, EGR_ERR_ARG, "egr_flashsr_forward: null / empty argument");
     m->st = (hipStream_t)stream;
+    ForwardGuard guard(m->device, m->st);
     return forward(m, x, noise, rows, lowpass, y, stages);
 }
 
@@ -1073,6 +1103,7 @@ extern "C" int egr_flashsr_infer(egr_flashsr* m, const float* x, int rows, int l
                                  void* stream) {
     EGR_CHECK(m && x && y && rows >= 1, EGR_ERR_ARG, "egr_flashsr_infer: null / empty argument");
     m->st = (hipStream_t)stream;
+    ForwardGuard guard(m->device, m->st);
     const egr_flashsr_config& c = m->cfg;
     const int64_t per_row = (int64_t)m->lat_h * m->lat_w * c.z_ch;
     for (int lo = 0; lo < rows; lo += m->rows_per_pass) {

@@ -10,7 +10,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from . import audio_glue, fatllama_engine, native, wavio
+from . import audio_glue, audio_io, fatllama_engine, native
 
 RETURN_TYPES = ("AUDIO",)
 FUNCTION = "run"
@@ -33,13 +33,13 @@ def resolve_input(AUDIO=None, audio_path: str = "", audio_url: str = ""):
         p = Path(audio_path)
         if not p.exists():
             raise RuntimeError(f"audio_path not found: {audio_path}")
-        y, sr = wavio.read_wav(str(p))
+        y, sr = audio_io.read_audio(str(p))
         return torch.from_numpy(audio_glue.channels_first(y)), int(sr)
     if audio_url:
         import requests
         r = requests.get(audio_url, timeout=60)
         r.raise_for_status()
-        y, sr = wavio.read_wav_bytes(r.content)
+        y, sr = audio_io.read_audio_bytes(r.content)
         return torch.from_numpy(audio_glue.channels_first(y)), int(sr)
     raise RuntimeError("No AUDIO provided.")
 

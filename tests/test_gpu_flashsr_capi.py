@@ -167,3 +167,30 @@ def test_full_size_handle_equals_python_driver_bit_for_bit(pack):
         assert torch.equal(sa[k].reshape(-1), sb[k].reshape(-1)), k
     assert torch.equal(ya, yb)
     e.close()
+
+
+def test_forwards_from_different_streams_never_overlap_on_the_device(pack):
+    """Reproducer of the open co-residency erratum (k_stft_frames next to another stream's k_conv_s3 returns wrong
+    bins) at the library boundary: two full-size forwards issued back to back on two streams that the runtime maps to different
+    hardware queues.  The library chains forwards of one device with an event (ForwardGuard, csrc/egr_flashsr.cpp), so both results
+    must equal the single-stream ones bit for bit -- 10 rounds."""
+    from egregora_amd import flashsr_arch as A, flashsr_engine as E, streams
+    cfg = A.FlashSRConfig()
+    e = E.FlashSREngine(cfg, A.init_params(cfg, 0))
+    x = 0.2 * torch.randn(8, cfg.chunk, generator=torch.Generator().manual_seed(9)).cuda()
+    nz = e.noise(8, None, 0)
+    ref = [e.c_forward(x[:4], nz[:4]).clone(), e.c_forward(x[4:], nz[4:]).clone()]
+    torch.cuda.synchronize()
+    side = streams.side_streams(1)
+    if not side:
+        pytest.skip("the runtime gave no stream that overlaps with the current one")
+    cur = torch.cuda.current_stream()
+    for _ in range(10):
+        ready = cur.record_event()
+        side[0].wait_event(ready)
+        with torch.cuda.stream(side[0]):
+            a = e.c_forward(x[:4], nz[:4])
+        b = e.c_forward(x[4:], nz[4:])
+        torch.cuda.synchronize()
+        assert torch.equal(a, ref[0]) and torch.equal(b, ref[1])
+    e.close()
