@@ -189,6 +189,42 @@ __device__ __forceinline__ void fft_stage(const cplx* __restrict__ in, cplx* __r
     __syncthreads();
 }
 
+// One stage of ANY radix R (used for prime factors > 13): every thread produces ONE output element as a direct R-term sum read
+// from LDS -- R times the LDS reads of a register butterfly, which is irrelevant for the single such stage an STFT frame has.
+// Both twiddles come from the W_L table: stage twiddle W_L^(k twstep t) and DFT kernel W_R^(t u) = W_L^((t u mod R) L / R).
+template <bool SEQFAST>
+__device__ __forceinline__ void fft_stage_generic(const cplx* __restrict__ in, cplx* __restrict__ out, int L, int Ns, int R,
+                                                  const cplx* __restrict__ tw, int nseq, int seq_log2, int es, int ss,
+                                                  bool swap_in, bool swap_out) {
+    const int nb = L / R;
+    const int twstep = L / (Ns * R), rstep = L / R;
+    const int total = L * nseq;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        int s, o;
+        if (SEQFAST) { s = e & (nseq - 1); o = e >> seq_log2; }
+        else { s = (e >= L) ? 1 : 0; o = e - s * L; }
+        const int u = o / nb, j = o - u * nb;          // output u of butterfly j
+        const int k = j % Ns;
+        const cplx* src = in + s * ss;
+        float ax = 0.f, ay = 0.f;
+        int i1 = 0, i2 = 0;                            // (k twstep t) mod L and (t u mod R) rstep, advanced incrementally
+        const int d1 = (k * twstep) % L, d2 = u * rstep;
+        for (int t = 0; t < R; ++t) {
+            cplx x = src[(j + t * nb) * es];
+            if (swap_in) x = make_float2(x.y, x.x);
+            int idx = i1 + i2;
+            if (idx >= L) idx -= L;
+            const cplx w = tw[idx];
+            ax += x.x * w.x - x.y * w.y;
+            ay += x.x * w.y + x.y * w.x;
+            i1 += d1; if (i1 >= L) i1 -= L;
+            i2 += d2; if (i2 >= L) i2 -= L;
+        }
+        out[s * ss + ((j - k) * R + k + u * Ns) * es] = swap_out ? make_float2(ay, ax) : make_float2(ax, ay);
+    }
+    __syncthreads();
+}
+
 // Full transform of the sequences in `cur`; result ends in `cur` (pointers are swapped per stage).
 // Caller must __syncthreads() after filling `cur`.
 template <bool SEQFAST>
@@ -219,7 +255,8 @@ __device__ __forceinline__ void lds_fft(cplx*& cur, cplx*& alt, const FftDesc& d
             case 25: fft_stage<25, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
 #endif
             case 11: fft_stage<11, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
-            default: fft_stage<13, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+            case 13: fft_stage<13, SEQFAST>(cur, alt, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+            default: fft_stage_generic<SEQFAST>(cur, alt, d.L, Ns, d.radix[s], tw, nseq, seq_log2, es, ss, si, so); break;
         }
         cplx* t = cur; cur = alt; alt = t;
     }

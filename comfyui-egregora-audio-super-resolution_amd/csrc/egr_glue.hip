@@ -142,7 +142,7 @@ static int stft_tables(int n_fft, StftTables* out) {
     if (it != g_stft.end()) { *out = it->second; return EGR_OK; }
     StftTables t;
     const int Mh = n_fft / 2;
-    EGR_CHECK(make_schedule(Mh, &t.fd), EGR_ERR_UNSUPPORTED, "n_fft=%d: n_fft/2 must be {2,3,5,7,11,13}-smooth", n_fft);
+    EGR_CHECK(make_schedule(Mh, &t.fd, 127), EGR_ERR_UNSUPPORTED, "n_fft=%d: n_fft/2 has a prime factor above 127", n_fft);
     std::vector<float2> h;
     make_twiddles(h, Mh, 1, Mh);
     EGR_HIP(hipMalloc((void**)&t.tw, h.size() * sizeof(float2)));

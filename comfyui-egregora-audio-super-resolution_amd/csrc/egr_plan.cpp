@@ -27,7 +27,7 @@ void set_error(const char* fmt, ...) {
 
 const char* last_error_cstr() { return g_err.c_str(); }
 
-bool make_schedule(int L, FftDesc* d) {
+bool make_schedule(int L, FftDesc* d, int max_prime) {
     memset(d, 0, sizeof(*d));
     d->L = L;
     int n = L, st = 0, ns = 1;
@@ -72,6 +72,14 @@ bool make_schedule(int L, FftDesc* d) {
 #endif
     const int odd[] = {3, 5, 7, 11, 13};
     for (int p : odd) {
+        while (n % p == 0) {
+            if (!push(p)) return false;
+            n /= p;
+        }
+    }
+    // larger primes (STFT frame lengths of the metrics widgets, e.g. n_fft = 2176 = 2^7 * 17): one generic stage each, evaluated
+    // as a direct r-point DFT from LDS (fft_stage_generic)
+    for (int p = 17; p <= max_prime && n > 1; p += 2) {
         while (n % p == 0) {
             if (!push(p)) return false;
             n /= p;

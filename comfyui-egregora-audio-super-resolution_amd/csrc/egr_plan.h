@@ -8,8 +8,9 @@
 namespace egr {
 
 // Radix schedule for an in-LDS transform of length L: 4s first, one 2, then odd primes ascending.
-// Returns false when L has a prime factor > 13 or needs more than EGR_MAX_STAGES stages.
-bool make_schedule(int L, FftDesc* d);
+// Returns false when L has a prime factor > max_prime or needs more than EGR_MAX_STAGES stages.  Primes <= 13 are register
+// butterflies; max_prime > 13 admits generic stages (direct DFT from LDS) for the prime factors 17 .. max_prime.
+bool make_schedule(int L, FftDesc* d, int max_prime = 13);
 
 // W_L^j = exp(-2*pi*i*j/L * mul), j in [0,count), evaluated in double, rounded once to float.
 // (general form: exp(-2*pi*i * j * num / den))

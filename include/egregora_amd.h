@@ -182,7 +182,8 @@ int egr_si_sdr_terms(const float* s, int cs, int64_t stride_s, const float* s_ha
 /* STFT magnitude, Hann-windowed frames, no centring, mono downmix = mean over channels:
  *   frames = 1 + max(0,(n - n_fft)/hop); out: [frames][n_fft/2+1] float32 (frame-major; the reference's
  *   array is the transpose).  window: device float[n_fft] (caller supplies np.hanning(n_fft) so the
- *   window is bit-identical to the reference's).  n_fft must be even and {2,3,5,7,11,13}-smooth, <= 8192.
+ *   window is bit-identical to the reference's).  n_fft even, <= 8192; prime factors of n_fft/2 up to 13 run as register
+ *   butterflies, larger ones (e.g. 2176 = 2^7 * 17, any value of the reference widget's 512..8192 step-128 grid) as one generic stage.
  * Replaces: _stft_mag at egregora_audio_eval_pack.py:389-402 (twin egregora_null_test_suite.py:167-180). */
 int egr_stft_mag(const float* x, int channels, int64_t n, int n_fft, int hop, const float* window, float* out,
                  void* stream);

@@ -136,3 +136,25 @@ def test_resample_node_matches_reference(pack):
         t_new = np.linspace(0.0, 1.0, n_new, endpoint=False)
         want = np.stack([np.interp(t_new, t_old, a[c]) for c in range(2)]).astype(np.float32)
         assert lin["samples"].shape == want.shape and np.abs(lin["samples"] - want).max() <= 1e-6
+
+
+@pytest.mark.gpu
+def test_stft_magnitude_on_the_whole_widget_grid(pack):
+    """The reference's Metrics / Null Test widgets offer n_fft = 512 .. 8192 in steps of 128 (np.fft.rfft takes any of them); 19 of
+    the 61 values have a prime factor above 13 in n_fft / 2 (2176 = 2^7 * 17, 2432, 2944, ...) and run one generic radix stage.
+    Every grid value against the oracle's float64 STFT: <= 3e-6 of the frame maximum."""
+    import torch
+    from egregora_amd import device_ops
+    from oracle import metrics as om
+    rng = np.random.Generator(np.random.PCG64(5))
+    x = (0.3 * rng.standard_normal((2, 20000))).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    worst = 0.0
+    for n_fft in range(512, 8192 + 1, 128):
+        got = device_ops.stft_mag(xt, n_fft, n_fft // 4).cpu().numpy()          # [bins][frames] like the oracle
+        want = om.stft_mag(x, n_fft, n_fft // 4)
+        assert got.shape == want.shape, n_fft
+        err = float(np.abs(got - want).max() / np.abs(want).max())
+        worst = max(worst, err)
+        assert err <= 3e-6, (n_fft, err)
+    print(f"\nSTFT grid 512..8192/128: worst relative error {worst:.2e}")
