@@ -1,7 +1,9 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for one round on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh r01
-# Writes gpurun_out/<tag>/{stats,pmc_fetch,pmc_write}/... and a text summary; copy what should be judged to profiles/.
+#   tools/profile_round.sh r02
+# Writes gpurun_out/<tag>/{stats,pmc_*}/... and text summaries; copy what should be judged to profiles/<tag>/.
+# Counter passes are counters-only (--kernel-trace + --pmc, nothing else), one pass per counter group (SQ: 8 slots, TCC: FETCH_SIZE
+# and WRITE_SIZE cannot share a pass) as MI355X_MICROARCH.md prescribes.
 set -u
 TAG=${1:-rXX}
 export TMPDIR=/tmp
@@ -9,8 +11,11 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o chain -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --lean > $OUT/bench_stats.log 2>&1
 grep '^{' $OUT/bench_stats.log | tail -1 > $OUT/bench_stats.json
-# PMC passes: counters only, each in its own run (no trace domains besides kernel-trace); short Fat-Llama loop
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o chain -- python bench.py --steps 1 --warmup 0 --iters 20 --no-cpu-baseline --lean > $OUT/bench_pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o chain -- python bench.py --steps 1 --warmup 0 --iters 20 --no-cpu-baseline --lean > $OUT/bench_pmc_write.log 2>&1
+# matrix-pipe occupancy of the contraction kernels (north_star: "MFMA-busy counters") and the wait / LDS picture of the Fat-Llama loop
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_mfma -o chain -- python bench.py --steps 1 --warmup 0 --iters 20 --no-cpu-baseline --lean > $OUT/bench_pmc_mfma.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc_wait -o chain -- python bench.py --only fatllama --steps 1 --warmup 0 --iters 60 --no-cpu-baseline --lean > $OUT/bench_pmc_wait.log 2>&1
 python tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
-cat $OUT/summary.txt
+python tools/summarize_counters.py $OUT > $OUT/counters.txt 2>&1
+cat $OUT/summary.txt $OUT/counters.txt
