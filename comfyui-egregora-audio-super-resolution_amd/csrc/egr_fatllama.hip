@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "egr_common.h"
@@ -27,6 +28,8 @@
 #include "egr_plan.h"
 
 namespace egr {
+
+#define EGR_STAMP(P, SLOT) do { if ((P).trace && threadIdx.x == 0) (P).trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (SLOT)] = wall_clock64(); } while (0)
 
 // Twiddle W_T^r for r < T as a product of two table entries: thi[r >> sh] * tlo[r & (2^sh - 1)]
 // (tables of ~sqrt(T) entries each, generated in long double).  The tables and the product are DOUBLE precision and the
@@ -55,6 +58,8 @@ struct ColP {
     int TC, TClog2, ntiles, tiles_per_xcd;
     const cplx* tw;        // W_L stage table
     const dcplx* twd;      // the same table in double precision (power-twiddle path)
+    const cplx* stw;       // per-stage butterfly-ordered tables of a compile-time schedule (k_col<MODE, SCHED > 0>)
+    long long* trace;      // dev: 100 MHz wall-clock stamps per phase, [block][8] (EGR_FL_TRACE)
     Tw2 big;               // W_(L*ncols)^r
 };
 
@@ -64,6 +69,8 @@ struct RowP {
     int L, R, Ma, Mb;
     const cplx* tw;        // W_L stage table
     const dcplx* twd;      // the same table in double precision (power-twiddle path)
+    const cplx* stw;       // per-stage butterfly-ordered tables of a compile-time schedule (k_row<., SCHED > 0>)
+    long long* trace;      // dev: 100 MHz wall-clock stamps per phase, [block][8] (EGR_FL_TRACE)
     Tw2 wo;                // W_N^o, o < R
     const dcplx* wk;       // W_(2L)^k = W_N^(R*k), k < L (double: multiplied with W_N^o in double, rounded once)
     float thr2, inv_M;
@@ -105,8 +112,15 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // MODE 4: forward (state -> FFT -> twiddle -> state)                        [inner pass of a 3-level plan]
 // MODE 5: last, plain (state -> twiddle^-1 -> IFFT -> out = d)               [spectral-gain filter]
 // thr_rel (MODE 0 only, optional): per-channel max|y| as float bits; the time-domain level becomes thr * max|y| (SPEC.md section 3).
-template <int MODE>
-__global__ __launch_bounds__(1024) void k_col(ColP p, long long M, long long N, float thr, cplx* __restrict__ work,
+// SCHED 0: run-time radix schedule (any plan).  SCHED 2: L = 625 as 25 x 25 with compile-time stages (egr_fft_device.h).
+template <int SCHED>
+__device__ __forceinline__ void col_fft(cplx*& cur, cplx*& alt, const ColP& p, int TC, int lg, bool inverse) {
+    if (SCHED == 2) lds_fft_sched<true, 25, 25, 1>(cur, alt, p.L, p.stw, TC, lg, TC, 1, inverse);
+    else lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, inverse, p.twd);
+}
+
+template <int MODE, int SCHED = 0>
+__global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? 4 : 1) void k_col(ColP p, long long M, long long N, float thr, cplx* __restrict__ work,
                                               float* __restrict__ out, unsigned* __restrict__ peak_out,
                                               const unsigned* __restrict__ thr_rel = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -125,6 +139,7 @@ __global__ __launch_bounds__(1024) void k_col(ColP p, long long M, long long N, 
     float2* Y = (float2*)(out + (size_t)ch * N) + poff;
     const int nel = L * TC;
     if (MODE == 0 && thr_rel) thr *= __uint_as_float(thr_rel[ch]);
+    EGR_STAMP(p, 0);
 
     for (int e = threadIdx.x; e < nel; e += blockDim.x) {
         const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
@@ -144,7 +159,9 @@ __global__ __launch_bounds__(1024) void k_col(ColP p, long long M, long long N, 
         cur[e] = v;
     }
     __syncthreads();
-    if (MODE == 1 || MODE == 2 || MODE == 3 || MODE == 5) lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, true, p.twd);
+    EGR_STAMP(p, 1);
+    if (MODE == 1 || MODE == 2 || MODE == 3 || MODE == 5) col_fft<SCHED>(cur, alt, p, TC, lg, true);
+    EGR_STAMP(p, 2);
     if (MODE == 5) {
         for (int e = threadIdx.x; e < nel; e += blockDim.x) {
             const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
@@ -176,18 +193,27 @@ __global__ __launch_bounds__(1024) void k_col(ColP p, long long M, long long N, 
         }
         return;
     }
-    lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, false, p.twd);
+    col_fft<SCHED>(cur, alt, p, TC, lg, false);
+    EGR_STAMP(p, 3);
     for (int e = threadIdx.x; e < nel; e += blockDim.x) {
         const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
         if (col < nc) W[(size_t)i * nc + col] = cmul(cur[e], tw2(p.big, (unsigned)col * (unsigned)i));
     }
+    EGR_STAMP(p, 4);
 }
 
 // Row-pair kernel: outer indices oa = pair, ob = R - pair of the in-place state.
 // MAXONLY: forward transform + real split only, max_k |X[k]|^2 of the channel -> p.max2_out[ch] (nothing is written back): the
 // reduction a threshold RELATIVE to the spectrum's maximum needs before any bin can be judged.
-template <bool MAXONLY>
-__global__ __launch_bounds__(1024) void k_row(RowP p, long long M, cplx* __restrict__ work) {
+// SCHED 1: L = 2304 as 16 x 16 x 9 with compile-time stages.
+template <int SCHED>
+__device__ __forceinline__ void row_fft(cplx*& cur, cplx*& alt, const RowP& p, int nrows, int L, bool inverse) {
+    if (SCHED == 1) lds_fft_sched<false, 16, 16, 9>(cur, alt, L, p.stw, nrows, 0, 1, L, inverse);
+    else lds_fft<false>(cur, alt, p.f, p.tw, nrows, 0, 1, L, inverse, p.twd);
+}
+
+template <bool MAXONLY, int SCHED = 0>
+__global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? 4 : 1) void k_row(RowP p, long long M, cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float red[16];
     const int L = p.L, R = p.R;
@@ -204,12 +230,15 @@ __global__ __launch_bounds__(1024) void k_row(RowP p, long long M, cplx* __restr
     cplx* ga = W + (size_t)ra * L;
     cplx* gb = W + (size_t)rbw * L;
 
+    EGR_STAMP(p, 0);
     for (int e = threadIdx.x; e < L; e += blockDim.x) {
         cur[e] = ga[e];
         if (!self) cur[L + e] = gb[e];
     }
     __syncthreads();
-    lds_fft<false>(cur, alt, p.f, p.tw, nrows, 0, 1, L, false, p.twd);
+    EGR_STAMP(p, 1);
+    row_fft<SCHED>(cur, alt, p, nrows, L, false);
+    EGR_STAMP(p, 2);
 
     // real-split, threshold, un-split on the (k, M-k) pairs; Z[o + R*k] sits at row(o)[k]
     const dcplx wa = tw2d(p.wo, (unsigned)oa);
@@ -289,11 +318,14 @@ __global__ __launch_bounds__(1024) void k_row(RowP p, long long M, cplx* __restr
         return;
     }
     __syncthreads();
-    lds_fft<false>(cur, alt, p.f, p.tw, nrows, 0, 1, L, true, p.twd);
+    EGR_STAMP(p, 3);
+    row_fft<SCHED>(cur, alt, p, nrows, L, true);
+    EGR_STAMP(p, 4);
     for (int e = threadIdx.x; e < L; e += blockDim.x) {
         ga[e] = cur[e];
         if (!self) gb[e] = cur[L + e];
     }
+    EGR_STAMP(p, 5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -576,6 +608,7 @@ struct egr_fatllama_plan {
     size_t max2_cap;
     bool profiling;
     int threads;                  // workgroup size of the loop kernels (256 or 512)
+    int row_sched, col_sched;     // compile-time schedule ids of the loop kernels (0: run-time schedule)
     int nstreams;                 // channel groups run as concurrent pipelines (1 or 2)
     hipStream_t side;             // second pipeline's stream (forked from / joined to the caller's stream by events)
     int side_owned;               // 0: `side` was handed in by egr_fatllama_set_side_stream (not destroyed with the plan)
@@ -617,6 +650,24 @@ static int upload_dtab(egr_fatllama_plan* p, int64_t count, int64_t num, int64_t
     EGR_HIP(hipMemcpy(ptr, h.data(), h.size() * sizeof(double2), hipMemcpyHostToDevice));
     *d = (const dcplx*)ptr;
     return EGR_OK;
+}
+
+// butterfly-ordered stage tables of a compile-time schedule (R0, R1, R2; R2 = 1: two stages): for stage s >= 1 with
+// Ns = product of the earlier radices, row k < Ns holds W_(Ns R)^(k t), t = 0 .. R-1, padded to an even entry count
+static int upload_sched_tables(egr_fatllama_plan* p, int R0, int R1, int R2, const cplx** d) {
+    std::vector<float2> h;
+    const long double two_pi = 6.283185307179586476925286766559L;
+    auto add = [&](int Ns, int R) {
+        const int RS = (R + 1) & ~1;
+        for (int k = 0; k < Ns; ++k)
+            for (int t = 0; t < RS; ++t) {
+                const long double ang = t < R ? -two_pi * (long double)((long long)k * t % ((long long)Ns * R)) / (long double)((long long)Ns * R) : 0.0L;
+                h.push_back(make_float2((float)cosl(ang), (float)sinl(ang)));
+            }
+    };
+    add(R0, R1);
+    if (R2 > 1) add(R0 * R1, R2);
+    return upload(p, h, d);
 }
 
 // tables for W_T^r, r < T
@@ -739,6 +790,13 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     }
     r.inv_M = (float)(1.0 / (double)M);
     r.inv_M_d = 1.0 / (double)M;
+    // compile-time schedules for the hot factor lengths (EGR_FL_SCHED=0: always the run-time schedule)
+    p->row_sched = p->col_sched = 0;
+    {
+        const bool off = getenv("EGR_FL_SCHED") && atoi(getenv("EGR_FL_SCHED")) == 0;
+        if (!off && !p->bluestein && r.L == 2304) { if ((rc = upload_sched_tables(p, 16, 16, 9, &r.stw))) return fail(rc); p->row_sched = 1; }
+        if (!off && !p->bluestein && a.L == 625 && a.TC <= 8) { if ((rc = upload_sched_tables(p, 25, 25, 1, &a.stw))) return fail(rc); p->col_sched = 2; }
+    }
     if (hipMalloc((void**)&p->d_work, (size_t)channels * M * sizeof(float2)) != hipSuccess ||
         hipMalloc((void**)&p->d_peaks, 3 * channels * sizeof(unsigned)) != hipSuccess) {
         set_error("hipMalloc of the %lld-byte loop state failed", (long long)(channels * M * 8));
@@ -755,6 +813,11 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_row<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_row<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_row<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_row<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
@@ -864,6 +927,63 @@ extern "C" int egr_fatllama_plan_create_ex(egr_fatllama_plan** out, int64_t n_in
     return build_plan(out, n_in, channels, factor, sp);
 }
 
+// dev: one k_row and one k_col<1> launch over the plan's state with per-workgroup phase stamps (100 MHz wall clock);
+// prints min / median / max of each phase in microseconds and the launch skew.  Not part of the public header.
+extern "C" int egr_fatllama_trace_once(egr_fatllama_plan* p, void* stream) {
+    EGR_CHECK(p && !p->bluestein, EGR_ERR_ARG, "packed plan wanted");
+    hipStream_t st = (hipStream_t)stream;
+    const int C = p->C;
+    const long long M = p->sp.M, N = p->sp.N;
+    ColP A = p->colA; RowP R = p->row;
+    R.thr2 = 0.36f; R.thr = 0.6f;
+    const dim3 gA(8 * A.tiles_per_xcd, C), grow(R.R / 2 + 1, C), blk(p->threads);
+    const size_t nblk = (size_t)std::max(gA.x * gA.y, grow.x * grow.y);
+    long long* tr = nullptr;
+    EGR_HIP(hipMalloc((void**)&tr, nblk * 8 * sizeof(long long)));
+    std::vector<long long> h(nblk * 8);
+    for (int which = 0; which < 2; ++which) {
+        EGR_HIP(hipMemsetAsync(tr, 0, nblk * 8 * sizeof(long long), st));
+        R.trace = tr; A.trace = tr;
+        for (int rep = 0; rep < 3; ++rep) {          // the last repetition's stamps survive
+            if (which == 0) {
+                if (p->row_sched == 1) hipLaunchKernelGGL((k_row<false, 1>), grow, blk, p->sp.lds_row, st, R, M, p->d_work);
+                else hipLaunchKernelGGL(k_row<false>, grow, blk, p->sp.lds_row, st, R, M, p->d_work);
+            } else {
+                if (p->col_sched == 2) hipLaunchKernelGGL((k_col<1, 2>), gA, blk, p->sp.lds_col, st, A, M, N, 0.6f, p->d_work, (float*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr);
+                else hipLaunchKernelGGL(k_col<1>, gA, blk, p->sp.lds_col, st, A, M, N, 0.6f, p->d_work, (float*)nullptr, (unsigned*)nullptr);
+            }
+        }
+        EGR_HIP(hipStreamSynchronize(st));
+        EGR_HIP(hipMemcpy(h.data(), tr, nblk * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+        const size_t nb = which == 0 ? (size_t)grow.x * grow.y : (size_t)gA.x * gA.y;
+        const int nph = which == 0 ? 5 : 4;
+        long long t0 = -1, t1 = 0;
+        std::vector<std::vector<double>> ph(nph);
+        std::vector<double> starts;
+        for (size_t b = 0; b < nb; ++b) {
+            const long long* s = &h[b * 8];
+            if (s[0] == 0) continue;
+            if (t0 < 0 || s[0] < t0) t0 = s[0];
+            if (s[nph] > t1) t1 = s[nph];
+            for (int i = 0; i < nph; ++i) ph[i].push_back((s[i + 1] - s[i]) * 0.01);
+            starts.push_back((double)s[0]);
+        }
+        printf("%s: %zu workgroups stamped, first start -> last end %.2f us\n", which == 0 ? "k_row" : "k_col<1>", starts.size(), (t1 - t0) * 0.01);
+        std::sort(starts.begin(), starts.end());
+        if (!starts.empty()) printf("   start skew: median %.2f us, max %.2f us after the first\n", (starts[starts.size() / 2] - starts[0]) * 0.01, (starts.back() - starts[0]) * 0.01);
+        static const char* rn[5] = {"load", "fwd fft", "hook", "inv fft", "store"};
+        static const char* cn[4] = {"load+tw", "inv fft", "fwd fft", "tw+store"};
+        for (int i = 0; i < nph; ++i) {
+            auto& v = ph[i];
+            if (v.empty()) continue;
+            std::sort(v.begin(), v.end());
+            printf("   %-9s min %.2f  median %.2f  max %.2f us\n", which == 0 ? rn[i] : cn[i], v[0], v[v.size() / 2], v.back());
+        }
+    }
+    hipFree(tr);
+    return EGR_OK;
+}
+
 extern "C" int egr_fatllama_set_profiling(egr_fatllama_plan* p, int enable) {
     EGR_CHECK(p != nullptr, EGR_ERR_ARG, "plan is null");
     p->profiling = enable != 0;
@@ -960,6 +1080,7 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         // workgroups, so two channel groups run as concurrent pipelines on two streams (fork/join by events) and one
         // group's k_row overlaps the other's k_col.
         const int ngroups = (p->nstreams == 2 && C >= 2) ? 2 : 1;
+        const bool rs1 = p->row_sched == 1 && p->threads <= 512, cs2 = p->col_sched == 2 && p->threads <= 512 && !three;
         if (ngroups == 2 && !p->side) {
             EGR_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
             p->side_owned = 1;
@@ -977,18 +1098,21 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
             unsigned* pk = peak_out + c0;
             const dim3 gAg(gA.x, cn), gBg(gB.x, cn * (three ? B.nplanes : 1)), growg(grow.x, cn);
             if (first) {
-                hipLaunchKernelGGL(k_col<0>, gAg, blk, lc, sg, A, M, N, thr0, wk, og, pk, thr0_rel ? thr0_rel + c0 : nullptr);
+                if (cs2) hipLaunchKernelGGL((k_col<0, 2>), gAg, blk, lc, sg, A, M, N, thr0, wk, og, pk, thr0_rel ? thr0_rel + c0 : nullptr);
+                else hipLaunchKernelGGL(k_col<0>, gAg, blk, lc, sg, A, M, N, thr0, wk, og, pk, thr0_rel ? thr0_rel + c0 : nullptr);
                 if (three) hipLaunchKernelGGL(k_col<4>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
             }
             for (int it = it0; it < it1; ++it) {
                 RowP Rg = R;
                 if (relative) {        // this iteration's spectrum maximum first (forward row transforms + split, no write-back)
                     Rg.max2_out = p->d_max2 + (size_t)it * C + c0;
-                    hipLaunchKernelGGL(k_row<true>, growg, blk, lr, sg, Rg, M, wk);
+                    if (rs1) hipLaunchKernelGGL((k_row<true, 1>), growg, blk, lr, sg, Rg, M, wk);
+                    else hipLaunchKernelGGL(k_row<true>, growg, blk, lr, sg, Rg, M, wk);
                     Rg.max2 = Rg.max2_out;
                 }
                 if (prof) prof_begin(p, 0, sg, &slot);
-                hipLaunchKernelGGL(k_row<false>, growg, blk, lr, sg, Rg, M, wk);
+                if (rs1) hipLaunchKernelGGL((k_row<false, 1>), growg, blk, lr, sg, Rg, M, wk);
+                else hipLaunchKernelGGL(k_row<false>, growg, blk, lr, sg, Rg, M, wk);
                 if (prof) prof_end(p, sg, &slot);
                 if (three) {
                     if (prof) prof_begin(p, 2, sg, &slot);
@@ -997,7 +1121,8 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
                 }
                 if (it + 1 < max_iter) {
                     if (prof) prof_begin(p, 1, sg, &slot);
-                    hipLaunchKernelGGL(k_col<1>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
+                    if (cs2) hipLaunchKernelGGL((k_col<1, 2>), gAg, blk, lc, sg, A, M, N, thr, wk, og, pk, (const unsigned*)nullptr);
+                    else hipLaunchKernelGGL(k_col<1>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
                     if (prof) prof_end(p, sg, &slot);
                     if (three) {
                         if (prof) prof_begin(p, 2, sg, &slot);
@@ -1006,7 +1131,10 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
                     }
                 }
             }
-            if (last) hipLaunchKernelGGL(k_col<2>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
+            if (last) {
+                if (cs2) hipLaunchKernelGGL((k_col<2, 2>), gAg, blk, lc, sg, A, M, N, thr, wk, og, pk, (const unsigned*)nullptr);
+                else hipLaunchKernelGGL(k_col<2>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
+            }
         };
         auto fork = [&](hipStream_t s0) -> int {
             if (ngroups == 2) {

@@ -189,6 +189,67 @@ __device__ __forceinline__ void fft_stage(const cplx* __restrict__ in, cplx* __r
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Compile-time schedules (the hot Fat-Llama plans): big register butterflies (16 = 4x4, 25 = 5x5, 9 = 3x3) cut the number
+// of barrier-separated LDS round trips of a transform (2304 = 16 16 9: 3 instead of 4; 625 = 25 25: 2 instead of 4), and a
+// kernel instantiated for ONE schedule keeps only that schedule's registers (the all-radix kernel needed 190 VGPRs with
+// the composites in).  Stage twiddles come from a per-stage table laid out for the butterfly: row k holds W^(k t), t = 0..R-1
+// (padded to an even count so rows are 16-byte aligned), rounded once from long double -- no fp64 power chains in the loop.
+constexpr int sched_row_stride(int R) { return (R + 1) & ~1; }
+
+template <int R, int NS, bool SEQFAST>
+__device__ __forceinline__ void fft_stage_tab(const cplx* __restrict__ in, cplx* __restrict__ out, int L, const cplx* __restrict__ stw,
+                                              int nseq, int seq_log2, int es, int ss, bool swap_in, bool swap_out) {
+    constexpr int RS = sched_row_stride(R);
+    const int nb = L / R;
+    const int total = nb * nseq;
+    for (int b = threadIdx.x; b < total; b += blockDim.x) {
+        int s, j;
+        if (SEQFAST) { s = b & (nseq - 1); j = b >> seq_log2; }
+        else { s = (b >= nb) ? 1 : 0; j = b - s * nb; }
+        const int k = (NS == 1) ? 0 : j % NS;
+        cplx v[R];
+        const cplx* src = in + s * ss;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const cplx x = src[(j + t * nb) * es];
+            v[t] = swap_in ? make_float2(x.y, x.x) : x;
+        }
+        if (NS > 1) {
+            const float4* tp = (const float4*)(stw + (size_t)k * RS);
+#pragma unroll
+            for (int t2 = 0; t2 < RS / 2; ++t2) {
+                const float4 w = tp[t2];
+                if (2 * t2 >= 1 && 2 * t2 < R) v[2 * t2] = cmul(v[2 * t2], make_float2(w.x, w.y));
+                if (2 * t2 + 1 < R) v[2 * t2 + 1] = cmul(v[2 * t2 + 1], make_float2(w.z, w.w));
+            }
+        }
+        Bfly<R>::run(v);
+        cplx* dst = out + s * ss + ((j - k) * R + k) * es;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const cplx x = v[t];
+            dst[t * NS * es] = swap_out ? make_float2(x.y, x.x) : x;
+        }
+    }
+    __syncthreads();
+}
+
+// Transform with the compile-time schedule <R0, R1, R2> (R2 = 1: two stages); tables of stage 1 at stw, of stage 2 behind them.
+template <bool SEQFAST, int R0, int R1, int R2>
+__device__ __forceinline__ void lds_fft_sched(cplx*& cur, cplx*& alt, int L, const cplx* __restrict__ stw, int nseq, int seq_log2, int es,
+                                              int ss, bool inverse) {
+    constexpr int NST = R2 > 1 ? 3 : 2;
+    fft_stage_tab<R0, 1, SEQFAST>(cur, alt, L, stw, nseq, seq_log2, es, ss, inverse, false);
+    { cplx* t = cur; cur = alt; alt = t; }
+    fft_stage_tab<R1, R0, SEQFAST>(cur, alt, L, stw, nseq, seq_log2, es, ss, false, inverse && NST == 2);
+    { cplx* t = cur; cur = alt; alt = t; }
+    if (R2 > 1) {
+        fft_stage_tab<(R2 > 1 ? R2 : 2), R0 * R1, SEQFAST>(cur, alt, L, stw + R0 * sched_row_stride(R1), nseq, seq_log2, es, ss, false, inverse);
+        cplx* t = cur; cur = alt; alt = t;
+    }
+}
+
 // One stage of ANY radix R (used for prime factors > 13): every thread produces ONE output element as a direct R-term sum read
 // from LDS -- R times the LDS reads of a register butterfly, which is irrelevant for the single such stage an STFT frame has.
 // Both twiddles come from the W_L table: stage twiddle W_L^(k twstep t) and DFT kernel W_R^(t u) = W_L^((t u mod R) L / R).

@@ -239,6 +239,27 @@ def test_full_size_properties_c3_shape(pack):
     assert float(np.max(np.abs(k - 2.0 * y))) <= 3e-5 * s
 
 
+def test_c3_factorisation_with_compile_time_schedules_matches_oracle(pack):
+    """N = 2 880 000 (the C3 length: M = 625 x 2304) takes the loop kernels instantiated for fixed radix schedules -- rows 2304 =
+    16 x 16 x 9, columns 625 = 25 x 25, butterfly-ordered float stage tables (k_row<., 1>, k_col<., 2>) -- which no smaller test
+    length reaches.  One channel, 3 iterations against the oracle and the float64 yardstick; and EGR_FL_SCHED=0 selects the run-time-schedule
+    kernels for the same plan."""
+    from egregora_amd import fatllama_engine as fe
+    info = fe.plan_info(2880000, 1)
+    assert (info["M1"], info["M2"]) == (625, 2304)
+    x = synth(1, 2880000, seed=2880)
+    want = ofl.enhance_channels(x, 1, 3, 0.6, normalize=False, autoscale=False)
+    exact = ofl.enhance_channels(x, 1, 3, 0.6, normalize=False, autoscale=False, exact=True)
+    got = run_gpu(pack, x, 1, 3, 0.6)
+    scale = float(np.max(np.abs(want)))
+    rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
+    print(f"\nC3 length, scheduled kernels: max err {float(np.max(np.abs(got - exact))):.3e} (oracle32 {float(np.max(np.abs(want - exact))):.3e}), "
+          f"rms {rms(got - exact):.3e} / {rms(want - exact):.3e}, peak {scale:.0f}")
+    assert float(np.max(np.abs(got - want))) <= 2e-5 * scale
+    assert rms(got - exact) <= 2.5 * rms(want - exact) + 1e-9 * scale
+    assert om.lsd_audio(want[:, :960000], got[:, :960000])[0] <= 1e-3
+
+
 def c1_signal():
     """BASELINE configs[0] input (SURVEY 8(d) recipe): 10 s mono 16 kHz, 8 log-spaced sines 80 Hz..6 kHz (1/k) + noise, peak 0.5."""
     n, sr = 160000, 16000
