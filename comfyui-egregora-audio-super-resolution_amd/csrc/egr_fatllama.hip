@@ -344,6 +344,8 @@ struct ChirpP {
     int band;                // 1: the spectrum hook keeps bins min(n, N - n) >= band_lo instead of thresholding
     unsigned long long band_lo;
     int soft;                // 1: soft shrink X max(0, 1 - thr/|X|) instead of the hard threshold
+    const unsigned* max2;    // relative threshold: max_k |X[k]|^2 of this iteration per channel (float bits); level = thr sqrt(.)
+    unsigned* max2_out;      // k_colz<3, 1> only: where that maximum goes
 };
 __device__ __forceinline__ cplx chirp(const ChirpP& c, unsigned long long n) {
     const unsigned long long r = (n * n) % (2ULL * c.N);
@@ -353,10 +355,11 @@ __device__ __forceinline__ cplx chirp(const ChirpP& c, unsigned long long n) {
 // MODE 0: first (y real -> time threshold -> a = d w -> FFT -> twiddle)
 // MODE 1: mid   (twiddle^-1 -> IFFT -> hook -> FFT -> twiddle); HOOK 1 = spectrum side, HOOK 2 = time side
 // MODE 2: last  (twiddle^-1 -> IFFT -> d = Re(w c)/N -> out = y + d, peak)
+// MODE 3: spectrum maximum only (twiddle^-1 -> IFFT -> max |w c|^2 -> cp.max2_out[ch]; nothing written back)
 template <int MODE, int HOOK>
 __global__ __launch_bounds__(256) void k_colz(ColP p, ChirpP cp, long long P, float thr, float thr2,
                                                cplx* __restrict__ work, float* __restrict__ out,
-                                               unsigned* __restrict__ peak_out) {
+                                               unsigned* __restrict__ peak_out, const unsigned* __restrict__ thr_rel = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float red[8];
     const int tile = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
@@ -370,6 +373,7 @@ __global__ __launch_bounds__(256) void k_colz(ColP p, ChirpP cp, long long P, fl
     float* Y = out + (size_t)ch * cp.N;
     const int nel = L * TC;
     const unsigned long long N = cp.N;
+    if (MODE == 0 && thr_rel) thr *= __uint_as_float(thr_rel[ch]);
 
     for (int e = threadIdx.x; e < nel; e += blockDim.x) {
         const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
@@ -391,6 +395,24 @@ __global__ __launch_bounds__(256) void k_colz(ColP p, ChirpP cp, long long P, fl
     }
     __syncthreads();
     if (MODE != 0) lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, true, p.twd);
+    if (MODE == 3) {
+        float mx = 0.f;
+        for (int e = threadIdx.x; e < nel; e += blockDim.x) {
+            const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
+            const unsigned long long n = (unsigned long long)i * nc + col;
+            if (col < nc && n < N) {
+                const cplx X = cmul(chirp(cp, n), cur[e]);
+                mx = fmaxf(mx, X.x * X.x + X.y * X.y);
+            }
+        }
+        mx = block_max(mx, red);
+        if (threadIdx.x == 0) atomicMax(cp.max2_out + ch, __float_as_uint(mx));
+        return;
+    }
+    if (MODE == 1 && HOOK == 1 && cp.max2) {
+        thr *= sqrtf(__uint_as_float(cp.max2[ch]));
+        thr2 = thr * thr;
+    }
     if (MODE == 2) {
         float mx = 0.f;
         for (int e = threadIdx.x; e < nel; e += blockDim.x) {
@@ -821,6 +843,7 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_rowconv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_rowconv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
@@ -1023,8 +1046,6 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
     R.soft = (flags & EGR_FL_THR_SOFT) ? 1 : 0;
     const bool relative = (flags & EGR_FL_THR_RELATIVE) != 0;
     const bool no_init = (flags & EGR_FL_NO_INIT_THR) != 0;
-    EGR_CHECK(!(relative && p->bluestein), EGR_ERR_UNSUPPORTED,
-              "the relative-to-maximum threshold is built for packed-real plans only (this length takes the chirp-z path)");
     unsigned* peak_in = p->d_peaks;
     unsigned* peak_out = p->d_peaks + C;
     unsigned* peak_y = p->d_peaks + 2 * C;
@@ -1066,9 +1087,14 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
                                p->d_work);
             if (three) hipLaunchKernelGGL(k_col<3>, gB, blk, lb, st, B, P, N, thr, p->d_work, out, peak_out);
         };
-        hipLaunchKernelGGL((k_colz<0, 0>), gA, blk, lc, st, A, cp, P, thr0, thr2, p->d_work, out, peak_out);
+        hipLaunchKernelGGL((k_colz<0, 0>), gA, blk, lc, st, A, cp, P, thr0, thr2, p->d_work, out, peak_out, thr0_rel);
         for (int it = 0; it < max_iter; ++it) {
             conv();
+            if (relative) {                 // this iteration's spectrum maximum first (same pass, no write-back)
+                cp.max2_out = p->d_max2 + (size_t)it * C;
+                hipLaunchKernelGGL((k_colz<3, 1>), gA, blk, lc, st, A, cp, P, thr, thr2, p->d_work, out, peak_out, (const unsigned*)nullptr);
+                cp.max2 = cp.max2_out;
+            }
             hipLaunchKernelGGL((k_colz<1, 1>), gA, blk, lc, st, A, cp, P, thr, thr2, p->d_work, out, peak_out);
             conv();
             if (it + 1 < max_iter)

@@ -39,30 +39,83 @@ enum { EW_ADD = 0, EW_AXPBY = 1, EW_SILU = 2, EW_SCALE = 3, EW_COPY = 4, EW_ADD_
     } while (0)
 
 // ------------------------------------------------------------------------------------------------ scratch arena
-// Exact-size free lists over hipMalloc'ed blocks.  Everything runs on ONE stream, so a block may be handed out again as soon as
-// the host has enqueued its last consumer (stream order does the rest).  Layer shapes repeat, so after the first forward of a
-// given row count no allocation reaches the runtime.
+// Best-fit allocator with splitting and coalescing over a few large hipMalloc'ed slabs.  Everything runs on ONE stream, so a
+// block may be handed out again as soon as the host has enqueued its last consumer (stream order does the rest).  After the first
+// forward of a given row count no allocation reaches the runtime, and the footprint stays near the peak of simultaneously live
+// activations (exact-size free lists, the first version, held 47 GB for a 26-row pass; this holds the live peak + slab slack).
 struct Arena {
-    std::unordered_map<size_t, std::vector<void*>> free_;
-    std::vector<void*> all_;
+    struct Slab {
+        char* base = nullptr;
+        size_t size = 0;
+        std::map<char*, size_t> by_addr;                 // free blocks
+        std::multimap<size_t, char*> by_size;
+        void insert(char* p, size_t n) { by_addr[p] = n; by_size.emplace(n, p); }
+        void erase(char* p, size_t n) {
+            by_addr.erase(p);
+            auto r = by_size.equal_range(n);
+            for (auto it = r.first; it != r.second; ++it) if (it->second == p) { by_size.erase(it); break; }
+        }
+    };
+    std::vector<Slab> slabs;
     size_t total = 0;
+    static size_t round_up(size_t b) { b = (b + 255) & ~(size_t)255; return b ? b : 256; }
     void* get(size_t bytes) {
-        bytes = (bytes + 255) & ~(size_t)255;
-        if (bytes == 0) bytes = 256;
-        auto& v = free_[bytes];
-        if (!v.empty()) { void* p = v.back(); v.pop_back(); return p; }
-        void* p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) { set_error("FlashSR scratch arena: hipMalloc(%zu) failed (%zu bytes held)", bytes, total); return nullptr; }
-        all_.push_back(p);
-        total += bytes;
+        bytes = round_up(bytes);
+        Slab* best = nullptr;
+        std::multimap<size_t, char*>::iterator bi;
+        for (auto& s : slabs) {
+            auto it = s.by_size.lower_bound(bytes);
+            if (it != s.by_size.end() && (!best || it->first < bi->first)) { best = &s; bi = it; }
+        }
+        if (!best) {
+            Slab s;
+            s.size = std::max(bytes, (size_t)1 << 31);                      // 2 GiB slabs, or one request if larger
+            if (hipMalloc((void**)&s.base, s.size) != hipSuccess) {
+                s.size = bytes;                                             // memory is tight: exactly what is needed
+                if (hipMalloc((void**)&s.base, s.size) != hipSuccess) {
+                    set_error("FlashSR scratch arena: hipMalloc(%zu) failed (%zu bytes held)", bytes, total);
+                    return nullptr;
+                }
+            }
+            total += s.size;
+            s.insert(s.base, s.size);
+            slabs.push_back(std::move(s));
+            best = &slabs.back();
+            bi = best->by_size.lower_bound(bytes);
+        }
+        char* p = bi->second;
+        const size_t have = bi->first;
+        best->erase(p, have);
+        if (have > bytes) best->insert(p + bytes, have - bytes);
         return p;
     }
-    void put(void* p, size_t bytes) {
-        bytes = (bytes + 255) & ~(size_t)255;
-        if (bytes == 0) bytes = 256;
-        free_[bytes].push_back(p);
+    void put(void* ptr, size_t bytes) {
+        bytes = round_up(bytes);
+        char* p = (char*)ptr;
+        for (auto& s : slabs) {
+            if (p < s.base || p >= s.base + s.size) continue;
+            auto nx = s.by_addr.lower_bound(p);
+            if (nx != s.by_addr.end() && nx->first == p + bytes) {          // merge with the block behind
+                const size_t n = nx->second;
+                s.erase(nx->first, n);
+                bytes += n;
+            }
+            auto pv = s.by_addr.lower_bound(p);
+            if (pv != s.by_addr.begin()) {
+                --pv;
+                if (pv->first + pv->second == p) {                          // merge with the block in front
+                    char* q = pv->first;
+                    const size_t n = pv->second;
+                    s.erase(q, n);
+                    p = q;
+                    bytes += n;
+                }
+            }
+            s.insert(p, bytes);
+            return;
+        }
     }
-    ~Arena() { for (void* p : all_) hipFree(p); }
+    ~Arena() { for (auto& s : slabs) hipFree(s.base); }
 };
 
 struct Ten {                       // an fp32 activation owned by the arena (move-only)

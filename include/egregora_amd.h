@@ -82,7 +82,7 @@ int egr_fatllama_plan_destroy(egr_fatllama_plan* plan);
  *       (autoscale) -> (normalise) -> (NODE_POST).
  * All max_iter iterations are executed (no fixed-point early exit).  The EGR_FL_THR_* / NO_INIT_THR / ZERO_STUFF flags select
  * the other readings of upstream's threshold and interpolation (SPEC.md section 3; oracle: FatLlamaSpec fields of the same
- * names); EGR_FL_THR_RELATIVE adds one reduction pass per iteration and is refused (EGR_ERR_UNSUPPORTED) on chirp-z plans. */
+ * names); EGR_FL_THR_RELATIVE adds one reduction pass per iteration (packed-real and chirp-z plans alike). */
 int egr_fatllama_enhance(egr_fatllama_plan* plan, const float* x, float* out, int max_iter, float threshold,
                          unsigned flags, void* stream);
 

@@ -335,11 +335,11 @@ VARIANTS = [  # (variant list for the device, FatLlamaSpec overrides, threshold,
 
 
 @pytest.mark.parametrize("variant,over,thr,scale", VARIANTS)
-@pytest.mark.parametrize("C,n,f,iters", [(2, 4800, 1, 4), (1, 3000, 3, 6), (2, 48000, 2, 60)])
+@pytest.mark.parametrize("C,n,f,iters", [(2, 4800, 1, 4), (1, 3000, 3, 6), (2, 48000, 2, 60), (2, 4801, 1, 4), (1, 1013, 3, 5)])
 def test_threshold_and_interpolation_variants_match_the_oracle(pack, variant, over, thr, scale, C, n, f, iters):
     """SPEC.md section 3: absolute / relative-to-maximum level x hard / soft shrink, with or without the time-domain pre-threshold,
     linear or zero-insertion up-rating -- each against the oracle run with the matching FatLlamaSpec, at thresholds that really
-    gate bins.  A hard threshold may flip a borderline bin, so the bar is energy-relative (1e-6 of the output energy, as in
+    gate bins; the last two lengths (odd, prime factor 1013) run the chirp-z path.  A hard threshold may flip a borderline bin, so the bar is energy-relative (1e-6 of the output energy, as in
     test_large_threshold_actually_gates_bins); the soft shrink is continuous and is also held to 2e-5 of the peak."""
     import dataclasses
     spec = dataclasses.replace(ofl.DEFAULT_SPEC, **over)
@@ -355,9 +355,3 @@ def test_threshold_and_interpolation_variants_match_the_oracle(pack, variant, ov
     assert num / den < 1e-6, (variant, num / den)
     if "soft" in variant:
         assert float(np.max(np.abs(got - want))) <= 2e-5 * float(np.max(np.abs(want))), variant
-
-
-def test_relative_threshold_on_a_chirp_z_length_is_refused_loudly(pack):
-    from egregora_amd import fatllama_engine as fe
-    with pytest.raises(RuntimeError, match="relative"):
-        fe.enhance_device(torch.zeros(1, 101, device="cuda"), 1, 2, 0.5, False, False, False, False, variant="relative")
