@@ -201,15 +201,12 @@ def main():
         dom_ms = max(kt["row_ms"], kt["col_ms"])
         dom = "k_row" if kt["row_ms"] >= kt["col_ms"] else "k_col<1>"
         hbm_ach = row_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
-        try:
-            traffic = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get("fatllama_c3", {}).get(dom)
-            traffic = traffic / groups if traffic else None
-        except Exception:
-            pass
-        conv_traffic = None
-        try:
-            conv_traffic = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get("flashsr_chain60", {}).get(dom_conv)
+        traffic = conv_traffic = None
+        try:                # HBM bytes per launch from the committed PMC passes (tools/make_traffic_json.py)
+            tk = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get("kernels", {})
+            cands = ["k_row<false, 1>", "k_row<false, 0>", "k_row<false>"] if dom == "k_row" else ["k_col<1, 2>", "k_col<1, 0>", "k_col<1>"]
+            traffic = next((tk[c]["bytes"] for c in cands if c in tk), None)
+            conv_traffic = tk.get(dom_conv, {}).get("bytes")
         except Exception:
             pass
         info = fe.plan_info(SEG, 1)
