@@ -158,11 +158,27 @@ struct ProfRec { std::string kind; double flops; hipEvent_t a, b; };
 
 }  // namespace
 
+// Everything one in-flight forward owns: its stream, scratch arena and workspaces.  Context 0 runs on the caller's stream; the
+// others on the handle's side streams when a pass is split into concurrent row groups (egr_flashsr_infer).
+struct FsrCtx {
+    hipStream_t st = nullptr;
+    Arena arena;
+    void* gn_ws = nullptr;
+    size_t gn_ws_bytes = 0;
+    std::map<int, egr_fatllama_plan*> lp_plans;       // input low-pass: spectral-gain plans per row count
+    hipEvent_t done = nullptr;
+};
+
 struct egr_flashsr {
     egr_flashsr_config cfg;
     unsigned flags = 0;
     int device = 0;
-    Arena arena;
+    std::vector<std::unique_ptr<FsrCtx>> ctxs;        // [0] = the caller's stream
+    FsrCtx* cx = nullptr;                             // context of the forward being enqueued
+    int max_groups = 2;                               // concurrent row groups per pass (EGREGORA_FLASHSR_STREAMS)
+    int min_group_rows = 6;
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipStream_t> verified_for;            // caller streams the side streams were checked against
     std::vector<void*> owned;                         // weight allocations
     std::unordered_map<std::string, Wt> W;
     std::vector<std::string> blk_name;                // UNet block table (flashsr_arch.unet_blocks)
@@ -175,9 +191,8 @@ struct egr_flashsr {
     double flops = 0.0; bool count_flops = false;
     bool profiling = false;
     std::vector<ProfRec> prof;
-    std::map<int, egr_fatllama_plan*> lp_plans;       // input low-pass: spectral-gain plans per row count
-    void* gn_ws = nullptr; size_t gn_ws_bytes = 0;
-    hipStream_t st = nullptr;                         // stream of the call in flight
+    hipStream_t st = nullptr;                         // stream of the forward being enqueued (= cx->st)
+    void use(FsrCtx* c) { cx = c; st = c->st; }
 
     bool f32_mfma() const { return (flags & EGR_FSR_F32_MFMA) != 0; }
     bool has(const std::string& k) const { return W.find(k) != W.end(); }
@@ -202,9 +217,9 @@ int new_ten(M* m, Ten& t, std::initializer_list<int64_t> shape) {
     t.release();
     t.view(shape);
     t.bytes = (size_t)t.numel() * sizeof(float);
-    t.p = (float*)m->arena.get(t.bytes);
+    t.p = (float*)m->cx->arena.get(t.bytes);
     if (!t.p) return EGR_ERR_ALLOC;
-    t.a = &m->arena;
+    t.a = &m->cx->arena;
     return EGR_OK;
 }
 
@@ -440,10 +455,11 @@ int conv(M* m, Ten& y, const Ten& x, const std::string& wkey, int B, int H, int 
 }
 
 int gn_scratch(M* m, size_t need) {
-    if (m->gn_ws_bytes < need) {
-        if (m->gn_ws) { hipStreamSynchronize(m->st); hipFree(m->gn_ws); m->gn_ws = nullptr; m->gn_ws_bytes = 0; }
-        if (hipMalloc(&m->gn_ws, need + 1024) != hipSuccess) { set_error("hipMalloc(GroupNorm workspace) failed"); return EGR_ERR_ALLOC; }
-        m->gn_ws_bytes = need + 1024;
+    FsrCtx* c = m->cx;
+    if (c->gn_ws_bytes < need) {
+        if (c->gn_ws) { hipStreamSynchronize(m->st); hipFree(c->gn_ws); c->gn_ws = nullptr; c->gn_ws_bytes = 0; }
+        if (hipMalloc(&c->gn_ws, need + 1024) != hipSuccess) { set_error("hipMalloc(GroupNorm workspace) failed"); return EGR_ERR_ALLOC; }
+        c->gn_ws_bytes = need + 1024;
     }
     return EGR_OK;
 }
@@ -456,10 +472,10 @@ int groupnorm(M* m, Ten& y, const Ten& x, const std::string& key, float eps, boo
     y.release();
     y.nd = x.nd; memcpy(y.d, x.d, sizeof(y.d));
     y.bytes = (size_t)y.numel() * 4;
-    y.p = (float*)m->arena.get(y.bytes);
+    y.p = (float*)m->cx->arena.get(y.bytes);
     if (!y.p) return EGR_ERR_ALLOC;
-    y.a = &m->arena;
-    return egr_groupnorm_nhwc(x.p, m->ptr(key + ".weight"), m->ptr(key + ".bias"), y.p, B, HW, Cc, G, eps, silu ? 1 : 0, m->gn_ws, m->st);
+    y.a = &m->cx->arena;
+    return egr_groupnorm_nhwc(x.p, m->ptr(key + ".weight"), m->ptr(key + ".bias"), y.p, B, HW, Cc, G, eps, silu ? 1 : 0, m->cx->gn_ws, m->st);
 }
 
 int gn_coeff(M* m, Ten& sc, Ten& sh, const Ten& x, const std::string& key, float eps) {
@@ -475,7 +491,7 @@ int gn_coeff(M* m, Ten& sc, Ten& sh, const Ten& x, const std::string& key, float
         OKR(egr_groupnorm_stats_from_partials(x.part->p, B, x.part_tiles, Cc, G, (double*)stats.p, m->st));
         return egr_groupnorm_coeff_from_stats((const double*)stats.p, m->ptr(key + ".weight"), m->ptr(key + ".bias"), B, HW, Cc, G, eps, sc.p, sh.p, m->st);
     }
-    return egr_groupnorm_coeff(x.p, m->ptr(key + ".weight"), m->ptr(key + ".bias"), B, HW, Cc, G, eps, m->gn_ws, sc.p, sh.p, m->st);
+    return egr_groupnorm_coeff(x.p, m->ptr(key + ".weight"), m->ptr(key + ".bias"), B, HW, Cc, G, eps, m->cx->gn_ws, sc.p, sh.p, m->st);
 }
 
 int conv_winograd(M* m, Ten& y, const Ten& x, const std::string& key, int act, const float* res, const float* bias_t, const float* gsc = nullptr,
@@ -640,9 +656,9 @@ int eltwise(M* m, Ten& y, const Ten& a, const float* b, int op, float s0 = 0.f, 
     y.release();
     y.nd = a.nd; memcpy(y.d, a.d, sizeof(y.d));
     y.bytes = (size_t)y.numel() * 4;
-    y.p = (float*)m->arena.get(y.bytes);
+    y.p = (float*)m->cx->arena.get(y.bytes);
     if (!y.p) return EGR_ERR_ALLOC;
-    y.a = &m->arena;
+    y.a = &m->cx->arena;
     return egr_eltwise(a.p, b, y.p, a.numel(), op, s0, s1, m->st);
 }
 
@@ -745,7 +761,7 @@ int lowpass(M* m, Ten& y, const float* x, int B, int L) {
     const int64_t nbins = L / 2 + 1;
     OKR(new_ten(m, gain, {B, nbins}));
     OKR(egr_lowpass_gain(mag.p, B, T, m->ldm, nb, 0.985f, (float)c.sr, 8, 0.05f, nbins, (int*)cut.p, gain.p, m->st));
-    egr_fatllama_plan*& plan = m->lp_plans[B];
+    egr_fatllama_plan*& plan = m->cx->lp_plans[B];
     if (!plan) OKR(egr_fatllama_plan_create(&plan, L, B, 1, 0, 0));
     OKR(new_ten(m, y, {B, L}));
     return egr_spectral_gain(plan, x, gain.p, y.p, m->st);
@@ -1072,9 +1088,15 @@ extern "C" int egr_flashsr_destroy(egr_flashsr* m) {
     if (!m) return EGR_OK;
     hipDeviceSynchronize();
     for (void* p : m->owned) hipFree(p);
-    for (auto& kv : m->lp_plans) egr_fatllama_plan_destroy(kv.second);
+    for (size_t i = 0; i < m->ctxs.size(); ++i) {
+        FsrCtx* c = m->ctxs[i].get();
+        for (auto& kv : c->lp_plans) egr_fatllama_plan_destroy(kv.second);
+        if (c->gn_ws) hipFree(c->gn_ws);
+        if (c->done) hipEventDestroy(c->done);
+        if (i > 0 && c->st) hipStreamDestroy(c->st);
+    }
+    if (m->ev_fork) hipEventDestroy(m->ev_fork);
     for (auto& r : m->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
-    if (m->gn_ws) hipFree(m->gn_ws);
     delete m;
     return EGR_OK;
 }
@@ -1092,8 +1114,11 @@ extern "C" int egr_flashsr_create(egr_flashsr** out, const egr_flashsr_config* c
     egr_flashsr* m = new egr_flashsr();
     m->cfg = *cfg;
     m->flags = flags;
-    m->st = (hipStream_t)stream;
+    m->ctxs.emplace_back(new FsrCtx());
+    m->ctxs[0]->st = (hipStream_t)stream;
+    m->use(m->ctxs[0].get());
     hipGetDevice(&m->device);
+    if (const char* e = getenv("EGREGORA_FLASHSR_STREAMS")) { const int g = atoi(e); if (g >= 1 && g <= 4) m->max_groups = g; }
     if (const char* e = getenv("EGREGORA_FLASHSR_WINOGRAD_MIN_CH")) m->wino_min_ch = atoi(e);
     if (const char* e = getenv("EGREGORA_FLASHSR_ROWS")) { const int r = atoi(e); if (r >= 1) m->rows_per_pass = r; }
     build_blocks(m);
@@ -1144,7 +1169,8 @@ extern "C" int egr_flashsr_set_rows_per_pass(egr_flashsr* m, int rows) {
 extern "C" int egr_flashsr_forward(egr_flashsr* m, const float* x, const float* noise, int rows, int lowpass, float* y, float* const* stages,
                                    void* stream) {
     EGR_CHECK(m && x && noise && y && rows >= 1, EGR_ERR_ARG, "egr_flashsr_forward: null / empty argument");
-    m->st = (hipStream_t)stream;
+    m->ctxs[0]->st = (hipStream_t)stream;
+    m->use(m->ctxs[0].get());
     ForwardGuard guard(m->device, m->st);
     return forward(m, x, noise, rows, lowpass, y, stages);
 }
@@ -1152,29 +1178,105 @@ extern "C" int egr_flashsr_forward(egr_flashsr* m, const float* x, const float* 
 // x [rows][chunk] -> y [rows][chunk]; rows = chunks x channels ride the batch dimension (reference :366-368) and are processed
 // rows_per_pass at a time; the noise of row r is a function of (seed, row_ids[r] or r) only, so results do not depend on how the
 // rows are spread over passes or ranks.
+extern "C" int egr_streams_overlap_us(void* stream_a, void* stream_b, int spin_us, double* elapsed_us);
+
+// Side streams for concurrent row groups.  HIP multiplexes its streams onto a few hardware queues and two streams on one queue
+// run in order, so candidates are CHECKED: two 300 us spin kernels take ~300 us together on different queues, ~600 us on one.
+// Verified against the caller's stream and against each other; re-checked when the caller's stream changes.
+static int ensure_side_streams(egr_flashsr* m, hipStream_t caller, int want) {
+    bool known = false;
+    for (hipStream_t s : m->verified_for) known = known || s == caller;
+    auto overlaps = [&](hipStream_t a, hipStream_t b) {
+        double best = 1e9, us = 0;
+        for (int i = 0; i < 2; ++i) { if (egr_streams_overlap_us(a, b, 300, &us) != EGR_OK) return false; best = std::min(best, us); }
+        return best < 450.0;
+    };
+    if (!known) {                                    // drop side contexts that do not overlap with THIS caller stream
+        for (size_t i = 1; i < m->ctxs.size();) {
+            if (overlaps(caller, m->ctxs[i]->st)) { ++i; continue; }
+            hipStreamSynchronize(m->ctxs[i]->st);
+            for (auto& kv : m->ctxs[i]->lp_plans) egr_fatllama_plan_destroy(kv.second);
+            if (m->ctxs[i]->gn_ws) hipFree(m->ctxs[i]->gn_ws);
+            if (m->ctxs[i]->done) hipEventDestroy(m->ctxs[i]->done);
+            hipStreamDestroy(m->ctxs[i]->st);
+            m->ctxs.erase(m->ctxs.begin() + i);
+        }
+        m->verified_for.assign(1, caller);
+    }
+    for (int tries = 0; (int)m->ctxs.size() - 1 < want && tries < 12; ++tries) {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+        bool ok = overlaps(caller, s);
+        for (size_t i = 1; ok && i < m->ctxs.size(); ++i) ok = overlaps(m->ctxs[i]->st, s);
+        if (!ok) { hipStreamDestroy(s); continue; }
+        m->ctxs.emplace_back(new FsrCtx());
+        m->ctxs.back()->st = s;
+        hipEventCreateWithFlags(&m->ctxs.back()->done, hipEventDisableTiming);
+    }
+    return (int)m->ctxs.size() - 1;
+}
+
+// x [rows][chunk] -> y [rows][chunk]; rows = chunks x channels ride the batch dimension (reference :366-368) and are processed
+// rows_per_pass at a time; the noise of row r is a function of (seed, row_ids[r] or r) only, so results do not depend on how the
+// rows are spread over passes, groups or ranks (beyond fp32 round-off: tile choices follow the row count of a forward).
+// A pass of >= 2 * min_group_rows rows is split into up to max_groups contiguous ROW GROUPS that run as concurrent forwards on the
+// handle's verified side streams, each with its own scratch arena (fork / join by events around the pass): one group's
+// matrix-bound kernels overlap another's HBM-bound ones and fill each other's tails (26 rows: 260 ms in one forward).
 extern "C" int egr_flashsr_infer(egr_flashsr* m, const float* x, int rows, int lowpass, uint64_t seed, const int64_t* row_ids, float* y,
                                  void* stream) {
     EGR_CHECK(m && x && y && rows >= 1, EGR_ERR_ARG, "egr_flashsr_infer: null / empty argument");
-    m->st = (hipStream_t)stream;
-    ForwardGuard guard(m->device, m->st);
+    hipStream_t st0 = (hipStream_t)stream;
+    m->ctxs[0]->st = st0;
+    m->use(m->ctxs[0].get());
+    ForwardGuard guard(m->device, st0);
     const egr_flashsr_config& c = m->cfg;
     const int64_t per_row = (int64_t)m->lat_h * m->lat_w * c.z_ch;
-    for (int lo = 0; lo < rows; lo += m->rows_per_pass) {
-        const int n = std::min(m->rows_per_pass, rows - lo);
-        Ten nz, ids;
-        OKR(new_ten(m, nz, {n, per_row}));
-        const int64_t* idp = row_ids ? row_ids + lo : nullptr;
-        if (!row_ids && lo > 0) {                 // implicit ids continue across passes
-            std::vector<int64_t> h(n);
-            for (int i = 0; i < n; ++i) h[i] = lo + i;
-            OKR(new_ten(m, ids, {2 * (int64_t)n}));
-            EGR_HIP(hipMemcpyAsync(ids.p, h.data(), (size_t)n * 8, hipMemcpyHostToDevice, m->st));
-            EGR_HIP(hipStreamSynchronize(m->st));
-            idp = (const int64_t*)ids.p;
-        }
-        OKR(egr_randn(nz.p, per_row, n, seed, idp, m->st));
-        OKR(forward(m, x + (size_t)lo * c.chunk, nz.p, n, lowpass, y + (size_t)lo * c.chunk, nullptr));
+    int groups_max = m->profiling ? 1 : m->max_groups;          // per-kernel timing wants the kernels alone on the chip
+    if (groups_max > 1 && std::min(rows, m->rows_per_pass) >= 2 * m->min_group_rows)
+        groups_max = 1 + ensure_side_streams(m, st0, groups_max - 1);
+    else
+        groups_max = 1;
+    Ten ids;                                                      // implicit ids 0 .. rows-1 as a device array (groups need offsets)
+    if (!row_ids && (rows > m->rows_per_pass || groups_max > 1)) {
+        std::vector<int64_t> h(rows);
+        for (int i = 0; i < rows; ++i) h[i] = i;
+        OKR(new_ten(m, ids, {2 * (int64_t)rows}));
+        EGR_HIP(hipMemcpyAsync(ids.p, h.data(), (size_t)rows * 8, hipMemcpyHostToDevice, st0));
+        EGR_HIP(hipStreamSynchronize(st0));
+        row_ids = (const int64_t*)ids.p;
     }
+    if (groups_max > 1 && !m->ev_fork) EGR_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    int rc = EGR_OK;
+    for (int lo = 0; lo < rows && rc == EGR_OK; lo += m->rows_per_pass) {
+        const int n = std::min(m->rows_per_pass, rows - lo);
+        const int G = std::max(1, std::min(groups_max, n / m->min_group_rows));
+        if (G > 1) EGR_HIP(hipEventRecord(m->ev_fork, st0));
+        int done_rows = 0;
+        for (int g = 0; g < G && rc == EGR_OK; ++g) {
+            const int ng = (n - done_rows + (G - g) - 1) / (G - g);
+            const int glo = lo + done_rows;
+            FsrCtx* cx = m->ctxs[g].get();
+            if (g > 0) EGR_HIP(hipStreamWaitEvent(cx->st, m->ev_fork, 0));
+            m->use(cx);
+            Ten nz;
+            rc = new_ten(m, nz, {ng, per_row});
+            if (rc == EGR_OK) rc = egr_randn(nz.p, per_row, ng, seed, row_ids ? row_ids + glo : nullptr, m->st);
+            if (rc == EGR_OK) rc = forward(m, x + (size_t)glo * c.chunk, nz.p, ng, lowpass, y + (size_t)glo * c.chunk, nullptr);
+            if (g > 0) {                                          // join even after an error: nothing may outlive the call unordered
+                hipEventRecord(cx->done, cx->st);
+                hipStreamWaitEvent(st0, cx->done, 0);
+            }
+            done_rows += ng;
+        }
+        m->use(m->ctxs[0].get());
+    }
+    return rc;
+}
+
+extern "C" int egr_flashsr_set_streams(egr_flashsr* m, int max_groups, int min_group_rows) {
+    EGR_CHECK(m && max_groups >= 1 && max_groups <= 4 && min_group_rows >= 1, EGR_ERR_ARG, "bad argument");
+    m->max_groups = max_groups;
+    m->min_group_rows = min_group_rows;
     return EGR_OK;
 }
 
@@ -1214,7 +1316,8 @@ extern "C" int egr_flashsr_profile(egr_flashsr* m, int index, char* kind_buf, si
 // Dense-contraction flops of one forward over `rows` rows (dry run with counting on; 2 Cin Cout Kh Kw Hout Wout per conv as executed).
 extern "C" int egr_flashsr_flop_count(egr_flashsr* m, int rows, double* flops, void* stream) {
     EGR_CHECK(m && flops && rows >= 1, EGR_ERR_ARG, "bad argument");
-    m->st = (hipStream_t)stream;
+    m->ctxs[0]->st = (hipStream_t)stream;
+    m->use(m->ctxs[0].get());
     const egr_flashsr_config& c = m->cfg;
     Ten x, nz, y;
     OKR(new_ten(m, x, {rows, c.chunk}));
@@ -1230,7 +1333,11 @@ extern "C" int egr_flashsr_flop_count(egr_flashsr* m, int rows, double* flops, v
     return rc;
 }
 
-extern "C" int64_t egr_flashsr_scratch_bytes(egr_flashsr* m) { return m ? (int64_t)m->arena.total : 0; }
+extern "C" int64_t egr_flashsr_scratch_bytes(egr_flashsr* m) {
+    int64_t t = 0;
+    if (m) for (auto& c : m->ctxs) t += (int64_t)c->arena.total;
+    return t;
+}
 
 // ---------------------------------------------------------------------------------------------------- weight blob files
 // "EGRW" container: what `egr_flashsr_create` takes, on disk -- written once by the host that owns checkpoint I/O

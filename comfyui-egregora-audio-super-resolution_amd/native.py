@@ -96,6 +96,7 @@ SIGNATURES = {
     "egr_flashsr_infer": (_i, [_vp, _vp, _i, _i, C.c_uint64, _vp, _vp, _vp]),
     "egr_flashsr_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "egr_flashsr_set_rows_per_pass": (_i, [_vp, _i]),
+    "egr_flashsr_set_streams": (_i, [_vp, _i, _i]),
     "egr_flashsr_set_profiling": (_i, [_vp, _i]),
     "egr_flashsr_profile": (_i, [_vp, _i, C.c_char_p, C.c_size_t, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                  C.POINTER(_i)]),

@@ -398,6 +398,10 @@ int egr_flashsr_infer(egr_flashsr* h, const float* x, int rows, int lowpass_inpu
 int egr_flashsr_forward(egr_flashsr* h, const float* x, const float* noise, int rows, int lowpass_input, float* y, float* const* stages,
                         void* stream);
 int egr_flashsr_set_rows_per_pass(egr_flashsr* h, int rows);
+/* Concurrent row groups inside egr_flashsr_infer: a pass of >= 2 * min_group_rows rows is split into up to max_groups (1..4,
+ * default 2; EGREGORA_FLASHSR_STREAMS) contiguous groups run as simultaneous forwards on side streams the handle creates and
+ * verifies to sit on other hardware queues than the caller's; fork / join by events, so the call still looks single-stream. */
+int egr_flashsr_set_streams(egr_flashsr* h, int max_groups, int min_group_rows);
 /* HIP-event timing of the MFMA contraction launches, aggregated per kernel instantiation (bench.py's roofline): switch on, run,
  * then read entry `index` (kind_buf NULL: only *count).  egr_flashsr_flop_count: executed dense flops of one pass over `rows`. */
 int egr_flashsr_set_profiling(egr_flashsr* h, int enable);
