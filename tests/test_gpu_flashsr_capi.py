@@ -170,10 +170,9 @@ def test_full_size_handle_equals_python_driver_bit_for_bit(pack):
 
 
 def test_forwards_from_different_streams_never_overlap_on_the_device(pack):
-    """Reproducer of the open co-residency erratum (k_stft_frames next to another stream's k_conv_s3 returns wrong
-    bins) at the library boundary: two full-size forwards issued back to back on two streams that the runtime maps to different
-    hardware queues.  The library chains forwards of one device with an event (ForwardGuard, csrc/egr_flashsr.cpp), so both results
-    must equal the single-stream ones bit for bit -- 10 rounds."""
+    """ONE handle called from two streams: a handle owns one scratch arena per context and serves one caller stream at a time, so the
+    library chains the calls with an event (ForwardGuard, csrc/egr_flashsr.cpp) -- issued back to back on two streams that the
+    runtime maps to different hardware queues, both results must equal the single-stream ones bit for bit, 10 rounds."""
     from egregora_amd import flashsr_arch as A, flashsr_engine as E, streams
     cfg = A.FlashSRConfig()
     e = E.FlashSREngine(cfg, A.init_params(cfg, 0))
@@ -193,4 +192,48 @@ def test_forwards_from_different_streams_never_overlap_on_the_device(pack):
         b = e.c_forward(x[4:], nz[4:])
         torch.cuda.synchronize()
         assert torch.equal(a, ref[0]) and torch.equal(b, ref[1])
+    e.close()
+
+
+def test_two_handles_run_concurrently_and_stay_bit_exact(pack):
+    """The co-residency erratum of DESIGN.md 4.4a, closed: packed-fp32 VALU instructions with component-swapped operands return wrong
+    values in lanes 48-63 while a bf16-MFMA wave of another kernel shares the SIMD (tools/ubench/coresidency.hip pins the
+    instruction class); k_stft_frames next to another stream's k_conv_s3 was the first casualty.  The VALU kernels are now built
+    without SLP-formed packed arithmetic, so two full-size forwards of two handles that REALLY overlap on the GPU (guard off, in a
+    subprocess because the switch is read once) give the single-stream bits -- 12 rounds."""
+    import os, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, EGR_FSR_NO_STREAM_GUARD="1")
+    r = subprocess.run([sys.executable, str(root / "tools" / "probe_two_stream_forwards.py"), "12"], cwd=str(root), env=env,
+                       capture_output=True, text=True, timeout=900)
+    print(r.stdout[-400:])
+    assert r.returncode == 0 and "bad rounds: 0 of 12" in r.stdout, r.stdout[-800:] + r.stderr[-800:]
+
+
+def test_concurrent_row_groups_inside_infer(pack):
+    """egr_flashsr_infer splits a pass of >= 12 rows into row groups that run as simultaneous forwards on the handle's verified side
+    streams (own arena each).  Rows are independent and the noise is keyed by row id, so the grouped result equals the one-group
+    result up to the fp32 round-off of tile choices that follow a forward's row count -- and equals, bit for bit, separate infer
+    calls on the same sub-batches."""
+    import ctypes as C
+    from egregora_amd import flashsr_arch as A, flashsr_engine as E, native
+    cfg = A.tiny_config()
+    e = E.FlashSREngine(cfg, A.init_params(cfg, 2))
+    L = native.lib()
+    x = rows(cfg, 14, 12)
+    ids = torch.arange(100, 114, dtype=torch.int64, device="cuda")
+    h = C.c_void_p(e.handle)
+    native.check(L.egr_flashsr_set_streams(h, 1, 6), "set_streams")
+    one = e.c_infer(x, ids, 3)
+    native.check(L.egr_flashsr_set_streams(h, 2, 6), "set_streams")
+    two = e.c_infer(x, ids, 3)
+    two_again = e.c_infer(x, ids, 3)
+    native.check(L.egr_flashsr_set_streams(h, 1, 6), "set_streams")
+    parts = torch.cat([e.c_infer(x[:7], ids[:7], 3), e.c_infer(x[7:], ids[7:], 3)])
+    torch.cuda.synchronize()
+    assert torch.equal(two, two_again) and torch.equal(two, parts)
+    assert float((one - two).abs().max()) <= 2e-4 * float(one.abs().max())
+    native.check(L.egr_flashsr_set_streams(h, 2, 6), "set_streams")
+    assert torch.equal(e.c_infer(x, None, 3), e.c_infer(x, torch.arange(14, dtype=torch.int64, device="cuda"), 3))     # implicit ids
     e.close()
