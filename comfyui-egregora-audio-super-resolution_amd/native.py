@@ -152,7 +152,7 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = Path(os.environ.get("EGREGORA_AMD_LIB", str(LIB_PATH)))
+    path = Path(os.environ.get("EGREGORA_AMD_LIB") or str(LIB_PATH))
     if not path.exists():
         raise RuntimeError(
             f"libegregora_amd.so not found at {path}. Build it with `make -C {LIB_PATH.parent / 'csrc'}` "
