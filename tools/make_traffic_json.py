@@ -22,7 +22,7 @@ out = {"_note": "HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from the roc
        "kernels": {}}
 for k in sorted(set(per["FETCH_SIZE"]) | set(per["WRITE_SIZE"])):
     f, w = per["FETCH_SIZE"].get(k, 0.0), per["WRITE_SIZE"].get(k, 0.0)
-    if 2 * f + w >= 1e6:
+    if 2 * f + w >= 1e6 and k.startswith("k_"):
         out["kernels"][k] = {"bytes": round(2 * f + w), "fetch_x2": round(2 * f), "write": round(w)}
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps({k: v["bytes"] for k, v in list(out["kernels"].items())[:40]}, indent=0))

@@ -11,6 +11,10 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o chain -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --lean > $OUT/bench_stats.log 2>&1
 grep '^{' $OUT/bench_stats.log | tail -1 > $OUT/bench_stats.json
+# the same with ONE row group per pass: every contraction launch then has the 26-row shape bench.py's roofline object times
+# (egr_flashsr_set_profiling runs one group), so the per-kernel averages of this pass are the ones that must agree with it
+EGREGORA_FLASHSR_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_g1 -o chain -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --lean > $OUT/bench_stats_g1.log 2>&1
+grep '^{' $OUT/bench_stats_g1.log | tail -1 > $OUT/bench_stats_g1.json
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o chain -- python bench.py --steps 1 --warmup 0 --iters 20 --no-cpu-baseline --lean > $OUT/bench_pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o chain -- python bench.py --steps 1 --warmup 0 --iters 20 --no-cpu-baseline --lean > $OUT/bench_pmc_write.log 2>&1
 # matrix-pipe occupancy of the contraction kernels (north_star: "MFMA-busy counters") and the wait / LDS picture of the Fat-Llama loop
