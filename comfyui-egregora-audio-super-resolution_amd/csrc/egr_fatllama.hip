@@ -511,6 +511,7 @@ __global__ __launch_bounds__(256) void k_chirp_b(ChirpP cp, long long P, cplx* _
 __global__ __launch_bounds__(256) void k_prepare(const float* __restrict__ x, float* __restrict__ y, long long n_in,
                                                   int f, int pcm_in, int zero_stuff, unsigned* __restrict__ peak_in,
                                                   unsigned* __restrict__ peak_y) {
+#pragma clang fp contract(off)      // the roundings below are the PCM arithmetic of the reference, written out
     __shared__ float red[8];
     const int ch = blockIdx.y;
     const float* xc = x + (size_t)ch * n_in;
@@ -577,6 +578,7 @@ __global__ __launch_bounds__(256) void k_noiter(float* __restrict__ y, long long
 __global__ __launch_bounds__(256) void k_finalize(float* __restrict__ out, long long N, int C, unsigned flags,
                                                    const unsigned* __restrict__ peak_in,
                                                    const unsigned* __restrict__ peak_out) {
+#pragma clang fp contract(off)      // the roundings below are the PCM arithmetic of the reference, written out
     const int ch = blockIdx.y;
     float s_auto = 1.f;
     float joint = 0.f;
