@@ -237,3 +237,33 @@ def test_concurrent_row_groups_inside_infer(pack):
     native.check(L.egr_flashsr_set_streams(h, 2, 6), "set_streams")
     assert torch.equal(e.c_infer(x, None, 3), e.c_infer(x, torch.arange(14, dtype=torch.int64, device="cuda"), 3))     # implicit ids
     e.close()
+
+
+def test_fat_llama_next_to_a_flashsr_forward_on_another_stream(pack):
+    """Product-level form of the erratum check: the Fat-Llama loop (complex arithmetic everywhere) on one stream while a full-size
+    FlashSR forward (bf16-MFMA contraction kernels) runs on another -- what two ComfyUI workers, or one node graph with side
+    streams, would do.  Before the VALU kernels were rebuilt without packed fp32 this returned a wrong result in EVERY sample
+    (profiles/r02/cr19.log); now both results equal their solo runs bit for bit, 6 rounds."""
+    from egregora_amd import fatllama_engine as fe, flashsr_arch as A, flashsr_engine as E, streams
+    cfg = A.FlashSRConfig()
+    e = E.FlashSREngine(cfg, A.init_params(cfg, 0))
+    x = 0.2 * torch.randn(9, cfg.chunk, generator=torch.Generator().manual_seed(4)).cuda()
+    nz = e.noise(9, None, 0)
+    a = (3000.0 * torch.randn(1, 480000, generator=torch.Generator().manual_seed(5))).round().cuda()
+    ref_sr = e.c_forward(x, nz).clone()
+    ref_fl = fe.enhance_device(a, 1, 40, 0.6, False, False, False, False, profile=True).clone()
+    torch.cuda.synchronize()
+    side = streams.side_streams(1)
+    if not side:
+        pytest.skip("the runtime gave no stream that overlaps with the current one")
+    cur = torch.cuda.current_stream()
+    for _ in range(6):
+        ready = cur.record_event()
+        side[0].wait_event(ready)
+        with torch.cuda.stream(side[0]):
+            y_sr = e.c_forward(x, nz)
+        y_fl = [fe.enhance_device(a, 1, 40, 0.6, False, False, False, False, profile=True) for _ in range(6)]
+        torch.cuda.synchronize()
+        assert torch.equal(y_sr, ref_sr)
+        assert all(torch.equal(y, ref_fl) for y in y_fl)
+    e.close()
