@@ -113,14 +113,23 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // MODE 5: last, plain (state -> twiddle^-1 -> IFFT -> out = d)               [spectral-gain filter]
 // thr_rel (MODE 0 only, optional): per-channel max|y| as float bits; the time-domain level becomes thr * max|y| (SPEC.md section 3).
 // SCHED 0: run-time radix schedule (any plan).  SCHED 2: L = 625 as 25 x 25 with compile-time stages (egr_fft_device.h).
+// The compile-time schedules run IN PLACE (one buffer, two barriers per stage): half the LDS of the ping-pong form, so that
+// three 512-thread workgroups share a CU (6 waves per SIMD) and the two channels' kernels are fully resident together.
+#ifndef EGR_FL_INPLACE
+#define EGR_FL_INPLACE 1
+#endif
+#ifndef EGR_FL_SCHED_WAVES
+#define EGR_FL_SCHED_WAVES (EGR_FL_INPLACE ? 6 : 4)
+#endif
 template <int SCHED>
 __device__ __forceinline__ void col_fft(cplx*& cur, cplx*& alt, const ColP& p, int TC, int lg, bool inverse) {
-    if (SCHED == 2) lds_fft_sched<true, 25, 25, 1>(cur, alt, p.L, p.stw, TC, lg, TC, 1, inverse);
+    if (SCHED == 2 && EGR_FL_INPLACE) lds_fft_sched_inplace<true, 25, 25, 1>(cur, p.L, p.stw, TC, lg, TC, 1, inverse);
+    else if (SCHED == 2) lds_fft_sched<true, 25, 25, 1>(cur, alt, p.L, p.stw, TC, lg, TC, 1, inverse);
     else lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, inverse, p.twd);
 }
 
 template <int MODE, int SCHED = 0>
-__global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? 4 : 1) void k_col(ColP p, long long M, long long N, float thr, cplx* __restrict__ work,
+__global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1) void k_col(ColP p, long long M, long long N, float thr, cplx* __restrict__ work,
                                               float* __restrict__ out, unsigned* __restrict__ peak_out,
                                               const unsigned* __restrict__ thr_rel = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -208,12 +217,13 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? 4 : 1) void k_col(ColP 
 // SCHED 1: L = 2304 as 16 x 16 x 9 with compile-time stages.
 template <int SCHED>
 __device__ __forceinline__ void row_fft(cplx*& cur, cplx*& alt, const RowP& p, int nrows, int L, bool inverse) {
-    if (SCHED == 1) lds_fft_sched<false, 16, 16, 9>(cur, alt, L, p.stw, nrows, 0, 1, L, inverse);
+    if (SCHED == 1 && EGR_FL_INPLACE) lds_fft_sched_inplace<false, 16, 16, 9>(cur, L, p.stw, nrows, 0, 1, L, inverse);
+    else if (SCHED == 1) lds_fft_sched<false, 16, 16, 9>(cur, alt, L, p.stw, nrows, 0, 1, L, inverse);
     else lds_fft<false>(cur, alt, p.f, p.tw, nrows, 0, 1, L, inverse, p.twd);
 }
 
 template <bool MAXONLY, int SCHED = 0>
-__global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? 4 : 1) void k_row(RowP p, long long M, cplx* __restrict__ work) {
+__global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1) void k_row(RowP p, long long M, cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float red[16];
     const int L = p.L, R = p.R;
@@ -971,10 +981,10 @@ extern "C" int egr_fatllama_trace_once(egr_fatllama_plan* p, void* stream) {
         R.trace = tr; A.trace = tr;
         for (int rep = 0; rep < 3; ++rep) {          // the last repetition's stamps survive
             if (which == 0) {
-                if (p->row_sched == 1) hipLaunchKernelGGL((k_row<false, 1>), grow, blk, p->sp.lds_row, st, R, M, p->d_work);
+                if (p->row_sched == 1) hipLaunchKernelGGL((k_row<false, 1>), grow, blk, p->sp.lds_row / (EGR_FL_INPLACE ? 2 : 1), st, R, M, p->d_work);
                 else hipLaunchKernelGGL(k_row<false>, grow, blk, p->sp.lds_row, st, R, M, p->d_work);
             } else {
-                if (p->col_sched == 2) hipLaunchKernelGGL((k_col<1, 2>), gA, blk, p->sp.lds_col, st, A, M, N, 0.6f, p->d_work, (float*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr);
+                if (p->col_sched == 2) hipLaunchKernelGGL((k_col<1, 2>), gA, blk, p->sp.lds_col / (EGR_FL_INPLACE ? 2 : 1), st, A, M, N, 0.6f, p->d_work, (float*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr);
                 else hipLaunchKernelGGL(k_col<1>, gA, blk, p->sp.lds_col, st, A, M, N, 0.6f, p->d_work, (float*)nullptr, (unsigned*)nullptr);
             }
         }
@@ -1108,7 +1118,10 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         // workgroups, so two channel groups run as concurrent pipelines on two streams (fork/join by events) and one
         // group's k_row overlaps the other's k_col.
         const int ngroups = (p->nstreams == 2 && C >= 2) ? 2 : 1;
-        const bool rs1 = p->row_sched == 1 && p->threads <= 512, cs2 = p->col_sched == 2 && p->threads <= 512 && !three;
+        // the in-place schedules need one thread per butterfly (288 / 512 row, 200 column butterflies per stage): 512 threads
+        const bool sched_ok = EGR_FL_INPLACE ? p->threads == 512 : p->threads <= 512;
+        const bool rs1 = p->row_sched == 1 && sched_ok, cs2 = p->col_sched == 2 && sched_ok && !three;
+        const size_t lrs = EGR_FL_INPLACE ? lr / 2 : lr, lcs = EGR_FL_INPLACE ? lc / 2 : lc;   // no ping-pong buffer
         if (ngroups == 2 && !p->side) {
             EGR_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
             p->side_owned = 1;
@@ -1126,7 +1139,7 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
             unsigned* pk = peak_out + c0;
             const dim3 gAg(gA.x, cn), gBg(gB.x, cn * (three ? B.nplanes : 1)), growg(grow.x, cn);
             if (first) {
-                if (cs2) hipLaunchKernelGGL((k_col<0, 2>), gAg, blk, lc, sg, A, M, N, thr0, wk, og, pk, thr0_rel ? thr0_rel + c0 : nullptr);
+                if (cs2) hipLaunchKernelGGL((k_col<0, 2>), gAg, blk, lcs, sg, A, M, N, thr0, wk, og, pk, thr0_rel ? thr0_rel + c0 : nullptr);
                 else hipLaunchKernelGGL(k_col<0>, gAg, blk, lc, sg, A, M, N, thr0, wk, og, pk, thr0_rel ? thr0_rel + c0 : nullptr);
                 if (three) hipLaunchKernelGGL(k_col<4>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
             }
@@ -1134,12 +1147,12 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
                 RowP Rg = R;
                 if (relative) {        // this iteration's spectrum maximum first (forward row transforms + split, no write-back)
                     Rg.max2_out = p->d_max2 + (size_t)it * C + c0;
-                    if (rs1) hipLaunchKernelGGL((k_row<true, 1>), growg, blk, lr, sg, Rg, M, wk);
+                    if (rs1) hipLaunchKernelGGL((k_row<true, 1>), growg, blk, lrs, sg, Rg, M, wk);
                     else hipLaunchKernelGGL(k_row<true>, growg, blk, lr, sg, Rg, M, wk);
                     Rg.max2 = Rg.max2_out;
                 }
                 if (prof) prof_begin(p, 0, sg, &slot);
-                if (rs1) hipLaunchKernelGGL((k_row<false, 1>), growg, blk, lr, sg, Rg, M, wk);
+                if (rs1) hipLaunchKernelGGL((k_row<false, 1>), growg, blk, lrs, sg, Rg, M, wk);
                 else hipLaunchKernelGGL(k_row<false>, growg, blk, lr, sg, Rg, M, wk);
                 if (prof) prof_end(p, sg, &slot);
                 if (three) {
@@ -1149,7 +1162,7 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
                 }
                 if (it + 1 < max_iter) {
                     if (prof) prof_begin(p, 1, sg, &slot);
-                    if (cs2) hipLaunchKernelGGL((k_col<1, 2>), gAg, blk, lc, sg, A, M, N, thr, wk, og, pk, (const unsigned*)nullptr);
+                    if (cs2) hipLaunchKernelGGL((k_col<1, 2>), gAg, blk, lcs, sg, A, M, N, thr, wk, og, pk, (const unsigned*)nullptr);
                     else hipLaunchKernelGGL(k_col<1>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
                     if (prof) prof_end(p, sg, &slot);
                     if (three) {
@@ -1160,7 +1173,7 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
                 }
             }
             if (last) {
-                if (cs2) hipLaunchKernelGGL((k_col<2, 2>), gAg, blk, lc, sg, A, M, N, thr, wk, og, pk, (const unsigned*)nullptr);
+                if (cs2) hipLaunchKernelGGL((k_col<2, 2>), gAg, blk, lcs, sg, A, M, N, thr, wk, og, pk, (const unsigned*)nullptr);
                 else hipLaunchKernelGGL(k_col<2>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
             }
         };

@@ -235,6 +235,61 @@ __device__ __forceinline__ void fft_stage_tab(const cplx* __restrict__ in, cplx*
     __syncthreads();
 }
 
+// In-place form of the stage above for workgroups with at least one thread per butterfly (L / R * nseq <= blockDim.x): every
+// butterfly is read into registers, a barrier retires the reads, then the results overwrite the same buffer.  Two barriers per
+// stage instead of one, half the LDS (no ping-pong buffer) -- which is what lets a third workgroup share the CU.
+template <int R, int NS, bool SEQFAST>
+__device__ __forceinline__ void fft_stage_tab_inplace(cplx* __restrict__ buf, int L, const cplx* __restrict__ stw, int nseq, int seq_log2,
+                                                      int es, int ss, bool swap_in, bool swap_out) {
+    constexpr int RS = sched_row_stride(R);
+    const int nb = L / R;
+    const int b = threadIdx.x;
+    const bool on = b < nb * nseq;
+    int s = 0, j = 0;
+    if (SEQFAST) { s = b & (nseq - 1); j = b >> seq_log2; }
+    else { s = (b >= nb) ? 1 : 0; j = b - s * nb; }
+    const int k = (NS == 1) ? 0 : j % NS;
+    cplx v[R];
+    if (on) {
+        const cplx* src = buf + s * ss;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const cplx x = src[(j + t * nb) * es];
+            v[t] = swap_in ? make_float2(x.y, x.x) : x;
+        }
+        if (NS > 1) {
+            const float4* tp = (const float4*)(stw + (size_t)k * RS);
+#pragma unroll
+            for (int t2 = 0; t2 < RS / 2; ++t2) {
+                const float4 w = tp[t2];
+                if (2 * t2 >= 1 && 2 * t2 < R) v[2 * t2] = cmul(v[2 * t2], make_float2(w.x, w.y));
+                if (2 * t2 + 1 < R) v[2 * t2 + 1] = cmul(v[2 * t2 + 1], make_float2(w.z, w.w));
+            }
+        }
+        Bfly<R>::run(v);
+    }
+    __syncthreads();
+    if (on) {
+        cplx* dst = buf + s * ss + ((j - k) * R + k) * es;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const cplx x = v[t];
+            dst[t * NS * es] = swap_out ? make_float2(x.y, x.x) : x;
+        }
+    }
+    __syncthreads();
+}
+
+template <bool SEQFAST, int R0, int R1, int R2>
+__device__ __forceinline__ void lds_fft_sched_inplace(cplx* buf, int L, const cplx* __restrict__ stw, int nseq, int seq_log2, int es, int ss,
+                                                      bool inverse) {
+    constexpr int NST = R2 > 1 ? 3 : 2;
+    fft_stage_tab_inplace<R0, 1, SEQFAST>(buf, L, stw, nseq, seq_log2, es, ss, inverse, false);
+    fft_stage_tab_inplace<R1, R0, SEQFAST>(buf, L, stw, nseq, seq_log2, es, ss, false, inverse && NST == 2);
+    if (R2 > 1)
+        fft_stage_tab_inplace<(R2 > 1 ? R2 : 2), R0 * R1, SEQFAST>(buf, L, stw + R0 * sched_row_stride(R1), nseq, seq_log2, es, ss, false, inverse);
+}
+
 // Transform with the compile-time schedule <R0, R1, R2> (R2 = 1: two stages); tables of stage 1 at stw, of stage 2 behind them.
 template <bool SEQFAST, int R0, int R1, int R2>
 __device__ __forceinline__ void lds_fft_sched(cplx*& cur, cplx*& alt, int L, const cplx* __restrict__ stw, int nseq, int seq_log2, int es,
