@@ -141,6 +141,9 @@ __global__ __launch_bounds__(256, 2) void k_aggr(float* sink, int iters) {
 // M 0: packed-fp32 FMA chain, all lanes active.  1: the same under a partial EXEC mask (16 of 64 lanes).  2: packed ops with
 // component swizzles (op_sel forms: complex multiply).  3: plain scalar fp32 FMA chain (control).  4: registers only -- 48 values
 // are held across a long scalar spin and written back unchanged (is the register file itself disturbed?).  5: v_sqrt chain.
+// 6: v_pk_add_f32 without swizzle, with and without neg modifiers (clean).  7: the same add with op_sel swapping the second operand's
+// halves (20/20 runs wrong).  8: v_pk_mov_b32 with swapped halves -- a pure MOVE (15/20 runs wrong): the fault sits in the VOP3P
+// op_sel routing of a high source dword into the low lane, not in the arithmetic.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int Mv>
 __global__ __launch_bounds__(256) void k_micro(const float* __restrict__ in, float* __restrict__ out, int iters) {
@@ -179,6 +182,31 @@ __global__ __launch_bounds__(256) void k_micro(const float* __restrict__ in, flo
 #pragma unroll
         for (int j = 0; j < 48; ++j) { asm volatile("" : "+v"(r[j])); sacc += r[j] * (float)(1 + (j & 3)); }
         acc.x = sacc; acc.y = r[17];
+    } else if (Mv == 6) {                                         // unswizzled packed add / subtract (neg modifiers), as csrc cadd / csub
+        for (int i = 0; i < iters; ++i) {
+            f32x2 t;
+            asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(t) : "v"(acc), "v"(x));
+            asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(x) : "v"(acc), "v"(x));
+            acc.x = t.x * 0.5f; acc.y = t.y * 0.25f; x.x *= 0.75f; x.y *= 0.5f;
+            asm volatile("" : "+v"(acc), "+v"(x));
+        }
+    } else if (Mv == 7) {                                         // the same add with the second operand's halves swapped (op_sel)
+        for (int i = 0; i < iters; ++i) {
+            f32x2 t;
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(acc), "v"(x));
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(x) : "v"(acc), "v"(x));
+            acc.x = t.x * 0.5f; acc.y = t.y * 0.25f; x.x *= 0.75f; x.y *= 0.5f;
+            asm volatile("" : "+v"(acc), "+v"(x));
+        }
+    } else if (Mv == 8) {                                         // packed MOVE with swapped halves between scalar arithmetic
+        for (int i = 0; i < iters; ++i) {
+            f32x2 t;
+            asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(t) : "v"(acc), "v"(x));
+            acc.x = fmaf(t.x, 0.5f, x.y); acc.y = fmaf(t.y, 0.25f, x.x);
+            asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(x) : "v"(x), "v"(x));
+            x.x *= 0.75f; x.y *= 0.5f;
+            asm volatile("" : "+v"(acc), "+v"(x));
+        }
     } else {
         float a0 = fabsf(x.x) + 1.f, a1 = fabsf(x.y) + 2.f;
         for (int i = 0; i < iters; ++i) { a0 = sqrtf(a0 * 1.5f + 1.f); asm volatile("" : "+v"(a0)); a1 = sqrtf(a1 + a0); asm volatile("" : "+v"(a1)); }
@@ -332,8 +360,10 @@ int main() {
         std::vector<float> hi(n), hr(n), hg(n);
         for (auto& v : hi) v = ((rand() % 2001) / 1000.0f - 1.0f);
         CK(hipMemcpy(min_, hi.data(), n * 4, hipMemcpyHostToDevice));
-        const char* mn[6] = {"packed-fp32 FMA chain, full EXEC", "packed-fp32 FMA chain, 16 of 64 lanes", "packed-fp32 with swizzled operands (op_sel)",
-                             "scalar fp32 FMA chain", "48 registers held across a scalar spin", "v_sqrt_f32 chain"};
+        const char* mn[9] = {"packed-fp32 FMA chain, full EXEC", "packed-fp32 FMA chain, 16 of 64 lanes", "packed-fp32 with swizzled operands (op_sel)",
+                             "scalar fp32 FMA chain", "48 registers held across a scalar spin", "v_sqrt_f32 chain",
+                             "v_pk_add_f32 unswizzled, with and without neg", "v_pk_add_f32 with swapped halves (op_sel)",
+                             "v_pk_mov_b32 with swapped halves"};
         auto micro = [&](int Mv, hipStream_t st, float* o) {
             switch (Mv) {
                 case 0: hipLaunchKernelGGL(k_micro<0>, dim3(nwg), dim3(256), 0, st, min_, o, 200); break;
@@ -341,10 +371,13 @@ int main() {
                 case 2: hipLaunchKernelGGL(k_micro<2>, dim3(nwg), dim3(256), 0, st, min_, o, 200); break;
                 case 3: hipLaunchKernelGGL(k_micro<3>, dim3(nwg), dim3(256), 0, st, min_, o, 200); break;
                 case 4: hipLaunchKernelGGL(k_micro<4>, dim3(nwg), dim3(256), 0, st, min_, o, 200); break;
+                case 6: hipLaunchKernelGGL(k_micro<6>, dim3(nwg), dim3(256), 0, st, min_, o, 200); break;
+                case 7: hipLaunchKernelGGL(k_micro<7>, dim3(nwg), dim3(256), 0, st, min_, o, 200); break;
+                case 8: hipLaunchKernelGGL(k_micro<8>, dim3(nwg), dim3(256), 0, st, min_, o, 200); break;
                 default: hipLaunchKernelGGL(k_micro<5>, dim3(nwg), dim3(256), 0, st, min_, o, 200); break;
             }
         };
-        for (int Mv = 0; Mv < 6; ++Mv) {
+        for (int Mv = 0; Mv < 9; ++Mv) {
             micro(Mv, s[1], mref);
             CK(hipDeviceSynchronize());
             CK(hipMemcpy(hr.data(), mref, n * 4, hipMemcpyDeviceToHost));
