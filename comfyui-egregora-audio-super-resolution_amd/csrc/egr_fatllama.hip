@@ -118,6 +118,10 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 #ifndef EGR_FL_INPLACE
 #define EGR_FL_INPLACE 1
 #endif
+// rows of the in-place 2304-point schedule are stored with one pad element per 16 (lds_pad): conflict-free first-stage writes
+#ifndef EGR_FL_ROW_PAD
+#define EGR_FL_ROW_PAD 4
+#endif
 #ifndef EGR_FL_SCHED_WAVES
 #define EGR_FL_SCHED_WAVES (EGR_FL_INPLACE ? 6 : 4)
 #endif
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
 // SCHED 1: L = 2304 as 16 x 16 x 9 with compile-time stages.
 template <int SCHED>
 __device__ __forceinline__ void row_fft(cplx*& cur, cplx*& alt, const RowP& p, int nrows, int L, bool inverse) {
-    if (SCHED == 1 && EGR_FL_INPLACE) lds_fft_sched_inplace<false, 16, 16, 9>(cur, L, p.stw, nrows, 0, 1, L, inverse);
+    if (SCHED == 1 && EGR_FL_INPLACE) lds_fft_sched_inplace<false, 16, 16, 9, EGR_FL_ROW_PAD>(cur, L, p.stw, nrows, 0, 1, lds_pad<EGR_FL_ROW_PAD>(L), inverse);
     else if (SCHED == 1) lds_fft_sched<false, 16, 16, 9>(cur, alt, L, p.stw, nrows, 0, 1, L, inverse);
     else lds_fft<false>(cur, alt, p.f, p.tw, nrows, 0, 1, L, inverse, p.twd);
 }
@@ -240,10 +244,12 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
     cplx* ga = W + (size_t)ra * L;
     cplx* gb = W + (size_t)rbw * L;
 
+    constexpr int PSH = (SCHED == 1 && EGR_FL_INPLACE) ? EGR_FL_ROW_PAD : 0;      // LDS row layout: element i at lds_pad<PSH>(i)
+    const int Lp = lds_pad<PSH>(L);
     EGR_STAMP(p, 0);
     for (int e = threadIdx.x; e < L; e += blockDim.x) {
-        cur[e] = ga[e];
-        if (!self) cur[L + e] = gb[e];
+        cur[lds_pad<PSH>(e)] = ga[e];
+        if (!self) cur[Lp + lds_pad<PSH>(e)] = gb[e];
     }
     __syncthreads();
     EGR_STAMP(p, 1);
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
     const dcplx wa = tw2d(p.wo, (unsigned)oa);
     int cnt, boff;          // partner of row-a element k is row-b element (boff - k) mod L
     cplx* rb;
-    if (!self) { cnt = L; boff = L - 1; rb = cur + L; }
+    if (!self) { cnt = L; boff = L - 1; rb = cur + Lp; }
     else if (oa == 0) { cnt = L / 2 + 1; boff = L; rb = cur; }
     else { cnt = (L + 1) / 2; boff = L - 1; rb = cur; }
     const float sc = p.inv_M;
@@ -270,8 +276,9 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
         int pb = boff - k2;
         if (pb >= L) pb -= L;
         const bool same = self && (pb == k2);
-        const cplx Za = cur[k2];
-        const cplx Zb = rb[pb];
+        const int ia = lds_pad<PSH>(k2), ib = lds_pad<PSH>(pb);
+        const cplx Za = cur[ia];
+        const cplx Zb = rb[ib];
         const dcplx Wkd = dcmul(wa, p.wk[k2]);
         const cplx Wk = make_float2((float)Wkd.x, (float)Wkd.y);
         // E = (Za + conj Zb)/2 ; O = (Za - conj Zb)/(2i)
@@ -283,8 +290,8 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
             cplx Rk = cmulc(O, E);
             const float inv = sc / (sqrtf(Rk.x * Rk.x + Rk.y * Rk.y) + 1e-12f);
             Rk.x *= inv; Rk.y *= inv;
-            cur[k2] = Rk;
-            if (!same) rb[pb] = make_float2(Rk.x, -Rk.y);
+            cur[ia] = Rk;
+            if (!same) rb[ib] = make_float2(Rk.x, -Rk.y);
             continue;
         }
         const cplx WO = cmul(Wk, O);
@@ -319,8 +326,8 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
         const cplx H = make_float2(0.5f * (Xk.x - Xm.x), 0.5f * (Xk.y - Xm.y));
         const cplx O2 = cmulc(H, Wk);
         // Za' = E2 + i*O2 ; Zb' = conj(E2 - i*O2)
-        cur[k2] = make_float2((float)(scd * (double)(E2.x - O2.y)), (float)(scd * (double)(E2.y + O2.x)));
-        if (!same) rb[pb] = make_float2((float)(scd * (double)(E2.x + O2.y)), -(float)(scd * (double)(E2.y - O2.x)));
+        cur[ia] = make_float2((float)(scd * (double)(E2.x - O2.y)), (float)(scd * (double)(E2.y + O2.x)));
+        if (!same) rb[ib] = make_float2((float)(scd * (double)(E2.x + O2.y)), -(float)(scd * (double)(E2.y - O2.x)));
     }
     if (MAXONLY) {
         mx2 = block_max(mx2, red);
@@ -332,8 +339,8 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
     row_fft<SCHED>(cur, alt, p, nrows, L, true);
     EGR_STAMP(p, 4);
     for (int e = threadIdx.x; e < L; e += blockDim.x) {
-        ga[e] = cur[e];
-        if (!self) gb[e] = cur[L + e];
+        ga[e] = cur[lds_pad<PSH>(e)];
+        if (!self) gb[e] = cur[Lp + lds_pad<PSH>(e)];
     }
     EGR_STAMP(p, 5);
 }
@@ -981,7 +988,7 @@ extern "C" int egr_fatllama_trace_once(egr_fatllama_plan* p, void* stream) {
         R.trace = tr; A.trace = tr;
         for (int rep = 0; rep < 3; ++rep) {          // the last repetition's stamps survive
             if (which == 0) {
-                if (p->row_sched == 1) hipLaunchKernelGGL((k_row<false, 1>), grow, blk, p->sp.lds_row / (EGR_FL_INPLACE ? 2 : 1), st, R, M, p->d_work);
+                if (p->row_sched == 1) hipLaunchKernelGGL((k_row<false, 1>), grow, blk, EGR_FL_INPLACE ? (size_t)2 * (R.L + (EGR_FL_ROW_PAD ? R.L >> EGR_FL_ROW_PAD : 0)) * sizeof(cplx) : p->sp.lds_row, st, R, M, p->d_work);
                 else hipLaunchKernelGGL(k_row<false>, grow, blk, p->sp.lds_row, st, R, M, p->d_work);
             } else {
                 if (p->col_sched == 2) hipLaunchKernelGGL((k_col<1, 2>), gA, blk, p->sp.lds_col / (EGR_FL_INPLACE ? 2 : 1), st, A, M, N, 0.6f, p->d_work, (float*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr);
@@ -1121,7 +1128,9 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         // the in-place schedules need one thread per butterfly (288 / 512 row, 200 column butterflies per stage): 512 threads
         const bool sched_ok = EGR_FL_INPLACE ? p->threads == 512 : p->threads <= 512;
         const bool rs1 = p->row_sched == 1 && sched_ok, cs2 = p->col_sched == 2 && sched_ok && !three;
-        const size_t lrs = EGR_FL_INPLACE ? lr / 2 : lr, lcs = EGR_FL_INPLACE ? lc / 2 : lc;   // no ping-pong buffer
+        // no ping-pong buffer; the row kernel's two rows are padded by one element per 2^EGR_FL_ROW_PAD
+        const size_t lrs = EGR_FL_INPLACE ? (size_t)2 * (R.L + (EGR_FL_ROW_PAD ? R.L >> EGR_FL_ROW_PAD : 0)) * sizeof(cplx) : lr;
+        const size_t lcs = EGR_FL_INPLACE ? lc / 2 : lc;
         if (ngroups == 2 && !p->side) {
             EGR_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
             p->side_owned = 1;

@@ -238,7 +238,12 @@ __device__ __forceinline__ void fft_stage_tab(const cplx* __restrict__ in, cplx*
 // In-place form of the stage above for workgroups with at least one thread per butterfly (L / R * nseq <= blockDim.x): every
 // butterfly is read into registers, a barrier retires the reads, then the results overwrite the same buffer.  Two barriers per
 // stage instead of one, half the LDS (no ping-pong buffer) -- which is what lets a third workgroup share the CU.
-template <int R, int NS, bool SEQFAST>
+// PSH > 0: element i of a sequence sits at i + (i >> PSH) (one pad element per 2^PSH): the first Stockham stage of a contiguous
+// sequence writes butterfly j's outputs at j R + t -- a lane stride of 8 R bytes, every lane of a half-wave on the same two banks --
+// and the pad turns that into a stride of 8 R + 8 (conflict-free); the strided reads stay conflict-free.
+template <int PSH> __device__ __forceinline__ int lds_pad(int i) { return PSH ? i + (i >> PSH) : i; }
+
+template <int R, int NS, bool SEQFAST, int PSH = 0>
 __device__ __forceinline__ void fft_stage_tab_inplace(cplx* __restrict__ buf, int L, const cplx* __restrict__ stw, int nseq, int seq_log2,
                                                       int es, int ss, bool swap_in, bool swap_out) {
     constexpr int RS = sched_row_stride(R);
@@ -254,7 +259,7 @@ __device__ __forceinline__ void fft_stage_tab_inplace(cplx* __restrict__ buf, in
         const cplx* src = buf + s * ss;
 #pragma unroll
         for (int t = 0; t < R; ++t) {
-            const cplx x = src[(j + t * nb) * es];
+            const cplx x = src[lds_pad<PSH>(j + t * nb) * es];
             v[t] = swap_in ? make_float2(x.y, x.x) : x;
         }
         if (NS > 1) {
@@ -270,24 +275,25 @@ __device__ __forceinline__ void fft_stage_tab_inplace(cplx* __restrict__ buf, in
     }
     __syncthreads();
     if (on) {
-        cplx* dst = buf + s * ss + ((j - k) * R + k) * es;
+        cplx* dst = buf + s * ss;
+        const int o0 = (j - k) * R + k;
 #pragma unroll
         for (int t = 0; t < R; ++t) {
             const cplx x = v[t];
-            dst[t * NS * es] = swap_out ? make_float2(x.y, x.x) : x;
+            dst[lds_pad<PSH>(o0 + t * NS) * es] = swap_out ? make_float2(x.y, x.x) : x;
         }
     }
     __syncthreads();
 }
 
-template <bool SEQFAST, int R0, int R1, int R2>
+template <bool SEQFAST, int R0, int R1, int R2, int PSH = 0>
 __device__ __forceinline__ void lds_fft_sched_inplace(cplx* buf, int L, const cplx* __restrict__ stw, int nseq, int seq_log2, int es, int ss,
                                                       bool inverse) {
     constexpr int NST = R2 > 1 ? 3 : 2;
-    fft_stage_tab_inplace<R0, 1, SEQFAST>(buf, L, stw, nseq, seq_log2, es, ss, inverse, false);
-    fft_stage_tab_inplace<R1, R0, SEQFAST>(buf, L, stw, nseq, seq_log2, es, ss, false, inverse && NST == 2);
+    fft_stage_tab_inplace<R0, 1, SEQFAST, PSH>(buf, L, stw, nseq, seq_log2, es, ss, inverse, false);
+    fft_stage_tab_inplace<R1, R0, SEQFAST, PSH>(buf, L, stw, nseq, seq_log2, es, ss, false, inverse && NST == 2);
     if (R2 > 1)
-        fft_stage_tab_inplace<(R2 > 1 ? R2 : 2), R0 * R1, SEQFAST>(buf, L, stw + R0 * sched_row_stride(R1), nseq, seq_log2, es, ss, false, inverse);
+        fft_stage_tab_inplace<(R2 > 1 ? R2 : 2), R0 * R1, SEQFAST, PSH>(buf, L, stw + R0 * sched_row_stride(R1), nseq, seq_log2, es, ss, false, inverse);
 }
 
 // Transform with the compile-time schedule <R0, R1, R2> (R2 = 1: two stages); tables of stage 1 at stw, of stage 2 behind them.
