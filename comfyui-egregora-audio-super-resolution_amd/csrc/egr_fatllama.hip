@@ -115,20 +115,30 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // SCHED 0: run-time radix schedule (any plan).  SCHED 2: L = 625 as 25 x 25 with compile-time stages (egr_fft_device.h).
 // The compile-time schedules run IN PLACE (one buffer, two barriers per stage): half the LDS of the ping-pong form, so that
 // three 512-thread workgroups share a CU (6 waves per SIMD) and the two channels' kernels are fully resident together.
-#ifndef EGR_FL_INPLACE
-#define EGR_FL_INPLACE 1
-#endif
 // rows of the in-place 2304-point schedule are stored with one pad element per 16 (lds_pad): conflict-free first-stage writes
 #ifndef EGR_FL_ROW_PAD
 #define EGR_FL_ROW_PAD 4
 #endif
+// radix schedules of the two hot lengths (each a product of up to five radices with a register butterfly)
+#ifndef EGR_FL_ROW_RADICES
+#define EGR_FL_ROW_RADICES 16, 12, 12
+#endif
+// column tile of the 625-point schedule: columns per workgroup (64-byte = 8, 32-byte = 4 segments per row) and workgroup size
+#ifndef EGR_FL_COL_TC
+#define EGR_FL_COL_TC 4
+#endif
+#ifndef EGR_FL_COL_THREADS
+#define EGR_FL_COL_THREADS 512
+#endif
+#ifndef EGR_FL_COL_RADICES
+#define EGR_FL_COL_RADICES 25, 25
+#endif
 #ifndef EGR_FL_SCHED_WAVES
-#define EGR_FL_SCHED_WAVES (EGR_FL_INPLACE ? 6 : 4)
+#define EGR_FL_SCHED_WAVES 6
 #endif
 template <int SCHED>
 __device__ __forceinline__ void col_fft(cplx*& cur, cplx*& alt, const ColP& p, int TC, int lg, bool inverse) {
-    if (SCHED == 2 && EGR_FL_INPLACE) lds_fft_sched_inplace<true, 25, 25, 1>(cur, p.L, p.stw, TC, lg, TC, 1, inverse);
-    else if (SCHED == 2) lds_fft_sched<true, 25, 25, 1>(cur, alt, p.L, p.stw, TC, lg, TC, 1, inverse);
+    if (SCHED == 2) lds_fft_sched_inplace<true, 0, 625 * EGR_FL_COL_TC, EGR_FL_COL_THREADS, EGR_FL_COL_RADICES>(cur, p.L, p.stw, TC, lg, TC, 1, inverse);
     else lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, inverse, p.twd);
 }
 
@@ -221,8 +231,7 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
 // SCHED 1: L = 2304 as 16 x 16 x 9 with compile-time stages.
 template <int SCHED>
 __device__ __forceinline__ void row_fft(cplx*& cur, cplx*& alt, const RowP& p, int nrows, int L, bool inverse) {
-    if (SCHED == 1 && EGR_FL_INPLACE) lds_fft_sched_inplace<false, 16, 16, 9, EGR_FL_ROW_PAD>(cur, L, p.stw, nrows, 0, 1, lds_pad<EGR_FL_ROW_PAD>(L), inverse);
-    else if (SCHED == 1) lds_fft_sched<false, 16, 16, 9>(cur, alt, L, p.stw, nrows, 0, 1, L, inverse);
+    if (SCHED == 1) lds_fft_sched_inplace<false, EGR_FL_ROW_PAD, 2304 * 2, 512, EGR_FL_ROW_RADICES>(cur, L, p.stw, nrows, 0, 1, lds_pad<EGR_FL_ROW_PAD>(L), inverse);
     else lds_fft<false>(cur, alt, p.f, p.tw, nrows, 0, 1, L, inverse, p.twd);
 }
 
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
     cplx* ga = W + (size_t)ra * L;
     cplx* gb = W + (size_t)rbw * L;
 
-    constexpr int PSH = (SCHED == 1 && EGR_FL_INPLACE) ? EGR_FL_ROW_PAD : 0;      // LDS row layout: element i at lds_pad<PSH>(i)
+    constexpr int PSH = SCHED == 1 ? EGR_FL_ROW_PAD : 0;      // LDS row layout: element i at lds_pad<PSH>(i)
     const int Lp = lds_pad<PSH>(L);
     EGR_STAMP(p, 0);
     for (int e = threadIdx.x; e < L; e += blockDim.x) {
@@ -695,7 +704,7 @@ static int upload_dtab(egr_fatllama_plan* p, int64_t count, int64_t num, int64_t
 
 // butterfly-ordered stage tables of a compile-time schedule (R0, R1, R2; R2 = 1: two stages): for stage s >= 1 with
 // Ns = product of the earlier radices, row k < Ns holds W_(Ns R)^(k t), t = 0 .. R-1, padded to an even entry count
-static int upload_sched_tables(egr_fatllama_plan* p, int R0, int R1, int R2, const cplx** d) {
+static int upload_sched_tables(egr_fatllama_plan* p, std::initializer_list<int> radices, const cplx** d) {
     std::vector<float2> h;
     const long double two_pi = 6.283185307179586476925286766559L;
     auto add = [&](int Ns, int R) {
@@ -706,8 +715,12 @@ static int upload_sched_tables(egr_fatllama_plan* p, int R0, int R1, int R2, con
                 h.push_back(make_float2((float)cosl(ang), (float)sinl(ang)));
             }
     };
-    add(R0, R1);
-    if (R2 > 1) add(R0 * R1, R2);
+    int ns = 1, s = 0;
+    for (int r : radices) {
+        if (s > 0 && r > 1) add(ns, r);
+        ns *= r;
+        ++s;
+    }
     return upload(p, h, d);
 }
 
@@ -835,8 +848,8 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     p->row_sched = p->col_sched = 0;
     {
         const bool off = getenv("EGR_FL_SCHED") && atoi(getenv("EGR_FL_SCHED")) == 0;
-        if (!off && !p->bluestein && r.L == 2304) { if ((rc = upload_sched_tables(p, 16, 16, 9, &r.stw))) return fail(rc); p->row_sched = 1; }
-        if (!off && !p->bluestein && a.L == 625 && a.TC <= 8) { if ((rc = upload_sched_tables(p, 25, 25, 1, &a.stw))) return fail(rc); p->col_sched = 2; }
+        if (!off && !p->bluestein && r.L == 2304) { if ((rc = upload_sched_tables(p, {EGR_FL_ROW_RADICES}, &r.stw))) return fail(rc); p->row_sched = 1; }
+        if (!off && !p->bluestein && a.L == 625 && a.TC <= EGR_FL_COL_TC) { if ((rc = upload_sched_tables(p, {EGR_FL_COL_RADICES}, &a.stw))) return fail(rc); p->col_sched = 2; }
     }
     if (hipMalloc((void**)&p->d_work, (size_t)channels * M * sizeof(float2)) != hipSuccess ||
         hipMalloc((void**)&p->d_peaks, 3 * channels * sizeof(unsigned)) != hipSuccess) {
@@ -933,6 +946,8 @@ extern "C" int egr_fatllama_plan_create(egr_fatllama_plan** out, int64_t n_in, i
     if (m1_hint <= 0) { if (const char* e = getenv("EGR_FL_M1")) m1_hint = atoi(e); }
     if (tc_hint <= 0) { if (const char* e = getenv("EGR_FL_TC")) tc_hint = atoi(e); }
     FlSplit sp = plan_split(N, m1_hint, tc_hint);
+    // the 625-point column schedule is instantiated for one tile width
+    if (tc_hint <= 0 && sp.ok && sp.levels == 2 && sp.M1 == 625 && sp.TC != EGR_FL_COL_TC) sp = plan_split(N, m1_hint, EGR_FL_COL_TC);
     if (!sp.ok) {
         if (N >= 2 && bluestein_length(2 * N - 1, &sp)) return build_plan(out, n_in, channels, factor, sp, N);
         set_error(kUnsupported, (long long)N);
@@ -988,10 +1003,10 @@ extern "C" int egr_fatllama_trace_once(egr_fatllama_plan* p, void* stream) {
         R.trace = tr; A.trace = tr;
         for (int rep = 0; rep < 3; ++rep) {          // the last repetition's stamps survive
             if (which == 0) {
-                if (p->row_sched == 1) hipLaunchKernelGGL((k_row<false, 1>), grow, blk, EGR_FL_INPLACE ? (size_t)2 * (R.L + (EGR_FL_ROW_PAD ? R.L >> EGR_FL_ROW_PAD : 0)) * sizeof(cplx) : p->sp.lds_row, st, R, M, p->d_work);
+                if (p->row_sched == 1) hipLaunchKernelGGL((k_row<false, 1>), grow, blk, (size_t)2 * (R.L + (EGR_FL_ROW_PAD ? R.L >> EGR_FL_ROW_PAD : 0)) * sizeof(cplx), st, R, M, p->d_work);
                 else hipLaunchKernelGGL(k_row<false>, grow, blk, p->sp.lds_row, st, R, M, p->d_work);
             } else {
-                if (p->col_sched == 2) hipLaunchKernelGGL((k_col<1, 2>), gA, blk, p->sp.lds_col / (EGR_FL_INPLACE ? 2 : 1), st, A, M, N, 0.6f, p->d_work, (float*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr);
+                if (p->col_sched == 2) hipLaunchKernelGGL((k_col<1, 2>), gA, dim3(EGR_FL_COL_THREADS), p->sp.lds_col / 2, st, A, M, N, 0.6f, p->d_work, (float*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr);
                 else hipLaunchKernelGGL(k_col<1>, gA, blk, p->sp.lds_col, st, A, M, N, 0.6f, p->d_work, (float*)nullptr, (unsigned*)nullptr);
             }
         }
@@ -1126,11 +1141,12 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         // group's k_row overlaps the other's k_col.
         const int ngroups = (p->nstreams == 2 && C >= 2) ? 2 : 1;
         // the in-place schedules need one thread per butterfly (288 / 512 row, 200 column butterflies per stage): 512 threads
-        const bool sched_ok = EGR_FL_INPLACE ? p->threads == 512 : p->threads <= 512;
+        const bool sched_ok = p->threads == 512;
+        const dim3 blkc(EGR_FL_COL_THREADS);      // the scheduled column kernels' own workgroup size
         const bool rs1 = p->row_sched == 1 && sched_ok, cs2 = p->col_sched == 2 && sched_ok && !three;
         // no ping-pong buffer; the row kernel's two rows are padded by one element per 2^EGR_FL_ROW_PAD
-        const size_t lrs = EGR_FL_INPLACE ? (size_t)2 * (R.L + (EGR_FL_ROW_PAD ? R.L >> EGR_FL_ROW_PAD : 0)) * sizeof(cplx) : lr;
-        const size_t lcs = EGR_FL_INPLACE ? lc / 2 : lc;
+        const size_t lrs = (size_t)2 * (R.L + (EGR_FL_ROW_PAD ? R.L >> EGR_FL_ROW_PAD : 0)) * sizeof(cplx);
+        const size_t lcs = lc / 2;
         if (ngroups == 2 && !p->side) {
             EGR_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
             p->side_owned = 1;
@@ -1148,7 +1164,7 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
             unsigned* pk = peak_out + c0;
             const dim3 gAg(gA.x, cn), gBg(gB.x, cn * (three ? B.nplanes : 1)), growg(grow.x, cn);
             if (first) {
-                if (cs2) hipLaunchKernelGGL((k_col<0, 2>), gAg, blk, lcs, sg, A, M, N, thr0, wk, og, pk, thr0_rel ? thr0_rel + c0 : nullptr);
+                if (cs2) hipLaunchKernelGGL((k_col<0, 2>), gAg, blkc, lcs, sg, A, M, N, thr0, wk, og, pk, thr0_rel ? thr0_rel + c0 : nullptr);
                 else hipLaunchKernelGGL(k_col<0>, gAg, blk, lc, sg, A, M, N, thr0, wk, og, pk, thr0_rel ? thr0_rel + c0 : nullptr);
                 if (three) hipLaunchKernelGGL(k_col<4>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
             }
@@ -1171,7 +1187,7 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
                 }
                 if (it + 1 < max_iter) {
                     if (prof) prof_begin(p, 1, sg, &slot);
-                    if (cs2) hipLaunchKernelGGL((k_col<1, 2>), gAg, blk, lcs, sg, A, M, N, thr, wk, og, pk, (const unsigned*)nullptr);
+                    if (cs2) hipLaunchKernelGGL((k_col<1, 2>), gAg, blkc, lcs, sg, A, M, N, thr, wk, og, pk, (const unsigned*)nullptr);
                     else hipLaunchKernelGGL(k_col<1>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
                     if (prof) prof_end(p, sg, &slot);
                     if (three) {
@@ -1182,7 +1198,7 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
                 }
             }
             if (last) {
-                if (cs2) hipLaunchKernelGGL((k_col<2, 2>), gAg, blk, lcs, sg, A, M, N, thr, wk, og, pk, (const unsigned*)nullptr);
+                if (cs2) hipLaunchKernelGGL((k_col<2, 2>), gAg, blkc, lcs, sg, A, M, N, thr, wk, og, pk, (const unsigned*)nullptr);
                 else hipLaunchKernelGGL(k_col<2>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
             }
         };

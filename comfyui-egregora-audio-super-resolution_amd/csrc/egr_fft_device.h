@@ -121,6 +121,9 @@ template <int R1, int R2> struct BflyComp {
     }
 };
 template <> struct Bfly<8> { static __device__ __forceinline__ void run(cplx (&v)[8]) { BflyComp<4, 2>::run(v); } };
+template <> struct Bfly<6> { static __device__ __forceinline__ void run(cplx (&v)[6]) { BflyComp<3, 2>::run(v); } };
+template <> struct Bfly<12> { static __device__ __forceinline__ void run(cplx (&v)[12]) { BflyComp<4, 3>::run(v); } };
+template <> struct Bfly<10> { static __device__ __forceinline__ void run(cplx (&v)[10]) { BflyComp<5, 2>::run(v); } };
 template <> struct Bfly<9> { static __device__ __forceinline__ void run(cplx (&v)[9]) { BflyComp<3, 3>::run(v); } };
 template <> struct Bfly<16> { static __device__ __forceinline__ void run(cplx (&v)[16]) { BflyComp<4, 4>::run(v); } };
 template <> struct Bfly<25> { static __device__ __forceinline__ void run(cplx (&v)[25]) { BflyComp<5, 5>::run(v); } };
@@ -190,52 +193,15 @@ __device__ __forceinline__ void fft_stage(const cplx* __restrict__ in, cplx* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Compile-time schedules (the hot Fat-Llama plans): big register butterflies (16 = 4x4, 25 = 5x5, 9 = 3x3) cut the number
-// of barrier-separated LDS round trips of a transform (2304 = 16 16 9: 3 instead of 4; 625 = 25 25: 2 instead of 4), and a
-// kernel instantiated for ONE schedule keeps only that schedule's registers (the all-radix kernel needed 190 VGPRs with
-// the composites in).  Stage twiddles come from a per-stage table laid out for the butterfly: row k holds W^(k t), t = 0..R-1
-// (padded to an even count so rows are 16-byte aligned), rounded once from long double -- no fp64 power chains in the loop.
+// Compile-time schedules (the hot Fat-Llama plans): a kernel instantiated for ONE radix schedule keeps only that schedule's
+// registers (the all-radix kernel needed 190 VGPRs with the composite butterflies in) and its stages run in place.  Measured on
+// the C3 plan (gpurun_out/sw48 - sw50): rows 2304 = 16 12 12 beats 16 16 9, 8 8 6 6, 4 4 4 4 9 and every order starting with 12 or 9
+// (the pad of lds_pad is matched to a first radix of 16); columns 625 = 25 25 beats 5 5 5 5 and 25 5 5.  Stage twiddles come
+// from a per-stage table laid out for the butterfly: row k holds W^(k t), t = 0..R-1 (padded to an even count so rows are
+// 16-byte aligned), rounded once from long double -- no fp64 power chains in the loop.
 constexpr int sched_row_stride(int R) { return (R + 1) & ~1; }
 
-template <int R, int NS, bool SEQFAST>
-__device__ __forceinline__ void fft_stage_tab(const cplx* __restrict__ in, cplx* __restrict__ out, int L, const cplx* __restrict__ stw,
-                                              int nseq, int seq_log2, int es, int ss, bool swap_in, bool swap_out) {
-    constexpr int RS = sched_row_stride(R);
-    const int nb = L / R;
-    const int total = nb * nseq;
-    for (int b = threadIdx.x; b < total; b += blockDim.x) {
-        int s, j;
-        if (SEQFAST) { s = b & (nseq - 1); j = b >> seq_log2; }
-        else { s = (b >= nb) ? 1 : 0; j = b - s * nb; }
-        const int k = (NS == 1) ? 0 : j % NS;
-        cplx v[R];
-        const cplx* src = in + s * ss;
-#pragma unroll
-        for (int t = 0; t < R; ++t) {
-            const cplx x = src[(j + t * nb) * es];
-            v[t] = swap_in ? make_float2(x.y, x.x) : x;
-        }
-        if (NS > 1) {
-            const float4* tp = (const float4*)(stw + (size_t)k * RS);
-#pragma unroll
-            for (int t2 = 0; t2 < RS / 2; ++t2) {
-                const float4 w = tp[t2];
-                if (2 * t2 >= 1 && 2 * t2 < R) v[2 * t2] = cmul(v[2 * t2], make_float2(w.x, w.y));
-                if (2 * t2 + 1 < R) v[2 * t2 + 1] = cmul(v[2 * t2 + 1], make_float2(w.z, w.w));
-            }
-        }
-        Bfly<R>::run(v);
-        cplx* dst = out + s * ss + ((j - k) * R + k) * es;
-#pragma unroll
-        for (int t = 0; t < R; ++t) {
-            const cplx x = v[t];
-            dst[t * NS * es] = swap_out ? make_float2(x.y, x.x) : x;
-        }
-    }
-    __syncthreads();
-}
-
-// In-place form of the stage above for workgroups with at least one thread per butterfly (L / R * nseq <= blockDim.x): every
+// A stage runs IN PLACE: every
 // butterfly is read into registers, a barrier retires the reads, then the results overwrite the same buffer.  Two barriers per
 // stage instead of one, half the LDS (no ping-pong buffer) -- which is what lets a third workgroup share the CU.
 // PSH > 0: element i of a sequence sits at i + (i >> PSH) (one pad element per 2^PSH): the first Stockham stage of a contiguous
@@ -243,72 +209,80 @@ __device__ __forceinline__ void fft_stage_tab(const cplx* __restrict__ in, cplx*
 // and the pad turns that into a stride of 8 R + 8 (conflict-free); the strided reads stay conflict-free.
 template <int PSH> __device__ __forceinline__ int lds_pad(int i) { return PSH ? i + (i >> PSH) : i; }
 
-template <int R, int NS, bool SEQFAST, int PSH = 0>
+// NBT butterflies per thread (b = tid + n * THREADS, THREADS = the workgroup size), all held in registers across the first barrier.
+template <int R, int NS, bool SEQFAST, int PSH, int NBT, int THREADS>
 __device__ __forceinline__ void fft_stage_tab_inplace(cplx* __restrict__ buf, int L, const cplx* __restrict__ stw, int nseq, int seq_log2,
                                                       int es, int ss, bool swap_in, bool swap_out) {
     constexpr int RS = sched_row_stride(R);
     const int nb = L / R;
-    const int b = threadIdx.x;
-    const bool on = b < nb * nseq;
-    int s = 0, j = 0;
-    if (SEQFAST) { s = b & (nseq - 1); j = b >> seq_log2; }
-    else { s = (b >= nb) ? 1 : 0; j = b - s * nb; }
-    const int k = (NS == 1) ? 0 : j % NS;
-    cplx v[R];
-    if (on) {
-        const cplx* src = buf + s * ss;
+    const int total = nb * nseq;
+    cplx v[NBT][R];
 #pragma unroll
-        for (int t = 0; t < R; ++t) {
-            const cplx x = src[lds_pad<PSH>(j + t * nb) * es];
-            v[t] = swap_in ? make_float2(x.y, x.x) : x;
+    for (int n = 0; n < NBT; ++n) {
+        const int b = threadIdx.x + n * THREADS;
+        if (b < total) {
+            int s, j;
+            if (SEQFAST) { s = b & (nseq - 1); j = b >> seq_log2; }
+            else { s = (b >= nb) ? 1 : 0; j = b - s * nb; }
+            const int k = (NS == 1) ? 0 : j % NS;
+            const cplx* src = buf + s * ss;
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                const cplx x = src[lds_pad<PSH>(j + t * nb) * es];
+                v[n][t] = swap_in ? make_float2(x.y, x.x) : x;
+            }
+            if (NS > 1) {
+                const float2* tp = (const float2*)(stw + (size_t)k * RS);
+                if (RS % 2 == 0) {
+                    const float4* tp4 = (const float4*)tp;
+#pragma unroll
+                    for (int t2 = 0; t2 < RS / 2; ++t2) {
+                        const float4 w = tp4[t2];
+                        if (2 * t2 >= 1 && 2 * t2 < R) v[n][2 * t2] = cmul(v[n][2 * t2], make_float2(w.x, w.y));
+                        if (2 * t2 + 1 < R) v[n][2 * t2 + 1] = cmul(v[n][2 * t2 + 1], make_float2(w.z, w.w));
+                    }
+                }
+            }
+            Bfly<R>::run(v[n]);
         }
-        if (NS > 1) {
-            const float4* tp = (const float4*)(stw + (size_t)k * RS);
+    }
+    __syncthreads();
 #pragma unroll
-            for (int t2 = 0; t2 < RS / 2; ++t2) {
-                const float4 w = tp[t2];
-                if (2 * t2 >= 1 && 2 * t2 < R) v[2 * t2] = cmul(v[2 * t2], make_float2(w.x, w.y));
-                if (2 * t2 + 1 < R) v[2 * t2 + 1] = cmul(v[2 * t2 + 1], make_float2(w.z, w.w));
+    for (int n = 0; n < NBT; ++n) {
+        const int b = threadIdx.x + n * THREADS;
+        if (b < total) {
+            int s, j;
+            if (SEQFAST) { s = b & (nseq - 1); j = b >> seq_log2; }
+            else { s = (b >= nb) ? 1 : 0; j = b - s * nb; }
+            const int k = (NS == 1) ? 0 : j % NS;
+            cplx* dst = buf + s * ss;
+            const int o0 = (j - k) * R + k;
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                const cplx x = v[n][t];
+                dst[lds_pad<PSH>(o0 + t * NS) * es] = swap_out ? make_float2(x.y, x.x) : x;
             }
         }
-        Bfly<R>::run(v);
-    }
-    __syncthreads();
-    if (on) {
-        cplx* dst = buf + s * ss;
-        const int o0 = (j - k) * R + k;
-#pragma unroll
-        for (int t = 0; t < R; ++t) {
-            const cplx x = v[t];
-            dst[lds_pad<PSH>(o0 + t * NS) * es] = swap_out ? make_float2(x.y, x.x) : x;
-        }
     }
     __syncthreads();
 }
 
-template <bool SEQFAST, int R0, int R1, int R2, int PSH = 0>
+// In-place transform with the compile-time schedule <R0 .. R4> (1 = unused).  LTOT: elements of all sequences of the workgroup (fixes
+// the butterflies per thread of every stage).  Stage s > 0 reads its table behind those of the stages before it.
+constexpr int sched_nbt(int ltot, int r, int threads) { return (ltot / r + threads - 1) / threads; }
+template <bool SEQFAST, int PSH, int LTOT, int THREADS, int R0, int R1, int R2 = 1, int R3 = 1, int R4 = 1>
 __device__ __forceinline__ void lds_fft_sched_inplace(cplx* buf, int L, const cplx* __restrict__ stw, int nseq, int seq_log2, int es, int ss,
                                                       bool inverse) {
-    constexpr int NST = R2 > 1 ? 3 : 2;
-    fft_stage_tab_inplace<R0, 1, SEQFAST, PSH>(buf, L, stw, nseq, seq_log2, es, ss, inverse, false);
-    fft_stage_tab_inplace<R1, R0, SEQFAST, PSH>(buf, L, stw, nseq, seq_log2, es, ss, false, inverse && NST == 2);
-    if (R2 > 1)
-        fft_stage_tab_inplace<(R2 > 1 ? R2 : 2), R0 * R1, SEQFAST, PSH>(buf, L, stw + R0 * sched_row_stride(R1), nseq, seq_log2, es, ss, false, inverse);
-}
-
-// Transform with the compile-time schedule <R0, R1, R2> (R2 = 1: two stages); tables of stage 1 at stw, of stage 2 behind them.
-template <bool SEQFAST, int R0, int R1, int R2>
-__device__ __forceinline__ void lds_fft_sched(cplx*& cur, cplx*& alt, int L, const cplx* __restrict__ stw, int nseq, int seq_log2, int es,
-                                              int ss, bool inverse) {
-    constexpr int NST = R2 > 1 ? 3 : 2;
-    fft_stage_tab<R0, 1, SEQFAST>(cur, alt, L, stw, nseq, seq_log2, es, ss, inverse, false);
-    { cplx* t = cur; cur = alt; alt = t; }
-    fft_stage_tab<R1, R0, SEQFAST>(cur, alt, L, stw, nseq, seq_log2, es, ss, false, inverse && NST == 2);
-    { cplx* t = cur; cur = alt; alt = t; }
-    if (R2 > 1) {
-        fft_stage_tab<(R2 > 1 ? R2 : 2), R0 * R1, SEQFAST>(cur, alt, L, stw + R0 * sched_row_stride(R1), nseq, seq_log2, es, ss, false, inverse);
-        cplx* t = cur; cur = alt; alt = t;
-    }
+    constexpr int NST = 2 + (R2 > 1) + (R3 > 1) + (R4 > 1);
+    constexpr int o2 = R0 * sched_row_stride(R1), o3 = o2 + R0 * R1 * sched_row_stride(R2), o4 = o3 + R0 * R1 * R2 * sched_row_stride(R3);
+    fft_stage_tab_inplace<R0, 1, SEQFAST, PSH, sched_nbt(LTOT, R0, THREADS), THREADS>(buf, L, stw, nseq, seq_log2, es, ss, inverse, false);
+    fft_stage_tab_inplace<R1, R0, SEQFAST, PSH, sched_nbt(LTOT, R1, THREADS), THREADS>(buf, L, stw, nseq, seq_log2, es, ss, false, inverse && NST == 2);
+    if constexpr (R2 > 1)
+        fft_stage_tab_inplace<R2, R0 * R1, SEQFAST, PSH, sched_nbt(LTOT, R2, THREADS), THREADS>(buf, L, stw + o2, nseq, seq_log2, es, ss, false, inverse && NST == 3);
+    if constexpr (R3 > 1)
+        fft_stage_tab_inplace<R3, R0 * R1 * R2, SEQFAST, PSH, sched_nbt(LTOT, R3, THREADS), THREADS>(buf, L, stw + o3, nseq, seq_log2, es, ss, false, inverse && NST == 4);
+    if constexpr (R4 > 1)
+        fft_stage_tab_inplace<R4, R0 * R1 * R2 * R3, SEQFAST, PSH, sched_nbt(LTOT, R4, THREADS), THREADS>(buf, L, stw + o4, nseq, seq_log2, es, ss, false, inverse);
 }
 
 // One stage of ANY radix R (used for prime factors > 13): every thread produces ONE output element as a direct R-term sum read
