@@ -255,6 +255,7 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
 
     constexpr int PSH = SCHED == 1 ? EGR_FL_ROW_PAD : 0;      // LDS row layout: element i at lds_pad<PSH>(i)
     const int Lp = lds_pad<PSH>(L);
+    dcplx wk_next = p.wk[threadIdx.x < (unsigned)L ? threadIdx.x : 0];          // first pair twiddle of this thread (see the hook loop)
     EGR_STAMP(p, 0);
     for (int e = threadIdx.x; e < L; e += blockDim.x) {
         cur[lds_pad<PSH>(e)] = ga[e];
@@ -282,13 +283,17 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
     const bool variant = !MAXONLY && (p.max2 != nullptr || p.soft);
     float mx2 = 0.f;
     for (int k2 = threadIdx.x; k2 < cnt; k2 += blockDim.x) {
+        // the table entry of the NEXT pair is requested before this one is worked on (the first was requested before the
+        // forward transform): the 16-byte L2 round trip per pair is off the dependent chain
+        const dcplx wk_cur = wk_next;
+        if (k2 + (int)blockDim.x < cnt) wk_next = p.wk[k2 + blockDim.x];
         int pb = boff - k2;
         if (pb >= L) pb -= L;
         const bool same = self && (pb == k2);
         const int ia = lds_pad<PSH>(k2), ib = lds_pad<PSH>(pb);
         const cplx Za = cur[ia];
         const cplx Zb = rb[ib];
-        const dcplx Wkd = dcmul(wa, p.wk[k2]);
+        const dcplx Wkd = dcmul(wa, wk_cur);
         const cplx Wk = make_float2((float)Wkd.x, (float)Wkd.y);
         // E = (Za + conj Zb)/2 ; O = (Za - conj Zb)/(2i)
         const cplx E = make_float2(0.5f * (Za.x + Zb.x), 0.5f * (Za.y - Zb.y));
