@@ -388,7 +388,7 @@ __device__ __forceinline__ cplx chirp(const ChirpP& c, unsigned long long n) {
 // MODE 2: last  (twiddle^-1 -> IFFT -> d = Re(w c)/N -> out = y + d, peak)
 // MODE 3: spectrum maximum only (twiddle^-1 -> IFFT -> max |w c|^2 -> cp.max2_out[ch]; nothing written back)
 template <int MODE, int HOOK>
-__global__ __launch_bounds__(256) void k_colz(ColP p, ChirpP cp, long long P, float thr, float thr2,
+__global__ __launch_bounds__(1024) void k_colz(ColP p, ChirpP cp, long long P, float thr, float thr2,
                                                cplx* __restrict__ work, float* __restrict__ out,
                                                unsigned* __restrict__ peak_out, const unsigned* __restrict__ thr_rel = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void k_colz(ColP p, ChirpP cp, long long P, fl
 // rows r0 = 2*blockIdx.x, r0+1 of R rows of length L.  CONV: FFT . x bhat[row][k] . IFFT ; else FFT . x scale
 // (used once to build bhat itself).
 template <bool CONV>
-__global__ __launch_bounds__(256) void k_rowconv(FftDesc f, int L, int R, const cplx* __restrict__ tw,
+__global__ __launch_bounds__(1024) void k_rowconv(FftDesc f, int L, int R, const cplx* __restrict__ tw,
                                                   const cplx* __restrict__ bhat, float scale, long long P,
                                                   cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -751,6 +751,11 @@ static void fill_info(const FlSplit& sp, int64_t info[EGR_FL_INFO_LEN]) {
 }
 
 static bool bluestein_length(int64_t want, FlSplit* sp_out);
+// workgroup size of the chirp-z loop kernels (their tiles take most of a CU's LDS: one workgroup per CU, so a large one)
+static int blue_threads() {
+    static const int t = [] { const char* e = getenv("EGR_FL_BLUE_THREADS"); const int v = e ? atoi(e) : 1024; return (v == 256 || v == 512 || v == 1024) ? v : 1024; }();
+    return t;
+}
 
 static const char* kUnsupported =
     "length %lld unsupported: needs even N whose half factors into 2 or 3 lengths (columns <= 1024, row <= 4096) with "
@@ -923,7 +928,9 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
 
 // smallest P >= want whose packed plan (M = P) exists; P has only the prime factors 2, 3, 5, 7
 static bool bluestein_length(int64_t want, FlSplit* sp_out) {
+    // smallest cost, not smallest length: a three-level plan runs ~1.6x the passes of a two-level one per transform
     int64_t best = -1;
+    double best_cost = 1e300;
     FlSplit best_sp;
     for (int64_t p7 = 1; p7 <= 8 * want; p7 *= 7)
         for (int64_t p5 = p7; p5 <= 8 * want; p5 *= 5)
@@ -931,9 +938,12 @@ static bool bluestein_length(int64_t want, FlSplit* sp_out) {
                 int64_t v = p3;
                 while (v < want) v *= 2;
                 for (int rep = 0; rep < 2; ++rep, v *= 2) {          // v and 2v: the first may not factor into tiles
-                    if (best > 0 && v >= best) break;
-                    FlSplit sp = plan_split(2 * v, 0, 0);
-                    if (sp.ok) { best = v; best_sp = sp; break; }
+                    if ((double)v >= best_cost) break;
+                    FlSplit sp = plan_split(2 * v, 0, 0, 2048);
+                    if (!sp.ok) continue;
+                    const double cost = (double)v * (sp.levels == 3 ? 1.6 : 1.0);
+                    if (cost < best_cost) { best_cost = cost; best = v; best_sp = sp; }
+                    break;
                 }
             }
     if (best < 0) return false;
@@ -1107,7 +1117,7 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
                            (flags & EGR_FL_PCM_IN) ? 1 : 0, (flags & EGR_FL_ZERO_STUFF) ? 1 : 0, peak_in, peak_y);
     }
     const dim3 gA(8 * A.tiles_per_xcd, C), gB(8 * B.tiles_per_xcd, C * (three ? B.nplanes : 1)), grow(R.R / 2 + 1, C),
-        blk(p->bluestein ? 256 : p->threads), blk256(256);
+        blk(p->bluestein ? blue_threads() : p->threads), blk256(256);
     const size_t lc = p->sp.lds_col, lb = p->sp.lds_colb, lr = p->sp.lds_row;
     size_t slot = 0;
     if (max_iter == 0) {

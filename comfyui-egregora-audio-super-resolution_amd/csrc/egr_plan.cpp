@@ -121,7 +121,8 @@ static void finish_split_impl(FlSplit& best, int tc_hint);
 static inline void finish_split(FlSplit& best, int tc_hint) { finish_split_impl(best, tc_hint); }
 
 static int pick_tc(int L, int ncols, int hint) {
-    int tc = hint > 0 ? hint : (L > 512 ? 8 : 16);
+    int tc = hint > 0 ? hint : (L > 1024 ? 4 : (L > 512 ? 8 : 16));
+    if (L > 1024 && tc > 4) tc = 4;                   // 2 L TC 8 bytes of LDS: columns of up to 2048 points take 4-column tiles
     if (L == 1 && hint <= 0) tc = 256;               // degenerate column pass: plain streaming
     int l2 = ilog2(tc);
     tc = 1 << l2;
@@ -129,7 +130,7 @@ static int pick_tc(int L, int ncols, int hint) {
     return tc;
 }
 
-FlSplit plan_split(int64_t N, int m1_hint, int tc_hint) {
+FlSplit plan_split(int64_t N, int m1_hint, int tc_hint, int max_col) {
     FlSplit best;
     memset(&best, 0, sizeof(best));
     best.ok = false;
@@ -138,7 +139,9 @@ FlSplit plan_split(int64_t N, int m1_hint, int tc_hint) {
     if (N < 2 || (N & 1)) return best;
     const int64_t M = N / 2;
     best.M = M;
-    const int64_t MAX_COL = 1024, MAX_ROW = 4096;   // LDS-capacity limits of k_col / k_row
+    // LDS-capacity limits of k_col / k_row: columns up to 1024 points, rows up to 4096; chirp-z plans (which choose
+    // their own length) may ask for outer columns of up to 2048 points on 4-column tiles to stay at two levels
+    const int64_t MAX_COL = max_col > 1024 ? 2048 : 1024, MAX_COL_INNER = 1024, MAX_ROW = 4096;
     double best_score = 1e300;
     // ---- two levels: M = M1 * M2 ----
     for (int64_t m1 = 1; m1 <= MAX_COL && m1 <= M; ++m1) {
@@ -171,7 +174,7 @@ FlSplit plan_split(int64_t N, int m1_hint, int tc_hint) {
             for (int64_t m1 = 2; m1 <= MAX_COL && m1 <= R; ++m1) {
                 if (R % m1) continue;
                 const int64_t m2 = R / m1;
-                if (m2 > MAX_COL || m2 < 2) continue;
+                if (m2 > MAX_COL_INNER || m2 < 2) continue;
                 if (m1_hint > 0 && m1 != m1_hint) continue;
                 FftDesc f1, f2;
                 if (!make_schedule((int)m1, &f1) || !make_schedule((int)m2, &f2)) continue;
@@ -202,7 +205,7 @@ FlSplit plan_split_explicit(int64_t N, int m1, int m2, int m3, int tc_hint) {
     if ((int64_t)m1 * m2 * m3 != sp.M) return sp;
     sp.levels = m3 > 1 ? 3 : 2;
     sp.M1 = m1; sp.M2 = m2; sp.M3 = m3;
-    if (m1 > 1024 || (sp.levels == 3 ? (m2 > 1024 || m3 > 4096) : m2 > 4096)) return sp;
+    if (m1 > 2048 || (sp.levels == 3 ? (m2 > 1024 || m3 > 4096) : m2 > 4096)) return sp;
     if (!make_schedule(m1, &sp.f1) || !make_schedule(m2, &sp.f2)) return sp;
     if (sp.levels == 3 && !make_schedule(m3, &sp.f3)) return sp;
     sp.ok = true;
