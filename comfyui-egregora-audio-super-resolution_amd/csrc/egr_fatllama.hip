@@ -133,6 +133,17 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 #ifndef EGR_FL_COL_RADICES
 #define EGR_FL_COL_RADICES 25, 25
 #endif
+// pad of the chirp-z row kernel's LDS rows (0: dense)
+#ifndef EGR_FL_CONV_PAD
+#define EGR_FL_CONV_PAD 0
+#endif
+// rows per workgroup and workgroup size of k_rowconv (in place: rows * L <= 8 * threads)
+#ifndef EGR_FL_CONV_ROWS
+#define EGR_FL_CONV_ROWS 1
+#endif
+#ifndef EGR_FL_CONV_THREADS
+#define EGR_FL_CONV_THREADS 512
+#endif
 #ifndef EGR_FL_SCHED_WAVES
 #define EGR_FL_SCHED_WAVES 6
 #endif
@@ -496,29 +507,43 @@ __global__ __launch_bounds__(1024) void k_colz(ColP p, ChirpP cp, long long P, f
     }
 }
 
-// rows r0 = 2*blockIdx.x, r0+1 of R rows of length L.  CONV: FFT . x bhat[row][k] . IFFT ; else FFT . x scale
+// rows r0 = EGR_FL_CONV_ROWS * blockIdx.x (, r0 + 1) of R rows of length L.  CONV: FFT . x bhat[row][k] . IFFT ; else FFT . x scale
 // (used once to build bhat itself).
 template <bool CONV>
-__global__ __launch_bounds__(1024) void k_rowconv(FftDesc f, int L, int R, const cplx* __restrict__ tw,
+__global__ __launch_bounds__(EGR_FL_CONV_THREADS) void k_rowconv(FftDesc f, int L, int R, const cplx* __restrict__ tw,
                                                   const cplx* __restrict__ bhat, float scale, long long P,
                                                   cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int r0 = 2 * blockIdx.x;
-    const int nrows = (r0 + 1 < R) ? 2 : 1;
+    const int r0 = EGR_FL_CONV_ROWS * blockIdx.x;
+    const int nrows = (r0 + 1 < R && EGR_FL_CONV_ROWS == 2) ? 2 : 1;
+    constexpr int PSH = EGR_FL_CONV_PAD;                 // rows in LDS: element i at lds_pad<PSH>(i), stages in place
+    const int Lp = lds_pad<PSH>(L);
     cplx* cur = (cplx*)smem;
-    cplx* alt = cur + 2 * (size_t)L;
     cplx* g = work + (size_t)blockIdx.y * P + (size_t)r0 * L;
-    for (int e = threadIdx.x; e < nrows * L; e += blockDim.x) cur[e] = g[e];
+    for (int e = threadIdx.x; e < nrows * L; e += blockDim.x) {
+        const int r = e >= L ? 1 : 0, i = e - r * L;
+        cur[r * Lp + lds_pad<PSH>(i)] = g[e];
+    }
     __syncthreads();
-    lds_fft<false>(cur, alt, f, tw, nrows, 0, 1, L, false);
+    lds_fft_ip<false, PSH, false>(cur, f, tw, nrows, 0, 1, Lp, false);
     if (CONV) {
         const cplx* bh = bhat + (size_t)r0 * L;
-        for (int e = threadIdx.x; e < nrows * L; e += blockDim.x) cur[e] = cmul(cur[e], bh[e]);
+        for (int e = threadIdx.x; e < nrows * L; e += blockDim.x) {
+            const int r = e >= L ? 1 : 0, i = e - r * L, a = r * Lp + lds_pad<PSH>(i);
+            cur[a] = cmul(cur[a], bh[e]);
+        }
         __syncthreads();
-        lds_fft<false>(cur, alt, f, tw, nrows, 0, 1, L, true);
-        for (int e = threadIdx.x; e < nrows * L; e += blockDim.x) g[e] = cur[e];
+        lds_fft_ip<false, PSH, false>(cur, f, tw, nrows, 0, 1, Lp, true);
+        for (int e = threadIdx.x; e < nrows * L; e += blockDim.x) {
+            const int r = e >= L ? 1 : 0, i = e - r * L;
+            g[e] = cur[r * Lp + lds_pad<PSH>(i)];
+        }
     } else {
-        for (int e = threadIdx.x; e < nrows * L; e += blockDim.x) g[e] = make_float2(cur[e].x * scale, cur[e].y * scale);
+        for (int e = threadIdx.x; e < nrows * L; e += blockDim.x) {
+            const int r = e >= L ? 1 : 0, i = e - r * L;
+            const cplx c = cur[r * Lp + lds_pad<PSH>(i)];
+            g[e] = make_float2(c.x * scale, c.y * scale);
+        }
     }
 }
 
@@ -751,6 +776,8 @@ static void fill_info(const FlSplit& sp, int64_t info[EGR_FL_INFO_LEN]) {
 }
 
 static bool bluestein_length(int64_t want, FlSplit* sp_out);
+// LDS of k_rowconv: two rows, stages in place
+static size_t rowconv_lds(int L) { return (size_t)EGR_FL_CONV_ROWS * (L + (EGR_FL_CONV_PAD ? L >> EGR_FL_CONV_PAD : 0)) * sizeof(cplx); }
 // workgroup size of the chirp-z loop kernels (their tiles take most of a CU's LDS: one workgroup per CU, so a large one)
 static int blue_threads() {
     static const int t = [] { const char* e = getenv("EGR_FL_BLUE_THREADS"); const int v = e ? atoi(e) : 1024; return (v == 256 || v == 512 || v == 1024) ? v : 1024; }();
@@ -910,7 +937,7 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
         if (sp.levels == 3)
             hipLaunchKernelGGL(k_col<4>, dim3(8 * p->colB.tiles_per_xcd, p->colB.nplanes), blk, sp.lds_colb, 0, p->colB,
                                (long long)M, (long long)N, 0.f, p->d_bhat, (float*)nullptr, (unsigned*)nullptr);
-        hipLaunchKernelGGL(k_rowconv<false>, dim3((r.R + 1) / 2, 1), blk, sp.lds_row, 0, r.f, r.L, r.R, r.tw,
+        hipLaunchKernelGGL(k_rowconv<false>, dim3((r.R + EGR_FL_CONV_ROWS - 1) / EGR_FL_CONV_ROWS, 1), dim3(EGR_FL_CONV_THREADS), rowconv_lds(r.L), 0, r.f, r.L, r.R, r.tw,
                            (const cplx*)nullptr, (float)(1.0 / (double)M), (long long)M, p->d_bhat);
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) {
             set_error("building the Bluestein chirp spectrum failed");
@@ -1128,11 +1155,11 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         ChirpP cp = p->chirp;
         cp.soft = R.soft;
         const long long P = M;
-        const dim3 grc((R.R + 1) / 2, C);
+        const dim3 grc((R.R + EGR_FL_CONV_ROWS - 1) / EGR_FL_CONV_ROWS, C);
         const float thr2 = thr * thr;
         auto conv = [&]() {
             if (three) hipLaunchKernelGGL(k_col<4>, gB, blk, lb, st, B, P, N, thr, p->d_work, out, peak_out);
-            hipLaunchKernelGGL(k_rowconv<true>, grc, blk, lr, st, R.f, R.L, R.R, R.tw, (const cplx*)p->d_bhat, 1.0f, P,
+            hipLaunchKernelGGL(k_rowconv<true>, grc, dim3(EGR_FL_CONV_THREADS), rowconv_lds(R.L), st, R.f, R.L, R.R, R.tw, (const cplx*)p->d_bhat, 1.0f, P,
                                p->d_work);
             if (three) hipLaunchKernelGGL(k_col<3>, gB, blk, lb, st, B, P, N, thr, p->d_work, out, peak_out);
         };
@@ -1380,11 +1407,11 @@ extern "C" int egr_band_filter(egr_fatllama_plan* p, const float* x, int64_t ban
         ChirpP cp = p->chirp;
         cp.band = 1; cp.band_lo = (unsigned long long)band_lo;
         const long long P = M;
-        const dim3 grc((R.R + 1) / 2, C);
+        const dim3 grc((R.R + EGR_FL_CONV_ROWS - 1) / EGR_FL_CONV_ROWS, C);
         unsigned* pk = p->d_peaks + C;
         auto conv = [&]() {
             if (three) hipLaunchKernelGGL(k_col<4>, gB, blk, lb, st, B, P, N, 0.f, p->d_work, y, pk);
-            hipLaunchKernelGGL(k_rowconv<true>, grc, blk, lr, st, R.f, R.L, R.R, R.tw, (const cplx*)p->d_bhat, 1.0f, P, p->d_work);
+            hipLaunchKernelGGL(k_rowconv<true>, grc, dim3(EGR_FL_CONV_THREADS), rowconv_lds(R.L), st, R.f, R.L, R.R, R.tw, (const cplx*)p->d_bhat, 1.0f, P, p->d_work);
             if (three) hipLaunchKernelGGL(k_col<3>, gB, blk, lb, st, B, P, N, 0.f, p->d_work, y, pk);
         };
         hipLaunchKernelGGL((k_colz<0, 0>), gA, blk, lc, st, A, cp, P, -1.0f, 0.f, p->d_work, xs, pk);

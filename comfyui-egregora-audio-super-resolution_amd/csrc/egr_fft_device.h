@@ -321,6 +321,99 @@ __device__ __forceinline__ void fft_stage_generic(const cplx* __restrict__ in, c
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// In-place run-time-schedule transform (any plan): the stage of fft_stage with every butterfly of a thread held in registers
+// across a barrier and written back to the SAME buffer -- half the LDS of the ping-pong form, i.e. a second workgroup per CU for
+// the big tiles of the chirp-z passes.  A workgroup of T threads may hold up to 8 T elements (NBT = ceil(8 / R) butterflies per
+// thread): 1024 threads cover the largest tiles the planner makes (2 x 4096 row points, 2048 x 4 / 1024 x 8 column points).
+constexpr int ip_nbt(int R) { return (8 + R - 1) / R; }
+template <int R, bool SEQFAST, int PSH, bool TWPOW>
+__device__ __forceinline__ void fft_stage_ip(cplx* __restrict__ buf, int L, int Ns, float inv_ns, const cplx* __restrict__ tw,
+                                             const dcplx* __restrict__ twd, int nseq, int seq_log2, int es, int ss, bool swap_in,
+                                             bool swap_out, bool tw_pow) {
+    constexpr int NBT = ip_nbt(R);
+    const int nb = L / R;
+    const int total = nb * nseq;
+    const int twstep = L / (Ns * R);
+    cplx v[NBT][R];
+#pragma unroll
+    for (int n = 0; n < NBT; ++n) {
+        const int b = threadIdx.x + n * blockDim.x;
+        if (b < total) {
+            int s, j;
+            if (SEQFAST) { s = b & (nseq - 1); j = b >> seq_log2; }
+            else { s = (b >= nb) ? 1 : 0; j = b - s * nb; }
+            const int q = (int)(((float)j + 0.5f) * inv_ns);
+            const int k = j - q * Ns;
+            const cplx* src = buf + s * ss;
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                const cplx x = src[lds_pad<PSH>(j + t * nb) * es];
+                v[n][t] = swap_in ? make_float2(x.y, x.x) : x;
+            }
+            if (Ns > 1) {
+                const int base = k * twstep;
+                if (TWPOW && tw_pow) {
+                    dcplx w[R];
+                    w[1] = twd[base];
+#pragma unroll
+                    for (int t = 2; t < R; ++t) w[t] = dcmul(w[t >> 1], w[t - (t >> 1)]);
+#pragma unroll
+                    for (int t = 1; t < R; ++t) v[n][t] = cmul(v[n][t], make_float2((float)w[t].x, (float)w[t].y));
+                } else {
+#pragma unroll
+                    for (int t = 1; t < R; ++t) v[n][t] = cmul(v[n][t], tw[base * t]);
+                }
+            }
+            Bfly<R>::run(v[n]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NBT; ++n) {
+        const int b = threadIdx.x + n * blockDim.x;
+        if (b < total) {
+            int s, j;
+            if (SEQFAST) { s = b & (nseq - 1); j = b >> seq_log2; }
+            else { s = (b >= nb) ? 1 : 0; j = b - s * nb; }
+            const int q = (int)(((float)j + 0.5f) * inv_ns);
+            const int k = j - q * Ns;
+            cplx* dst = buf + s * ss;
+            const int o0 = (j - k) * R + k;
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                const cplx x = v[n][t];
+                dst[lds_pad<PSH>(o0 + t * Ns) * es] = swap_out ? make_float2(x.y, x.x) : x;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// In-place transform of the sequences in `buf` (radices 2 .. 13; the caller guarantees nseq * L <= 8 * blockDim.x).
+template <bool SEQFAST, int PSH = 0, bool TWPOW = true>
+__device__ __forceinline__ void lds_fft_ip(cplx* buf, const FftDesc& d, const cplx* __restrict__ tw, int nseq, int seq_log2, int es,
+                                           int ss, bool inverse, const dcplx* __restrict__ twd = nullptr) {
+    for (int s = 0; s < d.nst; ++s) {
+        const bool si = inverse && (s == 0);
+        const bool so = inverse && (s == d.nst - 1);
+        const int Ns = d.ns[s];
+        const float inv = d.inv_ns[s];
+        const bool tp = d.tw_pow != 0 && twd != nullptr;
+        switch (d.radix[s]) {
+            case 2: fft_stage_ip<2, SEQFAST, PSH, TWPOW>(buf, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+            case 3: fft_stage_ip<3, SEQFAST, PSH, TWPOW>(buf, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+            case 4: fft_stage_ip<4, SEQFAST, PSH, TWPOW>(buf, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+            case 5: fft_stage_ip<5, SEQFAST, PSH, TWPOW>(buf, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+            case 7: fft_stage_ip<7, SEQFAST, PSH, TWPOW>(buf, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+            case 8: fft_stage_ip<8, SEQFAST, PSH, TWPOW>(buf, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+            case 9: fft_stage_ip<9, SEQFAST, PSH, TWPOW>(buf, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+            case 11: fft_stage_ip<11, SEQFAST, PSH, TWPOW>(buf, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+            default: fft_stage_ip<13, SEQFAST, PSH, TWPOW>(buf, d.L, Ns, inv, tw, twd, nseq, seq_log2, es, ss, si, so, tp); break;
+        }
+    }
+}
+
 // Full transform of the sequences in `cur`; result ends in `cur` (pointers are swapped per stage).
 // Caller must __syncthreads() after filling `cur`.
 template <bool SEQFAST>
