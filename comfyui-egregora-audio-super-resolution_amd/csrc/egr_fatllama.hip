@@ -798,7 +798,7 @@ static int blue_threads() {
 }
 
 static const char* kUnsupported =
-    "length %lld unsupported: needs even N whose half factors into 2 or 3 lengths (columns <= 1024, row <= 4096) with "
+    "length %lld unsupported: needs even N whose half factors into 2 or 3 lengths (outer columns <= 2048, inner columns <= 1024, row <= 4096) with "
     "prime factors <= 13";
 
 extern "C" int egr_fatllama_plan_query(int64_t n_in, int factor, int m1_hint, int64_t info[EGR_FL_INFO_LEN]) {

@@ -45,8 +45,9 @@ def test_abi_version_and_host_only_planning(pack):
     assert i["lds_col"] <= 160 * 1024 and i["lds_row"] <= 160 * 1024 and i["levels"] == 2
     big = fe.plan_info(172800000, 1)            # BASELINE C5: 30 min at 96 kHz per channel
     assert big["supported"] and big["levels"] == 3 and big["M1"] * big["M2"] * big["M3"] == 86400000
-    assert max(big["M1"], big["M2"]) <= 1024 and big["M3"] <= 4096
-    assert fe.plan_info(9600000, 1)["levels"] == 3
+    assert big["M1"] <= 2048 and big["M2"] <= 1024 and big["M3"] <= 4096
+    assert fe.plan_info(9600000, 1)["levels"] == 2          # two levels reach 2 * 2048 * 4096 samples (outer columns up to 2048)
+    assert fe.plan_info(28800000, 1)["levels"] == 3
 
 
 def test_planner_matches_python_model_schedule(pack):
