@@ -121,7 +121,7 @@ static void finish_split_impl(FlSplit& best, int tc_hint);
 static inline void finish_split(FlSplit& best, int tc_hint) { finish_split_impl(best, tc_hint); }
 
 static int pick_tc(int L, int ncols, int hint) {
-    int tc = hint > 0 ? hint : (L > 1024 ? 4 : (L > 512 ? 8 : 16));
+    int tc = hint > 0 ? hint : (L > 512 ? 4 : 16);
     if (L > 1024 && tc > 4) tc = 4;                   // 2 L TC 8 bytes of LDS: columns of up to 2048 points take 4-column tiles
     if (L == 1 && hint <= 0) tc = 256;               // degenerate column pass: plain streaming
     int l2 = ilog2(tc);
