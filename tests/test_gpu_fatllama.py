@@ -170,7 +170,8 @@ def test_zero_iterations_and_edge_inputs(pack):
 
 
 @pytest.mark.parametrize("C,n,f,iters", [(1, 101, 1, 3), (2, 2 * 7919, 1, 3), (1, 7919, 1, 2), (1, 4801, 2, 3),
-                                         (2, 3, 1, 2), (1, 33333, 1, 4), (1, 1000003, 1, 2)])
+                                         (2, 3, 1, 2), (1, 33333, 1, 4), (1, 1000003, 1, 2),
+                                         (1, 2400001, 1, 2)])     # P >= 4.8 M: a two-level chirp-z plan with columns above 1024 points
 def test_arbitrary_lengths_take_the_bluestein_path(pack, C, n, f, iters):
     """Odd / prime / non-smooth lengths: exact length-N DFTs through the chirp-z fallback, vs the oracle.
     Tolerance: the convolution length is >= 2N and adds two chirp multiplies per transform, so round-off is a few
@@ -178,6 +179,8 @@ def test_arbitrary_lengths_take_the_bluestein_path(pack, C, n, f, iters):
     from egregora_amd import fatllama_engine as fe
     info = fe.plan_info(n, f)
     assert info["supported"] and info["bluestein"] and info["M"] >= 2 * n * f - 1
+    if n > 2200000:
+        assert info["levels"] == 2 and info["M1"] > 1024 and info["TC"] == 4
     x = synth(C, n, seed=n)
     want = ofl.enhance_channels(x, f, iters, 0.6, normalize=False, autoscale=False)
     exact = ofl.enhance_channels(x, f, iters, 0.6, normalize=False, autoscale=False, exact=True)
