@@ -175,6 +175,18 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
     if (MODE == 0 && thr_rel) thr *= __uint_as_float(thr_rel[ch]);
     EGR_STAMP(p, 0);
 
+    // scheduled mid pass on full tiles: two adjacent columns per thread and step -- 16-byte state loads / stores and LDS accesses,
+    // half the memory instructions of the element-wise loops below
+    const bool pairwise = MODE == 1 && SCHED == 2 && c0 + TC <= nc;
+    if (pairwise) {
+        for (int e = 2 * threadIdx.x; e < nel; e += 2 * blockDim.x) {
+            const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
+            const float4 w2 = *(const float4*)(W + (size_t)i * nc + col);
+            const cplx a = cmulc(make_float2(w2.x, w2.y), tw2(p.big, (unsigned)col * (unsigned)i));
+            const cplx b = cmulc(make_float2(w2.z, w2.w), tw2(p.big, (unsigned)(col + 1) * (unsigned)i));
+            *(float4*)(cur + e) = make_float4(a.x, a.y, b.x, b.y);
+        }
+    } else
     for (int e = threadIdx.x; e < nel; e += blockDim.x) {
         const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
         cplx v = make_float2(0.f, 0.f);
@@ -229,6 +241,15 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
     }
     col_fft<SCHED>(cur, alt, p, TC, lg, false);
     EGR_STAMP(p, 3);
+    if (pairwise) {
+        for (int e = 2 * threadIdx.x; e < nel; e += 2 * blockDim.x) {
+            const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
+            const float4 v2 = *(const float4*)(cur + e);
+            const cplx a = cmul(make_float2(v2.x, v2.y), tw2(p.big, (unsigned)col * (unsigned)i));
+            const cplx b = cmul(make_float2(v2.z, v2.w), tw2(p.big, (unsigned)(col + 1) * (unsigned)i));
+            *(float4*)(W + (size_t)i * nc + col) = make_float4(a.x, a.y, b.x, b.y);
+        }
+    } else
     for (int e = threadIdx.x; e < nel; e += blockDim.x) {
         const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
         if (col < nc) W[(size_t)i * nc + col] = cmul(cur[e], tw2(p.big, (unsigned)col * (unsigned)i));
@@ -268,6 +289,19 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
     const int Lp = lds_pad<PSH>(L);
     dcplx wk_next = p.wk[threadIdx.x < (unsigned)L ? threadIdx.x : 0];          // first pair twiddle of this thread (see the hook loop)
     EGR_STAMP(p, 0);
+    if (SCHED == 1) {                     // 16-byte state loads (two elements; a pair never straddles a pad position)
+        for (int e = 2 * threadIdx.x; e < L; e += 2 * blockDim.x) {
+            const float4 a = *(const float4*)(ga + e);
+            cplx* d = cur + lds_pad<PSH>(e);
+            d[0] = make_float2(a.x, a.y);
+            d[1] = make_float2(a.z, a.w);
+            if (!self) {
+                const float4 b = *(const float4*)(gb + e);
+                d[Lp] = make_float2(b.x, b.y);
+                d[Lp + 1] = make_float2(b.z, b.w);
+            }
+        }
+    } else
     for (int e = threadIdx.x; e < L; e += blockDim.x) {
         cur[lds_pad<PSH>(e)] = ga[e];
         if (!self) cur[Lp + lds_pad<PSH>(e)] = gb[e];
@@ -363,6 +397,13 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
     EGR_STAMP(p, 3);
     row_fft<SCHED>(cur, alt, p, nrows, L, true);
     EGR_STAMP(p, 4);
+    if (SCHED == 1) {
+        for (int e = 2 * threadIdx.x; e < L; e += 2 * blockDim.x) {
+            const cplx* d = cur + lds_pad<PSH>(e);
+            *(float4*)(ga + e) = make_float4(d[0].x, d[0].y, d[1].x, d[1].y);
+            if (!self) *(float4*)(gb + e) = make_float4(d[Lp].x, d[Lp].y, d[Lp + 1].x, d[Lp + 1].y);
+        }
+    } else
     for (int e = threadIdx.x; e < L; e += blockDim.x) {
         ga[e] = cur[lds_pad<PSH>(e)];
         if (!self) gb[e] = cur[Lp + lds_pad<PSH>(e)];
