@@ -144,12 +144,15 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 #ifndef EGR_FL_CONV_THREADS
 #define EGR_FL_CONV_THREADS 512
 #endif
+#ifndef EGR_FL_COL_STW_LDS
+#define EGR_FL_COL_STW_LDS 1
+#endif
 #ifndef EGR_FL_SCHED_WAVES
 #define EGR_FL_SCHED_WAVES 6
 #endif
 template <int SCHED>
-__device__ __forceinline__ void col_fft(cplx*& cur, cplx*& alt, const ColP& p, int TC, int lg, bool inverse) {
-    if (SCHED == 2) lds_fft_sched_inplace<true, 0, 625 * EGR_FL_COL_TC, EGR_FL_COL_THREADS, EGR_FL_COL_RADICES>(cur, p.L, p.stw, TC, lg, TC, 1, inverse);
+__device__ __forceinline__ void col_fft(cplx*& cur, cplx*& alt, const ColP& p, int TC, int lg, bool inverse, const cplx* stw) {
+    if (SCHED == 2) lds_fft_sched_inplace<true, 0, 625 * EGR_FL_COL_TC, EGR_FL_COL_THREADS, EGR_FL_COL_RADICES>(cur, p.L, stw, TC, lg, TC, 1, inverse);
     else lds_fft<true>(cur, alt, p.f, p.tw, TC, lg, TC, 1, inverse, p.twd);
 }
 
@@ -173,6 +176,16 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
     float2* Y = (float2*)(out + (size_t)ch * N) + poff;
     const int nel = L * TC;
     if (MODE == 0 && thr_rel) thr *= __uint_as_float(thr_rel[ch]);
+    // the 25 x 26 stage-twiddle table of the 25 25 schedule is copied into LDS (5.2 KB): its reads then cost an LDS round trip
+    constexpr int col_radices[] = {EGR_FL_COL_RADICES};
+    static_assert(!EGR_FL_COL_STW_LDS || (sizeof(col_radices) / sizeof(int) == 2 && col_radices[0] == 25 && col_radices[1] == 25),
+                  "the LDS copy of the stage table is sized for the 25 25 schedule");
+    __shared__ cplx stw_lds[(SCHED == 2 && EGR_FL_COL_STW_LDS) ? 25 * 26 : 1];
+    const cplx* stw = p.stw;
+    if (SCHED == 2 && EGR_FL_COL_STW_LDS) {
+        for (int e = threadIdx.x; e < 25 * 26; e += blockDim.x) stw_lds[e] = p.stw[e];
+        stw = stw_lds;
+    }
     EGR_STAMP(p, 0);
 
     // scheduled mid pass on full tiles: two adjacent columns per thread and step -- 16-byte state loads / stores and LDS accesses,
@@ -206,7 +219,7 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
     }
     __syncthreads();
     EGR_STAMP(p, 1);
-    if (MODE == 1 || MODE == 2 || MODE == 3 || MODE == 5) col_fft<SCHED>(cur, alt, p, TC, lg, true);
+    if (MODE == 1 || MODE == 2 || MODE == 3 || MODE == 5) col_fft<SCHED>(cur, alt, p, TC, lg, true, stw);
     EGR_STAMP(p, 2);
     if (MODE == 5) {
         for (int e = threadIdx.x; e < nel; e += blockDim.x) {
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
         }
         return;
     }
-    col_fft<SCHED>(cur, alt, p, TC, lg, false);
+    col_fft<SCHED>(cur, alt, p, TC, lg, false, stw);
     EGR_STAMP(p, 3);
     if (pairwise) {
         for (int e = 2 * threadIdx.x; e < nel; e += 2 * blockDim.x) {
