@@ -470,7 +470,7 @@ __global__ __launch_bounds__(1024) void k_colz(ColP p, ChirpP cp, long long P, f
                                                cplx* __restrict__ work, float* __restrict__ out,
                                                unsigned* __restrict__ peak_out, const unsigned* __restrict__ thr_rel = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ float red[8];
+    __shared__ float red[16];                 // one slot per wave: up to 1024 threads
     const int tile = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
     if (tile >= p.ntiles) return;
     const int ch = blockIdx.y;
@@ -587,6 +587,11 @@ __global__ __launch_bounds__(EGR_FL_CONV_THREADS) void k_rowconv(FftDesc f, int 
     const int Lp = lds_pad<PSH>(L);
     cplx* cur = (cplx*)smem;
     cplx* g = work + (size_t)blockIdx.y * P + (size_t)r0 * L;
+    // 16-byte accesses (two elements per thread and step) when rows start 16-byte aligned; one row per workgroup then
+    const bool pairwise = PSH == 0 && EGR_FL_CONV_ROWS == 1 && (L & 1) == 0;
+    if (pairwise) {
+        for (int e = 2 * threadIdx.x; e < L; e += 2 * blockDim.x) *(float4*)(cur + e) = *(const float4*)(g + e);
+    } else
     for (int e = threadIdx.x; e < nrows * L; e += blockDim.x) {
         const int r = e >= L ? 1 : 0, i = e - r * L;
         cur[r * Lp + lds_pad<PSH>(i)] = g[e];
@@ -595,12 +600,22 @@ __global__ __launch_bounds__(EGR_FL_CONV_THREADS) void k_rowconv(FftDesc f, int 
     lds_fft_ip<false, PSH, false>(cur, f, tw, nrows, 0, 1, Lp, false);
     if (CONV) {
         const cplx* bh = bhat + (size_t)r0 * L;
+        if (pairwise) {
+            for (int e = 2 * threadIdx.x; e < L; e += 2 * blockDim.x) {
+                const float4 c = *(const float4*)(cur + e), b = *(const float4*)(bh + e);
+                const cplx u = cmul(make_float2(c.x, c.y), make_float2(b.x, b.y)), v = cmul(make_float2(c.z, c.w), make_float2(b.z, b.w));
+                *(float4*)(cur + e) = make_float4(u.x, u.y, v.x, v.y);
+            }
+        } else
         for (int e = threadIdx.x; e < nrows * L; e += blockDim.x) {
             const int r = e >= L ? 1 : 0, i = e - r * L, a = r * Lp + lds_pad<PSH>(i);
             cur[a] = cmul(cur[a], bh[e]);
         }
         __syncthreads();
         lds_fft_ip<false, PSH, false>(cur, f, tw, nrows, 0, 1, Lp, true);
+        if (pairwise) {
+            for (int e = 2 * threadIdx.x; e < L; e += 2 * blockDim.x) *(float4*)(g + e) = *(const float4*)(cur + e);
+        } else
         for (int e = threadIdx.x; e < nrows * L; e += blockDim.x) {
             const int r = e >= L ? 1 : 0, i = e - r * L;
             g[e] = cur[r * Lp + lds_pad<PSH>(i)];
