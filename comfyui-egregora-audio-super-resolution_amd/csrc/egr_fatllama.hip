@@ -300,7 +300,10 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
 
     constexpr int PSH = SCHED == 1 ? EGR_FL_ROW_PAD : 0;      // LDS row layout: element i at lds_pad<PSH>(i)
     const int Lp = lds_pad<PSH>(L);
-    dcplx wk_next = p.wk[threadIdx.x < (unsigned)L ? threadIdx.x : 0];          // first pair twiddle of this thread (see the hook loop)
+    // default hook (hard threshold on |X|^2, two distinct rows) of the scheduled kernel: two (k, M-k) pairs per thread and step
+    const bool fast2 = SCHED == 1 && !MAXONLY && !self && !p.phat && !p.band && !p.gain && !p.soft && p.max2 == nullptr;
+    dcplx wk_next = p.wk[fast2 ? 2 * threadIdx.x : (threadIdx.x < (unsigned)L ? threadIdx.x : 0)];   // first pair twiddle(s) of this thread
+    dcplx wk_next1 = p.wk[fast2 ? 2 * threadIdx.x + 1 : 0];
     EGR_STAMP(p, 0);
     if (SCHED == 1) {                     // 16-byte state loads (two elements; a pair never straddles a pad position)
         for (int e = 2 * threadIdx.x; e < L; e += 2 * blockDim.x) {
@@ -340,6 +343,37 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
     }
     const bool variant = !MAXONLY && (p.max2 != nullptr || p.soft);
     float mx2 = 0.f;
+    if (fast2) {
+        // the same arithmetic as the default branch of the loop below, on elements k2, k2 + 1 of row a and their partners
+        // L - 1 - k2, L - 2 - k2 of row b: adjacent LDS elements on both sides (a pair never straddles a pad position)
+        auto one = [&](const cplx Za, const cplx Zb, const dcplx wkd, cplx& na, cplx& nb) {
+            const dcplx Wkd = dcmul(wa, wkd);
+            const cplx Wk = make_float2((float)Wkd.x, (float)Wkd.y);
+            const cplx E = make_float2(0.5f * (Za.x + Zb.x), 0.5f * (Za.y - Zb.y));
+            const cplx O = make_float2(0.5f * (Za.y + Zb.y), -0.5f * (Za.x - Zb.x));
+            const cplx WO = cmul(Wk, O);
+            cplx Xk = cadd(E, WO), Xm = csub(E, WO);
+            if (!(Xk.x * Xk.x + Xk.y * Xk.y > thr2)) Xk = make_float2(0.f, 0.f);
+            if (!(Xm.x * Xm.x + Xm.y * Xm.y > thr2)) Xm = make_float2(0.f, 0.f);
+            const cplx E2 = make_float2(0.5f * (Xk.x + Xm.x), 0.5f * (Xk.y + Xm.y));
+            const cplx H = make_float2(0.5f * (Xk.x - Xm.x), 0.5f * (Xk.y - Xm.y));
+            const cplx O2 = cmulc(H, Wk);
+            na = make_float2((float)(scd * (double)(E2.x - O2.y)), (float)(scd * (double)(E2.y + O2.x)));
+            nb = make_float2((float)(scd * (double)(E2.x + O2.y)), -(float)(scd * (double)(E2.y - O2.x)));
+        };
+        for (int k2 = 2 * threadIdx.x; k2 < L; k2 += 2 * blockDim.x) {
+            const dcplx w0 = wk_next, w1 = wk_next1;
+            if (k2 + 2 * (int)blockDim.x < L) { wk_next = p.wk[k2 + 2 * blockDim.x]; wk_next1 = p.wk[k2 + 2 * blockDim.x + 1]; }
+            cplx* da = cur + lds_pad<PSH>(k2);
+            cplx* db = rb + lds_pad<PSH>(L - 2 - k2);
+            const cplx Za0 = da[0], Za1 = da[1], Zb1 = db[0], Zb0 = db[1];
+            cplx na0, nb0, na1, nb1;
+            one(Za0, Zb0, w0, na0, nb0);
+            one(Za1, Zb1, w1, na1, nb1);
+            da[0] = na0; da[1] = na1;
+            db[1] = nb0; db[0] = nb1;
+        }
+    } else
     for (int k2 = threadIdx.x; k2 < cnt; k2 += blockDim.x) {
         // the table entry of the NEXT pair is requested before this one is worked on (the first was requested before the
         // forward transform): the 16-byte L2 round trip per pair is off the dependent chain
