@@ -15,95 +15,9 @@
 // Long inputs add a third factor (state [M1][M2][M3], inner column pass k_col<3>/<4>); lengths without a packed
 // plan (odd, large primes) run the chirp-z path further down (k_colz, k_rowconv); egr_spectral_gain reuses the
 // passes as a zero-phase filter.  DESIGN.md section 2 has the derivations.
-#include <math.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include <algorithm>
-#include <vector>
-
-#include "egr_common.h"
-#include "egr_fft_device.h"
-#include "egr_plan.h"
+#include "egr_fatllama_int.h"
 
 namespace egr {
-
-#define EGR_STAMP(P, SLOT) do { if ((P).trace && threadIdx.x == 0) (P).trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (SLOT)] = wall_clock64(); } while (0)
-
-// Twiddle W_T^r for r < T as a product of two table entries: thi[r >> sh] * tlo[r & (2^sh - 1)]
-// (tables of ~sqrt(T) entries each, generated in long double).  The tables and the product are DOUBLE precision and the
-// result is rounded to float once: every loop iteration multiplies element e by the same W on the way in and conj(W) on
-// the way out, so |W|^2 - 1 is a per-element gain that compounds over the iterations -- (1 + eps)^800.  A product of two
-// float-rounded factors leaves eps ~ 1.2e-7, the single rounding ~ 4e-8 (what any float32 twiddle table has); measured
-// on 800 iterations: rms error vs float64 2.9x -> 1.xx the pocketfft oracle's (tests/test_gpu_fatllama.py).
-struct Tw2 {
-    const dcplx* hi;
-    const dcplx* lo;
-    int sh;
-};
-__device__ __forceinline__ dcplx tw2d(const Tw2& t, unsigned r) {
-    return dcmul(t.hi[r >> t.sh], t.lo[r & ((1u << t.sh) - 1u)]);
-}
-__device__ __forceinline__ cplx tw2(const Tw2& t, unsigned r) {
-    const dcplx w = tw2d(t, r);
-    return make_float2((float)w.x, (float)w.y);
-}
-
-// One strided ("column") pass: `nplanes` matrices [L][ncols] (row-major), transform along L for a tile of TC
-// adjacent columns, twiddle W_(L*ncols)^(col*k).
-struct ColP {
-    FftDesc f;
-    int L, ncols, nplanes;
-    int TC, TClog2, ntiles, tiles_per_xcd;
-    const cplx* tw;        // W_L stage table
-    const dcplx* twd;      // the same table in double precision (power-twiddle path)
-    const cplx* stw;       // per-stage butterfly-ordered tables of a compile-time schedule (k_col<MODE, SCHED > 0>)
-    long long* trace;      // dev: 100 MHz wall-clock stamps per phase, [block][8] (EGR_FL_TRACE)
-    Tw2 big;               // W_(L*ncols)^r
-};
-
-// The contiguous ("row") pass: R rows of length L; row rho(o) holds Z[o + R*k], o = ka + Ma*kb, rho = ka*Mb + kb.
-struct RowP {
-    FftDesc f;
-    int L, R, Ma, Mb;
-    const cplx* tw;        // W_L stage table
-    const dcplx* twd;      // the same table in double precision (power-twiddle path)
-    const cplx* stw;       // per-stage butterfly-ordered tables of a compile-time schedule (k_row<., SCHED > 0>)
-    long long* trace;      // dev: 100 MHz wall-clock stamps per phase, [block][8] (EGR_FL_TRACE)
-    Tw2 wo;                // W_N^o, o < R
-    const dcplx* wk;       // W_(2L)^k = W_N^(R*k), k < L (double: multiplied with W_N^o in double, rounded once)
-    float thr2, inv_M;
-    double inv_M_d;        // 1/M in double: the loop's scaling is applied in double and rounded once (a float 1/M is off by up to
-                           // 6e-8 relative, the SAME way every iteration -- 5e-5 after 800)
-    const float* gain;     // optional [C][M+1] real gain per half-spectrum bin (replaces the threshold)
-    int phat;              // 1: the state is z = a + i b of two REAL signals; replace it by the PHAT-weighted cross-spectrum
-    long long band_lo;     // > 0: keep half-spectrum bins k >= band_lo, zero the others (replaces the threshold); band = 1 selects it
-    int band;
-    // threshold variants (SPEC.md section 3).  max2 != nullptr: the level is thr * sqrt(max2[ch]) with max2[ch] = max_k |X[k]|^2 of
-    // THIS iteration's spectrum (float bits, written by k_row<true>); soft: X max(0, 1 - t/|X|) instead of X [|X| > t].
-    const unsigned* max2;
-    unsigned* max2_out;    // k_row<true> only: where the maximum goes
-    float thr;
-    int soft;
-};
-
-__device__ __forceinline__ void atomic_max_abs(unsigned* slot, float v) {
-    // non-negative IEEE floats order like unsigned ints
-    atomicMax(slot, __float_as_uint(v));
-}
-
-__device__ __forceinline__ float block_max(float v, float* red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) red[w] = v;
-    __syncthreads();
-    float r = red[0];
-    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fmaxf(r, red[i]);
-    __syncthreads();
-    return r;
-}
 
 // MODE 0: first   (y -> time threshold -> FFT -> twiddle -> state)          [outermost pass only]
 // MODE 1: middle  (state -> twiddle^-1 -> IFFT -> FFT -> twiddle -> state)  [outermost pass only]
@@ -467,34 +381,6 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
 // One loop iteration = spectrum hook (X = w c; threshold; a' = conj(X) w) and time hook (d = Re(w c')/N; a = d w),
 // each followed by a convolution: 4 launches over 8P-byte states instead of 2 over 4N-byte ones (slow path).
 // ------------------------------------------------------------------------------------------------
-struct ChirpP {
-    Tw2 w;                   // W_(2N)^r
-    unsigned long long N;    // transform length
-    float inv_N;
-    double inv_2N_d;         // 1 / (2 N) for the remainder estimate of chirp()
-    int band;                // 1: the spectrum hook keeps bins min(n, N - n) >= band_lo instead of thresholding
-    unsigned long long band_lo;
-    int soft;                // 1: soft shrink X max(0, 1 - thr/|X|) instead of the hard threshold
-    const unsigned* max2;    // relative threshold: max_k |X[k]|^2 of this iteration per channel (float bits); level = thr sqrt(.)
-    unsigned* max2_out;      // k_colz<3, 1> only: where that maximum goes
-};
-__device__ __forceinline__ cplx chirp(const ChirpP& c, unsigned long long n) {
-    // n^2 mod 2N without the 64-bit division (~150 instructions per element of every hook): n^2 < 2^53 is exact in double, the
-    // quotient estimate is off by at most one, two conditional corrections make the remainder exact
-    const unsigned long long m = 2ULL * c.N, n2 = n * n;
-    unsigned long long r;
-    if (n2 < (1ULL << 53)) {
-        const unsigned long long q = (unsigned long long)((double)n2 * c.inv_2N_d);
-        long long d = (long long)(n2 - q * m);
-        if (d < 0) d += (long long)m;
-        if (d >= (long long)m) d -= (long long)m;
-        r = (unsigned long long)d;
-    } else {
-        r = n2 % m;
-    }
-    return tw2(c.w, (unsigned)r);
-}
-
 // MODE 0: first (y real -> time threshold -> a = d w -> FFT -> twiddle)
 // MODE 1: mid   (twiddle^-1 -> IFFT -> hook -> FFT -> twiddle); HOOK 1 = spectrum side, HOOK 2 = time side
 // MODE 2: last  (twiddle^-1 -> IFFT -> d = Re(w c)/N -> out = y + d, peak)
@@ -788,35 +674,7 @@ __global__ __launch_bounds__(256) void k_finalize(float* __restrict__ out, long 
 
 using namespace egr;
 
-struct egr_fatllama_plan {
-    int64_t n_in;
-    int C, factor, device;
-    FlSplit sp;
-    ColP colA, colB;
-    RowP row;
-    std::vector<void*> dev_allocs;
-    bool bluestein;       // lengths outside the packed-real plans: chirp-z over P = sp.M complex points
-    ChirpP chirp;
-    cplx* d_bhat;         // FFT_P(b) / P in the passes' transposed layout
-    cplx* d_work;
-    unsigned* d_peaks;   // [3*C]: peak_in[C], peak_out[C], peak_y[C]
-    unsigned* d_max2;    // [max2_cap]: per (iteration, channel) max |X|^2 of the relative-threshold variant
-    size_t max2_cap;
-    bool profiling;
-    int threads;                  // workgroup size of the loop kernels (256 or 512)
-    int row_sched, col_sched;     // compile-time schedule ids of the loop kernels (0: run-time schedule)
-    int nstreams;                 // channel groups run as concurrent pipelines (1 or 2)
-    hipStream_t side;             // second pipeline's stream (forked from / joined to the caller's stream by events)
-    int side_owned;               // 0: `side` was handed in by egr_fatllama_set_side_stream (not destroyed with the plan)
-    hipEvent_t ev_fork, ev_join;
-    hipStream_t cap;              // private capture stream
-    hipGraphExec_t gexec;         // CH captured loop iterations of all pipelines (egr_fatllama_enhance)
-    const float* g_out; float g_thr; int g_groups, g_iter_odd, use_graph;
-    std::vector<hipEvent_t> ev;   // pairs (start, stop) tagged by kind
-    std::vector<int> ev_kind;     // 0 = row, 1 = outer column pass, 2 = inner column pass
-};
-
-static int upload(egr_fatllama_plan* p, const std::vector<float2>& h, const cplx** d) {
+int fl_upload(egr_fatllama_plan* p, const std::vector<float2>& h, const cplx** d) {
     void* ptr = nullptr;
     EGR_HIP(hipMalloc(&ptr, h.size() * sizeof(float2)));
     p->dev_allocs.push_back(ptr);
@@ -825,7 +683,7 @@ static int upload(egr_fatllama_plan* p, const std::vector<float2>& h, const cplx
     return EGR_OK;
 }
 
-static int upload_d(egr_fatllama_plan* p, int L, const dcplx** d) {
+int fl_upload_d(egr_fatllama_plan* p, int L, const dcplx** d) {
     std::vector<double2> h;
     make_twiddles_d(h, L, 1, L);
     void* ptr = nullptr;
@@ -837,7 +695,7 @@ static int upload_d(egr_fatllama_plan* p, int L, const dcplx** d) {
 }
 
 // exp(-2 pi i j num / den), j < count, as a double-precision device table
-static int upload_dtab(egr_fatllama_plan* p, int64_t count, int64_t num, int64_t den, const dcplx** d) {
+int fl_upload_dtab(egr_fatllama_plan* p, int64_t count, int64_t num, int64_t den, const dcplx** d) {
     std::vector<double2> h;
     make_twiddles_d(h, count, num, den);
     void* ptr = nullptr;
@@ -850,7 +708,7 @@ static int upload_dtab(egr_fatllama_plan* p, int64_t count, int64_t num, int64_t
 
 // butterfly-ordered stage tables of a compile-time schedule (R0, R1, R2; R2 = 1: two stages): for stage s >= 1 with
 // Ns = product of the earlier radices, row k < Ns holds W_(Ns R)^(k t), t = 0 .. R-1, padded to an even entry count
-static int upload_sched_tables(egr_fatllama_plan* p, std::initializer_list<int> radices, const cplx** d) {
+int fl_upload_sched_tables(egr_fatllama_plan* p, std::initializer_list<int> radices, const cplx** d) {
     std::vector<float2> h;
     const long double two_pi = 6.283185307179586476925286766559L;
     auto add = [&](int Ns, int R) {
@@ -867,16 +725,16 @@ static int upload_sched_tables(egr_fatllama_plan* p, std::initializer_list<int> 
         ns *= r;
         ++s;
     }
-    return upload(p, h, d);
+    return fl_upload(p, h, d);
 }
 
 // tables for W_T^r, r < T
-static int make_tw2(egr_fatllama_plan* p, int64_t T, Tw2* out) {
+int fl_make_tw2(egr_fatllama_plan* p, int64_t T, Tw2* out) {
     int sh = 0;
     while ((1LL << (2 * sh)) < T) ++sh;          // 2^sh >= sqrt(T)
     int rc;
-    if ((rc = upload_dtab(p, (T >> sh) + 1, 1LL << sh, T, &out->hi))) return rc;
-    if ((rc = upload_dtab(p, 1LL << sh, 1, T, &out->lo))) return rc;
+    if ((rc = fl_upload_dtab(p, (T >> sh) + 1, 1LL << sh, T, &out->hi))) return rc;
+    if ((rc = fl_upload_dtab(p, 1LL << sh, 1, T, &out->lo))) return rc;
     out->sh = sh;
     return EGR_OK;
 }
@@ -892,6 +750,9 @@ static void fill_info(const FlSplit& sp, int64_t info[EGR_FL_INFO_LEN]) {
 }
 
 static bool bluestein_length(int64_t want, FlSplit* sp_out);
+static bool pz_length(int64_t D, FlSplit* sp_out);
+// paired chirp-z kind for N real samples: 1 = even/odd packing (N even, D = N / 2), 2 = channel pairs (N odd, D = N)
+static inline int pz_kind_for(int64_t N) { return (N & 1) ? 2 : 1; }
 // LDS of k_rowconv: two rows, stages in place
 static size_t rowconv_lds(int L) { return (size_t)EGR_FL_CONV_ROWS * (L + (EGR_FL_CONV_PAD ? L >> EGR_FL_CONV_PAD : 0)) * sizeof(cplx); }
 // workgroup size of the chirp-z loop kernels (their tiles take most of a CU's LDS: one workgroup per CU, so a large one)
@@ -913,10 +774,13 @@ extern "C" int egr_fatllama_plan_query(int64_t n_in, int factor, int m1_hint, in
     info[1] = N;
     info[2] = N / 2;
     if (!sp.ok) {
-        if (N >= 2 && bluestein_length(2 * N - 1, &sp)) {      // chirp-z over P = sp.M complex points
+        const int kind = pz_kind_for(N);
+        if (N >= 2 && pz_length(kind == 1 ? N / 2 : N, &sp)) {      // paired chirp-z over P = sp.M complex points per state
             fill_info(sp, info);
             info[0] = 2;
             info[2] = sp.M;
+            info[40] = kind;
+            info[41] = kind == 1 ? N / 2 : N;
             return EGR_OK;
         }
         set_error(kUnsupported, (long long)N);
@@ -928,6 +792,7 @@ extern "C" int egr_fatllama_plan_query(int64_t n_in, int factor, int m1_hint, in
 
 extern "C" int egr_fatllama_plan_destroy(egr_fatllama_plan* p) {
     if (!p) return EGR_OK;
+    pz_destroy(p);
     for (void* q : p->dev_allocs) hipFree(q);
     hipFree(p->d_work); hipFree(p->d_peaks); hipFree(p->d_bhat); hipFree(p->d_max2);
     if (p->gexec) hipGraphExecDestroy(p->gexec);
@@ -941,10 +806,11 @@ extern "C" int egr_fatllama_plan_destroy(egr_fatllama_plan* p) {
 }
 
 static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int factor, const FlSplit& sp,
-                      int64_t bluestein_n = 0) {
+                      int64_t bluestein_n = 0, int pz_kind = 0) {
     egr_fatllama_plan* p = new egr_fatllama_plan();
     p->n_in = n_in; p->C = channels; p->factor = factor; p->sp = sp; p->profiling = false;
     p->bluestein = bluestein_n > 0;
+    p->pz_kind = pz_kind; p->pz = nullptr;
     p->nstreams = 2;
     if (const char* e = getenv("EGR_FL_STREAMS")) { const int t = atoi(e); if (t == 1 || t == 2) p->nstreams = t; }
     p->side = nullptr; p->side_owned = 0; p->ev_fork = nullptr; p->ev_join = nullptr;
@@ -967,9 +833,9 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     a.f = sp.f1; a.L = sp.M1; a.ncols = (int)(M / sp.M1); a.nplanes = 1;
     a.TC = sp.TC; a.TClog2 = sp.TClog2; a.ntiles = ceil_div(a.ncols, a.TC); a.tiles_per_xcd = ceil_div(a.ntiles, 8);
     make_twiddles(h, sp.M1, 1, sp.M1);
-    if ((rc = upload(p, h, &a.tw))) return fail(rc);
-    if ((rc = upload_d(p, sp.M1, &a.twd))) return fail(rc);
-    if ((rc = make_tw2(p, M, &a.big))) return fail(rc);
+    if ((rc = fl_upload(p, h, &a.tw))) return fail(rc);
+    if ((rc = fl_upload_d(p, sp.M1, &a.twd))) return fail(rc);
+    if ((rc = fl_make_tw2(p, M, &a.big))) return fail(rc);
     // ---- inner column pass B (3 levels): per k1 plane, L = M2, columns = M3 ----
     RowP& r = p->row;
     if (sp.levels == 3) {
@@ -977,22 +843,22 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
         b.f = sp.f2; b.L = sp.M2; b.ncols = sp.M3; b.nplanes = sp.M1;
         b.TC = sp.TCb; b.TClog2 = sp.TCblog2; b.ntiles = ceil_div(b.ncols, b.TC); b.tiles_per_xcd = ceil_div(b.ntiles, 8);
         make_twiddles(h, sp.M2, 1, sp.M2);
-        if ((rc = upload(p, h, &b.tw))) return fail(rc);
-        if ((rc = upload_d(p, sp.M2, &b.twd))) return fail(rc);
-        if ((rc = make_tw2(p, (int64_t)sp.M2 * sp.M3, &b.big))) return fail(rc);
+        if ((rc = fl_upload(p, h, &b.tw))) return fail(rc);
+        if ((rc = fl_upload_d(p, sp.M2, &b.twd))) return fail(rc);
+        if ((rc = fl_make_tw2(p, (int64_t)sp.M2 * sp.M3, &b.big))) return fail(rc);
         r.f = sp.f3; r.L = sp.M3; r.R = sp.M1 * sp.M2; r.Ma = sp.M1; r.Mb = sp.M2;
     } else {
         r.f = sp.f2; r.L = sp.M2; r.R = sp.M1; r.Ma = sp.M1; r.Mb = 1;
     }
     make_twiddles(h, r.L, 1, r.L);
-    if ((rc = upload(p, h, &r.tw))) return fail(rc);
-    if ((rc = upload_d(p, r.L, &r.twd))) return fail(rc);
-    if ((rc = upload_dtab(p, r.L, 1, 2 * (int64_t)r.L, &r.wk))) return fail(rc);
+    if ((rc = fl_upload(p, h, &r.tw))) return fail(rc);
+    if ((rc = fl_upload_d(p, r.L, &r.twd))) return fail(rc);
+    if ((rc = fl_upload_dtab(p, r.L, 1, 2 * (int64_t)r.L, &r.wk))) return fail(rc);
     {   // W_N^o for o < R, as hi/lo tables over the range [0, R)
         int sh = 0;
         while ((1LL << (2 * sh)) < r.R) ++sh;
-        if ((rc = upload_dtab(p, ((int64_t)r.R >> sh) + 1, 1LL << sh, N, &r.wo.hi))) return fail(rc);
-        if ((rc = upload_dtab(p, 1LL << sh, 1, N, &r.wo.lo))) return fail(rc);
+        if ((rc = fl_upload_dtab(p, ((int64_t)r.R >> sh) + 1, 1LL << sh, N, &r.wo.hi))) return fail(rc);
+        if ((rc = fl_upload_dtab(p, 1LL << sh, 1, N, &r.wo.lo))) return fail(rc);
         r.wo.sh = sh;
     }
     r.inv_M = (float)(1.0 / (double)M);
@@ -1001,16 +867,23 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     p->row_sched = p->col_sched = 0;
     {
         const bool off = getenv("EGR_FL_SCHED") && atoi(getenv("EGR_FL_SCHED")) == 0;
-        if (!off && !p->bluestein && r.L == 2304) { if ((rc = upload_sched_tables(p, {EGR_FL_ROW_RADICES}, &r.stw))) return fail(rc); p->row_sched = 1; }
-        if (!off && !p->bluestein && a.L == 625 && a.TC <= EGR_FL_COL_TC) { if ((rc = upload_sched_tables(p, {EGR_FL_COL_RADICES}, &a.stw))) return fail(rc); p->col_sched = 2; }
+        if (!off && !p->bluestein && r.L == 2304) { if ((rc = fl_upload_sched_tables(p, {EGR_FL_ROW_RADICES}, &r.stw))) return fail(rc); p->row_sched = 1; }
+        if (!off && !p->bluestein && a.L == 625 && a.TC >= 2 && a.TC <= EGR_FL_COL_TC) { if ((rc = fl_upload_sched_tables(p, {EGR_FL_COL_RADICES}, &a.stw))) return fail(rc); p->col_sched = 2; }
     }
-    if (hipMalloc((void**)&p->d_work, (size_t)channels * M * sizeof(float2)) != hipSuccess ||
+    const int nstates = pz_kind == 2 ? (channels + 1) / 2 : channels;      // a paired chirp-z state of kind 2 carries two channels
+    if (hipMalloc((void**)&p->d_work, (size_t)nstates * M * sizeof(float2)) != hipSuccess ||
         hipMalloc((void**)&p->d_peaks, 3 * channels * sizeof(unsigned)) != hipSuccess) {
         set_error("hipMalloc of the %lld-byte loop state failed", (long long)(channels * M * 8));
         return fail(EGR_ERR_ALLOC);
     }
-    // dynamic LDS above the 64 KiB default needs an explicit opt-in per kernel
-    const int lc = (int)(sp.lds_col > sp.lds_colb ? sp.lds_col : sp.lds_colb);
+    // dynamic LDS above the 64 KiB default needs an explicit opt-in per kernel.  The attribute is a process-wide cap per kernel, so it
+    // is always raised to the CU's 160 KiB (a later, smaller plan must not lower it under an earlier plan's needs); what a plan
+    // actually requests is checked here.
+    const int lc = EGR_LDS_MAX, lrow = EGR_LDS_MAX;
+    if (!pz_kind && (std::max(sp.lds_col, sp.lds_colb) > (size_t)EGR_LDS_MAX || sp.lds_row > (size_t)EGR_LDS_MAX)) {
+        set_error("plan needs %zu / %zu bytes of LDS per workgroup (limit %d)", std::max(sp.lds_col, sp.lds_colb), sp.lds_row, EGR_LDS_MAX);
+        return fail(EGR_ERR_UNSUPPORTED);
+    }
     hipError_t e = hipSuccess;
     e = hipFuncSetAttribute((const void*)k_col<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
@@ -1018,10 +891,10 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_row<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_row<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_row<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_row<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_row<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lrow);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_row<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lrow);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_row<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lrow);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_row<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lrow);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_col<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
@@ -1030,19 +903,21 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_colz<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lc);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_rowconv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_rowconv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_row);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_rowconv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lrow);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_rowconv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lrow);
     if (e != hipSuccess) {
         set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) -> %s", hipGetErrorString(e));
         return fail(EGR_ERR_HIP);
     }
-    if (p->bluestein) {
+    if (p->pz_kind) {
+        if ((rc = pz_build(p, p->pz_kind))) return fail(rc);
+    } else if (p->bluestein) {
         // chirp tables for W_(2N)^r and bhat = FFT_P(b)/P computed once with the plan's own passes
         ChirpP& c = p->chirp;
         c.N = (unsigned long long)bluestein_n;
         c.inv_N = (float)(1.0 / (double)bluestein_n);
         c.inv_2N_d = 1.0 / (2.0 * (double)bluestein_n);
-        if ((rc = make_tw2(p, 2 * bluestein_n, &c.w))) return fail(rc);
+        if ((rc = fl_make_tw2(p, 2 * bluestein_n, &c.w))) return fail(rc);
         if (hipMalloc((void**)&p->d_bhat, (size_t)M * sizeof(float2)) != hipSuccess) {
             set_error("hipMalloc of the %lld-byte chirp spectrum failed", (long long)(M * 8));
             return fail(EGR_ERR_ALLOC);
@@ -1095,6 +970,72 @@ static bool bluestein_length(int64_t want, FlSplit* sp_out) {
     return true;
 }
 
+// Convolution length and factorisation of a paired chirp-z plan for a length-D complex transform: P = L x nc >= 2 D - 1 with
+// nc % 8 == 0 (4-column tiles in mirrored pairs), rows of at most 4096 points (one row per workgroup, stages in place), columns
+// of at most 2048; smallest cost, where a plan whose column-tile pair does not fit one in-place call (L > 1024) and a third level
+// pay their extra barriers / passes.
+static bool pz_length(int64_t D, FlSplit* sp_out) {
+    const int64_t want = 2 * D - 1;
+    const int64_t limit = want < 64 ? 4096 : want + want / 2;
+    if (const char* e = getenv("EGR_PZ_SPLIT")) {            // dev: "L,nc" forces the factorisation
+        int L = 0, nc = 0;
+        if (sscanf(e, "%d,%d", &L, &nc) == 2 && (int64_t)L * nc >= want && nc % 8 == 0) {
+            FlSplit sp = plan_split_explicit(2 * (int64_t)L * nc, L, nc, 1, 4);
+            if (sp.ok && sp.TC == 4) { *sp_out = sp; return true; }
+        }
+    }
+    std::vector<int64_t> cand;                    // 13-smooth numbers in [want, limit]
+    {
+        const int primes[6] = {2, 3, 5, 7, 11, 13};
+        std::vector<int64_t> cur{1};
+        for (int pi = 0; pi < 6; ++pi) {
+            std::vector<int64_t> next;
+            for (int64_t v : cur)
+                for (int64_t x = v; x <= limit; x *= primes[pi]) next.push_back(x);
+            cur.swap(next);
+        }
+        for (int64_t v : cur) if (v >= want && v >= 8) cand.push_back(v);
+        std::sort(cand.begin(), cand.end());
+    }
+    double best_cost = 1e300;
+    FlSplit best;
+    best.ok = false;
+    for (int64_t v : cand) {
+        if ((double)v >= best_cost) break;
+        // two levels
+        double c2 = 1e300;
+        int bl = 0;
+        for (int64_t L = 1; L <= 2048 && L <= v; ++L) {
+            if (v % L) continue;
+            const int64_t nc = v / L;
+            if (nc % 8) continue;
+            const bool sched = nc <= 16384 && pz_sched_has((int)L, (int)nc);       // compile-time schedules on both passes
+            if (nc > 4096 && !sched) continue;
+            FftDesc f1, f2;
+            if (!make_schedule((int)L, &f1) || !make_schedule((int)nc, &f2)) continue;
+            double c = (double)v * (1.0 + 0.02 * (f1.nst + f2.nst));
+            if (L > 1024) c *= 1.15;
+            if (sched) c *= 0.55;
+            if (c < c2) { c2 = c; bl = (int)L; }
+        }
+        if (bl) {
+            if (c2 < best_cost) {
+                FlSplit sp = plan_split_explicit(2 * v, bl, (int)(v / bl), 1, 4, 16384);
+                if (sp.ok && sp.TC == 4) { best_cost = c2; best = sp; }
+            }
+            continue;
+        }
+        if (v <= 1024LL * 16384LL) continue;
+        FlSplit sp = plan_split(2 * v, 0, 4, 2048);
+        if (!sp.ok || sp.levels != 3 || sp.TC != 4 || ((int64_t)sp.M2 * sp.M3) % 8) continue;
+        const double c3 = (double)v * 1.6;
+        if (c3 < best_cost) { best_cost = c3; best = sp; }
+    }
+    if (!best.ok) return false;
+    *sp_out = best;
+    return true;
+}
+
 extern "C" int egr_fatllama_plan_create(egr_fatllama_plan** out, int64_t n_in, int channels, int factor,
                                         int m1_hint, int tc_hint) {
     EGR_CHECK(out != nullptr, EGR_ERR_ARG, "out is null");
@@ -1108,11 +1049,35 @@ extern "C" int egr_fatllama_plan_create(egr_fatllama_plan** out, int64_t n_in, i
     // the 625-point column schedule is instantiated for one tile width
     if (tc_hint <= 0 && sp.ok && sp.levels == 2 && sp.M1 == 625 && sp.TC != EGR_FL_COL_TC) sp = plan_split(N, m1_hint, EGR_FL_COL_TC);
     if (!sp.ok) {
+        const int kind = pz_kind_for(N);
+        const int64_t D = kind == 1 ? N / 2 : N;
+        if (N >= 2 && !(getenv("EGR_FL_LEGACY_CHIRPZ") && atoi(getenv("EGR_FL_LEGACY_CHIRPZ"))) && pz_length(D, &sp))
+            return build_plan(out, n_in, channels, factor, sp, D, kind);
         if (N >= 2 && bluestein_length(2 * N - 1, &sp)) return build_plan(out, n_in, channels, factor, sp, N);
         set_error(kUnsupported, (long long)N);
         return EGR_ERR_UNSUPPORTED;
     }
     return build_plan(out, n_in, channels, factor, sp);
+}
+
+// Force a chirp-z plan on any length (tests, A/B runs): kind 1 = paired, even/odd packing (N even); 2 = paired, channel pairs
+// (any N); 3 = the legacy full-complex form (one P >= 2N - 1 state per channel).
+extern "C" int egr_fatllama_plan_create_chirpz(egr_fatllama_plan** out, int64_t n_in, int channels, int factor, int kind) {
+    EGR_CHECK(out != nullptr, EGR_ERR_ARG, "out is null");
+    *out = nullptr;
+    EGR_CHECK(n_in >= 1 && factor >= 1 && channels >= 1 && channels <= 64 && n_in * factor >= 2, EGR_ERR_ARG,
+              "n_in=%lld channels=%d factor=%d out of range", (long long)n_in, channels, factor);
+    const int64_t N = n_in * factor;
+    if (kind == 0) kind = pz_kind_for(N);
+    if (kind == 3) return egr_fatllama_plan_create_bluestein(out, n_in, channels, factor);
+    EGR_CHECK(kind == 2 || (kind == 1 && !(N & 1)), EGR_ERR_ARG, "chirp-z kind %d does not fit N=%lld", kind, (long long)N);
+    FlSplit sp;
+    const int64_t D = kind == 1 ? N / 2 : N;
+    if (!pz_length(D, &sp)) {
+        set_error("no convolution length found for D=%lld", (long long)D);
+        return EGR_ERR_UNSUPPORTED;
+    }
+    return build_plan(out, n_in, channels, factor, sp, D, kind);
 }
 
 extern "C" int egr_fatllama_plan_create_bluestein(egr_fatllama_plan** out, int64_t n_in, int channels, int factor) {
@@ -1206,7 +1171,7 @@ extern "C" int egr_fatllama_set_profiling(egr_fatllama_plan* p, int enable) {
     return EGR_OK;
 }
 
-static inline void prof_begin(egr_fatllama_plan* p, int kind, hipStream_t st, size_t* slot) {
+void fl_prof_begin(egr_fatllama_plan* p, int kind, hipStream_t st, size_t* slot) {
     if (!p->profiling) return;
     if (*slot + 2 > p->ev.size()) {
         hipEvent_t a, b;
@@ -1218,7 +1183,7 @@ static inline void prof_begin(egr_fatllama_plan* p, int kind, hipStream_t st, si
     }
     hipEventRecord(p->ev[*slot], st);
 }
-static inline void prof_end(egr_fatllama_plan* p, hipStream_t st, size_t* slot) {
+void fl_prof_end(egr_fatllama_plan* p, hipStream_t st, size_t* slot) {
     if (!p->profiling) return;
     hipEventRecord(p->ev[*slot + 1], st);
     *slot += 2;
@@ -1265,9 +1230,12 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
     const size_t lc = p->sp.lds_col, lb = p->sp.lds_colb, lr = p->sp.lds_row;
     size_t slot = 0;
     if (max_iter == 0) {
-        const long long Nr = p->bluestein ? (long long)p->chirp.N : N;
+        const long long Nr = (long long)p->n_in * p->factor;
         const int nb = (int)((Nr + 255) / 256 < 2048 ? (Nr + 255) / 256 : 2048);
         hipLaunchKernelGGL(k_noiter, dim3(nb, C), blk256, 0, st, out, Nr, thr0, peak_out, thr0_rel);
+    } else if (p->pz) {
+        const int rc = pz_loop(p, out, max_iter, thr, thr0, thr0_rel, flags, peak_out, st);
+        if (rc) return rc;
     } else if (p->bluestein) {
         ChirpP cp = p->chirp;
         cp.soft = R.soft;
@@ -1335,24 +1303,24 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
                     else hipLaunchKernelGGL(k_row<true>, growg, blk, lr, sg, Rg, M, wk);
                     Rg.max2 = Rg.max2_out;
                 }
-                if (prof) prof_begin(p, 0, sg, &slot);
+                if (prof) fl_prof_begin(p, 0, sg, &slot);
                 if (rs1) hipLaunchKernelGGL((k_row<false, 1>), growg, blk, lrs, sg, Rg, M, wk);
                 else hipLaunchKernelGGL(k_row<false>, growg, blk, lr, sg, Rg, M, wk);
-                if (prof) prof_end(p, sg, &slot);
+                if (prof) fl_prof_end(p, sg, &slot);
                 if (three) {
-                    if (prof) prof_begin(p, 2, sg, &slot);
+                    if (prof) fl_prof_begin(p, 2, sg, &slot);
                     hipLaunchKernelGGL(k_col<3>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
-                    if (prof) prof_end(p, sg, &slot);
+                    if (prof) fl_prof_end(p, sg, &slot);
                 }
                 if (it + 1 < max_iter) {
-                    if (prof) prof_begin(p, 1, sg, &slot);
+                    if (prof) fl_prof_begin(p, 1, sg, &slot);
                     if (cs2) hipLaunchKernelGGL((k_col<1, 2>), gAg, blkc, lcs, sg, A, M, N, thr, wk, og, pk, (const unsigned*)nullptr);
                     else hipLaunchKernelGGL(k_col<1>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
-                    if (prof) prof_end(p, sg, &slot);
+                    if (prof) fl_prof_end(p, sg, &slot);
                     if (three) {
-                        if (prof) prof_begin(p, 2, sg, &slot);
+                        if (prof) fl_prof_begin(p, 2, sg, &slot);
                         hipLaunchKernelGGL(k_col<4>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
-                        if (prof) prof_end(p, sg, &slot);
+                        if (prof) fl_prof_end(p, sg, &slot);
                     }
                 }
             }
@@ -1419,7 +1387,7 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         if (rc) return rc;
     }
     if (flags & (EGR_FL_NORMALIZE | EGR_FL_AUTOSCALE | EGR_FL_NODE_POST)) {
-        const long long Nr = p->bluestein ? (long long)p->chirp.N : N;
+        const long long Nr = (long long)p->n_in * p->factor;
         const int nb = (int)((Nr + 255) / 256 < 2048 ? (Nr + 255) / 256 : 2048);
         hipLaunchKernelGGL(k_finalize, dim3(nb, C), blk256, 0, st, out, Nr, C, flags, peak_in, peak_out);
     }
@@ -1481,6 +1449,32 @@ extern "C" int egr_fatllama_kernel_times(egr_fatllama_plan* p, double* row_ms_av
     return EGR_OK;
 }
 
+extern "C" int egr_fatllama_kernel_times3(egr_fatllama_plan* p, double ms_avg[3], int64_t launches[3]) {
+    EGR_CHECK(p && ms_avg && launches, EGR_ERR_ARG, "null argument");
+    double sum[3] = {0, 0, 0};
+    int64_t cnt[3] = {0, 0, 0};
+    EGR_HIP(hipDeviceSynchronize());
+    for (size_t i = 0; i + 1 < p->ev.size() && i / 2 < p->ev_kind.size(); i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]) != hipSuccess) continue;
+        const int k = p->ev_kind[i / 2];
+        if (k < 0 || k > 2) continue;
+        sum[k] += ms;
+        cnt[k] += 1;
+    }
+    for (int k = 0; k < 3; ++k) { ms_avg[k] = cnt[k] ? sum[k] / cnt[k] : 0.0; launches[k] = cnt[k]; }
+    return EGR_OK;
+}
+
+// inner column pass of a three-level plan over `nstates` consecutive states (used by the chirp-z loops around their row pass)
+void fl_launch_inner(egr_fatllama_plan* p, bool forward, cplx* work, int nstates, hipStream_t st) {
+    const ColP& B = p->colB;
+    const dim3 gB(8 * B.tiles_per_xcd, nstates * B.nplanes), blk(1024);
+    const long long M = p->sp.M, N = p->sp.N;
+    if (forward) hipLaunchKernelGGL(k_col<4>, gB, blk, p->sp.lds_colb, st, B, M, N, 0.f, work, (float*)nullptr, (unsigned*)nullptr);
+    else hipLaunchKernelGGL(k_col<3>, gB, blk, p->sp.lds_colb, st, B, M, N, 0.f, work, (float*)nullptr, (unsigned*)nullptr);
+}
+
 // y = irfft(rfft(x) * gain): one forward transform, a real per-bin gain, one inverse, on the plan's passes.
 extern "C" int egr_spectral_gain(egr_fatllama_plan* p, const float* x, const float* gain, float* y, void* stream) {
     EGR_CHECK(p && x && gain && y, EGR_ERR_ARG, "null argument");
@@ -1511,6 +1505,7 @@ extern "C" int egr_band_filter(egr_fatllama_plan* p, const float* x, int64_t ban
     EGR_CHECK(p && x && y && band_lo >= 0, EGR_ERR_ARG, "bad argument");
     EGR_CHECK(p->factor == 1, EGR_ERR_UNSUPPORTED, "band filter needs a plan with factor 1");
     hipStream_t st = (hipStream_t)stream;
+    if (p->pz) return pz_band_filter(p, x, band_lo, y, st);
     const int C = p->C;
     const long long M = p->sp.M, N = p->sp.N;
     const bool three = p->sp.levels == 3;

@@ -198,7 +198,7 @@ FlSplit plan_split(int64_t N, int m1_hint, int tc_hint, int max_col) {
     return best;
 }
 
-FlSplit plan_split_explicit(int64_t N, int m1, int m2, int m3, int tc_hint) {
+FlSplit plan_split_explicit(int64_t N, int m1, int m2, int m3, int tc_hint, int max_row) {
     FlSplit sp;
     memset(&sp, 0, sizeof(sp));
     sp.N = N; sp.M = N / 2; sp.M3 = 1;
@@ -206,7 +206,7 @@ FlSplit plan_split_explicit(int64_t N, int m1, int m2, int m3, int tc_hint) {
     if ((int64_t)m1 * m2 * m3 != sp.M) return sp;
     sp.levels = m3 > 1 ? 3 : 2;
     sp.M1 = m1; sp.M2 = m2; sp.M3 = m3;
-    if (m1 > 2048 || (sp.levels == 3 ? (m2 > 1024 || m3 > 4096) : m2 > 4096)) return sp;
+    if (m1 > 2048 || (sp.levels == 3 ? (m2 > 1024 || m3 > max_row) : m2 > max_row)) return sp;
     if (!make_schedule(m1, &sp.f1) || !make_schedule(m2, &sp.f2)) return sp;
     if (sp.levels == 3 && !make_schedule(m3, &sp.f3)) return sp;
     sp.ok = true;

@@ -31,6 +31,6 @@ struct FlSplit {
 // Choose the factorisation of M = N/2 for the multi-step transform of the packed half-length complex sequence.
 FlSplit plan_split(int64_t N, int m1_hint, int tc_hint, int max_col = 2048);
 // Explicit factorisation (tests / tuning): m3 == 1 selects two levels.  ok == false when it does not fit.
-FlSplit plan_split_explicit(int64_t N, int m1, int m2, int m3, int tc_hint);
+FlSplit plan_split_explicit(int64_t N, int m1, int m2, int m3, int tc_hint, int max_row = 4096);
 
 }  // namespace egr

@@ -43,8 +43,9 @@ def upscale_factor(sr: int, channels: int, target_bitrate_kbps: int) -> int:
 
 
 def _plan(n_in: int, channels: int, factor: int, device: int, m1_hint: int = 0, tc_hint: int = 0, split=None):
-    """split = (m1, m2, m3) forces an explicit factorisation of N/2 (m3 = 1: two levels); split = "bluestein" forces
-    the chirp-z path that lengths without a packed-real plan take automatically."""
+    """split = (m1, m2, m3) forces an explicit factorisation of N/2 (m3 = 1: two levels); split = "chirpz" forces the paired chirp-z
+    path that lengths without a packed-real plan take automatically ("chirpz1" / "chirpz2": its even/odd-packing / channel-pair
+    kind), split = "bluestein" the legacy full-complex chirp-z."""
     key = (n_in, channels, factor, device, m1_hint, tc_hint, split)
     h = _PLANS.get(key)
     if h is not None:
@@ -55,6 +56,9 @@ def _plan(n_in: int, channels: int, factor: int, device: int, m1_hint: int = 0, 
     if split == "bluestein":
         native.check(L.egr_fatllama_plan_create_bluestein(C.byref(out), n_in, channels, factor),
                      "egr_fatllama_plan_create_bluestein")
+    elif isinstance(split, str) and split.startswith("chirpz"):
+        native.check(L.egr_fatllama_plan_create_chirpz(C.byref(out), n_in, channels, factor, int(split[6:] or 0)),
+                     "egr_fatllama_plan_create_chirpz")
     elif split is not None:
         native.check(L.egr_fatllama_plan_create_ex(C.byref(out), n_in, channels, factor, int(split[0]), int(split[1]),
                                                    int(split[2]), tc_hint), "egr_fatllama_plan_create_ex")
@@ -85,7 +89,7 @@ def plan_info(n_in: int, factor: int, m1_hint: int = 0) -> dict:
     v = list(info)
     d = {"supported": bool(v[0]) and rc == 0, "bluestein": v[0] == 2, "N": v[1], "M": v[2], "M1": v[3], "M2": v[4], "TC": v[5],
          "radix1": [r for r in v[8:8 + v[6]]], "radix2": [r for r in v[22:22 + v[7]]],
-         "lds_col": v[36], "lds_row": v[37], "M3": v[38], "levels": v[39]}
+         "lds_col": v[36], "lds_row": v[37], "M3": v[38], "levels": v[39], "chirpz_kind": v[40], "D": v[41]}
     if rc != 0:
         d["error"] = native.last_error()
     return d
@@ -146,7 +150,7 @@ def enhance_device(x_ct: torch.Tensor, factor: int, max_iterations: int, thresho
     flags = ((native.FL_NORMALIZE if normalize else 0) | (native.FL_AUTOSCALE if autoscale else 0) |
              (native.FL_PCM_IN if pcm_in else 0) | (native.FL_NODE_POST if node_post else 0) | variant_flags(variant))
     L = native.lib()
-    if Cn >= 2 and max_iterations > 100 and not profile and split != "bluestein":
+    if Cn >= 2 and max_iterations > 100 and not profile and split is None and not plan_info(T, factor)["bluestein"]:
         _tune_pipelines(L, plan, x_ct, out, float(threshold_value), flags, int(max_iterations))
     if profile:
         L.egr_fatllama_set_profiling(C.c_void_p(plan), 1)

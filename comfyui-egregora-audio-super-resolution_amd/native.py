@@ -13,7 +13,8 @@ LIB_PATH = Path(__file__).resolve().parent / "libegregora_amd.so"
 EGR_OK = 0
 FL_NORMALIZE, FL_AUTOSCALE, FL_PCM_IN, FL_NODE_POST = 0x1, 0x2, 0x4, 0x8
 FL_THR_RELATIVE, FL_THR_SOFT, FL_NO_INIT_THR, FL_ZERO_STUFF = 0x10, 0x20, 0x40, 0x80      # SPEC.md section 3
-FL_INFO_LEN = 40
+FL_INFO_LEN = 48
+ABI_VERSION = 2          # include/egregora_amd.h EGR_ABI_VERSION
 
 # name -> (restype, argtypes); must list every symbol of include/egregora_amd.h
 _vp, _i, _i64, _f, _u = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint
@@ -26,6 +27,7 @@ SIGNATURES = {
     "egr_fatllama_plan_create": (_i, [C.POINTER(_vp), _i64, _i, _i, _i, _i]),
     "egr_fatllama_plan_create_ex": (_i, [C.POINTER(_vp), _i64, _i, _i, _i, _i, _i, _i]),
     "egr_fatllama_plan_create_bluestein": (_i, [C.POINTER(_vp), _i64, _i, _i]),
+    "egr_fatllama_plan_create_chirpz": (_i, [C.POINTER(_vp), _i64, _i, _i, _i]),
     "egr_fatllama_plan_destroy": (_i, [_vp]),
     "egr_fatllama_enhance": (_i, [_vp, _vp, _vp, _i, _f, _u, _vp]),
     "egr_spectral_gain": (_i, [_vp, _vp, _vp, _vp, _vp]),
@@ -33,6 +35,7 @@ SIGNATURES = {
     "egr_fatllama_set_profiling": (_i, [_vp, _i]),
     "egr_fatllama_kernel_times": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64),
                                        C.POINTER(_i64)]),
+    "egr_fatllama_kernel_times3": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "egr_pcm16_roundtrip": (_i, [_vp, _vp, _i64, _f, _f, _vp]),
     "egr_stft_mag": (_i, [_vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
     "egr_dfn_workspace_bytes": (C.c_size_t, [_i, _i64]),
@@ -164,8 +167,8 @@ def lib():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)            # AttributeError here = ABI mismatch, which must be loud
         fn.restype, fn.argtypes = res, args
-    if L.egr_abi_version() != 1:
-        raise RuntimeError(f"libegregora_amd.so ABI {L.egr_abi_version()} != 1")
+    if L.egr_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libegregora_amd.so ABI {L.egr_abi_version()} != {ABI_VERSION} (stale build: run `make -C csrc`)")
     _LIB = L
     return L
 

@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define EGR_ABI_VERSION 1
+/* 2: paired chirp-z plans (egr_fatllama_plan_create_chirpz, info[40..41], egr_fatllama_kernel_times3), model handle, DFN / null-test entry points */
+#define EGR_ABI_VERSION 2
 
 #define EGR_OK 0
 #define EGR_ERR_ARG 1          /* bad argument */
@@ -60,10 +61,11 @@ typedef struct egr_fatllama_plan egr_fatllama_plan;
 #define EGR_FL_ZERO_STUFF   0x80u /* up-rate by zero insertion (y[i*f] = x[i]) instead of linear interpolation      */
 
 /* Host-only planning query (no GPU needed): fills info[] =
- *   {supported (1 = packed real plan, 2 = Bluestein over M = P complex points), N, M, M1, M2, TC, nst1, nst2,
- *    radix1[0..13], radix2[0..13], lds_col, lds_row, M3, levels}.
+ *   {supported (1 = packed real plan, 2 = chirp-z over M = P complex points per state), N, M, M1, M2, TC, nst1, nst2,
+ *    radix1[0..13], radix2[0..13], lds_col, lds_row, M3, levels,
+ *    [40] chirp-z kind (1 = even/odd packing, one state per channel; 2 = one state per channel pair), [41] transform length D}.
  * m1_hint <= 0 lets the planner choose. */
-#define EGR_FL_INFO_LEN 40
+#define EGR_FL_INFO_LEN 48
 int egr_fatllama_plan_query(int64_t n_in, int factor, int m1_hint, int64_t info[EGR_FL_INFO_LEN]);
 
 int egr_fatllama_plan_create(egr_fatllama_plan** out, int64_t n_in, int channels, int factor, int m1_hint,
@@ -74,6 +76,13 @@ int egr_fatllama_plan_create_ex(egr_fatllama_plan** out, int64_t n_in, int chann
 /* Force the chirp-z (Bluestein) path, which egr_fatllama_plan_create selects by itself for lengths the packed real
  * transform cannot take (odd, or N/2 with a prime factor > 13): exact length-N DFTs as length-P convolutions. */
 int egr_fatllama_plan_create_bluestein(egr_fatllama_plan** out, int64_t n_in, int channels, int factor);
+/* Chirp-z on ANY length (tests, A/B runs).  Lengths without a packed plan -- odd N, N/2 with a prime factor above 13: most real
+ * files; the reference transforms the whole file whatever its length, egregora_fat_llama_gpu.py:272-288 -- get the PAIRED form
+ * from egr_fatllama_plan_create by themselves: the real signal is first reduced to a complex sequence of length D (kind 1, N even:
+ * even/odd samples as re/im, D = N/2, one state per channel; kind 2, N odd: two channels as re/im, D = N, one state per channel
+ * pair) and the length-D DFT runs as a cyclic convolution of P >= 2D - 1 points (csrc/egr_fatllama_pz.hip).  kind 0 = that
+ * choice, 3 = the legacy full-complex form (P >= 2N - 1 per channel). */
+int egr_fatllama_plan_create_chirpz(egr_fatllama_plan** out, int64_t n_in, int channels, int factor, int kind);
 int egr_fatllama_plan_destroy(egr_fatllama_plan* plan);
 
 /* x: [channels][n_in] float32, out: [channels][n_in*factor] float32 (both device).
@@ -103,6 +112,9 @@ int egr_fatllama_last_peaks(egr_fatllama_plan* plan, float* host_pin, float* hos
 int egr_fatllama_set_profiling(egr_fatllama_plan* plan, int enable);
 int egr_fatllama_kernel_times(egr_fatllama_plan* plan, double* row_ms_avg, double* col_ms_avg, int64_t* row_launches,
                               int64_t* col_launches);
+/* The same by event kind: [0] row pass (packed: k_row; chirp-z: k_pz_rowconv), [1] outer column pass (k_col<1>; k_pzpair),
+ * [2] second column pass (inner pass of a three-level plan; chirp-z: the crop pass k_pzcol<1>). */
+int egr_fatllama_kernel_times3(egr_fatllama_plan* plan, double ms_avg[3], int64_t launches[3]);
 
 /* ------------------------------------------------------------------------------------------------
  * Host-glue arithmetic moved on device (FlashSR node path and the parity yardstick).

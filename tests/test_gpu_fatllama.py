@@ -169,44 +169,6 @@ def test_zero_iterations_and_edge_inputs(pack):
     assert np.all(out == 0)
 
 
-@pytest.mark.parametrize("C,n,f,iters", [(1, 101, 1, 3), (2, 2 * 7919, 1, 3), (1, 7919, 1, 2), (1, 4801, 2, 3),
-                                         (2, 3, 1, 2), (1, 33333, 1, 4), (1, 1000003, 1, 2),
-                                         (1, 2400001, 1, 2)])     # P >= 4.8 M: a two-level chirp-z plan with columns above 1024 points
-def test_arbitrary_lengths_take_the_bluestein_path(pack, C, n, f, iters):
-    """Odd / prime / non-smooth lengths: exact length-N DFTs through the chirp-z fallback, vs the oracle.
-    Tolerance: the convolution length is >= 2N and adds two chirp multiplies per transform, so round-off is a few
-    times the packed path's: max error <= 1e-4 of the peak, rms error <= 8x the float32 oracle's own."""
-    from egregora_amd import fatllama_engine as fe
-    info = fe.plan_info(n, f)
-    assert info["supported"] and info["bluestein"] and info["M"] >= 2 * n * f - 1
-    if n > 2200000:
-        assert info["levels"] == 2 and info["M1"] > 1024 and info["TC"] == 4
-    x = synth(C, n, seed=n)
-    want = ofl.enhance_channels(x, f, iters, 0.6, normalize=False, autoscale=False)
-    exact = ofl.enhance_channels(x, f, iters, 0.6, normalize=False, autoscale=False, exact=True)
-    got = run_gpu(pack, x, f, iters, 0.6)
-    assert got.shape == want.shape
-    scale = float(np.max(np.abs(want)))
-    rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
-    assert float(np.max(np.abs(got - want))) <= 1e-4 * scale
-    assert rms(got - exact) <= 8.0 * rms(want - exact) + 1e-7 * scale
-
-
-def test_bluestein_equals_packed_path_on_a_smooth_length(pack):
-    """Force the fallback on a length both paths support; gating threshold inside the data range."""
-    x = synth(2, 4800, seed=5, scale=100.0)
-    a = run_gpu(pack, x, 1, 3, 50.0)
-    b = run_gpu(pack, x, 1, 3, 50.0, split="bluestein")
-    num = float(np.sum((a - b) ** 2)); den = float(np.sum(a ** 2)) + 1e-30
-    assert num / den < 1e-6
-    # node arithmetic (normalise + PCM_16 hops) also runs on the fallback
-    cs = (synth(2, 5001, seed=3, scale=0.5, integer=False)).astype(np.float32)
-    want, _ = ofl.node_run(cs, 48000, 3, 0.6, 1536, True, True)
-    got = run_gpu(pack, cs, 1, 3, 0.6, True, True, pcm_in=True, node_post=True)
-    lsb = np.abs(got - want) * 32768.0
-    assert float(lsb.max()) <= 1.0 + 1e-6 and float(np.mean(lsb > 0.5)) <= 0.1
-
-
 def test_length_one_is_loud(pack):
     from egregora_amd import fatllama_engine as fe
     with pytest.raises(RuntimeError, match="unsupported|out of range"):
@@ -341,11 +303,11 @@ VARIANTS = [  # (variant list for the device, FatLlamaSpec overrides, threshold,
 
 
 @pytest.mark.parametrize("variant,over,thr,scale", VARIANTS)
-@pytest.mark.parametrize("C,n,f,iters", [(2, 4800, 1, 4), (1, 3000, 3, 6), (2, 48000, 2, 60), (2, 4801, 1, 4), (1, 1013, 3, 5)])
+@pytest.mark.parametrize("C,n,f,iters", [(2, 4800, 1, 4), (1, 3000, 3, 6), (2, 48000, 2, 60), (2, 4801, 1, 4), (1, 1013, 3, 5), (2, 2 * 1013, 1, 4)])
 def test_threshold_and_interpolation_variants_match_the_oracle(pack, variant, over, thr, scale, C, n, f, iters):
     """SPEC.md section 3: absolute / relative-to-maximum level x hard / soft shrink, with or without the time-domain pre-threshold,
     linear or zero-insertion up-rating -- each against the oracle run with the matching FatLlamaSpec, at thresholds that really
-    gate bins; the last two lengths (odd, prime factor 1013) run the chirp-z path.  A hard threshold may flip a borderline bin, so the bar is energy-relative (1e-6 of the output energy, as in
+    gate bins; the last three lengths (odd: channel pairs; prime factor 1013; even with N/2 prime: even/odd packing) run the paired chirp-z path.  A hard threshold may flip a borderline bin, so the bar is energy-relative (1e-6 of the output energy, as in
     test_large_threshold_actually_gates_bins); the soft shrink is continuous and is also held to 2e-5 of the peak."""
     import dataclasses
     spec = dataclasses.replace(ofl.DEFAULT_SPEC, **over)
