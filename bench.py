@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path on MI355X.  Prints ONE JSON line on rank 0.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: re-executes itself under torch.distributed.run)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Workload "chain60" (the two stages BASELINE.json's metric names, in the order of the reference's example workflow
@@ -13,11 +13,18 @@ LoadAudio -> EgregoraAudioUpscaler -> EgregoraFatLlamaGPU): per GPU 60 s of ster
   stage 2  Fat-Llama: each rank enhances its own 60 s slice of the stage-1 output, max_iterations = 800,
            threshold 0.6, normalise on, autoscale off, factor 1, PCM_16 hops included, every iteration executed.
 A step = stage 1 + stage 2; value = N x 60 audio-seconds / max-over-ranks step time  (weak scaling: per-GPU work
-is fixed as N grows).  `parts` reports each stage alone plus BASELINE configs[1] (one stereo 5.12 s chunk).
+is fixed as N grows).  `parts` reports each stage alone, BASELINE configs[1] (one stereo 5.12 s chunk), the Fat-Llama stage on
+lengths WITHOUT a packed plan (60 s + 2 samples, 60 s + 1 sample: the paired chirp-z path most real files take) and, with N > 1,
+BASELINE configs[3] (one 10-minute file chunk-sharded over the N GPUs: the strong-scaling claim of north_star).
+
+--dry-run: no GPU; gloo process group, stub stages (a sleep and the real chunk sharding + all-gather on CPU tensors): checks the
+launch / rank plumbing of this file on a CPU box (tests/test_bench_launch.py).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -36,10 +43,10 @@ SR = 48000
 SEG = 60 * SR                # samples per GPU
 
 
-def synth(seed, n, channels=2):
+def synth(seed, n, channels=2, sr=SR):
     """SURVEY 8(d) recipe: decorrelated channels, 8 log-spaced sines 80 Hz..6 kHz (1/k) + noise, peak 0.5 FS."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    t = np.arange(n, dtype=np.float64) / SR
+    t = np.arange(n, dtype=np.float64) / sr
     chans = []
     for c in range(channels):
         f = np.geomspace(80.0, 6000.0, 8) * (1.0 + 0.013 * c)
@@ -49,31 +56,142 @@ def synth(seed, n, channels=2):
     return (0.5 * x / np.max(np.abs(x))).astype(np.float32)
 
 
-def cpu_baseline_fatllama(x, budget_s=20.0):
-    """Oracle restatement of the Fat-Llama loop (scipy pocketfft complex64: one whole-signal FFT + threshold +
-    IFFT per iteration per channel) timed on the host cores on a bounded sample, scaled to 800 iterations x C."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_fatllama(x, budget_s, gpu_c1=None):
+    """the build's CPU restatement of the Fat-Llama path (oracle/fatllama.py on scipy pocketfft complex64:
+    one whole-signal FFT + threshold + inverse FFT per iteration per channel; the reference's own CPU node delegates to
+    fat-llama-fftw, egregora_fat_llama_cpu.py:126-134,147, which is absent) timed on the host cores, workers = all and = 1.
+      C1  (10 s mono 16 kHz, 50 iterations, 1411 kbps -> factor 6): the whole node path, median of 5 runs (workers = all)
+      C3  (the headline stage: 60 s stereo 48 kHz, 800 iterations): median of 5 iterations of one channel, scaled to 800 x C
+    gpu_c1(c1, sr, cpu_out): runs C1 through the device node and returns LSD(cpu_out, device_out) in dB (device metric kernel)."""
     import scipy.fft as sfft
     from oracle import fatllama as ofl
     cores = os.cpu_count() or 1
-    xi = ofl.pcm16_write(x).astype(np.float32)
     thr = np.float32(0.6)
-    d = np.where(np.abs(xi[0]) > thr, xi[0], np.float32(0)).astype(np.float32)
-    it, t0 = 0, time.perf_counter()
+    t_start = time.perf_counter()
+
+    def c3_iteration_times(workers, reps):
+        xi = ofl.pcm16_write(x).astype(np.float32)
+        d = np.where(np.abs(xi[0]) > thr, xi[0], np.float32(0)).astype(np.float32)
+        ts = []
+        with sfft.set_workers(workers):
+            for _ in range(reps + 1):
+                t0 = time.perf_counter()
+                X = sfft.fft(d.astype(np.complex64))
+                X = np.where(np.abs(X) > thr, X, 0).astype(np.complex64)
+                d = sfft.ifft(X).real.astype(np.float32)
+                ts.append(time.perf_counter() - t0)
+        return ts[1:]                                         # the first call plans
+
+    c3_all = c3_iteration_times(cores, 5)
+    c3_one = c3_iteration_times(1, 3)
+    per_all, per_one = float(np.median(c3_all)), float(np.median(c3_one))
+    audio_c3 = x.shape[1] / SR
+    # C1 exactly as BASELINE states it
+    n1, sr1 = 160000, 16000
+    c1 = synth(101, n1, channels=1, sr=sr1)
+    c1_runs, out_c1 = [], None
     with sfft.set_workers(cores):
-        while True:
-            X = sfft.fft(d.astype(np.complex64))
-            X = np.where(np.abs(X) > thr, X, 0).astype(np.complex64)
-            d = sfft.ifft(X).real.astype(np.float32)
-            it += 1
-            el = time.perf_counter() - t0
-            if (el > budget_s and it >= 2) or it >= 800:
+        for rep in range(5):
+            t0 = time.perf_counter()
+            out_c1, sr_out = ofl.node_run(c1, sr1, 50, 0.6, 1411, True, True)
+            c1_runs.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > budget_s and rep >= 1:
                 break
-    per = el / it
-    return {"value": (x.shape[1] / SR) / (per * 800 * x.shape[0]), "unit": "audio-sec/sec", "cores": cores,
-            "kind": "port",
-            "sample": f"Fat-Llama stage only: {it} iterations of one {x.shape[1]}-sample channel ({el:.1f} s) scaled to 800 "
-                      f"iterations x {x.shape[0]} channels; oracle/fatllama.py loop on scipy.fft complex64, workers={cores}",
-            "sec_per_iteration_channel": per}
+    c1_one = None
+    if time.perf_counter() - t_start < budget_s:
+        with sfft.set_workers(1):
+            t0 = time.perf_counter()
+            ofl.node_run(c1, sr1, 50, 0.6, 1411, True, True)
+            c1_one = time.perf_counter() - t0
+    lsd_c1 = gpu_c1(c1, sr1, out_c1) if gpu_c1 is not None else None
+    c1_med = float(np.median(c1_runs))
+    return {"value": audio_c3 / (per_all * 800 * x.shape[0]), "unit": "audio-sec/sec", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model(),
+            "sample": (f"Fat-Llama stage of the headline workload: median of {len(c3_all)} iterations of one {x.shape[1]}-sample channel "
+                       f"scaled to 800 iterations x {x.shape[0]} channels; oracle/fatllama.py loop on scipy.fft complex64, workers={cores}; "
+                       f"BASELINE configs[0] (10 s mono 16 kHz, 50 iterations, factor 6) timed in full, median of {len(c1_runs)} runs"),
+            "sec_per_iteration_channel": per_all,
+            "workers_1": {"sec_per_iteration_channel": per_one, "value": audio_c3 / (per_one * 800 * x.shape[0])},
+            "c1": {"seconds_median": c1_med, "runs": len(c1_runs), "xrt": 10.0 / c1_med, "workers": cores,
+                   "workers_1_seconds": c1_one, "workers_1_xrt": (10.0 / c1_one) if c1_one else None,
+                   "lsd_vs_gpu_db": lsd_c1,
+                   "lsd_note": "the reference's LSD (egregora_audio_eval_pack.py:389-411, device kernel device_ops.lsd) between the CPU "
+                               "restatement's and the device's C1 node outputs after the PCM_16 hop (both are k/32768; +-1 LSB flips "
+                               "on ~2 % of samples)"}}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def respawn(n):
+    """`python bench.py --gpus N` without a launcher: run the same command line as N ranks of ONE node."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world, dist):
+    """CPU plumbing check: the real chunk sharding + all-gather (shard.sharded_chunks) on small CPU tensors, a stub per-chunk
+    'model', the same barrier / max-over-ranks timing and JSON shape as the real run."""
+    from packload import load_pack
+    load_pack()
+    from egregora_amd import audio_glue as ag, shard
+    total = world * 20 * SR
+    n_chunks = len(ag.spans(total))
+    calls = []
+
+    def run_block(lo, hi):
+        calls.append((lo, hi))
+        time.sleep(0.002 * (hi - lo))
+        return (torch.arange(lo, hi, dtype=torch.float32)[:, None, None] + torch.zeros(1, 2, 8)).contiguous()
+
+    def step():
+        return shard.sharded_chunks(run_block, n_chunks, (2, 8), torch.device("cpu"))
+
+    def timed(n):
+        if dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = step()
+        if dist:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist:
+            tt = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, r
+
+    for _ in range(args.warmup):
+        step()
+    el, preds = timed(args.steps)
+    ok = bool(torch.equal(preds[:, 0, 0], torch.arange(n_chunks, dtype=torch.float32)))
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": args.steps * (total / SR) / el, "unit": "audio-sec/sec", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry-run (CPU stub, no GPU work)",
+                          "config": {"workload": "dry-run: chunk sharding + one all-gather on CPU tensors, stub model",
+                                     "chunks": n_chunks, "gathered_ok": ok, "blocks_of_rank0": calls[-1:]}}))
+    return 0 if ok else 1
 
 
 def main():
@@ -83,7 +201,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--iters", type=int, default=800, help="Fat-Llama max_iterations (headline = 800)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--cpu-budget", type=float, default=25.0)
     ap.add_argument("--rows", type=int, default=0, help="FlashSR rows per pass (default: engine setting)")
     ap.add_argument("--only", default="", help="'flashsr' or 'fatllama': time one stage only (dev)")
     ap.add_argument("--workload", default="chain60", choices=["chain60", "c4"],
@@ -92,22 +210,32 @@ def main():
                          "(strong scaling: north_star's '>= 6x chunk-parallel speed-up at 8 GPUs')")
     ap.add_argument("--lean", action="store_true", help="skip the untimed extras (parts); used under rocprofv3 so the "
                                                         "per-kernel averages cover the timed workload only")
+    ap.add_argument("--dry-run", action="store_true", help="CPU plumbing check (gloo, stub stages)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(respawn(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); n_gpus would be misreported")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if args.dry_run else "nccl", rank=rank, world_size=world)
+    if args.dry_run:
+        rc = dry_run(args, rank, world, dist)
+        if dist:
+            dist.destroy_process_group()
+        sys.exit(rc)
     torch.cuda.set_device(local_rank)
 
     from packload import load_pack
     load_pack()
-    from egregora_amd import (audio_glue as ag, fatllama_engine as fe, flashsr_arch as A,
-                              flashsr_engine as E, native)
+    from egregora_amd import (audio_glue as ag, device_ops, fatllama_engine as fe, flashsr_arch as A,
+                              flashsr_engine as E, native, shard)
     from egregora_amd.egregora_audio_super_resolution import upscale_48k
     arch = native.require_device()
     if args.rows > 0:
@@ -167,7 +295,6 @@ def main():
     el_fl, y_fl = timed(lambda: stage_fatllama(y48), 1)
     # sanity outside the timed region: every sample finite, and all `iters` iterations land where ONE iteration lands (the loop is
     # a projection; a drift between the two would mean the long run is not doing the arithmetic the metric names)
-    from egregora_amd import device_ops
     seg48 = y48[:, rank * SEG:(rank + 1) * SEG].contiguous() if not c4 else y48[:, :SEG].contiguous()
     y_one = fe.enhance_device(seg48, 1, 1, 0.6, **fl_flags)
     if c4:
@@ -176,10 +303,45 @@ def main():
     lsd_iters = device_ops.lsd(y_one[:, :20 * SR].contiguous(), y_fl[:, :20 * SR].contiguous())
     assert lsd_iters[0] < 0.05, lsd_iters
     el_c2 = None
+    arb = {}
+    c4_parts = {}
     if not args.lean:
         x_c2 = x_all[:, :cfg.chunk].contiguous()
         upscale_48k(x_c2, False)
         el_c2, _ = timed(lambda: upscale_48k(x_c2, False), 3)
+        # ---- the Fat-Llama stage on lengths WITHOUT a packed plan (the path most real files take; FlashSR returns its input length,
+        # so in the reference's example chain the second node sees whatever length the file has) ----
+        for tag, extra in (("60s_plus_2_samples", 2), ("60s_plus_1_sample", 1)):
+            n = SEG + extra
+            xa = torch.cat([seg48, seg48[:, :extra]], 1).contiguous()
+            info = fe.plan_info(n, 1)
+            fe.enhance_device(xa, 1, 20, 0.6, **fl_flags)              # plan + first-touch
+            e_a, ya = timed(lambda: fe.enhance_device(xa, 1, args.iters, 0.6, **fl_flags), 1)
+            assert bool(torch.isfinite(ya).all())
+            fe.enhance_device(xa, 1, 12, 0.6, profile=True, **fl_flags)
+            k3 = fe.kernel_times3(n, C, 1, local_rank)
+            states = C if info["chirpz_kind"] == 1 else (C + 1) // 2
+            groups = 2 if (states >= 2 and os.environ.get("EGR_FL_STREAMS", "2") != "1") else 1
+            arb[tag] = {"ms": 1e3 * e_a, "xrt": (n / SR) / e_a, "samples": n, "kind": info["chirpz_kind"], "D": info["D"],
+                        "P": info["M"], "split": [info["M1"], info["M2"], info["M3"]], "states": states,
+                        "k_pz_rowconv_ms": k3["ms"][0], "k_pzpair_ms": k3["ms"][1], "k_pzcol_crop_ms": k3["ms"][2],
+                        "states_per_launch": states // groups}
+        # ---- with N > 1: BASELINE configs[3] as north_star states it (ONE 10-minute stereo file over the N GPUs, strong scaling) ----
+        if world > 1 and not c4:
+            x_c4 = torch.from_numpy(synth(404, 600 * SR)).cuda()
+            nch = len(ag.spans(x_c4.shape[1]))
+            upscale_48k(x_c4, False)
+            e_c4, y_c4 = timed(lambda: upscale_48k(x_c4, False), 1)
+            lo, hi = shard.block_bounds(nch, world)[rank]
+            e_blk, preds = timed(lambda: E.infer_block(x_c4, lo, hi, ag.CHUNK_SAMPLES, ag.HOP_SAMPLES, False), 1)
+            e_wola, _ = timed(lambda: device_ops.wola_stitch(torch.zeros((nch, C, ag.CHUNK_SAMPLES), device="cuda"), x_c4.shape[1],
+                                                             ag.CHUNK_SAMPLES, ag.HOP_SAMPLES), 1)
+            est1 = world * e_blk + e_wola            # one GPU runs all N blocks back to back, then the same WOLA
+            c4_parts = {"c4_strong_xrt": 600.0 / e_c4, "c4_ms": 1e3 * e_c4, "c4_block_ms_max_over_ranks": 1e3 * e_blk,
+                        "c4_wola_ms": 1e3 * e_wola, "c4_speedup_vs_1gpu_estimate": est1 / e_c4,
+                        "c4_note": "ONE 10-minute stereo file (130 chunks) chunk-sharded over the ranks, one all-gather, WOLA on every rank; "
+                                   "the 1-GPU time is estimated as N x (slowest rank's block) + WOLA"}
+            del x_c4, y_c4, preds
     prof = eng.c_profile(stage_flashsr)           # HIP events around every MFMA contraction launch of the library's graph walk
     fe.enhance_device(seg48, 1, args.iters, 0.6, profile=True, **fl_flags)
     kt = fe.kernel_times(SEG, C, 1, local_rank)
@@ -201,12 +363,13 @@ def main():
         dom_ms = max(kt["row_ms"], kt["col_ms"])
         dom = "k_row" if kt["row_ms"] >= kt["col_ms"] else "k_col<1>"
         hbm_ach = row_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = conv_traffic = None
+        traffic = conv_traffic = pz_traffic = None
         try:                # HBM bytes per launch from the committed PMC passes (tools/make_traffic_json.py)
             tk = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get("kernels", {})
             cands = ["k_row<false, 1>", "k_row<false, 0>", "k_row<false>"] if dom == "k_row" else ["k_col<1, 2>", "k_col<1, 0>", "k_col<1>"]
             traffic = next((tk[c]["bytes"] for c in cands if c in tk), None)
             conv_traffic = tk.get(dom_conv, {}).get("bytes")
+            pz_traffic = next((v["bytes"] for k, v in tk.items() if k.startswith("k_pzpair<false")), None)
         except Exception:
             pass
         info = fe.plan_info(SEG, 1)
@@ -235,12 +398,16 @@ def main():
             "parts": {
                 "flashsr_stage_xrt": audio_s / el_fs, "flashsr_stage_ms": 1e3 * el_fs,
                 "fatllama_stage_xrt": audio_s / el_fl, "fatllama_stage_ms": 1e3 * el_fl,
+                "fatllama_arbitrary_length_ms": {k: v["ms"] for k, v in arb.items()} or None,
+                "fatllama_arbitrary_length": arb or None,
+                "chain60_with_arbitrary_length_fatllama_ms": (1e3 * el_fs + arb["60s_plus_2_samples"]["ms"]) if arb else None,
                 "configs1_flashsr_single_chunk_stereo_xrt": (3 * 5.12 / el_c2) if el_c2 else None,
                 "configs1_ms": (1e3 * el_c2 / 3) if el_c2 else None,
                 "flashsr_flops_per_row": fconv_all / max(1, (len(ag.spans(total)) + world - 1) // world * C),
                 "flashsr_scratch_arena_gb": native.lib().egr_flashsr_scratch_bytes(eng.handle) / 1e9,
                 "conv_variants": {k: {"launches": v[0], "tflops": v[1] / 1e12, "ms": v[2],
                                       "avg_launch_ms": v[2] / max(1, v[0])} for k, v in variants.items()},
+                **c4_parts,
             },
             # dominant kernel of the step: the implicit-GEMM convolution (all dense contractions of FlashSR)
             "roofline": {"bound": "mfma", "kernel": dom_conv, "achieved": conv_tfs * mfma_mult, "peak": mfma_peak,
@@ -261,8 +428,29 @@ def main():
                                                  "achieved": 32.0 * SEG * C * args.iters / (el_fl * 1e9),
                                                  "frac": 32.0 * SEG * C * args.iters / (el_fl * 1e9) / HBM_PEAK_GBS}},
         }
+        if arb:
+            # the chirp-z loop's dominant kernel: the spectrum pass on mirrored column-tile pairs.  A launch reads and writes the
+            # P-point complex state of its states once: 16 P bytes per state (what this design must move; per iteration the four
+            # launches move 64 P + 16 P (Bhat, twice) bytes per state against SURVEY's 32 N per channel for a length with a plan)
+            a = arb["60s_plus_2_samples"]
+            byt = 16.0 * a["P"] * a["states_per_launch"]
+            ach = byt / (a["k_pzpair_ms"] * 1e-3) / 1e9 if a["k_pzpair_ms"] > 0 else 0.0
+            out["roofline_fatllama_chirpz"] = {
+                "bound": "hbm", "kernel": "k_pzpair", "workload": "60 s + 2 samples stereo (N = 2 880 002 = 2 x 1 440 001: no packed plan), %d iterations" % args.iters,
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pz_traffic,
+                "bytes_per_launch": byt, "avg_launch_ms": a["k_pzpair_ms"], "k_pz_rowconv_ms": a["k_pz_rowconv_ms"],
+                "k_pzcol_crop_ms": a["k_pzcol_crop_ms"], "stage_ms": a["ms"], "plan": a["split"], "P": a["P"],
+                "vs_packed_stage": a["ms"] / (1e3 * el_fl),
+                "survey_32N": {"bytes_total": 32.0 * a["samples"] * C * args.iters,
+                               "achieved": 32.0 * a["samples"] * C * args.iters / (a["ms"] * 1e6),
+                               "frac": 32.0 * a["samples"] * C * args.iters / (a["ms"] * 1e6) / HBM_PEAK_GBS}}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline_fatllama(x_all[:, :SEG].cpu().numpy(), args.cpu_budget)
+            def gpu_c1(c1, sr1, cpu_out):
+                from packload import load_pack as _lp
+                node = _lp().NODE_CLASS_MAPPINGS["EgregoraFatLlamaCPU"]()
+                (res,) = node.run("wav", 50, 0.6, 1411, AUDIO={"waveform": torch.from_numpy(c1)[None], "sample_rate": sr1})
+                return device_ops.lsd(torch.from_numpy(np.ascontiguousarray(cpu_out)).cuda(), res["waveform"][0].cuda().contiguous())[0]
+            out["cpu_baseline"] = cpu_baseline_fatllama(x_all[:, :SEG].cpu().numpy(), args.cpu_budget, gpu_c1)
         print(json.dumps(out))
     if dist:
         dist.destroy_process_group()

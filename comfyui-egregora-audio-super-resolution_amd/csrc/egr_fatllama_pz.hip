@@ -77,11 +77,27 @@ __device__ __forceinline__ dcplx pz_chirp(const PzP& p, unsigned long long k) { 
 }
 
 // dev ablations (wrong results): EGR_PZ_ABL_NOTW drops the four-step twiddles, _NOFFT the in-LDS transforms, _NOHOOK the pair hook
+// Four-step twiddles of one thread's tile elements.  A thread's elements e = tid + k T (k < NE) sit in ONE column (T is a multiple of
+// the tile width) at rows i0 + k di, so their twiddles W_P^(col (i0 + k di)) are a geometric run: two double table products per
+// thread (first value, ratio) and one double multiply per element instead of a table product per element, rounded to float once
+// each; the eight values stay in registers from the tile's load to its store.
+template <int NE> struct PzTwRun {
+    cplx w[NE];
+    __device__ __forceinline__ void init(const PzP& p, int col, int i0, int di) {
 #ifdef EGR_PZ_ABL_NOTW
-#define PZ_TW(p, r) make_float2(1.f, 0.f)
+#pragma unroll
+        for (int k = 0; k < NE; ++k) w[k] = make_float2(1.f, 0.f);
 #else
-#define PZ_TW(p, r) tw2((p).big, (r))
+        dcplx cur = tw2d(p.big, (unsigned)col * (unsigned)i0);
+        const dcplx st = tw2d(p.big, (unsigned)(((unsigned long long)col * (unsigned long long)di) % (unsigned long long)p.P));
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            w[k] = make_float2((float)cur.x, (float)cur.y);
+            cur = dcmul(cur, st);
+        }
 #endif
+    }
+};
 __device__ __forceinline__ dcplx dmulf(dcplx w, cplx c) {          // w * c
     return make_double2(w.x * (double)c.x - w.y * (double)c.y, w.x * (double)c.y + w.y * (double)c.x);
 }
@@ -99,6 +115,8 @@ __device__ __forceinline__ cplx dmulc_f(dcplx a, dcplx w, double sc) {    // a *
 // this schedule only); the workgroup size is part of the type.
 template <bool FUSE> struct PzRt {
     static constexpr int MAXT = 1024;
+    static constexpr int NE1 = 8, NE2 = FUSE ? 8 : 16;       // elements per thread at most: one tile, a tile pair
+    static constexpr int MINW1 = 1, MINW2 = 1;
     static __device__ __forceinline__ void run(cplx* cur, const PzP& p, int ncols, int lg, bool inverse) {
 #ifdef EGR_PZ_ABL_NOFFT
         return;
@@ -123,6 +141,10 @@ template <int NCOLS, int R0, int R1, int R2, int R3 = 1> struct PzSched {
     static constexpr int RMIN = pz_min(pz_min(R0, R1), pz_min(R2, R3 > 1 ? R3 : R2));
     static constexpr int THREADS = pz_sched_threads(LTOT, RMIN);
     static constexpr int MAXT = THREADS;
+    static constexpr int NE1 = (LTOT + THREADS - 1) / THREADS, NE2 = NE1;
+    // register budget (waves per SIMD the kernel must leave room for): four single-tile workgroups or two tile-pair workgroups per CU
+    static constexpr int WAVES = THREADS / 64;
+    static constexpr int MINW1 = WAVES < 6 ? WAVES : 6, MINW2 = WAVES <= 12 ? (WAVES + 1) / 2 : 4;
     static __device__ __forceinline__ void run(cplx* cur, const PzP& p, int ncols, int lg, bool inverse) {
 #ifdef EGR_PZ_ABL_NOFFT
         return;
@@ -137,7 +159,7 @@ template <int NCOLS, int R0, int R1, int R2, int R3 = 1> struct PzSched {
 // MODE 2: last  (twiddle^-1 -> IFFT -> z = conj(w) c -> out = y + d, per-channel peak)
 // thr_rel (MODE 0, optional): per-channel max|y| as float bits; the level becomes thr * max|y|.
 template <int MODE, class F>
-__global__ __launch_bounds__(F::MAXT) void k_pzcol(PzP p, float thr, cplx* __restrict__ work, float* __restrict__ out,
+__global__ __launch_bounds__(F::MAXT, F::MINW1) void k_pzcol(PzP p, float thr, cplx* __restrict__ work, float* __restrict__ out,
                                                 unsigned* __restrict__ peak_out, const unsigned* __restrict__ thr_rel) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float red[16];
@@ -156,6 +178,10 @@ __global__ __launch_bounds__(F::MAXT) void k_pzcol(PzP p, float thr, cplx* __res
     const bool hasb = chb < p.C;
     float* Ya = out + (size_t)cha * p.N;
     float* Yb = out + (size_t)(hasb ? chb : cha) * p.N;
+    // this thread's column and its twiddle run (the workgroup size is a multiple of TC, at most 8 elements per thread)
+    const int tcol = c0 + ((int)threadIdx.x & (TC - 1));
+    PzTwRun<F::NE1> twr;
+    twr.init(p, tcol < nc ? tcol : 0, (int)threadIdx.x >> lg, (int)blockDim.x >> lg);
 
     if (MODE == 0) {
         float ta = thr, tb = thr;
@@ -176,11 +202,13 @@ __global__ __launch_bounds__(F::MAXT) void k_pzcol(PzP p, float thr, cplx* __res
             cur[e] = v;
         }
     } else {
-        for (int e = threadIdx.x; e < nel; e += blockDim.x) {
-            const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
-            cplx v = make_float2(0.f, 0.f);
-            if (col < nc) v = cmulc(W[(size_t)i * nc + col], PZ_TW(p, (unsigned)col * (unsigned)i));
-            cur[e] = v;
+#pragma unroll
+        for (int k = 0; k < F::NE1; ++k) {
+            const int e = threadIdx.x + k * blockDim.x;
+            if (e < nel) {
+                const int i = e >> lg;
+                cur[e] = tcol < nc ? cmulc(W[(size_t)i * nc + tcol], twr.w[k]) : make_float2(0.f, 0.f);
+            }
         }
     }
     __syncthreads();
@@ -231,9 +259,10 @@ __global__ __launch_bounds__(F::MAXT) void k_pzcol(PzP p, float thr, cplx* __res
         __syncthreads();
     }
     F::run(cur, p, TC, lg, false);
-    for (int e = threadIdx.x; e < nel; e += blockDim.x) {
-        const int c = e & (TC - 1), i = e >> lg, col = c0 + c;
-        if (col < nc) W[(size_t)i * nc + col] = cmul(cur[e], PZ_TW(p, (unsigned)col * (unsigned)i));
+#pragma unroll
+    for (int k = 0; k < F::NE1; ++k) {
+        const int e = threadIdx.x + k * blockDim.x;
+        if (e < nel && tcol < nc) W[(size_t)(e >> lg) * nc + tcol] = cmul(cur[e], twr.w[k]);
     }
 }
 
@@ -241,7 +270,7 @@ __global__ __launch_bounds__(F::MAXT) void k_pzcol(PzP p, float thr, cplx* __res
 // ascending order.  LDS holds both tiles interleaved: element i of right column t at i * 2TC + t, of left column t at
 // i * 2TC + TC + t.  MAXONLY: no write-back; max |X|^2 per channel -> h.max2_out (the relative threshold's reduction).
 template <bool MAXONLY, class F>
-__global__ __launch_bounds__(F::MAXT) void k_pzpair(PzP p, PzHook h, cplx* __restrict__ work) {
+__global__ __launch_bounds__(F::MAXT, F::MINW2) void k_pzpair(PzP p, PzHook h, cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float red[16];
     const int g = (blockIdx.x & 7) * p.g_per_xcd + (blockIdx.x >> 3);
@@ -262,16 +291,23 @@ __global__ __launch_bounds__(F::MAXT) void k_pzpair(PzP p, PzHook h, cplx* __res
         if (g == p.G - 1) { rmask = 1u; selfmask = 1u; lmask = 0u; }
     }
     const int nel2 = L * TC2;
-    for (int e = threadIdx.x; e < nel2; e += blockDim.x) {
-        const int t2 = e & (TC2 - 1), i = e >> (lg + 1);
+    // this thread's column of the tile pair (the workgroup size is a multiple of 2 TC, at most 8 elements per thread) and its twiddles
+    int tcol;
+    bool tactive;
+    {
+        const int t2 = (int)threadIdx.x & (TC2 - 1);
         const bool right = t2 < TC;
         const int t = right ? t2 : t2 - TC;
-        int col = right ? rs + t : ls + t;
-        if (col >= nc) col -= nc;
-        const bool active = ((right ? rmask : lmask) >> t) & 1u;
-        cplx v = make_float2(0.f, 0.f);
-        if (active) v = cmulc(W[(size_t)i * nc + col], PZ_TW(p, (unsigned)col * (unsigned)i));
-        cur[e] = v;
+        tcol = right ? rs + t : ls + t;
+        if (tcol >= nc) tcol -= nc;
+        tactive = ((right ? rmask : lmask) >> t) & 1u;
+    }
+    PzTwRun<F::NE2> twr;
+    twr.init(p, tcol, (int)threadIdx.x >> (lg + 1), (int)blockDim.x >> (lg + 1));
+#pragma unroll
+    for (int k = 0; k < F::NE2; ++k) {
+        const int e = threadIdx.x + k * blockDim.x;
+        if (e < nel2) cur[e] = tactive ? cmulc(W[(size_t)(e >> (lg + 1)) * nc + tcol], twr.w[k]) : make_float2(0.f, 0.f);
     }
     __syncthreads();
     F::run(cur, p, TC2, lg + 1, true);
@@ -400,13 +436,10 @@ __global__ __launch_bounds__(F::MAXT) void k_pzpair(PzP p, PzHook h, cplx* __res
     }
     __syncthreads();
     F::run(cur, p, TC2, lg + 1, false);
-    for (int e = threadIdx.x; e < nel2; e += blockDim.x) {
-        const int t2 = e & (TC2 - 1), i = e >> (lg + 1);
-        const bool right = t2 < TC;
-        const int t = right ? t2 : t2 - TC;
-        int col = right ? rs + t : ls + t;
-        if (col >= nc) col -= nc;
-        if (((right ? rmask : lmask) >> t) & 1u) W[(size_t)i * nc + col] = cmul(cur[e], PZ_TW(p, (unsigned)col * (unsigned)i));
+#pragma unroll
+    for (int k = 0; k < F::NE2; ++k) {
+        const int e = threadIdx.x + k * blockDim.x;
+        if (e < nel2 && tactive) W[(size_t)(e >> (lg + 1)) * nc + tcol] = cmul(cur[e], twr.w[k]);
     }
 }
 

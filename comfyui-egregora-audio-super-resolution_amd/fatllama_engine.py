@@ -170,6 +170,18 @@ def kernel_times(n_in: int, channels: int, factor: int, device: int = 0):
     return {"row_ms": r.value, "col_ms": c.value, "row_launches": nr.value, "col_launches": nc.value}
 
 
+def kernel_times3(n_in: int, channels: int, factor: int, device: int = 0):
+    """HIP-event averages of the last profiled run by pass: row pass, outer column pass, second column pass (packed plans: the
+    inner pass of a three-level plan; chirp-z plans: k_pz_rowconv, k_pzpair, the crop pass)."""
+    L = native.lib()
+    plan = _plan(n_in, channels, factor, device)
+    ms = (C.c_double * 3)()
+    cnt = (C.c_int64 * 3)()
+    native.check(L.egr_fatllama_kernel_times3(C.c_void_p(plan), ms, cnt), "egr_fatllama_kernel_times3")
+    L.egr_fatllama_set_profiling(C.c_void_p(plan), 0)
+    return {"ms": list(ms), "launches": list(cnt)}
+
+
 def node_run(cs: torch.Tensor, sr: int, max_iterations: int, threshold_value: float, target_bitrate_kbps: int,
              toggle_normalize: bool, toggle_autoscale: bool) -> Tuple[torch.Tensor, int]:
     """Whole node arithmetic for one AUDIO: [C,T] float (any device) -> ([C,T*f] float32 CUDA, sr*f)."""

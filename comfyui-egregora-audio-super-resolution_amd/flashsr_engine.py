@@ -879,16 +879,18 @@ def infer_rows(eng: FlashSREngine, rows_x: torch.Tensor, row_ids: torch.Tensor, 
 def infer_spans(x_ct: torch.Tensor, n_chunks: int, win: int, hop: int, lowpass: bool) -> torch.Tensor:
     """[C,T] @48 kHz on the GPU -> predictions [n_chunks, C, win].  Chunks are sharded over the ranks of the
     default process group when one exists (contiguous blocks, one all-gather; shard.py)."""
+    Cn = x_ct.shape[0]
+    return shard.sharded_chunks(lambda lo, hi: infer_block(x_ct, lo, hi, win, hop, lowpass), n_chunks, (Cn, win), x_ct.device)
+
+
+def infer_block(x_ct: torch.Tensor, lo: int, hi: int, win: int, hop: int, lowpass: bool) -> torch.Tensor:
+    """Predictions [hi - lo, C, win] of the chunks lo .. hi-1 of x_ct (one rank's share; noise keyed by the GLOBAL row id)."""
     eng = ensure_ready()
     Cn = x_ct.shape[0]
     if win != eng.cfg.chunk:
         raise RuntimeError(f"chunk length {win} != model chunk {eng.cfg.chunk}")
-
-    def run_block(lo: int, hi: int) -> torch.Tensor:
-        chunks = device_ops.chunk_gather(x_ct, win, hop, lo, hi - lo)                 # [n, C, win]
-        ids = (torch.arange(lo, hi, device=x_ct.device, dtype=torch.int64)[:, None] * Cn +
-               torch.arange(Cn, device=x_ct.device, dtype=torch.int64)[None, :]).reshape(-1)
-        y = infer_rows(eng, chunks.view(-1, win), ids, SEED, lowpass=bool(lowpass))
-        return y.view(hi - lo, Cn, win)
-
-    return shard.sharded_chunks(run_block, n_chunks, (Cn, win), x_ct.device)
+    chunks = device_ops.chunk_gather(x_ct, win, hop, lo, hi - lo)                 # [n, C, win]
+    ids = (torch.arange(lo, hi, device=x_ct.device, dtype=torch.int64)[:, None] * Cn +
+           torch.arange(Cn, device=x_ct.device, dtype=torch.int64)[None, :]).reshape(-1)
+    y = infer_rows(eng, chunks.view(-1, win), ids, SEED, lowpass=bool(lowpass))
+    return y.view(hi - lo, Cn, win)

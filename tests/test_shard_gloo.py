@@ -63,3 +63,59 @@ def test_block_bounds():
     assert shard.block_bounds(130, 8) == [(0, 17), (17, 34), (34, 51), (51, 68), (68, 85), (85, 102), (102, 119), (119, 130)]
     assert shard.block_bounds(3, 8)[:4] == [(0, 1), (1, 2), (2, 3), (3, 3)]
     assert shard.block_bounds(0, 2) == [(0, 0), (0, 0)]
+
+
+def _wola_worker(rank, world, port, total, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from packload import load_pack
+    load_pack()
+    from egregora_amd import shard
+    from oracle import glue as og
+    rng = np.random.Generator(np.random.PCG64(7))
+    x = rng.standard_normal((2, total)).astype(np.float32)          # the same file on every rank (replicated input)
+    spans = og.chunk_spans(total)
+
+    def run_block(lo, hi):          # a stand-in model that depends on the GLOBAL chunk index, like the row-id-keyed noise
+        out = np.zeros((hi - lo, 2, og.WIN), np.float32)
+        for k in range(lo, hi):
+            s, L = spans[k]
+            out[k - lo, :, :L] = x[:, s:s + L] * np.float32(1.0 + 0.01 * k)
+        return torch.from_numpy(out)
+
+    preds = shard.sharded_chunks(run_block, len(spans), (2, og.WIN), torch.device("cpu")).numpy()
+    y = og.wola([(preds[k], spans[k][0], spans[k][1]) for k in range(len(spans))], total)
+    q.put((rank, y))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_then_wola_across_ranks_equals_the_single_rank_stitch(world):
+    """Chunks meet only in WOLA (reference egregora_audio_super_resolution.py:407-420): per-rank chunk blocks, ONE all-gather, then
+    the reference's stitch on every rank -- bit-identical to one rank doing all chunks, on every rank."""
+    from oracle import glue as og
+    total = og.WIN + 4 * og.HOP + 12345            # 6 chunks, short last one
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + (os.getpid() % 500) + world
+    procs = [ctx.Process(target=_wola_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.Generator(np.random.PCG64(7))
+    x = rng.standard_normal((2, total)).astype(np.float32)
+    spans = og.chunk_spans(total)
+    single = []
+    for k, (s, L) in enumerate(spans):
+        c = np.zeros((2, og.WIN), np.float32)
+        c[:, :L] = x[:, s:s + L] * np.float32(1.0 + 0.01 * k)
+        single.append((c, s, L))
+    want = og.wola(single, total)
+    for rank, y in res:
+        np.testing.assert_array_equal(y, want)
