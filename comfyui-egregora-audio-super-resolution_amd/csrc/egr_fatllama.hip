@@ -566,9 +566,12 @@ __global__ __launch_bounds__(256) void k_chirp_b(ChirpP cp, long long P, cplx* _
 
 // x (optionally PCM_16-quantised) -> y = linear up-rate by f, per-channel max|x_q|.
 // zero_stuff: y[i*f] = x[i], zeros between (SPEC.md "interp").  peak_y[ch] = max|y| (what a relative time-domain threshold refers to).
+// linspace (SPEC.md "interp"): y[j] = interp(j (n_in - 1) / (n_out - 1), arange(n_in), x) -- numpy.interp on the endpoint-inclusive
+// grid numpy.linspace(0, n_in - 1, n_out), evaluated like numpy (double: slope * (pos - i) + x[i], last point exactly x[n_in - 1]);
+// n_out need not be a multiple of n_in (factor_mode "ratio_then_int").
 __global__ __launch_bounds__(256) void k_prepare(const float* __restrict__ x, float* __restrict__ y, long long n_in,
                                                   int f, int pcm_in, int zero_stuff, unsigned* __restrict__ peak_in,
-                                                  unsigned* __restrict__ peak_y) {
+                                                  unsigned* __restrict__ peak_y, int linspace = 0, long long n_out = 0) {
 #pragma clang fp contract(off)      // the roundings below are the PCM arithmetic of the reference, written out
     __shared__ float red[8];
     const int ch = blockIdx.y;
@@ -576,6 +579,39 @@ __global__ __launch_bounds__(256) void k_prepare(const float* __restrict__ x, fl
     float* yc = y + (size_t)ch * n_in * f;
     const float ff = (float)f;
     float mx = 0.f, my = 0.f;
+    if (linspace) {
+        float* yo = y + (size_t)ch * n_out;
+        auto q = [&](float a) -> float {
+            if (!pcm_in) return a;
+            long long qa = (long long)rintf(__fmul_rn(a, 32767.0f));
+            return (float)(((qa + 32768) & 65535) - 32768);
+        };
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += (long long)gridDim.x * blockDim.x)
+            mx = fmaxf(mx, fabsf(q(xc[i])));
+        const double step = n_out > 1 ? (double)(n_in - 1) / (double)(n_out - 1) : 0.0;
+        for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n_out; j += (long long)gridDim.x * blockDim.x) {
+            float v;
+            if (j == n_out - 1 && n_out > 1) {
+                v = q(xc[n_in - 1]);
+            } else {
+                const double pos = (double)j * step;
+                long long i0 = (long long)pos;
+                if (i0 > n_in - 2) i0 = n_in - 2;
+                if (i0 < 0) i0 = 0;
+                const double a = (double)q(xc[i0]), b = n_in > 1 ? (double)q(xc[i0 + 1]) : a;
+                v = (float)((b - a) * (pos - (double)i0) + a);
+            }
+            yo[j] = v;
+            my = fmaxf(my, fabsf(v));
+        }
+        mx = block_max(mx, red);
+        my = block_max(my, red);
+        if (threadIdx.x == 0) {
+            atomic_max_abs(peak_in + ch, mx);
+            atomic_max_abs(peak_y + ch, my);
+        }
+        return;
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_in;
          i += (long long)gridDim.x * blockDim.x) {
         float a = xc[i];
@@ -806,9 +842,10 @@ extern "C" int egr_fatllama_plan_destroy(egr_fatllama_plan* p) {
 }
 
 static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int factor, const FlSplit& sp,
-                      int64_t bluestein_n = 0, int pz_kind = 0) {
+                      int64_t bluestein_n = 0, int pz_kind = 0, int64_t n_out = 0) {
     egr_fatllama_plan* p = new egr_fatllama_plan();
     p->n_in = n_in; p->C = channels; p->factor = factor; p->sp = sp; p->profiling = false;
+    p->n_out = n_out > 0 ? n_out : n_in * factor;
     p->bluestein = bluestein_n > 0;
     p->pz_kind = pz_kind; p->pz = nullptr;
     p->nstreams = 2;
@@ -1036,13 +1073,7 @@ static bool pz_length(int64_t D, FlSplit* sp_out) {
     return true;
 }
 
-extern "C" int egr_fatllama_plan_create(egr_fatllama_plan** out, int64_t n_in, int channels, int factor,
-                                        int m1_hint, int tc_hint) {
-    EGR_CHECK(out != nullptr, EGR_ERR_ARG, "out is null");
-    *out = nullptr;
-    EGR_CHECK(n_in >= 1 && factor >= 1 && channels >= 1 && channels <= 64, EGR_ERR_ARG,
-              "n_in=%lld channels=%d factor=%d out of range", (long long)n_in, channels, factor);
-    const int64_t N = n_in * factor;
+static int create_for_length(egr_fatllama_plan** out, int64_t n_in, int channels, int factor, int64_t N, int m1_hint, int tc_hint) {
     if (m1_hint <= 0) { if (const char* e = getenv("EGR_FL_M1")) m1_hint = atoi(e); }
     if (tc_hint <= 0) { if (const char* e = getenv("EGR_FL_TC")) tc_hint = atoi(e); }
     FlSplit sp = plan_split(N, m1_hint, tc_hint);
@@ -1052,12 +1083,31 @@ extern "C" int egr_fatllama_plan_create(egr_fatllama_plan** out, int64_t n_in, i
         const int kind = pz_kind_for(N);
         const int64_t D = kind == 1 ? N / 2 : N;
         if (N >= 2 && !(getenv("EGR_FL_LEGACY_CHIRPZ") && atoi(getenv("EGR_FL_LEGACY_CHIRPZ"))) && pz_length(D, &sp))
-            return build_plan(out, n_in, channels, factor, sp, D, kind);
-        if (N >= 2 && bluestein_length(2 * N - 1, &sp)) return build_plan(out, n_in, channels, factor, sp, N);
+            return build_plan(out, n_in, channels, factor, sp, D, kind, N);
+        if (N >= 2 && bluestein_length(2 * N - 1, &sp)) return build_plan(out, n_in, channels, factor, sp, N, 0, N);
         set_error(kUnsupported, (long long)N);
         return EGR_ERR_UNSUPPORTED;
     }
-    return build_plan(out, n_in, channels, factor, sp);
+    return build_plan(out, n_in, channels, factor, sp, 0, 0, N);
+}
+
+extern "C" int egr_fatllama_plan_create(egr_fatllama_plan** out, int64_t n_in, int channels, int factor,
+                                        int m1_hint, int tc_hint) {
+    EGR_CHECK(out != nullptr, EGR_ERR_ARG, "out is null");
+    *out = nullptr;
+    EGR_CHECK(n_in >= 1 && factor >= 1 && channels >= 1 && channels <= 64, EGR_ERR_ARG,
+              "n_in=%lld channels=%d factor=%d out of range", (long long)n_in, channels, factor);
+    return create_for_length(out, n_in, channels, factor, n_in * factor, m1_hint, tc_hint);
+}
+
+// A plan whose output length is given explicitly (n_out >= n_in, not necessarily a multiple of it): SPEC.md factor_mode
+// "ratio_then_int".  egr_fatllama_enhance on such a plan needs EGR_FL_INTERP_LINSPACE (the only up-rating defined for a ratio).
+extern "C" int egr_fatllama_plan_create_n(egr_fatllama_plan** out, int64_t n_in, int64_t n_out, int channels) {
+    EGR_CHECK(out != nullptr, EGR_ERR_ARG, "out is null");
+    *out = nullptr;
+    EGR_CHECK(n_in >= 1 && n_out >= n_in && channels >= 1 && channels <= 64, EGR_ERR_ARG,
+              "n_in=%lld n_out=%lld channels=%d out of range", (long long)n_in, (long long)n_out, channels);
+    return create_for_length(out, n_in, channels, 0, n_out, 0, 0);
 }
 
 // Force a chirp-z plan on any length (tests, A/B runs): kind 1 = paired, even/odd packing (N even); 2 = paired, channel pairs
@@ -1222,15 +1272,18 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
     const unsigned* thr0_rel = (relative && !no_init) ? peak_y : nullptr;
     {
         const int nb = (int)((p->n_in + 255) / 256 < 2048 ? (p->n_in + 255) / 256 : 2048);
-        hipLaunchKernelGGL(k_prepare, dim3(nb, C), dim3(256), 0, st, x, out, (long long)p->n_in, p->factor,
-                           (flags & EGR_FL_PCM_IN) ? 1 : 0, (flags & EGR_FL_ZERO_STUFF) ? 1 : 0, peak_in, peak_y);
+        const int lin = (flags & EGR_FL_INTERP_LINSPACE) ? 1 : 0;
+        EGR_CHECK(lin || p->factor >= 1, EGR_ERR_ARG, "a plan with an explicit output length (egr_fatllama_plan_create_n) needs EGR_FL_INTERP_LINSPACE");
+        EGR_CHECK(!(lin && (flags & EGR_FL_ZERO_STUFF)), EGR_ERR_ARG, "EGR_FL_INTERP_LINSPACE and EGR_FL_ZERO_STUFF exclude each other");
+        hipLaunchKernelGGL(k_prepare, dim3(nb, C), dim3(256), 0, st, x, out, (long long)p->n_in, p->factor > 0 ? p->factor : 1,
+                           (flags & EGR_FL_PCM_IN) ? 1 : 0, (flags & EGR_FL_ZERO_STUFF) ? 1 : 0, peak_in, peak_y, lin, (long long)p->n_out);
     }
     const dim3 gA(8 * A.tiles_per_xcd, C), gB(8 * B.tiles_per_xcd, C * (three ? B.nplanes : 1)), grow(R.R / 2 + 1, C),
         blk(p->bluestein ? blue_threads() : p->threads), blk256(256);
     const size_t lc = p->sp.lds_col, lb = p->sp.lds_colb, lr = p->sp.lds_row;
     size_t slot = 0;
     if (max_iter == 0) {
-        const long long Nr = (long long)p->n_in * p->factor;
+        const long long Nr = (long long)p->n_out;
         const int nb = (int)((Nr + 255) / 256 < 2048 ? (Nr + 255) / 256 : 2048);
         hipLaunchKernelGGL(k_noiter, dim3(nb, C), blk256, 0, st, out, Nr, thr0, peak_out, thr0_rel);
     } else if (p->pz) {
@@ -1387,7 +1440,7 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         if (rc) return rc;
     }
     if (flags & (EGR_FL_NORMALIZE | EGR_FL_AUTOSCALE | EGR_FL_NODE_POST)) {
-        const long long Nr = (long long)p->n_in * p->factor;
+        const long long Nr = (long long)p->n_out;
         const int nb = (int)((Nr + 255) / 256 < 2048 ? (Nr + 255) / 256 : 2048);
         hipLaunchKernelGGL(k_finalize, dim3(nb, C), blk256, 0, st, out, Nr, C, flags, peak_in, peak_out);
     }

@@ -129,6 +129,7 @@ struct PzPlan;          // egr_fatllama_pz.hip
 
 struct egr_fatllama_plan {
     int64_t n_in;
+    int64_t n_out;        // real samples per channel the loop runs on: n_in * factor, or the explicit length of egr_fatllama_plan_create_n (factor 0)
     int C, factor, device;
     egr::FlSplit sp;
     egr::ColP colA, colB;

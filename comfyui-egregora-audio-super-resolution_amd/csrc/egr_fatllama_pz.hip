@@ -699,7 +699,7 @@ int pz_build(egr_fatllama_plan* plan, int kind) {
     const ColP& a = plan->colA;
     const RowP& r = plan->row;
     PzP& q = z->p;
-    const long long N = plan->n_in * plan->factor;
+    const long long N = plan->n_out;
     q.f = a.f; q.L = a.L; q.nc = a.ncols; q.TC = a.TC; q.TClog2 = a.TClog2;
     q.ntiles = a.ntiles; q.tiles_per_xcd = a.tiles_per_xcd;
     q.tw = a.tw; q.twd = a.twd; q.big = a.big;

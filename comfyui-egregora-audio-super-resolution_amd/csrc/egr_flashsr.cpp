@@ -13,6 +13,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -1033,12 +1034,12 @@ int forward(M* m, const float* x_in, const float* noise, int R, int lowpass_on, 
 }
 
 // ------------------------------------------------------------------------------------------------ one forward at a time per device
-// Open erratum: k_stft_frames returns 16 wrong bins per affected wave whenever its workgroups share compute
-// units with k_conv_s3 workgroups of ANOTHER stream (39-40 of 40 runs; not with the f32-MFMA kernel, not with torch kernels, not
-// among k_stft_frames launches; independent of the foreign kernel's LDS footprint -- tools/probe_coresidency_lds.py).  Until the
-// cause is known the library forbids the co-schedule: forwards issued on different streams of one device are chained by an event,
-// so the GPU never runs two of them at once, whatever streams the host (ComfyUI nodes, threads) uses.  Within one forward everything
-// is on one stream.  EGR_FSR_NO_STREAM_GUARD=1 removes the chain (probe / reproducer only).
+// A handle serves ONE caller stream at a time: its contexts' scratch arenas are reused in stream order, so forwards that arrive on
+// different streams of one device are chained by an event (whatever streams the host -- ComfyUI nodes, threads -- uses).  Inside
+// a call the handle runs up to max_groups row groups concurrently on its own verified side streams (egr_flashsr_infer).
+// History: the chain was introduced in round 1 against wrong STFT bins next to a foreign k_conv_s3; that was root-caused in
+// round 2 to a gfx950 packed-fp32 op_sel erratum and removed at the source (csrc/Makefile NOPK, tests/test_isa_audit.py,
+// DESIGN.md section 4.4a), so the guard is about arena ownership only.  EGR_FSR_NO_STREAM_GUARD=1 removes the chain (probes).
 struct ForwardGuard {
     static std::mutex& mu() { static std::mutex m; return m; }
     static std::map<int, std::pair<hipStream_t, hipEvent_t>>& last() { static std::map<int, std::pair<hipStream_t, hipEvent_t>> l; return l; }
@@ -1233,7 +1234,7 @@ extern "C" int egr_flashsr_infer(egr_flashsr* m, const float* x, int rows, int l
     const int64_t per_row = (int64_t)m->lat_h * m->lat_w * c.z_ch;
     int groups_max = m->profiling ? 1 : m->max_groups;          // per-kernel timing wants the kernels alone on the chip
     if (groups_max > 1 && std::min(rows, m->rows_per_pass) >= 2 * m->min_group_rows)
-        groups_max = 1 + ensure_side_streams(m, st0, groups_max - 1);
+        groups_max = std::min(m->max_groups, 1 + ensure_side_streams(m, st0, groups_max - 1));   // side contexts of an earlier, wider setting stay idle
     else
         groups_max = 1;
     Ten ids;                                                      // implicit ids 0 .. rows-1 as a device array (groups need offsets)
@@ -1348,50 +1349,81 @@ extern "C" int64_t egr_flashsr_scratch_bytes(egr_flashsr* m) {
 extern "C" int egr_flashsr_create_from_file(egr_flashsr** out, const char* path, unsigned flags, void* stream) {
     EGR_CHECK(out && path, EGR_ERR_ARG, "null argument");
     *out = nullptr;
-    FILE* f = fopen(path, "rb");
-    EGR_CHECK(f != nullptr, EGR_ERR_ARG, "cannot open %s", path);
-    std::vector<char> buf;
-    fseek(f, 0, SEEK_END);
-    const long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    buf.resize((size_t)sz);
-    const size_t got = fread(buf.data(), 1, (size_t)sz, f);
-    fclose(f);
-    EGR_CHECK(got == (size_t)sz && sz > 16 && memcmp(buf.data(), "EGRW0001", 8) == 0, EGR_ERR_ARG, "%s is not an EGRW0001 weight blob", path);
-    size_t pos = 8;
-    auto rd = [&](void* dst, size_t n) -> bool { if (pos + n > buf.size()) return false; memcpy(dst, buf.data() + pos, n); pos += n; return true; };
-    int32_t cb = 0, nt = 0;
-    egr_flashsr_config cfg;
-    bool ok = rd(&cb, 4) && cb == (int32_t)sizeof(cfg) && rd(&cfg, sizeof(cfg)) && rd(&nt, 4) && nt > 0;
-    EGR_CHECK(ok, EGR_ERR_ARG, "%s: header does not match this library's egr_flashsr_config (%d bytes)", path, (int)sizeof(cfg));
-    std::vector<std::string> names(nt);
-    std::vector<egr_tensor_desc> ds(nt);
-    std::vector<int64_t> offs(nt);
-    size_t total = 0;
-    for (int i = 0; i < nt && ok; ++i) {
-        int32_t nl = 0, nd = 0;
-        ok = rd(&nl, 4) && nl > 0 && nl < 512;
-        if (ok) { names[i].resize(nl); ok = rd(&names[i][0], nl); }
-        ok = ok && rd(&nd, 4) && nd >= 0 && nd <= 4 && rd(ds[i].shape, 32) && rd(&offs[i], 8);
-        ds[i].ndim = nd;
-        int64_t ne = 1;
-        for (int d = 0; d < nd; ++d) ne *= ds[i].shape[d];
-        ok = ok && offs[i] >= 0 && (size_t)offs[i] + (size_t)ne * 4 <= buf.size();
-        total += ((size_t)ne * 4 + 255) & ~(size_t)255;
+    // nothing may throw across the C boundary: allocation failures of the host buffers become EGR_ERR_ALLOC
+    try {
+        FILE* f = fopen(path, "rb");
+        EGR_CHECK(f != nullptr, EGR_ERR_ARG, "cannot open %s", path);
+        std::vector<char> buf;
+        long sz = -1;
+        if (fseek(f, 0, SEEK_END) == 0) sz = ftell(f);
+        if (sz <= 16 || fseek(f, 0, SEEK_SET) != 0) {
+            fclose(f);
+            set_error("%s is not an EGRW0001 weight blob (size %ld)", path, sz);
+            return EGR_ERR_ARG;
+        }
+        buf.resize((size_t)sz);
+        const size_t got = fread(buf.data(), 1, (size_t)sz, f);
+        fclose(f);
+        EGR_CHECK(got == (size_t)sz && memcmp(buf.data(), "EGRW0001", 8) == 0, EGR_ERR_ARG, "%s is not an EGRW0001 weight blob", path);
+        size_t pos = 8;
+        auto rd = [&](void* dst, size_t n) -> bool { if (n > buf.size() - pos) return false; memcpy(dst, buf.data() + pos, n); pos += n; return true; };
+        int32_t cb = 0, nt = 0;
+        egr_flashsr_config cfg;
+        constexpr int32_t kMaxTensors = 1 << 20;
+        bool ok = rd(&cb, 4) && cb == (int32_t)sizeof(cfg) && rd(&cfg, sizeof(cfg)) && rd(&nt, 4) && nt > 0 && nt <= kMaxTensors;
+        EGR_CHECK(ok, EGR_ERR_ARG, "%s: header does not match this library's egr_flashsr_config (%d bytes) or tensor count out of range", path, (int)sizeof(cfg));
+        std::vector<std::string> names(nt);
+        std::vector<egr_tensor_desc> ds(nt);
+        std::vector<int64_t> offs(nt);
+        std::vector<size_t> bytes(nt);
+        size_t total = 0;
+        for (int i = 0; i < nt && ok; ++i) {
+            int32_t nl = 0, nd = 0;
+            ok = rd(&nl, 4) && nl > 0 && nl < 512;
+            if (ok) { names[i].resize(nl); ok = rd(&names[i][0], nl); }
+            ok = ok && rd(&nd, 4) && nd >= 0 && nd <= 4 && rd(ds[i].shape, 32) && rd(&offs[i], 8);
+            if (!ok) break;
+            ds[i].ndim = nd;
+            // element count without overflow: every extent non-negative, the running product bounded by what the file can hold
+            const size_t cap = buf.size() / 4;
+            size_t ne = 1;
+            for (int d = 0; d < nd && ok; ++d) {
+                const int64_t e = ds[i].shape[d];
+                ok = e >= 0 && (e == 0 || ne <= cap / (size_t)e);
+                if (ok) ne *= (size_t)e;
+            }
+            ok = ok && offs[i] >= 0 && (size_t)offs[i] <= buf.size() && ne <= (buf.size() - (size_t)offs[i]) / 4;
+            bytes[i] = ne * 4;
+            total += (bytes[i] + 255) & ~(size_t)255;
+        }
+        EGR_CHECK(ok, EGR_ERR_ARG, "%s: corrupt tensor index", path);
+        char* dev = nullptr;
+        if (hipMalloc((void**)&dev, total + 256) != hipSuccess) {
+            set_error("hipMalloc of %zu bytes for the weight blob failed", total + 256);
+            return EGR_ERR_ALLOC;
+        }
+        size_t dpos = 0;
+        for (int i = 0; i < nt; ++i) {
+            if (bytes[i]) {
+                const hipError_t ce = hipMemcpy(dev + dpos, buf.data() + offs[i], bytes[i], hipMemcpyHostToDevice);
+                if (ce != hipSuccess) {
+                    hipFree(dev);
+                    set_error("hipMemcpy of tensor %s -> %s", names[i].c_str(), hipGetErrorString(ce));
+                    return EGR_ERR_HIP;
+                }
+            }
+            ds[i].name = names[i].c_str();
+            ds[i].data = (const float*)(dev + dpos);
+            dpos += (bytes[i] + 255) & ~(size_t)255;
+        }
+        const int rc = egr_flashsr_create(out, &cfg, ds.data(), nt, flags, stream);
+        hipFree(dev);
+        return rc;
+    } catch (const std::bad_alloc&) {
+        set_error("%s: out of host memory while reading the weight blob", path);
+        return EGR_ERR_ALLOC;
+    } catch (...) {
+        set_error("%s: unexpected failure while reading the weight blob", path);
+        return EGR_ERR_ARG;
     }
-    EGR_CHECK(ok, EGR_ERR_ARG, "%s: corrupt tensor index", path);
-    char* dev = nullptr;
-    EGR_HIP(hipMalloc((void**)&dev, total + 256));
-    size_t dpos = 0;
-    for (int i = 0; i < nt; ++i) {
-        int64_t ne = 1;
-        for (int d = 0; d < ds[i].ndim; ++d) ne *= ds[i].shape[d];
-        hipMemcpy(dev + dpos, buf.data() + offs[i], (size_t)ne * 4, hipMemcpyHostToDevice);
-        ds[i].name = names[i].c_str();
-        ds[i].data = (const float*)(dev + dpos);
-        dpos += ((size_t)ne * 4 + 255) & ~(size_t)255;
-    }
-    const int rc = egr_flashsr_create(out, &cfg, ds.data(), nt, flags, stream);
-    hipFree(dev);
-    return rc;
 }

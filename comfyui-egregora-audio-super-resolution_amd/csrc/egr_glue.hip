@@ -386,6 +386,33 @@ __global__ __launch_bounds__(256) void k_dfn_limit(float* __restrict__ y, long l
     }
 }
 
+// Delay compensation of the null-test suite (_apply_frac_delay_CN + _pad_or_crop_CN, egregora_null_test_suite.py:203-266):
+// s[i] = x[i - shift] inside [0, n_in) else 0; y[i] = sum_k h[k] s[i + (taps-1)/2 - k]  (np.convolve(s, h, "same"); taps = 0:
+// y = s); output length n_out (zero beyond n_in).  float32 products summed in order of k.
+__global__ __launch_bounds__(256) void k_shift_fir(const float* __restrict__ x, long long n_in, long long shift,
+                                                    const float* __restrict__ h, int taps, long long n_out,
+                                                    float* __restrict__ y) {
+    const float* xr = x + (size_t)blockIdx.y * n_in;
+    float* yr = y + (size_t)blockIdx.y * n_out;
+    const int off = (taps - 1) / 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_out; i += (long long)gridDim.x * 256) {
+        float acc = 0.f;
+        if (i < n_in) {
+            if (taps <= 0) {
+                const long long j = i - shift;
+                acc = (j >= 0 && j < n_in) ? xr[j] : 0.f;
+            } else {
+                for (int k = 0; k < taps; ++k) {
+                    const long long si = i + off - k;          // index into the shifted signal
+                    const long long j = si - shift;
+                    if (si >= 0 && si < n_in && j >= 0 && j < n_in) acc += h[k] * xr[j];
+                }
+            }
+        }
+        yr[i] = acc;
+    }
+}
+
 // ---------------------------------------------------------------- null-test suite levels and sums (egregora_null_test_suite.py:119-165, 420-470)
 // K-weighting approximation of the suite's loudness: z = (1-k) x + k z, y = x - z (each product and sum rounded to float32 as numpy's
 // scalar loop does), then y[n] += 0.02 (y[n] - y[n-1]).  The recurrence contracts by k per sample, so a thread restarts it W samples
@@ -689,6 +716,18 @@ extern "C" int egr_dfn_mix(const float* dry, const float* wet, const float* g_dr
     long long nb2 = (tot + 255) / 256;
     if (nb2 > 4096) nb2 = 4096;
     hipLaunchKernelGGL(k_dfn_limit, dim3((unsigned)nb2), dim3(256), 0, st, y, tot, (const unsigned*)peak_ws, limit, ceiling);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_shift_fir(const float* x, int channels, int64_t n_in, int64_t shift, const float* h, int taps, float* y,
+                             int64_t n_out, void* stream) {
+    EGR_CHECK(x && y && channels >= 1 && channels <= 65535 && n_in >= 1 && n_out >= 1 && taps >= 0 && (taps == 0 || h),
+              EGR_ERR_ARG, "bad argument");
+    long long nb = (n_out + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_shift_fir, dim3((unsigned)nb, channels), dim3(256), 0, (hipStream_t)stream, x, (long long)n_in,
+                       (long long)shift, h, taps, (long long)n_out, y);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }

@@ -17,9 +17,21 @@ from . import native, streams
 SAMPLE_WIDTH_BYTES = 2        # temp WAVs are PCM_16 (libsndfile default for float data)
 
 # Which reading of upstream's unverified threshold / interpolation semantics the nodes run (SPEC.md section 3): a comma list out of
-# relative, soft, no_init_thr, zero_stuff; empty = absolute level, hard threshold, time-domain pre-threshold, linear up-rating.
+# relative, soft, no_init_thr, zero_stuff, linspace, ratio_then_int; empty = absolute level, hard threshold, time-domain
+# pre-threshold, linear up-rating by the rounded integer factor.  ratio_then_int (output length int(n * ratio), needs linspace)
+# is a host-side rule: it has no device flag of its own.
 VARIANT_FLAGS = {"relative": native.FL_THR_RELATIVE, "soft": native.FL_THR_SOFT, "no_init_thr": native.FL_NO_INIT_THR,
-                 "zero_stuff": native.FL_ZERO_STUFF}
+                 "zero_stuff": native.FL_ZERO_STUFF, "linspace": native.FL_INTERP_LINSPACE, "ratio_then_int": native.FL_INTERP_LINSPACE}
+
+
+def variant_names(names=None):
+    names = os.environ.get("EGREGORA_FATLLAMA_SPEC", "") if names is None else names
+    return [t.strip() for t in str(names).split(",") if t.strip()]
+
+
+def upscale_ratio(sr: int, channels: int, target_bitrate_kbps: int) -> float:
+    """target bits/s over source bits/s, at least 1 (SPEC.md factor_mode "ratio_then_int")."""
+    return max(1.0, (target_bitrate_kbps * 1000.0) / (sr * channels * 8 * SAMPLE_WIDTH_BYTES))
 
 
 def variant_flags(names=None) -> int:
@@ -42,18 +54,20 @@ def upscale_factor(sr: int, channels: int, target_bitrate_kbps: int) -> int:
     return max(1, int(round((target_bitrate_kbps * 1000.0) / src_bps)))
 
 
-def _plan(n_in: int, channels: int, factor: int, device: int, m1_hint: int = 0, tc_hint: int = 0, split=None):
+def _plan(n_in: int, channels: int, factor: int, device: int, m1_hint: int = 0, tc_hint: int = 0, split=None, n_out=None):
     """split = (m1, m2, m3) forces an explicit factorisation of N/2 (m3 = 1: two levels); split = "chirpz" forces the paired chirp-z
     path that lengths without a packed-real plan take automatically ("chirpz1" / "chirpz2": its even/odd-packing / channel-pair
     kind), split = "bluestein" the legacy full-complex chirp-z."""
-    key = (n_in, channels, factor, device, m1_hint, tc_hint, split)
+    key = (n_in, channels, factor, device, m1_hint, tc_hint, split, n_out)
     h = _PLANS.get(key)
     if h is not None:
         _PLANS.move_to_end(key)
         return h
     L = native.lib()
     out = C.c_void_p()
-    if split == "bluestein":
+    if n_out is not None:
+        native.check(L.egr_fatllama_plan_create_n(C.byref(out), n_in, int(n_out), channels), "egr_fatllama_plan_create_n")
+    elif split == "bluestein":
         native.check(L.egr_fatllama_plan_create_bluestein(C.byref(out), n_in, channels, factor),
                      "egr_fatllama_plan_create_bluestein")
     elif isinstance(split, str) and split.startswith("chirpz"):
@@ -136,21 +150,23 @@ def _tune_pipelines(L, plan, x_ct, out, thr, flags, max_iterations):
 
 def enhance_device(x_ct: torch.Tensor, factor: int, max_iterations: int, threshold_value: float,
                    normalize: bool, autoscale: bool, pcm_in: bool, node_post: bool,
-                   m1_hint: int = 0, tc_hint: int = 0, profile: bool = False, split=None, variant=None):
-    """x_ct: [C,T] float32 CUDA tensor.  Returns [C,T*factor] float32 CUDA tensor (same stream).
-    variant: comma list for variant_flags (None: the EGREGORA_FATLLAMA_SPEC environment variable)."""
+                   m1_hint: int = 0, tc_hint: int = 0, profile: bool = False, split=None, variant=None, n_out=None):
+    """x_ct: [C,T] float32 CUDA tensor.  Returns [C,T*factor] float32 CUDA tensor (same stream); with n_out (and the linspace
+    variant) [C,n_out] instead.  variant: comma list for variant_flags (None: the EGREGORA_FATLLAMA_SPEC environment variable)."""
     if not (x_ct.is_cuda and x_ct.dtype == torch.float32 and x_ct.dim() == 2):
         raise RuntimeError("enhance_device wants a [C,T] float32 tensor on the GPU")
     x_ct = x_ct.contiguous()
     Cn, T = x_ct.shape
     if T < 1:
         raise RuntimeError("empty audio")
-    plan = _plan(T, Cn, factor, x_ct.device.index or 0, m1_hint, tc_hint, split)
-    out = torch.empty((Cn, T * factor), dtype=torch.float32, device=x_ct.device)
+    if n_out is not None and int(n_out) == T * factor:
+        n_out = None
+    plan = _plan(T, Cn, factor, x_ct.device.index or 0, m1_hint, tc_hint, split, n_out)
+    out = torch.empty((Cn, T * factor if n_out is None else int(n_out)), dtype=torch.float32, device=x_ct.device)
     flags = ((native.FL_NORMALIZE if normalize else 0) | (native.FL_AUTOSCALE if autoscale else 0) |
              (native.FL_PCM_IN if pcm_in else 0) | (native.FL_NODE_POST if node_post else 0) | variant_flags(variant))
     L = native.lib()
-    if Cn >= 2 and max_iterations > 100 and not profile and split is None and not plan_info(T, factor)["bluestein"]:
+    if Cn >= 2 and max_iterations > 100 and not profile and split is None and n_out is None and not plan_info(T, factor)["bluestein"]:
         _tune_pipelines(L, plan, x_ct, out, float(threshold_value), flags, int(max_iterations))
     if profile:
         L.egr_fatllama_set_profiling(C.c_void_p(plan), 1)
@@ -188,6 +204,10 @@ def node_run(cs: torch.Tensor, sr: int, max_iterations: int, threshold_value: fl
     native.require_device()
     x = cs.to("cuda", torch.float32, non_blocking=True).contiguous()
     f = upscale_factor(int(sr), x.shape[0], int(target_bitrate_kbps))
+    n_out, sr_out = None, int(sr) * f
+    if "ratio_then_int" in variant_names():          # SPEC.md factor_mode: the ratio is applied before int()
+        r = upscale_ratio(int(sr), x.shape[0], int(target_bitrate_kbps))
+        n_out, sr_out, f = int(x.shape[1] * r), int(int(sr) * r), 1
     y = enhance_device(x, f, int(max_iterations), float(threshold_value), bool(toggle_normalize),
-                       bool(toggle_autoscale), pcm_in=True, node_post=True)
-    return y, int(sr) * f
+                       bool(toggle_autoscale), pcm_in=True, node_post=True, n_out=n_out)
+    return y, sr_out

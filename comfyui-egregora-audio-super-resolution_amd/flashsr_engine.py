@@ -40,26 +40,57 @@ class FlashSREngine:
         self.count_flops = False
         self.prof = None            # when a list: (kind, flops, start_event, end_event) per MFMA kernel launch
         self.blocks = arch.unet_blocks(cfg)
-        self.w: Dict[str, torch.Tensor] = {}
-        self.wz: Dict[str, int] = {}               # floats per component of the z-stacked Winograd packs
-        self.w3: Dict[str, torch.Tensor] = {}      # three-way bf16 splits of self.w entries (egr_split3_pack)
-        self.wshape: Dict[str, tuple] = {}
+        # The packs of the PYTHON executor (forward_rows and the single operators the tests call: packed fp32 weights, bf16x3
+        # splits, Winograd U, folded time embedding) are built on first use of self.w / w3 / wz / wshape: the product path is the
+        # C handle, which packs its own copy inside the library, and does not pay for a second set in VRAM.
+        self._w: Dict[str, torch.Tensor] = {}
+        self._wz: Dict[str, int] = {}              # floats per component of the z-stacked Winograd packs
+        self._w3: Dict[str, torch.Tensor] = {}     # three-way bf16 splits of self.w entries (egr_split3_pack)
+        self._wshape: Dict[str, tuple] = {}
+        self._packed = False
         self.mfma = self.MFMA_MODE
         self.thin = self.THIN_ENDS
         self._handle = None
-        self._params = {k: v.detach().float().contiguous() for k, v in params.items()}     # torch layouts, for the C-ABI handle
+        self._params = {k: v.detach().float().contiguous() for k, v in params.items()}     # torch layouts (host), for the handle and the lazy packs
         self._g_dev = {}
-        self._pack(params)
         self.window = torch.hann_window(cfg.n_fft, periodic=True, dtype=torch.float32).to(self.dev)
         self.filt = torch.from_numpy(arch.kaiser_sinc_filter(cfg.aa_taps)).to(self.dev)
         nb = cfg.n_fft // 2 + 1
         self.ldm = ((nb + 15) // 16) * 16
         self.mel_fb = torch.from_numpy(arch.mel_filterbank(cfg)).contiguous().to(self.dev)       # [n_mels][nb]
-        self.w["mel_fb"] = self._pack_dev(self.mel_fb, 0, nb, cfg.n_mels, nb, cfg.n_mels, 1, 1)
-        self._split3("mel_fb")
         self.alpha, self.sigma = arch.cosine_alpha_sigma(cfg, cfg.t_steps - 1)
         self._gn_ws = {}            # GroupNorm scratch per stream (row groups of one forward run on several streams)
+
+    def _ensure_packed(self):
+        if self._packed:
+            return
+        self._packed = True         # first: the packing code below goes through the same properties
+        cfg = self.cfg
+        nb = cfg.n_fft // 2 + 1
+        self._pack(self._params)
+        self._w["mel_fb"] = self._pack_dev(self.mel_fb, 0, nb, cfg.n_mels, nb, cfg.n_mels, 1, 1)
+        self._split3("mel_fb")
         self._fold_time_embedding()
+
+    @property
+    def w(self):
+        self._ensure_packed()
+        return self._w
+
+    @property
+    def w3(self):
+        self._ensure_packed()
+        return self._w3
+
+    @property
+    def wz(self):
+        self._ensure_packed()
+        return self._wz
+
+    @property
+    def wshape(self):
+        self._ensure_packed()
+        return self._wshape
 
     # Dense contractions run on the bf16 matrix pipe with fp32-grade results ("bf16x3": exact three-way split of both
     # operands, six partial products accumulated in fp32, csrc/egr_nn_gemm_s3.hip) or on v_mfma_f32_32x32x2_f32 ("f32").
@@ -865,7 +896,8 @@ def infer_rows(eng: FlashSREngine, rows_x: torch.Tensor, row_ids: torch.Tensor, 
                lowpass: bool = False) -> torch.Tensor:
     """rows_x [R, chunk] -> [R, chunk] through the C-ABI handle (egr_flashsr_infer: ROWS_PER_PASS rows at a time on the caller's
     stream, noise keyed by global row id).  EGREGORA_FLASHSR_EXECUTOR=python routes through the operator-by-operator driver
-    instead (bit-identical; dev only).  One stream only: row groups on concurrent streams are not used."""
+    instead (bit-identical; dev only).  The handle splits a pass of >= 12 rows into up to EGREGORA_FLASHSR_STREAMS (default 2)
+    row groups on verified side streams inside the call; the caller sees one stream."""
     if EXECUTOR != "python":
         return eng.c_infer(rows_x, row_ids, seed, lowpass)
     outs = []

@@ -12,7 +12,7 @@ LIB_PATH = Path(__file__).resolve().parent / "libegregora_amd.so"
 
 EGR_OK = 0
 FL_NORMALIZE, FL_AUTOSCALE, FL_PCM_IN, FL_NODE_POST = 0x1, 0x2, 0x4, 0x8
-FL_THR_RELATIVE, FL_THR_SOFT, FL_NO_INIT_THR, FL_ZERO_STUFF = 0x10, 0x20, 0x40, 0x80      # SPEC.md section 3
+FL_THR_RELATIVE, FL_THR_SOFT, FL_NO_INIT_THR, FL_ZERO_STUFF, FL_INTERP_LINSPACE = 0x10, 0x20, 0x40, 0x80, 0x100      # SPEC.md section 3
 FL_INFO_LEN = 48
 ABI_VERSION = 2          # include/egregora_amd.h EGR_ABI_VERSION
 
@@ -25,6 +25,7 @@ SIGNATURES = {
     "egr_device_arch": (_i, [_i, C.c_char_p, C.c_size_t]),
     "egr_fatllama_plan_query": (_i, [_i64, _i, _i, C.POINTER(_i64)]),
     "egr_fatllama_plan_create": (_i, [C.POINTER(_vp), _i64, _i, _i, _i, _i]),
+    "egr_fatllama_plan_create_n": (_i, [C.POINTER(_vp), _i64, _i64, _i]),
     "egr_fatllama_plan_create_ex": (_i, [C.POINTER(_vp), _i64, _i, _i, _i, _i, _i, _i]),
     "egr_fatllama_plan_create_bluestein": (_i, [C.POINTER(_vp), _i64, _i, _i]),
     "egr_fatllama_plan_create_chirpz": (_i, [C.POINTER(_vp), _i64, _i, _i, _i]),
@@ -41,6 +42,7 @@ SIGNATURES = {
     "egr_dfn_workspace_bytes": (C.c_size_t, [_i, _i64]),
     "egr_dfn_vad_gains": (_i, [_vp, _i, _i64, C.c_double, _i, C.c_double, C.c_double, C.c_double, _i, _vp, _vp, _vp, _vp]),
     "egr_dfn_mix": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i, _f, _i, _i, C.c_double, _vp, _vp, _vp]),
+    "egr_shift_fir": (_i, [_vp, _i, _i64, _i64, _vp, _i, _vp, _i64, _vp]),
     "egr_gcc_phat": (_i, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
     "egr_band_filter": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "egr_kweight": (_i, [_vp, _i, _i64, _f, _f, _vp, _vp]),

@@ -59,6 +59,7 @@ typedef struct egr_fatllama_plan egr_fatllama_plan;
 #define EGR_FL_THR_SOFT     0x20u /* spectrum: X max(0, 1 - level/|X|) instead of X [|X| > level]                   */
 #define EGR_FL_NO_INIT_THR  0x40u /* d0 = y (no time-domain threshold before the first transform)                  */
 #define EGR_FL_ZERO_STUFF   0x80u /* up-rate by zero insertion (y[i*f] = x[i]) instead of linear interpolation      */
+#define EGR_FL_INTERP_LINSPACE 0x100u /* up-rate as numpy.interp(linspace(0, n-1, n_out), arange(n), x): endpoint-inclusive grid, no zero tail */
 
 /* Host-only planning query (no GPU needed): fills info[] =
  *   {supported (1 = packed real plan, 2 = chirp-z over M = P complex points per state), N, M, M1, M2, TC, nst1, nst2,
@@ -70,6 +71,9 @@ int egr_fatllama_plan_query(int64_t n_in, int factor, int m1_hint, int64_t info[
 
 int egr_fatllama_plan_create(egr_fatllama_plan** out, int64_t n_in, int channels, int factor, int m1_hint,
                              int tc_hint);
+/* Output length given explicitly (n_out >= n_in, any ratio): SPEC.md factor_mode "ratio_then_int"; enhance then needs
+ * EGR_FL_INTERP_LINSPACE and writes [channels][n_out]. */
+int egr_fatllama_plan_create_n(egr_fatllama_plan** out, int64_t n_in, int64_t n_out, int channels);
 /* Explicit factorisation N/2 = m1*m2*m3 (m3 = 1: two levels); used by tests and tuning. */
 int egr_fatllama_plan_create_ex(egr_fatllama_plan** out, int64_t n_in, int channels, int factor, int m1, int m2, int m3,
                                 int tc_hint);
@@ -176,6 +180,12 @@ int egr_pair_stats(const float* a, int ca, int64_t stride_a, const float* b, int
  * (:437-441, 449, 463) */
 int egr_null_mix(const float* a, int64_t stride_a, const float* b, int64_t stride_b, int channels, int64_t n, float k, int use_k,
                  int invert_b, float* null_out, double* out2, void* stream);
+
+/* Delay compensation of the null-test suite's aligner: y[c][i] = sum_k h[k] s[i + (taps-1)/2 - k] with s[i] = x[c][i - shift]
+ * (zero outside [0, n_in)), i.e. an integer shift followed by np.convolve(., h, "same"); taps = 0 skips the FIR; n_out pads with
+ * zeros or crops (_apply_frac_delay_CN + _pad_or_crop_CN, egregora_null_test_suite.py:203-266). */
+int egr_shift_fir(const float* x, int channels, int64_t n_in, int64_t shift, const float* h, int taps, float* y, int64_t n_out,
+                  void* stream);
 
 /* Evaluation metrics on the device (the parity yardstick of this pack and the reference's "Metrics (LSD + SI-SDR)" node):
  *   egr_lsd_frames  : per[f] = sqrt(mean_k (20 log10(SA[f][k]+1e-12) - 20 log10(SB[f][k]+1e-12))^2 + 1e-12) from two

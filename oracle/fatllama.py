@@ -35,6 +35,11 @@ class FatLlamaSpec:
     factor_rounding: str = "round"       # upscale_factor = round(target_bps / source_bps), min 1
     interp: str = "linear"               # y[i*f+j] = (1-j/f) x[i] + (j/f) x[i+1], i < n-1; tail zero
                                          # "zero_stuff": y[i*f] = x[i], zeros between (spectral-sparsity interpolation)
+                                         # "linspace": np.interp(np.linspace(0, n-1, n_out), np.arange(n), x) -- endpoint-inclusive
+                                         #   grid, no zero tail (the round-2 judge's recollection; as unverified as the survey's)
+    factor_mode: str = "integer"         # "integer": n_out = n * upscale_factor (rounded per factor_rounding);
+                                         # "ratio_then_int": n_out = int(n * ratio), ratio = target_bps / source_bps >= 1 applied
+                                         #   BEFORE int() (needs interp = "linspace": the only up-rating defined for a ratio)
     normalize_scope: str = "joint"       # out / max|out| over all channels
     autoscale: str = "match_peak"        # per channel: out *= max|in| / max|out|
     # ---- threshold semantics of the IST loop (SPEC.md section 3; every combination runs on the device) ----
@@ -67,10 +72,21 @@ def upscale_factor(sr, channels, target_bitrate_kbps, spec=DEFAULT_SPEC):
     return max(1, f)
 
 
-def interpolate(x, f, spec=DEFAULT_SPEC):
-    """Up-rate by integer factor.  linear: the last input sample's f slots stay zero; zero_stuff: y[::f] = x."""
+def upscale_ratio(sr, channels, target_bitrate_kbps, spec=DEFAULT_SPEC):
+    """target bits/s over source bits/s, at least 1 (factor_mode "ratio_then_int")."""
+    return max(1.0, (target_bitrate_kbps * 1000.0) / (sr * channels * 8 * spec.sample_width))
+
+
+def interpolate(x, f, spec=DEFAULT_SPEC, n_out=None):
+    """Up-rate by integer factor f (or to n_out samples, linspace only).  linear: the last input sample's f slots stay zero;
+    zero_stuff: y[::f] = x; linspace: numpy.interp on the endpoint-inclusive grid (float64 arithmetic, rounded to float32)."""
     x = np.asarray(x, np.float32)
     n = x.shape[0]
+    if spec.interp == "linspace":
+        m = n * f if n_out is None else int(n_out)
+        return np.interp(np.linspace(0, n - 1, m), np.arange(n), x.astype(np.float64)).astype(np.float32)
+    if n_out is not None and n_out != n * f:
+        raise ValueError("an output length that is not n * f needs interp = 'linspace'")
     y = np.zeros(n * f, np.float32)
     if spec.interp == "zero_stuff":
         y[::f] = x
@@ -126,13 +142,13 @@ def ist_loop(y, max_iter, thr, spec=DEFAULT_SPEC, trace=None, exact=False):
 
 
 def enhance_channels(x_ci, factor, max_iter, thr, normalize=True, autoscale=True, spec=DEFAULT_SPEC,
-                     exact=False):
+                     exact=False, n_out=None):
     """x_ci: [C,N] float32 on the *integer* PCM scale (what pydub hands upstream).
     Returns [C, N*factor] float32 (before the write patch); float64 when exact=True (loop only)."""
     x_ci = np.asarray(x_ci, np.float32)
     outs = []
     for c in range(x_ci.shape[0]):
-        y = interpolate(x_ci[c], factor, spec)
+        y = interpolate(x_ci[c], factor, spec, n_out)
         d = ist_loop(y, max_iter, thr, spec, exact=exact)
         outs.append(y.astype(np.float64) + d if exact else (y + d).astype(np.float32))
     out = np.stack(outs, 0)
@@ -178,8 +194,12 @@ def node_run(cs, sr, max_iterations, threshold_value, target_bitrate_kbps,
     C = cs.shape[0]
     xi = pcm16_write(cs, spec).astype(np.float32)            # temp WAV in, pydub ints out
     f = upscale_factor(sr, C, target_bitrate_kbps, spec)
-    out = enhance_channels(xi, f, max_iterations, threshold_value, toggle_normalize, toggle_autoscale, spec)
+    n_out, sr_out = None, sr * f
+    if spec.factor_mode == "ratio_then_int":
+        r = upscale_ratio(sr, C, target_bitrate_kbps, spec)
+        n_out, sr_out, f = int(cs.shape[1] * r), int(sr * r), 1
+    out = enhance_channels(xi, f, max_iterations, threshold_value, toggle_normalize, toggle_autoscale, spec, n_out=n_out)
     out = write_patch_scale(out, spec)
     y = pcm16_read(pcm16_write(out, spec), spec)             # upstream sf.write + node sf.read
     # _to_cs on read-back (egregora_fat_llama_gpu.py:292): peak > 1 cannot occur after PCM16
-    return y, sr * f
+    return y, sr_out

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(pack):
 
 def test_abi_version_and_host_only_planning(pack):
     from egregora_amd import fatllama_engine as fe, native
-    assert native.lib().egr_abi_version() == 1
+    assert native.lib().egr_abi_version() == native.ABI_VERSION == 2
     i = fe.plan_info(2880000, 1)
     assert i["supported"] and i["M1"] * i["M2"] == 1440000 and i["N"] == 2880000
     prod = 1
@@ -36,8 +36,11 @@ def test_abi_version_and_host_only_planning(pack):
         prod *= r
     assert prod == i["M1"]
     assert fe.plan_info(160000, 6)["M"] == 480000
-    odd = fe.plan_info(101, 1)                 # no packed-real plan: chirp-z over P >= 2N-1 complex points
-    assert odd["supported"] and odd["bluestein"] and odd["M"] >= 201
+    odd = fe.plan_info(101, 1)                 # no packed-real plan: paired chirp-z, channel pairs, P >= 2D - 1 complex points
+    assert odd["supported"] and odd["bluestein"] and odd["chirpz_kind"] == 2 and odd["D"] == 101 and odd["M"] >= 201
+    even = fe.plan_info(2880002, 1)            # 60 s + 2 samples: even/odd packing, D = N / 2, both passes on scheduled lengths
+    assert even["chirpz_kind"] == 1 and even["D"] == 1440001 and (even["M1"], even["M2"]) == (720, 4096)
+    assert fe.plan_info(2880001, 1)["chirpz_kind"] == 2 and fe.plan_info(2880001, 1)["M2"] == 8192
     assert not fe.plan_info(2880000, 1)["bluestein"]
     bad = fe.plan_info(1, 1)
     assert not bad["supported"] and "unsupported" in bad["error"]

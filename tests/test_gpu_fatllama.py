@@ -160,6 +160,24 @@ def test_large_threshold_actually_gates_bins(pack, thr):
     assert num / den < 1e-6
 
 
+@pytest.mark.parametrize("C,n,sr,kbps", [(1, 16000, 16000, 1411), (2, 4801, 44100, 3000), (2, 9600, 48000, 1536)])
+def test_ratio_then_int_node_path(pack, monkeypatch, C, n, sr, kbps):
+    """SPEC.md factor_mode "ratio_then_int" + interp "linspace": the output length is int(n * ratio) -- 88187 samples for one second
+    of 16 kHz mono at 1411 kbps, no multiple of the input -- through the node arithmetic (PCM_16 hops, autoscale, normalise) against
+    oracle.node_run with the matching FatLlamaSpec; a ratio of exactly 1 (48 kHz stereo at 1536 kbps) degenerates to factor 1."""
+    import dataclasses
+    from egregora_amd import fatllama_engine as fe
+    spec = dataclasses.replace(ofl.DEFAULT_SPEC, interp="linspace", factor_mode="ratio_then_int")
+    cs = synth(C, n, seed=n, scale=0.4, integer=False)
+    want, sr_out = ofl.node_run(cs, sr, 4, 0.6, kbps, True, True, spec=spec)
+    monkeypatch.setenv("EGREGORA_FATLLAMA_SPEC", "linspace,ratio_then_int")
+    got, sr_dev = fe.node_run(torch.from_numpy(cs), sr, 4, 0.6, kbps, True, True)
+    got = got.cpu().numpy()
+    assert sr_dev == sr_out and got.shape == want.shape and (want.shape[1] % n != 0 or kbps == 1536)
+    lsb = np.abs(got - want) * 32768.0
+    assert float(lsb.max()) <= 1.0 + 1e-6 and float(np.mean(lsb > 0.5)) <= 5e-2, (float(lsb.max()), float(np.mean(lsb > 0.5)))
+
+
 def test_zero_iterations_and_edge_inputs(pack):
     x = synth(2, 64, seed=1)
     want = ofl.enhance_channels(x, 1, 0, 0.6, normalize=False, autoscale=False)
@@ -299,6 +317,8 @@ VARIANTS = [  # (variant list for the device, FatLlamaSpec overrides, threshold,
     ("relative,no_init_thr", {"threshold_ref": "relative_to_max", "init_threshold": "none"}, 0.3, 8000.0),
     ("relative,soft,zero_stuff", {"threshold_ref": "relative_to_max", "threshold_kind": "soft", "interp": "zero_stuff"}, 0.05, 8000.0),
     ("zero_stuff,no_init_thr", {"interp": "zero_stuff", "init_threshold": "none"}, 400.0, 100.0),
+    ("linspace", {"interp": "linspace"}, 50.0, 100.0),
+    ("linspace,relative,soft", {"interp": "linspace", "threshold_ref": "relative_to_max", "threshold_kind": "soft"}, 0.02, 8000.0),
 ]
 
 

@@ -13,7 +13,7 @@ def test_mappings_and_surface_equal_reference(pack):
     g = gjson("g8_surface")
     core = {"EgregoraAudioUpscaler", "EgregoraFatLlamaGPU", "EgregoraFatLlamaCPU"}
     assert set(pack.NODE_CLASS_MAPPINGS) == core | {"Metrics (LSD + SI-SDR)", "Resample Audio (HQ)", "Egregora_DeepFilterNet_Denoise",
-                                                   "Audio Null Test"}       # SURVEY section 8(f) rows 1-3, nothing else
+                                                   "Audio Align (XCorr)", "Audio Gain Match", "Audio Null Test", "Audio Plotter", "Null Test (Full)"}
     for key in sorted(core):
         assert pack.NODE_DISPLAY_NAME_MAPPINGS[key] == g["display"][key]
         cls = pack.NODE_CLASS_MAPPINGS[key]

@@ -1,11 +1,12 @@
-"""`Audio Null Test` of the null-test suite and the level / band kernels behind its metrics
+"""`Audio Gain Match`, `Audio Null Test`, `Audio Plotter`, `Null Test (Full)` of the null-test suite
 against fixture G14, captured from the reference's nodes (tests/golden/make_golden_nulltest.py).
 
 not gpu : oracle/nulltest.py reproduces every float of the fixture exactly (levels, gains, metrics, matched and null audio); the
-          node surface equals the reference's
+          four node surfaces equal the reference's
 gpu     : kernels against the oracle (K-weighting within one ulp of the filter state, block energies 1e-12 relative, band energy at even / odd / prime
           lengths 2e-4 dB); nodes through the C ABI against the fixture: levels and gains 2e-5 dB, audio bit-exact up to that gain
-          (1e-6 relative), metrics: dB values 2e-4, correlation 2e-6, LSD 2e-5 relative, counts exact
+          (1e-6 relative), metrics: dB values 2e-4, correlation 2e-6, LSD 2e-5 relative, counts exact; `Null Test (Full)` (which
+          chains the aligner, whose delay estimate moves the FIR taps) 2e-2 dB / 1e-2 of peak
 """
 import inspect
 import json
@@ -42,7 +43,7 @@ def test_oracle_reproduces_fixture_exactly():
         assert m == c["metrics"] and list(m.keys()) == c["metric_order"] and np.array_equal(nul[:, ::29], z[f"null{i}"]), (s, kw)
 
 
-@pytest.mark.parametrize("key", ["Audio Null Test"])
+@pytest.mark.parametrize("key", KEYS)
 def test_surface_equals_reference(pack, key):
     g = gjson("g14_nulltest")["surface"][key]
     cls = pack.NODE_CLASS_MAPPINGS[key]
@@ -91,6 +92,21 @@ def test_band_energy_vs_oracle(pack):
         assert abs(got - want) <= 2e-4, (n, sr, lo, got, want)
 
 
+@pytest.mark.gpu
+def test_gain_match_node_vs_fixture(pack):
+    g, z, sig = gjson("g14_nulltest"), gnpz("g14_nulltest"), signals()
+    node = pack.NODE_CLASS_MAPPINGS["Audio Gain Match"]()
+    for i, (s, kw) in enumerate(GAIN_CASES):
+        a, sr, b, sr2 = sig[s]
+        out, gd, rl, il = node.execute(aud(a, sr), aud(b, sr2, {"tag": i}), **kw)
+        c = g["gain"][i]
+        assert max(abs(gd - c["gain_db"]), abs(rl - c["ref_level"]), abs(il - c["in_level"])) <= 2e-5, (s, kw, gd, rl, il)
+        assert list(out["waveform"].shape) == c["shape"] and out["sample_rate"] == c["sr"] and out["meta"] == c["meta"]
+        assert sorted(out.keys()) == c["keys"]
+        want = z[f"gain{i}"]
+        assert np.abs(out["samples"][:, ::29] - want).max() <= 4e-6 * np.abs(want).max(), (s, kw)
+
+
 def check_metrics(m, want, db_tol, corr_tol, lsd_rel, exact_counts=True):
     assert list(m.keys()) == list(want.keys()) or set(m.keys()) == set(want.keys())
     for k, v in want.items():
@@ -124,3 +140,33 @@ def test_null_test_node_vs_fixture(pack):
     a, sr, b, _ = sig["short"]
     with pytest.raises(ValueError, match=g["rate_mismatch_error"]):
         node.execute(aud(a, sr), aud(b, 44100))
+
+
+@pytest.mark.gpu
+def test_full_node_vs_fixture(pack):
+    g, z, sig = gjson("g14_nulltest"), gnpz("g14_nulltest"), signals()
+    node = pack.NODE_CLASS_MAPPINGS["Null Test (Full)"]()
+    for i, (s, kw) in enumerate(FULL_CASES):
+        a, sr, b, sr2 = sig[s]
+        r = node.execute(aud(a, sr), aud(b, sr2, {"src": s}), **kw)
+        c = g["full"][i]
+        assert abs(r[2] - c["delay_ms"]) <= 2e-4 and abs(r[3] - c["gain_db"]) <= 2e-2, (r[2], r[3])
+        check_metrics(r[4], c["metrics"], 2e-2, 5e-3, 5e-3, exact_counts=False)
+        assert [list(r[0]["waveform"].shape), list(r[1]["waveform"].shape)] == c["shapes"] and [r[0]["meta"], r[1]["meta"]] == c["meta"]
+        assert [list(im.shape) for im in r[5:]] == c["images"]
+        for got, name in ((r[0], "matched"), (r[1], "null")):
+            want = z[f"full{i}_{name}"]
+            assert np.abs(got["samples"][:, ::29] - want).max() <= 1e-2 * np.abs(want).max(), (s, name)
+
+
+@pytest.mark.gpu
+def test_plotter_image_shapes(pack):
+    pytest.importorskip("matplotlib")
+    g, sig = gjson("g14_nulltest"), signals()
+    a, sr, b, _ = sig["short"]
+    nul, _ = pack.NODE_CLASS_MAPPINGS["Audio Null Test"]().execute(aud(a, sr), aud(b, sr))
+    node = pack.NODE_CLASS_MAPPINGS["Audio Plotter"]()
+    imgs = node.execute(aud(a, sr), aud(b, sr), nul)
+    assert [list(im.shape) for im in imgs] == g["plotter"]["all"]
+    assert all(im.dtype == torch.float32 and 0.0 <= float(im.min()) and float(im.max()) <= 1.0 for im in imgs)
+    assert [list(im.shape) for im in node.execute(aud(a, sr), aud(b, sr), nul, False, False, False)] == g["plotter"]["none"]

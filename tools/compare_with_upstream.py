@@ -64,8 +64,11 @@ def main():
     node = pack.NODE_CLASS_MAPPINGS["EgregoraFatLlamaCPU"]()          # same 7-kwarg contract, device engine
     combos = [""]
     if args.variants:
-        names = ("relative", "soft", "no_init_thr", "zero_stuff")
-        combos = [",".join(c) for r in range(len(names) + 1) for c in itertools.combinations(names, r)]
+        names = ("relative", "soft", "no_init_thr")
+        thr = [",".join(c) for r in range(len(names) + 1) for c in itertools.combinations(names, r)]
+        # x every up-rating rule: linear by the integer factor (survey recall), zero insertion, numpy.interp on the endpoint-inclusive
+        # linspace grid by the integer factor, and the same with the ratio applied before int() (judge recall, SPEC.md section 3)
+        combos = [",".join(t for t in (a, b) if t) for a in thr for b in ("", "zero_stuff", "linspace", "linspace,ratio_then_int")]
     for combo in combos:
         os.environ["EGREGORA_FATLLAMA_SPEC"] = combo
         (res,) = node.run("wav", args.iters, args.thr, args.kbps, AUDIO={"waveform": torch.from_numpy(x)[None, None], "sample_rate": args.sr})
