@@ -88,6 +88,7 @@ template <int NE> struct PzTwRun {
 #pragma unroll
         for (int k = 0; k < NE; ++k) w[k] = make_float2(1.f, 0.f);
 #else
+        if (i0 >= p.L) i0 = 0;                       // a thread past the tile has no elements: keep its table index in range
         dcplx cur = tw2d(p.big, (unsigned)col * (unsigned)i0);
         const dcplx st = tw2d(p.big, (unsigned)(((unsigned long long)col * (unsigned long long)di) % (unsigned long long)p.P));
 #pragma unroll

@@ -48,6 +48,11 @@ class FlashSREngine:
         self._w3: Dict[str, torch.Tensor] = {}     # three-way bf16 splits of self.w entries (egr_split3_pack)
         self._wshape: Dict[str, tuple] = {}
         self._packed = False
+        # the class-level switches (MFMA_MODE, WINO_MIN_CH, THIN_ENDS ...) are frozen per engine at construction: the lazy packs and
+        # the handle flags must see the values this engine was built under, whatever the class holds later
+        for name in dir(type(self)):
+            if name.isupper() and not name.startswith("_"):
+                setattr(self, name, getattr(type(self), name))
         self.mfma = self.MFMA_MODE
         self.thin = self.THIN_ENDS
         self._handle = None
@@ -353,7 +358,7 @@ class FlashSREngine:
             self._split3(key)
 
     def _pack(self, P):
-        self.wshape = {}
+        self._wshape.clear()
         for k, v in P.items():
             if k.endswith(".weight") and v.dim() >= 2:
                 self.add_weight(k, v)

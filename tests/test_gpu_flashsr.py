@@ -148,8 +148,8 @@ def test_winograd_conv_vs_torch(eng, f4):
     components, and F(4x4,3x3) with 36 where H and W are multiples of 4 (other shapes fall back to F(2x2))."""
     e, cfg, P = eng
     g = torch.Generator().manual_seed(41)
-    oldf4 = type(e).WINO_F4
-    type(e).WINO_F4 = f4
+    oldf4 = e.WINO_F4          # the switches are frozen per engine at construction: set them on the instance
+    e.WINO_F4 = f4
     for (B, H, W, Ci, Co, use_res, act) in [(2, 8, 12, 32, 48, True, 1), (1, 16, 16, 64, 128, False, 0), (3, 6, 4, 144, 80, True, 0),
                                             (2, 4, 4, 16, 20, True, 1), (1, 8, 8, 24, 36, False, 1)]:     # last: Cin % 16 != 0 (f32 GEMMs)
         x = torch.randn(B, Ci, H, W, generator=g)
@@ -169,7 +169,7 @@ def test_winograd_conv_vs_torch(eng, f4):
         close(nchw(got), want, 3e-5)
         e.w.pop("wg.weight.wino")
         e.w.pop("wg.weight.wino4", None)
-    type(e).WINO_F4 = oldf4
+    e.WINO_F4 = oldf4
 
 
 def test_winograd4_error_vs_float64(eng):
@@ -232,9 +232,9 @@ def test_fused_groupnorm_conv_vs_torch(eng):
     """conv3x3(silu(groupnorm(x))) with the normalisation applied in the conv loader / the Winograd input transform."""
     e, cfg, P = eng
     g = torch.Generator().manual_seed(43)
-    old, oldf = e.cfg.gn_groups, type(e).FUSE_GN
+    old, oldf = e.cfg.gn_groups, e.FUSE_GN
     e.cfg.gn_groups = 8
-    type(e).FUSE_GN = "all"
+    e.FUSE_GN = "all"
     try:
         for wino in (False, True):
             for (B, H, W, Ci, Co) in [(2, 8, 12, 32, 48), (3, 6, 4, 64, 80)]:
@@ -255,7 +255,7 @@ def test_fused_groupnorm_conv_vs_torch(eng):
                 e.w.pop("fc.weight.wino4", None)
     finally:
         e.cfg.gn_groups = old
-        type(e).FUSE_GN = oldf
+        e.FUSE_GN = oldf
 
 
 def test_upsample_conv_as_four_phase_convs(eng):
