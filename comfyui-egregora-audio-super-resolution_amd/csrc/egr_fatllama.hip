@@ -75,6 +75,7 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
                                               float* __restrict__ out, unsigned* __restrict__ peak_out,
                                               const unsigned* __restrict__ thr_rel = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    EGR_LDS_CANARY_ARM(smem);
     __shared__ float red[16];
     // XCD-aware tile order: the dispatcher places block b on XCD b%8; give every XCD a contiguous run
     // of column tiles so the two tiles sharing a 128-byte line hit the same L2.
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
     const int ch = blockIdx.y / p.nplanes, plane = blockIdx.y - ch * p.nplanes;
     const int TC = p.TC, lg = p.TClog2, L = p.L, nc = p.ncols;
     const int c0 = tile * TC;
-    cplx* cur = (cplx*)smem;
+    cplx* cur = (cplx*)EGR_LDS_BASE(smem);
     cplx* alt = cur + (size_t)L * TC;
     const size_t poff = (size_t)plane * L * nc;
     cplx* W = work + (size_t)ch * M + poff;
@@ -197,6 +198,7 @@ __device__ __forceinline__ void row_fft(cplx*& cur, cplx*& alt, const RowP& p, i
 template <bool MAXONLY, int SCHED = 0>
 __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1) void k_row(RowP p, long long M, cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    EGR_LDS_CANARY_ARM(smem);
     __shared__ float red[16];
     const int L = p.L, R = p.R;
     const int oa = blockIdx.x;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
     const bool self = (oa == ob);
     const int nrows = self ? 1 : 2;
     const int ch = blockIdx.y;
-    cplx* cur = (cplx*)smem;
+    cplx* cur = (cplx*)EGR_LDS_BASE(smem);
     cplx* alt = cur + 2 * (size_t)L;
     cplx* W = work + (size_t)ch * M;
     const int ra = (oa % p.Ma) * p.Mb + oa / p.Ma;
@@ -390,13 +392,14 @@ __global__ __launch_bounds__(1024) void k_colz(ColP p, ChirpP cp, long long P, f
                                                cplx* __restrict__ work, float* __restrict__ out,
                                                unsigned* __restrict__ peak_out, const unsigned* __restrict__ thr_rel = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    EGR_LDS_CANARY_ARM(smem);
     __shared__ float red[16];                 // one slot per wave: up to 1024 threads
     const int tile = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
     if (tile >= p.ntiles) return;
     const int ch = blockIdx.y;
     const int TC = p.TC, lg = p.TClog2, L = p.L, nc = p.ncols;
     const int c0 = tile * TC;
-    cplx* cur = (cplx*)smem;
+    cplx* cur = (cplx*)EGR_LDS_BASE(smem);
     cplx* alt = cur + (size_t)L * TC;
     cplx* W = work + (size_t)ch * P;
     float* Y = out + (size_t)ch * cp.N;
@@ -501,11 +504,12 @@ __global__ __launch_bounds__(EGR_FL_CONV_THREADS) void k_rowconv(FftDesc f, int 
                                                   const cplx* __restrict__ bhat, float scale, long long P,
                                                   cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    EGR_LDS_CANARY_ARM(smem);
     const int r0 = EGR_FL_CONV_ROWS * blockIdx.x;
     const int nrows = (r0 + 1 < R && EGR_FL_CONV_ROWS == 2) ? 2 : 1;
     constexpr int PSH = EGR_FL_CONV_PAD;                 // rows in LDS: element i at lds_pad<PSH>(i), stages in place
     const int Lp = lds_pad<PSH>(L);
-    cplx* cur = (cplx*)smem;
+    cplx* cur = (cplx*)EGR_LDS_BASE(smem);
     cplx* g = work + (size_t)blockIdx.y * P + (size_t)r0 * L;
     // 16-byte accesses (two elements per thread and step) when rows start 16-byte aligned; one row per workgroup then
     const bool pairwise = PSH == 0 && EGR_FL_CONV_ROWS == 1 && (L & 1) == 0;
@@ -790,7 +794,7 @@ static bool pz_length(int64_t D, FlSplit* sp_out);
 // paired chirp-z kind for N real samples: 1 = even/odd packing (N even, D = N / 2), 2 = channel pairs (N odd, D = N)
 static inline int pz_kind_for(int64_t N) { return (N & 1) ? 2 : 1; }
 // LDS of k_rowconv: two rows, stages in place
-static size_t rowconv_lds(int L) { return (size_t)EGR_FL_CONV_ROWS * (L + (EGR_FL_CONV_PAD ? L >> EGR_FL_CONV_PAD : 0)) * sizeof(cplx); }
+static size_t rowconv_lds(int L) { return EGR_LDS((size_t)EGR_FL_CONV_ROWS * (L + (EGR_FL_CONV_PAD ? L >> EGR_FL_CONV_PAD : 0)) * sizeof(cplx)); }
 // workgroup size of the chirp-z loop kernels (their tiles take most of a CU's LDS: one workgroup per CU, so a large one)
 static int blue_threads() {
     static const int t = [] { const char* e = getenv("EGR_FL_BLUE_THREADS"); const int v = e ? atoi(e) : 1024; return (v == 256 || v == 512 || v == 1024) ? v : 1024; }();
@@ -961,10 +965,10 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
         }
         const dim3 blk(256);
         hipLaunchKernelGGL(k_chirp_b, dim3(2048), blk, 0, 0, c, (long long)M, p->d_bhat);
-        hipLaunchKernelGGL(k_col<4>, dim3(8 * a.tiles_per_xcd, 1), blk, sp.lds_col, 0, a, (long long)M, (long long)N, 0.f, p->d_bhat,
+        hipLaunchKernelGGL(k_col<4>, dim3(8 * a.tiles_per_xcd, 1), blk, EGR_LDS(sp.lds_col), 0, a, (long long)M, (long long)N, 0.f, p->d_bhat,
                            (float*)nullptr, (unsigned*)nullptr);
         if (sp.levels == 3)
-            hipLaunchKernelGGL(k_col<4>, dim3(8 * p->colB.tiles_per_xcd, p->colB.nplanes), blk, sp.lds_colb, 0, p->colB,
+            hipLaunchKernelGGL(k_col<4>, dim3(8 * p->colB.tiles_per_xcd, p->colB.nplanes), blk, EGR_LDS(sp.lds_colb), 0, p->colB,
                                (long long)M, (long long)N, 0.f, p->d_bhat, (float*)nullptr, (unsigned*)nullptr);
         hipLaunchKernelGGL(k_rowconv<false>, dim3((r.R + EGR_FL_CONV_ROWS - 1) / EGR_FL_CONV_ROWS, 1), dim3(EGR_FL_CONV_THREADS), rowconv_lds(r.L), 0, r.f, r.L, r.R, r.tw,
                            (const cplx*)nullptr, (float)(1.0 / (double)M), (long long)M, p->d_bhat);
@@ -1177,11 +1181,11 @@ extern "C" int egr_fatllama_trace_once(egr_fatllama_plan* p, void* stream) {
         R.trace = tr; A.trace = tr;
         for (int rep = 0; rep < 3; ++rep) {          // the last repetition's stamps survive
             if (which == 0) {
-                if (p->row_sched == 1) hipLaunchKernelGGL((k_row<false, 1>), grow, blk, (size_t)2 * (R.L + (EGR_FL_ROW_PAD ? R.L >> EGR_FL_ROW_PAD : 0)) * sizeof(cplx), st, R, M, p->d_work);
-                else hipLaunchKernelGGL(k_row<false>, grow, blk, p->sp.lds_row, st, R, M, p->d_work);
+                if (p->row_sched == 1) hipLaunchKernelGGL((k_row<false, 1>), grow, blk, EGR_LDS((size_t)2 * (R.L + (EGR_FL_ROW_PAD ? R.L >> EGR_FL_ROW_PAD : 0)) * sizeof(cplx)), st, R, M, p->d_work);
+                else hipLaunchKernelGGL(k_row<false>, grow, blk, EGR_LDS(p->sp.lds_row), st, R, M, p->d_work);
             } else {
-                if (p->col_sched == 2) hipLaunchKernelGGL((k_col<1, 2>), gA, dim3(EGR_FL_COL_THREADS), p->sp.lds_col / 2, st, A, M, N, 0.6f, p->d_work, (float*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr);
-                else hipLaunchKernelGGL(k_col<1>, gA, blk, p->sp.lds_col, st, A, M, N, 0.6f, p->d_work, (float*)nullptr, (unsigned*)nullptr);
+                if (p->col_sched == 2) hipLaunchKernelGGL((k_col<1, 2>), gA, dim3(EGR_FL_COL_THREADS), EGR_LDS(p->sp.lds_col / 2), st, A, M, N, 0.6f, p->d_work, (float*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr);
+                else hipLaunchKernelGGL(k_col<1>, gA, blk, EGR_LDS(p->sp.lds_col), st, A, M, N, 0.6f, p->d_work, (float*)nullptr, (unsigned*)nullptr);
             }
         }
         EGR_HIP(hipStreamSynchronize(st));
@@ -1280,7 +1284,7 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
     }
     const dim3 gA(8 * A.tiles_per_xcd, C), gB(8 * B.tiles_per_xcd, C * (three ? B.nplanes : 1)), grow(R.R / 2 + 1, C),
         blk(p->bluestein ? blue_threads() : p->threads), blk256(256);
-    const size_t lc = p->sp.lds_col, lb = p->sp.lds_colb, lr = p->sp.lds_row;
+    const size_t lc = EGR_LDS(p->sp.lds_col), lb = EGR_LDS(p->sp.lds_colb), lr = EGR_LDS(p->sp.lds_row);
     size_t slot = 0;
     if (max_iter == 0) {
         const long long Nr = (long long)p->n_out;
@@ -1325,8 +1329,8 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         const dim3 blkc(EGR_FL_COL_THREADS);      // the scheduled column kernels' own workgroup size
         const bool rs1 = p->row_sched == 1 && sched_ok, cs2 = p->col_sched == 2 && sched_ok && !three;
         // no ping-pong buffer; the row kernel's two rows are padded by one element per 2^EGR_FL_ROW_PAD
-        const size_t lrs = (size_t)2 * (R.L + (EGR_FL_ROW_PAD ? R.L >> EGR_FL_ROW_PAD : 0)) * sizeof(cplx);
-        const size_t lcs = lc / 2;
+        const size_t lrs = EGR_LDS((size_t)2 * (R.L + (EGR_FL_ROW_PAD ? R.L >> EGR_FL_ROW_PAD : 0)) * sizeof(cplx));
+        const size_t lcs = EGR_LDS(p->sp.lds_col / 2);
         if (ngroups == 2 && !p->side) {
             EGR_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
             p->side_owned = 1;
@@ -1524,8 +1528,8 @@ void fl_launch_inner(egr_fatllama_plan* p, bool forward, cplx* work, int nstates
     const ColP& B = p->colB;
     const dim3 gB(8 * B.tiles_per_xcd, nstates * B.nplanes), blk(1024);
     const long long M = p->sp.M, N = p->sp.N;
-    if (forward) hipLaunchKernelGGL(k_col<4>, gB, blk, p->sp.lds_colb, st, B, M, N, 0.f, work, (float*)nullptr, (unsigned*)nullptr);
-    else hipLaunchKernelGGL(k_col<3>, gB, blk, p->sp.lds_colb, st, B, M, N, 0.f, work, (float*)nullptr, (unsigned*)nullptr);
+    if (forward) hipLaunchKernelGGL(k_col<4>, gB, blk, EGR_LDS(p->sp.lds_colb), st, B, M, N, 0.f, work, (float*)nullptr, (unsigned*)nullptr);
+    else hipLaunchKernelGGL(k_col<3>, gB, blk, EGR_LDS(p->sp.lds_colb), st, B, M, N, 0.f, work, (float*)nullptr, (unsigned*)nullptr);
 }
 
 // y = irfft(rfft(x) * gain): one forward transform, a real per-bin gain, one inverse, on the plan's passes.
@@ -1541,7 +1545,7 @@ extern "C" int egr_spectral_gain(egr_fatllama_plan* p, const float* x, const flo
     R.gain = gain;
     R.phat = 0;
     const dim3 gA(8 * A.tiles_per_xcd, C), gB(8 * B.tiles_per_xcd, C * (three ? B.nplanes : 1)), grow(R.R / 2 + 1, C), blk(256);
-    const size_t lc = p->sp.lds_col, lb = p->sp.lds_colb, lr = p->sp.lds_row;
+    const size_t lc = EGR_LDS(p->sp.lds_col), lb = EGR_LDS(p->sp.lds_colb), lr = EGR_LDS(p->sp.lds_row);
     hipLaunchKernelGGL(k_col<0>, gA, blk, lc, st, A, M, N, -1.0f, p->d_work, const_cast<float*>(x), (unsigned*)nullptr);
     if (three) hipLaunchKernelGGL(k_col<4>, gB, blk, lb, st, B, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
     hipLaunchKernelGGL(k_row<false>, grow, blk, lr, st, R, M, p->d_work);
@@ -1566,7 +1570,7 @@ extern "C" int egr_band_filter(egr_fatllama_plan* p, const float* x, int64_t ban
     RowP R = p->row;
     R.gain = nullptr; R.phat = 0; R.band = 1; R.band_lo = band_lo;
     const dim3 gA(8 * A.tiles_per_xcd, C), gB(8 * B.tiles_per_xcd, C * (three ? B.nplanes : 1)), blk(256);
-    const size_t lc = p->sp.lds_col, lb = p->sp.lds_colb, lr = p->sp.lds_row;
+    const size_t lc = EGR_LDS(p->sp.lds_col), lb = EGR_LDS(p->sp.lds_colb), lr = EGR_LDS(p->sp.lds_row);
     float* xs = const_cast<float*>(x);          // read only (MODE 0 passes)
     if (p->bluestein) {
         ChirpP cp = p->chirp;
@@ -1669,7 +1673,7 @@ extern "C" int egr_gcc_phat(egr_fatllama_plan* p, const float* a, int64_t na, co
     if (nbk > 4096) nbk = 4096;
     hipLaunchKernelGGL(k_phat_pack, dim3((unsigned)nbk), dim3(256), 0, st, a, (long long)na, b, (long long)nb, n, (float2*)z);
     const dim3 gA(8 * A.tiles_per_xcd, 1), gB(8 * B.tiles_per_xcd, three ? B.nplanes : 1), grow(R.R / 2 + 1, 1), blk(256);
-    const size_t lc = p->sp.lds_col, lb = p->sp.lds_colb, lr = p->sp.lds_row;
+    const size_t lc = EGR_LDS(p->sp.lds_col), lb = EGR_LDS(p->sp.lds_colb), lr = EGR_LDS(p->sp.lds_row);
     hipLaunchKernelGGL(k_col<0>, gA, blk, lc, st, A, M, N, -1.0f, p->d_work, z, (unsigned*)nullptr);
     if (three) hipLaunchKernelGGL(k_col<4>, gB, blk, lb, st, B, M, N, 0.f, p->d_work, y, (unsigned*)nullptr);
     hipLaunchKernelGGL(k_row<false>, grow, blk, lr, st, R, M, p->d_work);
@@ -1678,4 +1682,50 @@ extern "C" int egr_gcc_phat(egr_fatllama_plan* p, const float* a, int64_t na, co
     hipLaunchKernelGGL(k_phat_peak, dim3(1), dim3(1024), 0, st, (const float2*)y, n, (long long)max_shift, out4);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
+}
+
+// ---- EGR_LDS_CANARY (debug builds): guard-band failures since the library was loaded, and a self-test of the guards' placement ----
+namespace egr {
+__global__ void k_canary_selftest(int where, int payload_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    EGR_LDS_CANARY_ARM(smem);
+    float* cur = (float*)EGR_LDS_BASE(smem);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (where == 1) cur[payload_bytes / 4] = 1.f;          // one element past the payload
+        if (where == 2) cur[-1] = 1.f;                         // one element before it
+        if (where == 0) cur[payload_bytes / 4 - 1] = 1.f;      // the last payload element: legal
+    }
+}
+}  // namespace egr
+
+static long long canary_read() {
+#ifdef EGR_LDS_CANARY
+    unsigned v = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(&v, HIP_SYMBOL(egr::g_lds_canary_fail), sizeof(v)) != hipSuccess) return -2;
+    return (long long)v;
+#else
+    return -1;
+#endif
+}
+
+extern "C" long long egr_lds_canary_failures(void) {
+#ifdef EGR_LDS_CANARY
+    const long long a = canary_read(), b = pz_canary_failures();
+    return (a < 0 || b < 0) ? -2 : a + b;
+#else
+    return -1;
+#endif
+}
+
+extern "C" long long egr_lds_canary_selftest(int where) {
+#ifdef EGR_LDS_CANARY
+    const long long before = canary_read();
+    hipLaunchKernelGGL(egr::k_canary_selftest, dim3(1), dim3(64), EGR_LDS(1024), 0, where, 1024);
+    const long long after = canary_read();
+    return (before < 0 || after < 0) ? -2 : after - before;
+#else
+    (void)where;
+    return -1;
+#endif
 }

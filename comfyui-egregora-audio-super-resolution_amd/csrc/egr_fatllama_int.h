@@ -16,7 +16,49 @@
 
 #define EGR_LDS_MAX (152 * 1024)      // dynamic LDS a kernel may ask for: the 160 KiB of a gfx950 CU minus room for its static arrays
 
+// Debug build flag EGR_LDS_CANARY (make CANARY=1): every dynamic LDS region of the Fat-Llama kernels gets a 64-byte guard band in
+// front of the payload and one behind it, filled with a sentinel when the kernel starts and checked when it returns (a
+// workgroup-local overflow -- a reduction scratch sized for fewer waves, a tile index past its end -- lands in a guard instead
+// of silently in a neighbour's data).  The host adds EGR_LDS_GUARD bytes to every dynamic-LDS request (EGR_LDS); the kernel finds
+// the end of its region from the dispatch packet (group_segment_size minus its static LDS).  Failures are counted per translation
+// unit and read with egr_lds_canary_failures().
+#ifdef EGR_LDS_CANARY
+#define EGR_LDS_GUARD 128
+#define EGR_LDS_HEAD 64
+#else
+#define EGR_LDS_GUARD 0
+#define EGR_LDS_HEAD 0
+#endif
+#define EGR_LDS(bytes) ((size_t)(bytes) + EGR_LDS_GUARD)
+#define EGR_LDS_BASE(smem) ((smem) + EGR_LDS_HEAD)
+
 namespace egr {
+
+#ifdef EGR_LDS_CANARY
+static __device__ unsigned g_lds_canary_fail;
+struct LdsCanary {
+    char* head;
+    char* tail;
+    __device__ __forceinline__ LdsCanary(char* smem) {
+        const unsigned total = ((const unsigned*)__builtin_amdgcn_dispatch_ptr())[7];          // group_segment_size
+        const unsigned dyn = total - __builtin_amdgcn_groupstaticsize();
+        head = smem;
+        tail = smem + dyn - 64;
+        if (threadIdx.x < 16) {
+            ((unsigned*)head)[threadIdx.x] = 0xC0FFEE00u + threadIdx.x;
+            ((unsigned*)tail)[threadIdx.x] = 0xC0FFEE00u + threadIdx.x;
+        }
+    }
+    __device__ __forceinline__ ~LdsCanary() {
+        __syncthreads();
+        if (threadIdx.x < 16 && (((unsigned*)head)[threadIdx.x] != 0xC0FFEE00u + threadIdx.x || ((unsigned*)tail)[threadIdx.x] != 0xC0FFEE00u + threadIdx.x))
+            atomicAdd(&g_lds_canary_fail, 1u);
+    }
+};
+#define EGR_LDS_CANARY_ARM(smem) LdsCanary lds_canary__(smem)
+#else
+#define EGR_LDS_CANARY_ARM(smem) do { } while (0)
+#endif
 
 #define EGR_STAMP(P, SLOT) do { if ((P).trace && threadIdx.x == 0) (P).trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (SLOT)] = wall_clock64(); } while (0)
 
@@ -173,6 +215,7 @@ void fl_launch_inner(egr_fatllama_plan* p, bool forward, egr::cplx* work, int ns
 
 // paired chirp-z (egr_fatllama_pz.hip)
 int pz_build(egr_fatllama_plan* p, int kind);
+long long pz_canary_failures();    // -1 without EGR_LDS_CANARY
 bool pz_sched_has(int L, int nc);  // column length L and row length nc both have compile-time schedules
 void pz_destroy(egr_fatllama_plan* p);
 int pz_loop(egr_fatllama_plan* p, float* out, int max_iter, float thr, float thr0, const unsigned* thr0_rel, unsigned flags,

@@ -163,13 +163,14 @@ template <int MODE, class F>
 __global__ __launch_bounds__(F::MAXT, F::MINW1) void k_pzcol(PzP p, float thr, cplx* __restrict__ work, float* __restrict__ out,
                                                 unsigned* __restrict__ peak_out, const unsigned* __restrict__ thr_rel) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    EGR_LDS_CANARY_ARM(smem);
     __shared__ float red[16];
     const int tile = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
     if (tile >= p.ntiles) return;
     const int st = blockIdx.y;
     const int TC = p.TC, lg = p.TClog2, L = p.L, nc = p.nc;
     const int c0 = tile * TC;
-    cplx* cur = (cplx*)smem;
+    cplx* cur = (cplx*)EGR_LDS_BASE(smem);
     cplx* W = work + (size_t)st * p.P;
     const int nel = L * TC;
     const unsigned long long D = p.D;
@@ -273,12 +274,13 @@ __global__ __launch_bounds__(F::MAXT, F::MINW1) void k_pzcol(PzP p, float thr, c
 template <bool MAXONLY, class F>
 __global__ __launch_bounds__(F::MAXT, F::MINW2) void k_pzpair(PzP p, PzHook h, cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    EGR_LDS_CANARY_ARM(smem);
     __shared__ float red[16];
     const int g = (blockIdx.x & 7) * p.g_per_xcd + (blockIdx.x >> 3);
     if (g >= p.G) return;
     const int st = blockIdx.y;
     const int TC = p.TC, lg = p.TClog2, L = p.L, nc = p.nc, TC2 = 2 * TC;
-    cplx* cur = (cplx*)smem;
+    cplx* cur = (cplx*)EGR_LDS_BASE(smem);
     cplx* W = work + (size_t)st * p.P;
     const unsigned long long D = p.D;
     const long long s = p.s;
@@ -450,7 +452,8 @@ template <bool CONJ>
 __global__ __launch_bounds__(512) void k_pz_rowconv(FftDesc f, int L, const cplx* __restrict__ tw, const cplx* __restrict__ bhat,
                                                      long long P, cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cplx* cur = (cplx*)smem;
+    EGR_LDS_CANARY_ARM(smem);
+    cplx* cur = (cplx*)EGR_LDS_BASE(smem);
     cplx* g = work + (size_t)blockIdx.y * P + (size_t)blockIdx.x * L;
     const cplx* bh = bhat + (size_t)blockIdx.x * L;
     if ((L & 1) == 0) {
@@ -504,9 +507,10 @@ template <bool CONJ, int NC, int R0, int R1, int R2, int R3>
 __global__ __launch_bounds__(NC / 16) void k_pz_rowconv_s(const cplx* __restrict__ stw, const cplx* __restrict__ bhat, long long P,
                                                           cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    EGR_LDS_CANARY_ARM(smem);
     constexpr int L = NC, T = NC / 16, PSH = EGR_PZ_ROW_PAD;
     static_assert(R0 * R1 * R2 * R3 == NC, "schedule does not match the row length");
-    cplx* cur = (cplx*)smem;
+    cplx* cur = (cplx*)EGR_LDS_BASE(smem);
     cplx* g = work + (size_t)blockIdx.y * P + (size_t)blockIdx.x * L;
     const cplx* bh = bhat + (size_t)blockIdx.x * L;
     float4 b[8];
@@ -754,9 +758,9 @@ int pz_build(egr_fatllama_plan* plan, int kind) {
                 z->rowconv = e.fn; z->rowconv_conj = e.fn_conj;
                 z->threads_row = e.NC / 16;
             }
-    z->lds_col = (size_t)q.L * q.TC * sizeof(cplx);
-    z->lds_pair = 2 * z->lds_col;
-    z->lds_row = z->stw_row ? (size_t)(r.L + (EGR_PZ_ROW_PAD ? r.L >> EGR_PZ_ROW_PAD : 0)) * sizeof(cplx) : (size_t)r.L * sizeof(cplx);
+    z->lds_col = EGR_LDS((size_t)q.L * q.TC * sizeof(cplx));
+    z->lds_pair = EGR_LDS(2 * (size_t)q.L * q.TC * sizeof(cplx));
+    z->lds_row = EGR_LDS(z->stw_row ? (size_t)(r.L + (EGR_PZ_ROW_PAD ? r.L >> EGR_PZ_ROW_PAD : 0)) * sizeof(cplx) : (size_t)r.L * sizeof(cplx));
     hipError_t e = hipSuccess;
     EGR_CHECK(z->lds_pair <= (size_t)EGR_LDS_MAX && z->lds_row <= (size_t)EGR_LDS_MAX, EGR_ERR_UNSUPPORTED, "plan needs %zu / %zu bytes of LDS", z->lds_pair, z->lds_row);
     // the attribute is a process-wide cap per kernel: always the CU's maximum (see build_plan)
@@ -929,4 +933,14 @@ int pz_band_filter(egr_fatllama_plan* plan, const float* x, int64_t band_lo, flo
     hipLaunchKernelGGL(z->last, gc, bc, z->lds_col, st, q, 0.f, plan->d_work, y, pk, (const unsigned*)nullptr);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
+}
+
+long long pz_canary_failures() {
+#ifdef EGR_LDS_CANARY
+    unsigned v = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(&v, HIP_SYMBOL(egr::g_lds_canary_fail), sizeof(v)) != hipSuccess) return -2;
+    return (long long)v;
+#else
+    return -1;
+#endif
 }

@@ -37,6 +37,8 @@ SIGNATURES = {
     "egr_fatllama_kernel_times": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64),
                                        C.POINTER(_i64)]),
     "egr_fatllama_kernel_times3": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "egr_lds_canary_failures": (C.c_longlong, []),
+    "egr_lds_canary_selftest": (C.c_longlong, [_i]),
     "egr_pcm16_roundtrip": (_i, [_vp, _vp, _i64, _f, _f, _vp]),
     "egr_stft_mag": (_i, [_vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
     "egr_dfn_workspace_bytes": (C.c_size_t, [_i, _i64]),

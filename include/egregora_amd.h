@@ -120,6 +120,13 @@ int egr_fatllama_kernel_times(egr_fatllama_plan* plan, double* row_ms_avg, doubl
  * [2] second column pass (inner pass of a three-level plan; chirp-z: the crop pass k_pzcol<1>). */
 int egr_fatllama_kernel_times3(egr_fatllama_plan* plan, double ms_avg[3], int64_t launches[3]);
 
+/* Debug builds only (make -C csrc CANARY=1 -> -DEGR_LDS_CANARY): every dynamic LDS region of the Fat-Llama kernels carries a 64-byte
+ * guard band on either side, armed at kernel start and checked at kernel exit.  egr_lds_canary_failures: workgroups that found a
+ * guard overwritten since the library was loaded (-1: this build has no canaries).  egr_lds_canary_selftest(where): one launch that
+ * writes the last payload element (0), one element past the payload (1) or one before it (2); returns the failures it caused. */
+long long egr_lds_canary_failures(void);
+long long egr_lds_canary_selftest(int where);
+
 /* ------------------------------------------------------------------------------------------------
  * Host-glue arithmetic moved on device (FlashSR node path and the parity yardstick).
  * ---------------------------------------------------------------------------------------------- */
