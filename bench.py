@@ -387,7 +387,7 @@ def main():
                                     "threshold variant '%s' (SPEC.md section 3: absolute level, hard threshold, time-domain "
                                     "pre-threshold, linear up-rating unless listed)" % (args.iters, os.environ.get("EGREGORA_FATLLAMA_SPEC", "") or "default"))
                                    + (f" [only={args.only}]" if args.only and not c4 else ""),
-                       "flashsr_executor": "egr_flashsr_infer (C ABI, csrc/egr_flashsr.cpp)" if E.EXECUTOR != "python" else "python driver",
+                       "flashsr_executor": "egr_flashsr_infer (C ABI, csrc/egr_flashsr.cpp)",
                        "lsd_800_vs_1_iteration_db": lsd_iters[0],
                        "mfma": ("fp32 operands split exactly into three bf16 terms, six partial products on "
                                 "v_mfma_f32_32x32x16_bf16 with fp32 accumulation: error vs float64 <= the f32-MFMA kernel's "

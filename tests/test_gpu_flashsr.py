@@ -15,6 +15,12 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+
+def PyDriverEngine(*a, **k):
+    """The operator-by-operator Python walk of the graph (tools/flashsr_pydriver.py: test tooling on top of the product engine)."""
+    from tools.flashsr_pydriver import PyDriverEngine as cls
+    return cls(*a, **k)
+
 pytestmark = pytest.mark.gpu
 
 
@@ -36,7 +42,7 @@ def eng(pack):
     from egregora_amd import flashsr_arch as A, flashsr_engine as E
     cfg = A.tiny_config()
     P = A.init_params(cfg, 0)
-    return E.FlashSREngine(cfg, P), cfg, P
+    return PyDriverEngine(cfg, P), cfg, P
 
 
 def nhwc(x):
@@ -130,9 +136,9 @@ def test_f32_mfma_mode_still_matches(pack):
     old = E.FlashSREngine.MFMA_MODE
     try:
         E.FlashSREngine.MFMA_MODE = "f32"
-        e1 = E.FlashSREngine(cfg, P)
+        e1 = PyDriverEngine(cfg, P)
         E.FlashSREngine.MFMA_MODE = "bf16x3"
-        e2 = E.FlashSREngine(cfg, P)
+        e2 = PyDriverEngine(cfg, P)
     finally:
         E.FlashSREngine.MFMA_MODE = old
     assert not e1.w3 and e2.w3
@@ -425,7 +431,7 @@ def test_lowpass_input_vs_torch(pack):
     import dataclasses
     cfg = A.tiny_config()
     cfg = dataclasses.replace(cfg, chunk=3840, n_fft=128, hop=30)
-    e = E.FlashSREngine(cfg, A.init_params(cfg, 0))
+    e = PyDriverEngine(cfg, A.init_params(cfg, 0))
     g = torch.Generator().manual_seed(11)
     t = torch.arange(cfg.chunk) / cfg.sr
     # band-limited rows (content below ~6 kHz / ~3 kHz) plus a little wide-band noise
@@ -535,7 +541,7 @@ def test_full_size_engine_vs_torch_reference_one_row(pack):
     from oracle import flashsr_torch as R, metrics as om
     cfg = A.FlashSRConfig()
     P = A.init_params(cfg, 0)
-    e = E.FlashSREngine(cfg, P)
+    e = PyDriverEngine(cfg, P)
     x = 0.2 * torch.randn(1, cfg.chunk, generator=torch.Generator().manual_seed(5))
     nz = e.noise(1, torch.zeros(1, dtype=torch.int64, device="cuda"), 0)
     got_st, want_st, ex_st = {}, {}, {}
@@ -572,7 +578,7 @@ def test_full_size_engine_shapes_and_determinism(pack):
     """Declared full-size architecture with synthetic weights: one row, shapes + finite output + same-seed repeatability."""
     from egregora_amd import flashsr_arch as A, flashsr_engine as E
     cfg = A.FlashSRConfig()
-    e = E.FlashSREngine(cfg, A.init_params(cfg, 0))
+    e = PyDriverEngine(cfg, A.init_params(cfg, 0))
     x = 0.2 * torch.randn(1, cfg.chunk, generator=torch.Generator().manual_seed(5))
     ids = torch.zeros(1, dtype=torch.int64, device="cuda")
     st = {}
@@ -648,9 +654,9 @@ def test_default_engine_within_north_star_lsd_of_the_strict_f32_engine(pack):
     P = A.init_params(cfg, 0)
     old = (E.FlashSREngine.MFMA_MODE, E.FlashSREngine.WINO_MIN_CH, E.FlashSREngine.THIN_ENDS)
     try:
-        e_fast = E.FlashSREngine(cfg, P)
+        e_fast = PyDriverEngine(cfg, P)
         E.FlashSREngine.MFMA_MODE, E.FlashSREngine.WINO_MIN_CH, E.FlashSREngine.THIN_ENDS = "f32", 1 << 30, False
-        e_ref = E.FlashSREngine(cfg, P)
+        e_ref = PyDriverEngine(cfg, P)
     finally:
         E.FlashSREngine.MFMA_MODE, E.FlashSREngine.WINO_MIN_CH, E.FlashSREngine.THIN_ENDS = old
     assert e_fast.w3 and not e_ref.w3 and not any(k.endswith(".wino4") or k.endswith(".taps") for k in e_ref.w)

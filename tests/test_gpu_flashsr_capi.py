@@ -2,7 +2,7 @@
 egr_flashsr_create_from_file / egr_flashsr_destroy (include/egregora_amd.h, csrc/egr_flashsr.cpp) stand in for the reference's
 `FlashSR(s, v, vae)` + `model(x, lowpass_input=...)` (egregora_audio_super_resolution.py:346-369).
 
-The library's graph walk must equal the operator-by-operator Python driver (`FlashSREngine.forward_rows`, itself pinned against
+The library's graph walk must equal the operator-by-operator Python driver (`PyDriverEngine.forward_rows` of tools/flashsr_pydriver.py, itself pinned against
 oracle/flashsr_torch.py in tests/test_gpu_flashsr.py) BIT FOR BIT: same kernels, same order, same operands (both pack weights with
 csrc/egr_flashsr_pack.hip) -- at the toy size with every stage tapped, at full size, with the input low-pass, in the strict
 f32-MFMA / no-Winograd configuration, across pass boundaries, and from a weight-blob file."""
@@ -11,6 +11,12 @@ import ctypes as C
 import numpy as np
 import pytest
 import torch
+
+
+def PyDriverEngine(*a, **k):
+    """The operator-by-operator Python walk of the graph (tools/flashsr_pydriver.py: test tooling on top of the product engine)."""
+    from tools.flashsr_pydriver import PyDriverEngine as cls
+    return cls(*a, **k)
 
 pytestmark = pytest.mark.gpu
 STAGES = ("mel", "z_cond", "v", "z0", "mel_hat", "y")
@@ -21,7 +27,7 @@ def tiny(pack):
     from egregora_amd import flashsr_arch as A, flashsr_engine as E
     cfg = A.tiny_config()
     P = A.init_params(cfg, 0)
-    e = E.FlashSREngine(cfg, P)
+    e = PyDriverEngine(cfg, P)
     yield e, cfg, P
     e.close()
 
@@ -54,8 +60,8 @@ def test_infer_keys_noise_by_row_id_and_is_independent_of_pass_boundaries(pack, 
     one = E.infer_rows(e, x, ids, 42)
     monkeypatch.setattr(E, "ROWS_PER_PASS", 3)                              # passes of 3 + 3 + 1 rows
     split = E.infer_rows(e, x, ids, 42)
-    monkeypatch.setattr(E, "EXECUTOR", "python")
-    py = E.infer_rows(e, x, ids, 42)
+    # the same passes driven operator by operator from Python (tools/flashsr_pydriver.py)
+    py = torch.cat([e.forward_rows(x[lo:lo + 3], e.noise(x[lo:lo + 3].shape[0], ids[lo:lo + 3].contiguous(), 42)) for lo in range(0, 7, 3)], 0)
     torch.cuda.synchronize()
     assert torch.equal(split, py)
     # rows are independent; tile choices follow the row count of a pass, so 7-row and 3-row passes agree to fp32 round-off only
@@ -126,7 +132,7 @@ def test_strict_configuration_flags(pack):
     old = (E.FlashSREngine.MFMA_MODE, E.FlashSREngine.WINO_MIN_CH, E.FlashSREngine.THIN_ENDS)
     try:
         E.FlashSREngine.MFMA_MODE, E.FlashSREngine.WINO_MIN_CH, E.FlashSREngine.THIN_ENDS = "f32", 1 << 30, False
-        e = E.FlashSREngine(cfg, P)
+        e = PyDriverEngine(cfg, P)
     finally:
         E.FlashSREngine.MFMA_MODE, E.FlashSREngine.WINO_MIN_CH, E.FlashSREngine.THIN_ENDS = old
     x = rows(cfg, 2, 6)
@@ -150,13 +156,13 @@ def test_profile_and_flop_count_agree_with_the_python_driver(pack, tiny):
         assert c[k][0] == py[k][0] and c[k][1] == pytest.approx(py[k][1]) and c[k][2] > 0
     fl = C.c_double()
     native.check(native.lib().egr_flashsr_flop_count(C.c_void_p(e.handle), 2, C.byref(fl), None), "egr_flashsr_flop_count")
-    assert fl.value == pytest.approx(e.flop_count(2))
+    assert fl.value == e.flop_count(2) == pytest.approx(e.flop_count_py(2))
 
 
 def test_full_size_handle_equals_python_driver_bit_for_bit(pack):
     from egregora_amd import flashsr_arch as A, flashsr_engine as E
     cfg = A.FlashSRConfig()
-    e = E.FlashSREngine(cfg, A.init_params(cfg, 0))
+    e = PyDriverEngine(cfg, A.init_params(cfg, 0))
     x = 0.2 * torch.randn(2, cfg.chunk, generator=torch.Generator().manual_seed(5))
     nz = e.noise(2, None, 0)
     sa, sb = {}, {}
@@ -175,7 +181,7 @@ def test_forwards_from_different_streams_never_overlap_on_the_device(pack):
     runtime maps to different hardware queues, both results must equal the single-stream ones bit for bit, 10 rounds."""
     from egregora_amd import flashsr_arch as A, flashsr_engine as E, streams
     cfg = A.FlashSRConfig()
-    e = E.FlashSREngine(cfg, A.init_params(cfg, 0))
+    e = PyDriverEngine(cfg, A.init_params(cfg, 0))
     x = 0.2 * torch.randn(8, cfg.chunk, generator=torch.Generator().manual_seed(9)).cuda()
     nz = e.noise(8, None, 0)
     ref = [e.c_forward(x[:4], nz[:4]).clone(), e.c_forward(x[4:], nz[4:]).clone()]
@@ -219,7 +225,7 @@ def test_concurrent_row_groups_inside_infer(pack):
     import ctypes as C
     from egregora_amd import flashsr_arch as A, flashsr_engine as E, native
     cfg = A.tiny_config()
-    e = E.FlashSREngine(cfg, A.init_params(cfg, 2))
+    e = PyDriverEngine(cfg, A.init_params(cfg, 2))
     L = native.lib()
     x = rows(cfg, 14, 12)
     ids = torch.arange(100, 114, dtype=torch.int64, device="cuda")
@@ -246,7 +252,7 @@ def test_fat_llama_next_to_a_flashsr_forward_on_another_stream(pack):
     (profiles/r02/cr19.log); now both results equal their solo runs bit for bit, 6 rounds."""
     from egregora_amd import fatllama_engine as fe, flashsr_arch as A, flashsr_engine as E, streams
     cfg = A.FlashSRConfig()
-    e = E.FlashSREngine(cfg, A.init_params(cfg, 0))
+    e = PyDriverEngine(cfg, A.init_params(cfg, 0))
     x = 0.2 * torch.randn(9, cfg.chunk, generator=torch.Generator().manual_seed(4)).cuda()
     nz = e.noise(9, None, 0)
     a = (3000.0 * torch.randn(1, 480000, generator=torch.Generator().manual_seed(5))).round().cuda()

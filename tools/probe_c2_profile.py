@@ -4,8 +4,9 @@ sys.path.insert(0, '.')
 import torch
 from packload import load_pack; load_pack()
 from egregora_amd import flashsr_arch as A, flashsr_engine as E
+from flashsr_pydriver import PyDriverEngine
 cfg = A.FlashSRConfig()
-e = E.FlashSREngine(cfg, A.init_params(cfg, 0))
+e = PyDriverEngine(cfg, A.init_params(cfg, 0))
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 x = 0.2 * torch.randn(rows, cfg.chunk, device="cuda")
 for _ in range(3): e.c_infer(x, None, 0)

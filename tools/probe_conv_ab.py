@@ -8,7 +8,8 @@ import torch, json
 from collections import defaultdict
 from packload import load_pack; load_pack()
 from egregora_amd import flashsr_arch as A, flashsr_engine as E
-cfg = A.FlashSRConfig(); e = E.FlashSREngine(cfg, A.init_params(cfg, 0))
+from flashsr_pydriver import PyDriverEngine
+cfg = A.FlashSRConfig(); e = PyDriverEngine(cfg, A.init_params(cfg, 0))
 x = 0.2 * torch.randn(26, cfg.chunk, device='cuda'); nz = e.noise(26, None, 0)
 for _ in range(2): e.forward_rows(x, nz)
 torch.cuda.synchronize()

@@ -4,7 +4,8 @@ import torch
 from collections import defaultdict
 from packload import load_pack; load_pack()
 from egregora_amd import flashsr_arch as A, flashsr_engine as E
-cfg = A.FlashSRConfig(); e = E.FlashSREngine(cfg, A.init_params(cfg, 0))
+from flashsr_pydriver import PyDriverEngine
+cfg = A.FlashSRConfig(); e = PyDriverEngine(cfg, A.init_params(cfg, 0))
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 26
 x = 0.2 * torch.randn(R, cfg.chunk, device='cuda'); nz = e.noise(R, None, 0)
 e.forward_rows(x, nz); torch.cuda.synchronize()

@@ -4,7 +4,8 @@ import os, sys; sys.path.insert(0, '.')
 import torch
 from packload import load_pack; load_pack()
 from egregora_amd import flashsr_arch as A, flashsr_engine as E, streams
-cfg = A.FlashSRConfig(); e = E.FlashSREngine(cfg, A.init_params(cfg, 0))
+from flashsr_pydriver import PyDriverEngine
+cfg = A.FlashSRConfig(); e = PyDriverEngine(cfg, A.init_params(cfg, 0))
 x = 0.2 * torch.randn(26, cfg.chunk, device='cuda')
 side = streams.side_streams(3)
 B3 = ((9, 17), (17, 26), (0, 9))

@@ -3,7 +3,8 @@ import sys, time; sys.path.insert(0, '.')
 import torch
 from packload import load_pack; load_pack()
 from egregora_amd import flashsr_arch as A, flashsr_engine as E
-cfg = A.FlashSRConfig(); e = E.FlashSREngine(cfg, A.init_params(cfg, 0))
+from flashsr_pydriver import PyDriverEngine
+cfg = A.FlashSRConfig(); e = PyDriverEngine(cfg, A.init_params(cfg, 0))
 for R in (1, 2, 4, 8):
     x = 0.2 * torch.randn(R, cfg.chunk, device='cuda'); nz = e.noise(R, None, 0)
     e.forward_rows(x, nz); torch.cuda.synchronize()

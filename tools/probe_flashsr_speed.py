@@ -3,8 +3,9 @@ import sys, time; sys.path.insert(0,'.')
 import torch
 from packload import load_pack; load_pack()
 from egregora_amd import flashsr_arch as A, flashsr_engine as E
+from flashsr_pydriver import PyDriverEngine
 cfg=A.FlashSRConfig(); t0=time.time(); P=A.init_params(cfg,0); print("init params %.1fs"%(time.time()-t0))
-e=E.FlashSREngine(cfg,P); print("engine ready %.1fs"%(time.time()-t0))
+e=PyDriverEngine(cfg,P); print("engine ready %.1fs"%(time.time()-t0))
 fl=e.flop_count(1); print("flops/row %.3e"%fl)
 def sync(): torch.cuda.synchronize()
 for R in (1,2,4,8):

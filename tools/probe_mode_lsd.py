@@ -4,10 +4,11 @@ import sys; sys.path.insert(0, '.')
 import numpy as np, torch
 from packload import load_pack; load_pack()
 from egregora_amd import flashsr_arch as A, flashsr_engine as E, device_ops
+from flashsr_pydriver import PyDriverEngine
 cfg = A.FlashSRConfig(); P = A.init_params(cfg, 0)
-e_fast = E.FlashSREngine(cfg, P)
+e_fast = PyDriverEngine(cfg, P)
 E.FlashSREngine.MFMA_MODE = "f32"; E.FlashSREngine.WINO_MIN_CH = 1 << 30
-e_ref = E.FlashSREngine(cfg, P)
+e_ref = PyDriverEngine(cfg, P)
 rng = np.random.Generator(np.random.PCG64(202)); t = np.arange(cfg.chunk) / 48000.0
 x = sum(np.sin(2 * np.pi * f * t + rng.uniform(0, 6.28)) / (k + 1) for k, f in enumerate(np.geomspace(80, 6000, 8))) + 0.01 * rng.standard_normal(cfg.chunk)
 x = torch.from_numpy((0.5 * x / np.abs(x).max()).astype(np.float32))[None].repeat(2, 1).cuda()

@@ -6,9 +6,10 @@ sys.path.insert(0, '.')
 import torch
 from packload import load_pack; load_pack()
 from egregora_amd import flashsr_arch as A, flashsr_engine as E, streams, native
+from flashsr_pydriver import PyDriverEngine
 import ctypes as C
 cfg = A.FlashSRConfig()
-e = E.FlashSREngine(cfg, A.init_params(cfg, 0))
+e = PyDriverEngine(cfg, A.init_params(cfg, 0))
 L = e.L
 g = torch.Generator().manual_seed(3)
 def rn(*s): return (0.5 * torch.randn(*s, generator=g)).cuda()

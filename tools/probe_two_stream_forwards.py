@@ -7,11 +7,12 @@ sys.path.insert(0, '.')
 import torch
 from packload import load_pack; load_pack()
 from egregora_amd import flashsr_arch as A, flashsr_engine as E, streams
+from flashsr_pydriver import PyDriverEngine
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 cfg = A.FlashSRConfig()
 P = A.init_params(cfg, 0)
-e = E.FlashSREngine(cfg, P)
-e2 = E.FlashSREngine(cfg, P)          # a second handle: its own scratch arena and workspaces (a handle serves ONE stream at a time)
+e = PyDriverEngine(cfg, P)
+e2 = PyDriverEngine(cfg, P)          # a second handle: its own scratch arena and workspaces (a handle serves ONE stream at a time)
 x = 0.2 * torch.randn(18, cfg.chunk, generator=torch.Generator().manual_seed(9)).cuda()
 nz = e.noise(18, None, 0)
 ref = [e.c_forward(x[:9], nz[:9]).clone(), e.c_forward(x[9:], nz[9:]).clone()]

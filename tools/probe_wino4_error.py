@@ -3,7 +3,8 @@ import sys; sys.path.insert(0, '.')
 import ctypes as C, math, torch
 from packload import load_pack; load_pack()
 from egregora_amd import native, flashsr_arch as A, flashsr_engine as E
-cfg = A.tiny_config(); e = E.FlashSREngine(cfg, A.init_params(cfg, 0)); L = e.L
+from flashsr_pydriver import PyDriverEngine
+cfg = A.tiny_config(); e = PyDriverEngine(cfg, A.init_params(cfg, 0)); L = e.L
 p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 BT = torch.tensor([[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],[0,2,-1,-2,1,0],[0,4,0,-5,0,1]], dtype=torch.float64)
 G = torch.tensor(e._g4(), dtype=torch.float64)
