@@ -374,6 +374,10 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
     EGR_STAMP(p, 5);
 }
 
+}  // namespace egr
+#include "egr_fatllama_wl.h"
+namespace egr {
+
 // ------------------------------------------------------------------------------------------------
 // Bluestein fallback for lengths the packed real transform cannot take (odd N, large prime factors):
 // the exact length-N DFT as a cyclic convolution of length P >= 2N-1 (P smooth):
@@ -832,6 +836,7 @@ extern "C" int egr_fatllama_plan_query(int64_t n_in, int factor, int m1_hint, in
 
 extern "C" int egr_fatllama_plan_destroy(egr_fatllama_plan* p) {
     if (!p) return EGR_OK;
+    hipDeviceSynchronize();          // nothing of the plan may still be in flight when its graph, streams and buffers go
     pz_destroy(p);
     for (void* q : p->dev_allocs) hipFree(q);
     hipFree(p->d_work); hipFree(p->d_peaks); hipFree(p->d_bhat); hipFree(p->d_max2);
@@ -910,6 +915,42 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
         const bool off = getenv("EGR_FL_SCHED") && atoi(getenv("EGR_FL_SCHED")) == 0;
         if (!off && !p->bluestein && r.L == 2304) { if ((rc = fl_upload_sched_tables(p, {EGR_FL_ROW_RADICES}, &r.stw))) return fail(rc); p->row_sched = 1; }
         if (!off && !p->bluestein && a.L == 625 && a.TC >= 2 && a.TC <= EGR_FL_COL_TC) { if ((rc = fl_upload_sched_tables(p, {EGR_FL_COL_RADICES}, &a.stw))) return fail(rc); p->col_sched = 2; }
+    }
+    // the two-barrier loop kernels (egr_fatllama_wl.h) for rows of 2304 / outer columns of 625 points; EGR_FL_WL=0 keeps the
+    // stage-by-stage kernels
+    p->wl_row = p->wl_col = 0;
+    {
+        const bool off = getenv("EGR_FL_WL") && atoi(getenv("EGR_FL_WL")) == 0;
+        auto table = [&](int n, int m, int T, const cplx** d) {          // [n][m]: W_T^(i j)
+            std::vector<float2> t;
+            t.resize((size_t)n * m);
+            const long double two_pi = 6.283185307179586476925286766559L;
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < m; ++j) {
+                    const long double ang = -two_pi * (long double)(((long long)i * j) % T) / (long double)T;
+                    t[(size_t)i * m + j] = make_float2((float)cosl(ang), (float)sinl(ang));
+                }
+            return fl_upload(p, t, d);
+        };
+        if (!off && !p->bluestein && p->row_sched == 1) {
+            if ((rc = table(144, 16, 2304, &p->wl_rt.t1))) return fail(rc);
+            if ((rc = table(12, 12, 144, &p->wl_rt.t2))) return fail(rc);
+            p->wl_row = 1;
+        }
+        if (!off && !p->bluestein && a.L == 625 && a.ncols % EGR_WL_COL_TC == 0) {
+            if ((rc = table(25, 25, 625, &p->wl_ct.t3))) return fail(rc);
+            p->wl_col = 1;
+        }
+        p->wl_inner = 0; p->wl_it = nullptr;
+        if (!off && !p->bluestein && sp.levels == 3 && wl_inner_supported(sp.M2)) {
+            int la, lb, tcw;
+            wl_inner_geometry(sp.M2, &la, &lb, &tcw);
+            if ((rc = table(lb, la, sp.M2, &p->wl_it))) return fail(rc);
+            p->wl_colB = p->colB;
+            p->wl_colB.TC = tcw; p->wl_colB.TClog2 = 0;
+            p->wl_colB.ntiles = ceil_div(p->colB.ncols, tcw); p->wl_colB.tiles_per_xcd = ceil_div(p->wl_colB.ntiles, 8);
+            p->wl_inner = 1;
+        }
     }
     const int nstates = pz_kind == 2 ? (channels + 1) / 2 : channels;      // a paired chirp-z state of kind 2 carries two channels
     if (hipMalloc((void**)&p->d_work, (size_t)nstates * M * sizeof(float2)) != hipSuccess ||
@@ -1181,10 +1222,15 @@ extern "C" int egr_fatllama_trace_once(egr_fatllama_plan* p, void* stream) {
         R.trace = tr; A.trace = tr;
         for (int rep = 0; rep < 3; ++rep) {          // the last repetition's stamps survive
             if (which == 0) {
-                if (p->row_sched == 1) hipLaunchKernelGGL((k_row<false, 1>), grow, blk, EGR_LDS((size_t)2 * (R.L + (EGR_FL_ROW_PAD ? R.L >> EGR_FL_ROW_PAD : 0)) * sizeof(cplx)), st, R, M, p->d_work);
+                if (p->wl_row) hipLaunchKernelGGL(k_row_wl, grow, dim3(EGR_WL_ROW_THREADS), EGR_LDS(EGR_WL_ROW_LDS), st, R, p->wl_rt, M, p->d_work);
+                else if (p->row_sched == 1) hipLaunchKernelGGL((k_row<false, 1>), grow, blk, EGR_LDS((size_t)2 * (R.L + (EGR_FL_ROW_PAD ? R.L >> EGR_FL_ROW_PAD : 0)) * sizeof(cplx)), st, R, M, p->d_work);
                 else hipLaunchKernelGGL(k_row<false>, grow, blk, EGR_LDS(p->sp.lds_row), st, R, M, p->d_work);
             } else {
-                if (p->col_sched == 2) hipLaunchKernelGGL((k_col<1, 2>), gA, dim3(EGR_FL_COL_THREADS), EGR_LDS(p->sp.lds_col / 2), st, A, M, N, 0.6f, p->d_work, (float*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr);
+                if (p->wl_col) {
+                    ColP Awl = A;
+                    Awl.TC = EGR_WL_COL_TC; Awl.TClog2 = 3; Awl.ntiles = A.ncols / EGR_WL_COL_TC; Awl.tiles_per_xcd = ceil_div(Awl.ntiles, 8);
+                    hipLaunchKernelGGL(k_col_wl, dim3(8 * Awl.tiles_per_xcd, C), dim3(EGR_WL_COL_THREADS), EGR_LDS(EGR_WL_COL_LDS), st, Awl, p->wl_ct, M, p->d_work);
+                } else if (p->col_sched == 2) hipLaunchKernelGGL((k_col<1, 2>), gA, dim3(EGR_FL_COL_THREADS), EGR_LDS(p->sp.lds_col / 2), st, A, M, N, 0.6f, p->d_work, (float*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr);
                 else hipLaunchKernelGGL(k_col<1>, gA, blk, EGR_LDS(p->sp.lds_col), st, A, M, N, 0.6f, p->d_work, (float*)nullptr, (unsigned*)nullptr);
             }
         }
@@ -1328,6 +1374,10 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         const bool sched_ok = p->threads == 512;
         const dim3 blkc(EGR_FL_COL_THREADS);      // the scheduled column kernels' own workgroup size
         const bool rs1 = p->row_sched == 1 && sched_ok, cs2 = p->col_sched == 2 && sched_ok && !three;
+        // the two-barrier kernels serve the default hook (hard threshold against an absolute level) and the middle column pass
+        const bool wlr = p->wl_row && !relative && !R.soft, wlc = p->wl_col != 0;
+        ColP Awl = A;
+        Awl.TC = EGR_WL_COL_TC; Awl.TClog2 = 3; Awl.ntiles = A.ncols / EGR_WL_COL_TC; Awl.tiles_per_xcd = ceil_div(Awl.ntiles, 8);
         // no ping-pong buffer; the row kernel's two rows are padded by one element per 2^EGR_FL_ROW_PAD
         const size_t lrs = EGR_LDS((size_t)2 * (R.L + (EGR_FL_ROW_PAD ? R.L >> EGR_FL_ROW_PAD : 0)) * sizeof(cplx));
         const size_t lcs = EGR_LDS(p->sp.lds_col / 2);
@@ -1350,7 +1400,10 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
             if (first) {
                 if (cs2) hipLaunchKernelGGL((k_col<0, 2>), gAg, blkc, lcs, sg, A, M, N, thr0, wk, og, pk, thr0_rel ? thr0_rel + c0 : nullptr);
                 else hipLaunchKernelGGL(k_col<0>, gAg, blk, lc, sg, A, M, N, thr0, wk, og, pk, thr0_rel ? thr0_rel + c0 : nullptr);
-                if (three) hipLaunchKernelGGL(k_col<4>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
+                if (three) {
+                    if (p->wl_inner) wl_launch_inner(p->wl_colB, p->wl_it, true, M, wk, cn, sg);
+                    else hipLaunchKernelGGL(k_col<4>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
+                }
             }
             for (int it = it0; it < it1; ++it) {
                 RowP Rg = R;
@@ -1361,22 +1414,26 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
                     Rg.max2 = Rg.max2_out;
                 }
                 if (prof) fl_prof_begin(p, 0, sg, &slot);
-                if (rs1) hipLaunchKernelGGL((k_row<false, 1>), growg, blk, lrs, sg, Rg, M, wk);
+                if (wlr) hipLaunchKernelGGL(k_row_wl, growg, dim3(EGR_WL_ROW_THREADS), EGR_LDS(EGR_WL_ROW_LDS), sg, Rg, p->wl_rt, M, wk);
+                else if (rs1) hipLaunchKernelGGL((k_row<false, 1>), growg, blk, lrs, sg, Rg, M, wk);
                 else hipLaunchKernelGGL(k_row<false>, growg, blk, lr, sg, Rg, M, wk);
                 if (prof) fl_prof_end(p, sg, &slot);
                 if (three) {
                     if (prof) fl_prof_begin(p, 2, sg, &slot);
-                    hipLaunchKernelGGL(k_col<3>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
+                    if (p->wl_inner) wl_launch_inner(p->wl_colB, p->wl_it, false, M, wk, cn, sg);
+                    else hipLaunchKernelGGL(k_col<3>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
                     if (prof) fl_prof_end(p, sg, &slot);
                 }
                 if (it + 1 < max_iter) {
                     if (prof) fl_prof_begin(p, 1, sg, &slot);
-                    if (cs2) hipLaunchKernelGGL((k_col<1, 2>), gAg, blkc, lcs, sg, A, M, N, thr, wk, og, pk, (const unsigned*)nullptr);
+                    if (wlc) hipLaunchKernelGGL(k_col_wl, dim3(8 * Awl.tiles_per_xcd, cn), dim3(EGR_WL_COL_THREADS), EGR_LDS(EGR_WL_COL_LDS), sg, Awl, p->wl_ct, M, wk);
+                    else if (cs2) hipLaunchKernelGGL((k_col<1, 2>), gAg, blkc, lcs, sg, A, M, N, thr, wk, og, pk, (const unsigned*)nullptr);
                     else hipLaunchKernelGGL(k_col<1>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
                     if (prof) fl_prof_end(p, sg, &slot);
                     if (three) {
                         if (prof) fl_prof_begin(p, 2, sg, &slot);
-                        hipLaunchKernelGGL(k_col<4>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
+                        if (p->wl_inner) wl_launch_inner(p->wl_colB, p->wl_it, true, M, wk, cn, sg);
+                        else hipLaunchKernelGGL(k_col<4>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
                         if (prof) fl_prof_end(p, sg, &slot);
                     }
                 }
@@ -1412,8 +1469,12 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         if (n_graph > 0) {
             rc = join(st);
             if (rc) return rc;
-            if (!(p->gexec && p->g_out == out && p->g_thr == thr && p->g_groups == ngroups && p->g_iter_odd == R.soft)) {
-                if (p->gexec) { EGR_HIP(hipGraphExecDestroy(p->gexec)); p->gexec = nullptr; }
+            // The captured middle iterations touch the plan's own state only (the row pass and the middle column pass never see
+            // `out`), so the executable graph is keyed by (threshold, pipelines, hook kind) and survives calls with other buffers.
+            // An executable graph is never destroyed while a launch of it may still be in flight (calls return asynchronously):
+            // the device is drained first -- a re-capture is a rare, millisecond-scale event anyway.
+            if (!(p->gexec && p->g_thr == thr && p->g_groups == ngroups && p->g_iter_odd == R.soft)) {
+                if (p->gexec) { EGR_HIP(hipDeviceSynchronize()); EGR_HIP(hipGraphExecDestroy(p->gexec)); p->gexec = nullptr; }
                 hipGraph_t graph = nullptr;
                 // captured on a private stream (the caller's may be the legacy default stream, which cannot capture)
                 if (!p->cap) EGR_HIP(hipStreamCreateWithFlags(&p->cap, hipStreamNonBlocking));
@@ -1461,7 +1522,7 @@ extern "C" int egr_fatllama_set_side_stream(egr_fatllama_plan* p, void* stream) 
     if (p->side && p->side_owned) EGR_HIP(hipStreamDestroy(p->side));
     p->side = (hipStream_t)stream;
     p->side_owned = 0;
-    if (p->gexec) { EGR_HIP(hipGraphExecDestroy(p->gexec)); p->gexec = nullptr; }
+    if (p->gexec) { EGR_HIP(hipDeviceSynchronize()); EGR_HIP(hipGraphExecDestroy(p->gexec)); p->gexec = nullptr; }
     return EGR_OK;
 }
 

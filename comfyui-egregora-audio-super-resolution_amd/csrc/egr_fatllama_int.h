@@ -119,6 +119,15 @@ struct RowP {
     int soft;
 };
 
+// tables of the two-barrier loop kernels (egr_fatllama_wl.h)
+struct WlRowT {
+    const cplx* t1;        // [144][16]: W_2304^(n2 k1)
+    const cplx* t2;        // [12][12]:  W_144^(b c)
+};
+struct WlColT {
+    const cplx* t3;        // [25][25]: W_625^(b c)
+};
+
 __device__ __forceinline__ void atomic_max_abs(unsigned* slot, float v) {
     // non-negative IEEE floats order like unsigned ints
     atomicMax(slot, __float_as_uint(v));
@@ -189,6 +198,12 @@ struct egr_fatllama_plan {
     bool profiling;
     int threads;                  // workgroup size of the loop kernels (256 or 512)
     int row_sched, col_sched;     // compile-time schedule ids of the loop kernels (0: run-time schedule)
+    int wl_row, wl_col;           // the two-barrier kernels of egr_fatllama_wl.h serve the row / outer column pass of the loop
+    int wl_inner;                 // ... and k_colb_wl the inner column pass of a three-level plan
+    egr::ColP wl_colB;            // colB with the tile geometry of k_colb_wl
+    const egr::cplx* wl_it;       // [LB][LA]: W_L^(b c) of the inner length
+    egr::WlRowT wl_rt;
+    egr::WlColT wl_ct;
     int nstreams;                 // channel groups run as concurrent pipelines (1 or 2)
     hipStream_t side;             // second pipeline's stream (forked from / joined to the caller's stream by events)
     int side_owned;               // 0: `side` was handed in by egr_fatllama_set_side_stream (not destroyed with the plan)

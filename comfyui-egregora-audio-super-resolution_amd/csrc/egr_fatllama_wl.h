@@ -1,0 +1,432 @@
+// Loop kernels of the hot Fat-Llama plan (rows of 2304 points, columns of 625 points) with TWO workgroup barriers each instead
+// of one or two per radix stage (k_row<false, 1>: 15, k_col<1, 2>: 10 -- 54-67 % of their wave cycles were spent parked at them,
+// profiles/r02/chain60_counters.txt).  Included by egr_fatllama.hip; same state layout, same arithmetic per element (tables rounded
+// once from long double, pair hook and 1/M in double), different factorisation order, so results agree with the stage-by-stage
+// kernels to float32 round-off, not bit for bit.
+//
+// k_row_wl -- a row of L = 2304 = 16 x 144 points as a four-step transform INSIDE the workgroup:
+//   n = 144 n1 + n2, k = k1 + 16 k2:  X[k1 + 16 k2] = sum_n2 W_144^(n2 k2) [ W_L^(n2 k1) sum_n1 x[144 n1 + n2] W_16^(n1 k1) ]
+//   "cross" step  (one thread per n2): 16 coalesced global loads -> radix-16 butterfly in registers -> x W_L^(n2 k1) -> LDS block k1
+//                 (the state never sits in LDS in natural order: the load IS the first stage, the store IS the last one)
+//   "local" step  (12 lanes of ONE wave per block): 144 = 12 x 12 -- radix-12 over a (n2 = 12 a + b), x W_144^(b c), a 12 x 12
+//                 transpose through the block's own LDS area (wave-local: program order of one wave's DS instructions, no
+//                 s_barrier), radix-12 over b: lane c ends with X[k1 + 16 (c + 12 d)], d = 0..11, in registers.
+//   The real-split partner of element k of row a is element L-1-k of row b = (block 15-k1, lane 11-c, register 11-d): the 12
+//   lanes that transform block k1 of row a also transform block 15-k1 of row b with the lane order reversed, so BOTH members of
+//   every (k, M-k) pair are registers of one thread and the hook needs no exchange at all.  The inverse runs the same steps
+//   backwards (conjugate twiddles): local, barrier, cross + coalesced global store.
+//   Barriers: after the cross-forward LDS writes, before the cross-inverse LDS reads.  LDS passes per element: 8 (was 16).
+//   A self-paired row (o = 0; o = R/2 for even R) takes its pairs from LDS with the generic loop of k_row (two more barriers).
+//
+// k_col_wl -- a tile of 8 adjacent columns of L = 625 = 25 x 25 points, one thread per (b, column):
+//   i = 25 a + b, n = c + 25 d:  thread (b, col) loads its 25 elements i = 25 a + b straight from global memory (64-byte row
+//   segments per 8 lanes, the same segments the staged tile load touched), x conj W_M^(col i) (a geometric run in double: two
+//   table products per thread, one double multiply per element), inverse radix-25 over a, LDS transpose (barrier), x conj
+//   W_625^(b c), inverse radix-25 over b: thread c holds the time-domain points n = c + 25 d -- which are exactly the inputs
+//   n = 25 a' + b' (b' = c) its forward radix-25 over a' wants: no exchange between the inverse and the forward transform.
+//   x W_625^(b' c''), written TRANSPOSED into the row of the matrix the thread itself has just read (no write-after-read
+//   hazard against other threads), barrier, forward radix-25 over b', x W_M^(col i), store to the addresses it loaded from.
+//   Barriers: 2 (+1 for the LDS copy of the 25 x 25 stage table, shared with the first).  LDS passes per element: 4 (was 10).
+#pragma once
+
+namespace egr {
+
+#define EGR_WL_ROW_THREADS 320          // 288 cross butterflies (2 rows x 144) on 4.5 waves; local work on 48 lanes of waves 0-3
+#define EGR_WL_ROW_S 172                // LDS block stride in elements (144 used; = 12 mod 32: the four units of a wave start 24 banks apart)
+#define EGR_WL_ROW_TS 14                // row stride of the 12 x 12 transpose inside a block (16-byte aligned rows, lane stride 28 banks)
+#define EGR_WL_ROW_LDS (2 * 16 * EGR_WL_ROW_S * 8)
+#define EGR_WL_COL_THREADS 256          // 25 x 8 = 200 active
+#define EGR_WL_COL_TC 8
+#define EGR_WL_COL_LDS (625 * EGR_WL_COL_TC * 8)
+
+__device__ __forceinline__ void wl_wave_sync() {
+    // orders one wave's LDS accesses for the compiler (the hardware executes a wave's DS instructions in program order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int R> __device__ __forceinline__ void wl_bfly_inv(cplx (&v)[R]) {      // unnormalised inverse DFT: swap . forward . swap
+#pragma unroll
+    for (int t = 0; t < R; ++t) v[t] = make_float2(v[t].y, v[t].x);
+    Bfly<R>::run(v);
+#pragma unroll
+    for (int t = 0; t < R; ++t) v[t] = make_float2(v[t].y, v[t].x);
+}
+
+// The default pair hook of k_row (hard threshold on |X|^2; identical arithmetic): Za = Z[k], Zb = Z[M-k], wkd = W_N^k in double.
+__device__ __forceinline__ void wl_pair_hook(const cplx Za, const cplx Zb, const dcplx Wkd, const float thr2, const double scd, cplx& na, cplx& nb) {
+    const cplx Wk = make_float2((float)Wkd.x, (float)Wkd.y);
+    const cplx E = make_float2(0.5f * (Za.x + Zb.x), 0.5f * (Za.y - Zb.y));
+    const cplx O = make_float2(0.5f * (Za.y + Zb.y), -0.5f * (Za.x - Zb.x));
+    const cplx WO = cmul(Wk, O);
+    cplx Xk = cadd(E, WO), Xm = csub(E, WO);
+    if (!(Xk.x * Xk.x + Xk.y * Xk.y > thr2)) Xk = make_float2(0.f, 0.f);
+    if (!(Xm.x * Xm.x + Xm.y * Xm.y > thr2)) Xm = make_float2(0.f, 0.f);
+    const cplx E2 = make_float2(0.5f * (Xk.x + Xm.x), 0.5f * (Xk.y + Xm.y));
+    const cplx H = make_float2(0.5f * (Xk.x - Xm.x), 0.5f * (Xk.y - Xm.y));
+    const cplx O2 = cmulc(H, Wk);
+    na = make_float2((float)(scd * (double)(E2.x - O2.y)), (float)(scd * (double)(E2.y + O2.x)));
+    nb = make_float2((float)(scd * (double)(E2.x + O2.y)), -(float)(scd * (double)(E2.y - O2.x)));
+}
+
+__global__ __launch_bounds__(EGR_WL_ROW_THREADS) void k_row_wl(RowP p, WlRowT tb, long long M, cplx* __restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    EGR_LDS_CANARY_ARM(smem);
+    constexpr int L = 2304, S = EGR_WL_ROW_S, TS = EGR_WL_ROW_TS, RS = 16 * S;
+    const int R = p.R;
+    const int oa = blockIdx.x;
+    const int ob = (R - oa) % R;
+    const bool self = (oa == ob);
+    const int ch = blockIdx.y;
+    cplx* lds = (cplx*)EGR_LDS_BASE(smem);
+    cplx* W = work + (size_t)ch * M;
+    const int ra = (oa % p.Ma) * p.Mb + oa / p.Ma;
+    const int rbw = (ob % p.Ma) * p.Mb + ob / p.Ma;
+    cplx* ga = W + (size_t)ra * L;
+    cplx* gb = W + (size_t)rbw * L;
+    const int tid = threadIdx.x;
+    // ---- roles
+    const int xr = tid >= 144 ? 1 : 0, xn2 = tid - 144 * xr;              // cross step: row, n2 (tid < 288)
+    const bool xact = tid < 288 && !(self && xr == 1);
+    const int wv = tid >> 6, lane = tid & 63, un = lane / 12, l = lane - 12 * un;
+    const int k1 = 4 * wv + un;                                            // local step: block k1 of row a, block 15 - k1 of row b
+    const bool lact = wv < 4 && lane < 48 && !(self && k1 >= 8);           // a self-paired row: blocks k1 and 15 - k1 of the SAME row
+    cplx* ba = lds + k1 * S;
+    cplx* bb = lds + (self ? 0 : RS) + (15 - k1) * S;
+    // the pair twiddles W_N^(o + R k), k = k1 + 16 l + 192 d: a geometric run in double over d (ratio W_(2L)^192 = W_24)
+    dcplx wrun = make_double2(1.0, 0.0);
+    if (lact) wrun = dcmul(tw2d(p.wo, (unsigned)oa), p.wk[k1 + 16 * l]);
+    EGR_STAMP(p, 0);
+
+    // ---- cross step, forward: global -> radix 16 -> twiddle -> LDS blocks
+    if (xact) {
+        const cplx* g = xr ? gb : ga;
+        cplx v[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = g[n1 * 144 + xn2];
+        const float4* tp = (const float4*)(tb.t1 + xn2 * 16);
+        float4 w[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) w[q] = tp[q];
+        Bfly<16>::run(v);
+        cplx* d = lds + xr * RS + xn2;
+        d[0] = v[0];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q > 0) d[(2 * q) * S] = cmul(v[2 * q], make_float2(w[q].x, w[q].y));
+            d[(2 * q + 1) * S] = cmul(v[2 * q + 1], make_float2(w[q].z, w[q].w));
+        }
+    }
+    __syncthreads();
+    EGR_STAMP(p, 1);
+
+    cplx A[12], B[12];
+    if (lact) {
+        // ---- local step, forward: 144 = 12 x 12 per block, wave-local transposes
+        const cplx* t2 = tb.t2 + l * 12;
+#pragma unroll
+        for (int a = 0; a < 12; ++a) { A[a] = ba[12 * a + l]; B[a] = bb[12 * a + l]; }
+        wl_wave_sync();
+        Bfly<12>::run(A);
+        Bfly<12>::run(B);
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+            const cplx w = t2[c];
+            ba[c * TS + l] = c ? cmul(A[c], w) : A[c];
+            bb[(11 - c) * TS + l] = c ? cmul(B[c], w) : B[c];          // row b: lane l will hold c' = 11 - l
+        }
+        wl_wave_sync();
+#pragma unroll
+        for (int b2 = 0; b2 < 12; b2 += 2) {
+            const float4 x = *(const float4*)(ba + l * TS + b2), y = *(const float4*)(bb + l * TS + b2);
+            A[b2] = make_float2(x.x, x.y); A[b2 + 1] = make_float2(x.z, x.w);
+            B[b2] = make_float2(y.x, y.y); B[b2 + 1] = make_float2(y.z, y.w);
+        }
+        wl_wave_sync();
+        Bfly<12>::run(A);          // A[d] = Xa[k1 + 16 (l + 12 d)]
+        Bfly<12>::run(B);          // B[d] = Xb[(15 - k1) + 16 ((11 - l) + 12 d)]
+    }
+    EGR_STAMP(p, 2);
+    const float thr2 = p.thr2;
+    const double scd = p.inv_M_d;
+    if (!self) {
+        if (lact) {
+            const dcplx st = make_double2(0.96592582628906828674974319972890, -0.25881904510252076234889883762405);   // W_24
+#pragma unroll
+            for (int d = 0; d < 12; ++d) {
+                cplx na, nb;
+                wl_pair_hook(A[d], B[11 - d], wrun, thr2, scd, na, nb);
+                A[d] = na; B[11 - d] = nb;
+                wrun = dcmul(wrun, st);
+            }
+        }
+    } else {
+        // a self-paired row: spectrum to LDS in (block, k2) order, the generic pair loop of k_row, back to registers
+        if (lact) {
+#pragma unroll
+            for (int d = 0; d < 12; ++d) { ba[l + 12 * d] = A[d]; bb[(11 - l) + 12 * d] = B[d]; }
+        }
+        __syncthreads();
+        const dcplx wa = tw2d(p.wo, (unsigned)oa);
+        int cnt, boff;
+        if (oa == 0) { cnt = L / 2 + 1; boff = L; } else { cnt = (L + 1) / 2; boff = L - 1; }
+        for (int k2 = tid; k2 < cnt; k2 += EGR_WL_ROW_THREADS) {
+            int pb = boff - k2;
+            if (pb >= L) pb -= L;
+            cplx* ea = lds + (k2 & 15) * S + (k2 >> 4);
+            cplx* eb = lds + (pb & 15) * S + (pb >> 4);
+            cplx na, nb;
+            wl_pair_hook(*ea, *eb, dcmul(wa, p.wk[k2]), thr2, scd, na, nb);
+            *ea = na;
+            if (pb != k2) *eb = nb;
+        }
+        __syncthreads();
+        if (lact) {
+#pragma unroll
+            for (int d = 0; d < 12; ++d) { A[d] = ba[l + 12 * d]; B[d] = bb[(11 - l) + 12 * d]; }
+            wl_wave_sync();
+        }
+    }
+    EGR_STAMP(p, 3);
+    if (lact) {
+        // ---- local step, inverse
+        const cplx* t2 = tb.t2 + l * 12;             // row a: c = l; W_144^(b c) is symmetric in (b, c)
+        const cplx* t2b = tb.t2 + (11 - l) * 12;     // row b: c' = 11 - l
+        wl_bfly_inv<12>(A);
+        wl_bfly_inv<12>(B);
+#pragma unroll
+        for (int b2 = 0; b2 < 12; b2 += 2) {
+            const cplx a0 = b2 ? cmulc(A[b2], t2[b2]) : A[b2], a1 = cmulc(A[b2 + 1], t2[b2 + 1]);
+            const cplx c0 = b2 ? cmulc(B[b2], t2b[b2]) : B[b2], c1 = cmulc(B[b2 + 1], t2b[b2 + 1]);
+            *(float4*)(ba + l * TS + b2) = make_float4(a0.x, a0.y, a1.x, a1.y);
+            *(float4*)(bb + l * TS + b2) = make_float4(c0.x, c0.y, c1.x, c1.y);
+        }
+        wl_wave_sync();
+#pragma unroll
+        for (int c = 0; c < 12; ++c) { A[c] = ba[c * TS + l]; B[c] = bb[(11 - c) * TS + l]; }
+        wl_wave_sync();
+        wl_bfly_inv<12>(A);
+        wl_bfly_inv<12>(B);
+#pragma unroll
+        for (int a = 0; a < 12; ++a) { ba[12 * a + l] = A[a]; bb[12 * a + l] = B[a]; }
+    }
+    __syncthreads();
+    EGR_STAMP(p, 4);
+    // ---- cross step, inverse: LDS blocks -> twiddle^-1 -> inverse radix 16 -> global
+    if (xact) {
+        cplx* g = xr ? gb : ga;
+        const float4* tp = (const float4*)(tb.t1 + xn2 * 16);
+        const cplx* s = lds + xr * RS + xn2;
+        cplx v[16];
+        v[0] = s[0];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 w = tp[q];
+            if (q > 0) v[2 * q] = cmulc(s[(2 * q) * S], make_float2(w.x, w.y));
+            v[2 * q + 1] = cmulc(s[(2 * q + 1) * S], make_float2(w.z, w.w));
+        }
+        wl_bfly_inv<16>(v);
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) g[n1 * 144 + xn2] = v[n1];
+    }
+    EGR_STAMP(p, 5);
+}
+
+// MODE 1 only (the middle pass of the loop): state -> twiddle^-1 -> IFFT_625 -> FFT_625 -> twiddle -> state, tiles of 8 columns.
+__global__ __launch_bounds__(EGR_WL_COL_THREADS) void k_col_wl(ColP p, WlColT tb, long long M, cplx* __restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    EGR_LDS_CANARY_ARM(smem);
+    __shared__ cplx t3s[625];
+    constexpr int TC = EGR_WL_COL_TC;
+    const int tile = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile >= p.ntiles) return;
+    const int ch = blockIdx.y / p.nplanes, plane = blockIdx.y - ch * p.nplanes;
+    const int nc = p.ncols;
+    cplx* lds = (cplx*)EGR_LDS_BASE(smem);
+    const int tid = threadIdx.x;
+    const int b = tid >> 3, cl = tid & 7, col = tile * TC + cl;
+    const bool act = tid < 25 * TC;
+    cplx* W = work + (size_t)ch * M + (size_t)plane * 625 * nc + col;
+    for (int e = tid; e < 625; e += EGR_WL_COL_THREADS) t3s[e] = tb.t3[e];
+    EGR_STAMP(p, 0);
+    cplx v[25];
+    // four-step twiddles W_M^(col (25 a + b)) of this thread's rows: first value and ratio from the hi/lo tables, in double
+    dcplx w0 = make_double2(1.0, 0.0), wst = w0;
+    if (act) {
+#pragma unroll
+        for (int a = 0; a < 25; ++a) v[a] = W[(size_t)(25 * a + b) * nc];
+        w0 = tw2d(p.big, (unsigned)col * (unsigned)b);
+        wst = tw2d(p.big, (unsigned)col * 25u);
+        dcplx cur = w0;
+#pragma unroll
+        for (int a = 0; a < 25; ++a) {
+            v[a] = cmulc(v[a], make_float2((float)cur.x, (float)cur.y));
+            cur = dcmul(cur, wst);
+        }
+        wl_bfly_inv<25>(v);                              // v[c] = Z[c][b]
+#pragma unroll
+        for (int c = 0; c < 25; ++c) lds[(c * 25 + b) * TC + cl] = v[c];
+    }
+    __syncthreads();
+    EGR_STAMP(p, 1);
+    if (act) {
+        const cplx* tr = t3s + b * 25;                   // this thread is now c = b of the first step; row c of the (symmetric) table
+#pragma unroll
+        for (int j = 0; j < 25; ++j) {
+            const cplx z = lds[(b * 25 + j) * TC + cl];
+            v[j] = j ? cmulc(z, tr[j]) : z;
+        }
+        wl_bfly_inv<25>(v);                              // v[d] = t[c + 25 d]: the time-domain column (nothing happens to it in the loop)
+        EGR_STAMP(p, 2);
+        Bfly<25>::run(v);                                // forward over a' = d: v[c''] = Z2[c''][b' = c]
+#pragma unroll
+        for (int j = 0; j < 25; ++j) lds[(b * 25 + j) * TC + cl] = j ? cmul(v[j], tr[j]) : v[j];      // transposed: into the row it has just read
+    }
+    __syncthreads();
+    if (act) {
+#pragma unroll
+        for (int j = 0; j < 25; ++j) v[j] = lds[(j * 25 + b) * TC + cl];         // Z2[c'' = b][b' = j]
+        Bfly<25>::run(v);                                // v[d''] = X[c'' + 25 d'']
+        EGR_STAMP(p, 3);
+        dcplx cur = w0;
+#pragma unroll
+        for (int a = 0; a < 25; ++a) {
+            W[(size_t)(25 * a + b) * nc] = cmul(v[a], make_float2((float)cur.x, (float)cur.y));
+            cur = dcmul(cur, wst);
+        }
+    }
+    EGR_STAMP(p, 4);
+}
+
+
+// k_colb_wl -- the INNER column pass of a three-level plan (length L = LA x LB <= 144 over n2 inside each k1 plane, stride M3), one
+// barrier: thread (b, col) loads n2 = LB a + b, radix-LA in registers, x W_L^(b c), transpose through LDS, thread (c, col) does the
+// radix-LB over b and stores k2 = c + LA d.  FWD: FFT then x W_(L nc)^(col k2) (k_col<4>); else x conj W^(col n2) then IFFT
+// (k_col<3>).  LB = 1: the whole transform is one register butterfly, no LDS.  The four-step twiddles are geometric runs in
+// double (two table products per thread).  Small tiles (L x TCW x 8 bytes <= 18 KB), so 8-10 workgroups stream per CU.
+template <int LA, int LB> struct WlInner {
+    static constexpr int T = LA > LB ? LA : LB;                                   // threads per column
+    static constexpr int TCW = LB == 1 ? 256 : (T >= 8 ? 16 : 32);               // columns per workgroup
+    static constexpr int THREADS = LB == 1 ? 256 : ((T * TCW + 63) / 64) * 64;
+    static constexpr int LDS = LB == 1 ? 0 : LA * LB * TCW * 8;
+};
+template <int R, bool INV> __device__ __forceinline__ void wl_bfly(cplx (&v)[R]) {
+    if (INV) wl_bfly_inv<R>(v); else Bfly<R>::run(v);
+}
+template <> __device__ __forceinline__ void wl_bfly<1, false>(cplx (&)[1]) {}
+template <> __device__ __forceinline__ void wl_bfly<1, true>(cplx (&)[1]) {}
+
+template <int LA, int LB, bool FWD>
+__global__ __launch_bounds__((WlInner<LA, LB>::THREADS)) void k_colb_wl(ColP p, const cplx* __restrict__ tab, long long M, cplx* __restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    EGR_LDS_CANARY_ARM(smem);
+    using G = WlInner<LA, LB>;
+    constexpr int TCW = G::TCW, L = LA * LB;
+    const int tile = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile >= p.ntiles) return;
+    const int ch = blockIdx.y / p.nplanes, plane = blockIdx.y - ch * p.nplanes;
+    const int nc = p.ncols;
+    cplx* lds = (cplx*)EGR_LDS_BASE(smem);
+    const int tid = threadIdx.x;
+    const int b = tid / TCW, cl = tid - b * TCW, col = tile * TCW + cl;
+    const bool incol = col < nc;
+    cplx* W = work + (size_t)ch * M + (size_t)plane * L * nc + col;
+    cplx v[LA];
+    if (incol && b < LB) {
+#pragma unroll
+        for (int a = 0; a < LA; ++a) v[a] = W[(size_t)(LB * a + b) * nc];
+        if (!FWD) {
+            dcplx cur = tw2d(p.big, (unsigned)col * (unsigned)b);
+            const dcplx st = tw2d(p.big, (unsigned)col * (unsigned)LB);
+#pragma unroll
+            for (int a = 0; a < LA; ++a) {
+                v[a] = cmulc(v[a], make_float2((float)cur.x, (float)cur.y));
+                cur = dcmul(cur, st);
+            }
+        }
+        wl_bfly<LA, !FWD>(v);
+        if (LB == 1) {
+            dcplx cur = make_double2(1.0, 0.0);
+            const dcplx st = tw2d(p.big, (unsigned)col);
+#pragma unroll
+            for (int c = 0; c < LA; ++c) {
+                W[(size_t)c * nc] = FWD ? cmul(v[c], make_float2((float)cur.x, (float)cur.y)) : v[c];
+                if (FWD) cur = dcmul(cur, st);
+            }
+        } else {
+            const cplx* t = tab + b * LA;
+#pragma unroll
+            for (int c = 0; c < LA; ++c) {
+                const cplx z = c ? (FWD ? cmul(v[c], t[c]) : cmulc(v[c], t[c])) : v[c];
+                lds[(c * LB + b) * TCW + cl] = z;
+            }
+        }
+    }
+    if (LB == 1) return;
+    __syncthreads();
+    if (incol && b < LA) {
+        const int c = b;
+        cplx u[LB];
+#pragma unroll
+        for (int j = 0; j < LB; ++j) u[j] = lds[(c * LB + j) * TCW + cl];
+        wl_bfly<LB, !FWD>(u);
+        dcplx cur = make_double2(1.0, 0.0), st = cur;
+        if (FWD) {
+            cur = tw2d(p.big, (unsigned)col * (unsigned)c);
+            st = tw2d(p.big, (unsigned)col * (unsigned)LA);
+        }
+#pragma unroll
+        for (int d = 0; d < LB; ++d) {
+            W[(size_t)(c + LA * d) * nc] = FWD ? cmul(u[d], make_float2((float)cur.x, (float)cur.y)) : u[d];
+            if (FWD) cur = dcmul(cur, st);
+        }
+    }
+}
+
+// inner lengths with a k_colb_wl instantiation: X(L, LA, LB) -- every 13-smooth length up to 64 that is one register butterfly
+// or a product of two, and a few larger ones
+#define EGR_WL_INNER_LIST(X) \
+    X(2, 2, 1) X(3, 3, 1) X(4, 4, 1) X(5, 5, 1) X(6, 6, 1) X(7, 7, 1) X(8, 8, 1) X(9, 9, 1) \
+    X(10, 10, 1) X(11, 11, 1) X(12, 12, 1) X(13, 13, 1) X(14, 2, 7) X(15, 3, 5) X(16, 16, 1) X(18, 3, 6) \
+    X(20, 4, 5) X(21, 3, 7) X(22, 2, 11) X(24, 4, 6) X(25, 5, 5) X(26, 2, 13) X(27, 3, 9) X(28, 4, 7) \
+    X(30, 5, 6) X(32, 4, 8) X(33, 3, 11) X(35, 5, 7) X(36, 6, 6) X(39, 3, 13) X(40, 5, 8) X(42, 6, 7) \
+    X(44, 4, 11) X(45, 5, 9) X(48, 6, 8) X(49, 7, 7) X(50, 5, 10) X(52, 4, 13) X(54, 6, 9) X(55, 5, 11) \
+    X(56, 7, 8) X(60, 6, 10) X(63, 7, 9) X(64, 8, 8) X(72, 8, 9) X(80, 8, 10) X(90, 9, 10) X(96, 8, 12) \
+    X(100, 10, 10) X(120, 10, 12) X(144, 12, 12)
+
+static bool wl_inner_supported(int L) {
+    switch (L) {
+#define X(LL, LA, LB) case LL:
+        EGR_WL_INNER_LIST(X)
+#undef X
+        return true;
+        default: return false;
+    }
+}
+static void wl_inner_geometry(int L, int* la, int* lb, int* tcw) {
+    switch (L) {
+#define X(LL, LA, LB) case LL: *la = LA; *lb = LB; *tcw = WlInner<LA, LB>::TCW; return;
+        EGR_WL_INNER_LIST(X)
+#undef X
+        default: *la = *lb = *tcw = 0;
+    }
+}
+// B: the plan's inner ColP with TC / ntiles / tiles_per_xcd set for WlInner<LA, LB>::TCW
+template <int LA, int LB> static void wl_launch_inner_t(const ColP& B, const cplx* tab, bool forward, long long M, cplx* work, int nstates, hipStream_t st) {
+    using G = WlInner<LA, LB>;
+    const dim3 grid(8 * B.tiles_per_xcd, nstates * B.nplanes), blk(G::THREADS);
+    const size_t lds = EGR_LDS(G::LDS);
+    if (forward) hipLaunchKernelGGL((k_colb_wl<LA, LB, true>), grid, blk, lds, st, B, tab, M, work);
+    else hipLaunchKernelGGL((k_colb_wl<LA, LB, false>), grid, blk, lds, st, B, tab, M, work);
+}
+static void wl_launch_inner(const ColP& B, const cplx* tab, bool forward, long long M, cplx* work, int nstates, hipStream_t st) {
+    switch (B.L) {
+#define X(LL, LA, LB) case LL: wl_launch_inner_t<LA, LB>(B, tab, forward, M, work, nstates, st); break;
+        EGR_WL_INNER_LIST(X)
+#undef X
+        default: break;
+    }
+}
+
+}  // namespace egr

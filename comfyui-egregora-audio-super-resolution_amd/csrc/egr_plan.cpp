@@ -165,6 +165,19 @@ FlSplit plan_split(int64_t N, int m1_hint, int tc_hint, int max_col) {
             best.f1 = f1; best.f2 = f2;
         }
     }
+    // ---- M = 625 x k x 2304 (whole minutes at 48 kHz, k >= 3): the outer column pass and the row pass run on the two-barrier
+    // kernels of egr_fatllama_wl.h (k_col_wl, k_row_wl) and the inner pass of length k on k_colb_wl where k has an instantiation.
+    // Measured against the planner's other choices (tools/probe_c5_plans.py, stereo, ms per iteration): k = 60 (N = 172.8 M,
+    // BASELINE configs[4]) 2.86 vs 6.03 (640 x 72 x 1875); k = 10: 0.46 vs 0.54; k = 5: 0.27 vs 0.47 for the TWO-level plan
+    // 1800 x 4000; k = 2 ties with 1125 x 2560 and keeps two levels.
+    if (m1_hint <= 0 && tc_hint <= 0 && M % (625LL * 2304LL) == 0) {
+        const int64_t k = M / (625LL * 2304LL);
+        FftDesc fk;
+        if (k >= 3 && k <= MAX_COL_INNER && make_schedule((int)k, &fk)) {
+            FlSplit sp = plan_split_explicit(N, 625, (int)k, 2304, 0);
+            if (sp.ok) return sp;
+        }
+    }
     // ---- three levels: M = M1 * M2 * M3 (only when two do not fit) ----
     if (!best.ok) {
         for (int64_t m3 = 2; m3 <= MAX_ROW && m3 <= M; ++m3) {

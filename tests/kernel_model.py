@@ -240,3 +240,66 @@ def ist3(p, y, max_iter, thr):
     d[0::2] = z.real.reshape(-1)
     d[1::2] = z.imag.reshape(-1)
     return d
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Lane / register maps of the two-barrier loop kernels (csrc/egr_fatllama_wl.h), element by element as the threads hold them.
+def _W(T, e):
+    return np.exp(-2j * np.pi * (np.asarray(e) % T) / T)
+
+
+def wl_row_forward(x):
+    """k_row_wl, forward half: row of 2304 = 16 x 144 -> regs[k1][lane c][d] = X[k1 + 16 (c + 12 d)] (cross step: one thread per n2,
+    radix 16 over n1 + twiddle W_2304^(n2 k1); local step: 12 lanes per block, radix 12 over a, twiddle W_144^(b c), 12 x 12
+    transpose, radix 12 over b)."""
+    L = 2304
+    F16 = _W(16, np.outer(np.arange(16), np.arange(16)))
+    F12 = _W(12, np.outer(np.arange(12), np.arange(12)))
+    Y = (F16 @ x.reshape(16, 144)) * _W(L, np.outer(np.arange(16), np.arange(144)))          # [k1][n2]
+    regs = np.zeros((16, 12, 12), complex)
+    for k1 in range(16):
+        blk = Y[k1].reshape(12, 12)                        # [a][b]
+        Z = (F12 @ blk) * _W(144, np.outer(np.arange(12), np.arange(12)))      # [c][b]
+        regs[k1] = Z @ F12                                  # [c][d] = sum_b Z[c][b] W_12^(b d)
+    return regs
+
+
+def wl_row_inverse(regs):
+    """the same steps backwards with conjugate twiddles (unnormalised)."""
+    L = 2304
+    F16 = np.conj(_W(16, np.outer(np.arange(16), np.arange(16))))
+    F12 = np.conj(_W(12, np.outer(np.arange(12), np.arange(12))))
+    Y = np.zeros((16, 144), complex)
+    for k1 in range(16):
+        Z = (regs[k1] @ F12) * np.conj(_W(144, np.outer(np.arange(12), np.arange(12))))      # [c][b]
+        Y[k1] = (F12 @ Z).reshape(144)                       # [a][b] -> n2 = 12 a + b
+    return (F16 @ (Y * np.conj(_W(L, np.outer(np.arange(16), np.arange(144)))))).reshape(L)
+
+
+def wl_row_partner(k1, c, d):
+    """(block, lane, register) of the real-split partner L - 1 - k of k = k1 + 16 (c + 12 d): what the reversed-lane row-b unit holds."""
+    return 15 - k1, 11 - c, 11 - d
+
+
+def wl_col_mid(u):
+    """k_col_wl on one column of 625 = 25 x 25 (without the four-step twiddles): inverse (thread b: radix 25 over a, x conj
+    W_625^(b c), transpose, thread c: radix 25 over b) -> the thread holds t[c + 25 d], which is the input n = 25 a' + b' (b' = c) of
+    its forward radix 25 -> x W_625^(b' c''), written into the row it read, transposed read, radix 25 over b'."""
+    F = _W(25, np.outer(np.arange(25), np.arange(25)))
+    T = _W(625, np.outer(np.arange(25), np.arange(25)))
+    Z = (np.conj(F) @ u.reshape(25, 25)) * np.conj(T)        # [c][b]
+    t_regs = Z @ np.conj(F)                                  # thread c, register d: t[c + 25 d]
+    t = t_regs.T.reshape(625)                                # natural order n = c + 25 d
+    Z2 = (F @ t_regs.T) * T                                  # thread b' = c holds a' = d: Z2[c''][b']
+    X_regs = Z2 @ F                                          # thread c'', register d'': X[c'' + 25 d'']
+    return t, X_regs.T.reshape(625)
+
+
+def wl_inner(x, la, lb, forward=True):
+    """k_colb_wl<LA, LB>: n2 = LB a + b -> k2 = c + LA d."""
+    L = la * lb
+    s = 1 if forward else -1
+    Fa = _W(la, s * np.outer(np.arange(la), np.arange(la)))
+    Fb = _W(lb, s * np.outer(np.arange(lb), np.arange(lb)))
+    Z = (Fa @ x.reshape(la, lb)) * _W(L, s * np.outer(np.arange(la), np.arange(lb)))          # [c][b]
+    return (Z @ Fb).T.reshape(L)                             # [c][d] -> k2 = c + LA d

@@ -17,6 +17,7 @@ CONFIGS = [
     ("packed-two-level", 2, 9600, 1, 5, 0.6, {}),
     ("packed-scheduled-c3-length", 2, 2880000, 1, 3, 0.6, {}),
     ("packed-three-level", 2, 48000, 1, 4, 0.6, {"split": (20, 24, 50)}),
+    ("packed-three-level-two-barrier-kernels", 2, 5760000, 1, 2, 0.6, {"split": (625, 2, 2304)}),
     ("packed-relative-soft", 2, 9600, 1, 5, 0.02, {"variant": "relative,soft"}),
     ("chirpz-pairs-odd-centre", 2, 2 * 7919, 1, 4, 0.6, {}),
     ("chirpz-pairs-integer-centre", 2, 4 * 1013, 1, 4, 0.6, {}),

@@ -1,0 +1,123 @@
+"""The two-barrier loop kernels of the hot Fat-Llama plan (csrc/egr_fatllama_wl.h: k_row_wl for rows of 2304 points, k_col_wl for
+outer columns of 625 points) against the stage-by-stage kernels they replace (EGR_FL_WL=0: k_row<false, 1> / k_col<1, 2>) and
+against the oracle.  Same state layout and per-element arithmetic, another factorisation order: agreement to float32 round-off.
+Upstream call site: /root/reference/egregora_fat_llama_gpu.py:213-224 (feed.upscale; parity unpinned, SPEC.md section 3)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fatllama as ofl
+from test_gpu_fatllama import synth
+
+pytestmark = pytest.mark.gpu
+FLAGS = dict(normalize=False, autoscale=False, pcm_in=False, node_post=False)
+
+
+def run(x, iters, thr=0.6, wl=True, **kw):
+    from egregora_amd import fatllama_engine as fe
+    old = os.environ.get("EGR_FL_WL")
+    os.environ["EGR_FL_WL"] = "1" if wl else "0"
+    try:
+        fe.release_plans()                      # the switch is read when a plan is built
+        y = fe.enhance_device(torch.from_numpy(x).cuda(), 1, iters, thr, **FLAGS, **kw).cpu().numpy()
+        fe.release_plans()
+    finally:
+        if old is None:
+            os.environ.pop("EGR_FL_WL", None)
+        else:
+            os.environ["EGR_FL_WL"] = old
+    return y
+
+
+def rms(a):
+    return float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
+
+
+@pytest.mark.parametrize("channels,iters", [(1, 1), (2, 3), (3, 2)])
+def test_two_barrier_kernels_agree_with_the_stage_by_stage_kernels(pack, channels, iters):
+    """C3 length (M = 625 x 2304): every row pair incl. the self-paired row 0, every column tile; 1-3 channels (one and two
+    channel pipelines)."""
+    x = synth(channels, 2880000, seed=77 + channels)
+    a = run(x, iters, wl=True)
+    b = run(x, iters, wl=False)
+    scale = float(np.max(np.abs(b)))
+    err = float(np.max(np.abs(a - b)))
+    print(f"\nwl vs stage-by-stage, {channels} ch, {iters} it: max diff {err:.3e} of peak {scale:.0f} ({err / scale:.2e}), rms {rms(a - b) / scale:.2e}")
+    assert np.isfinite(a).all()
+    assert err <= 4e-6 * scale
+    assert rms(a - b) <= 4e-7 * scale
+
+
+def test_two_barrier_kernels_with_a_threshold_that_gates_a_real_share_of_the_spectrum(pack):
+    """thr = 1.5e5 on PCM-scale data zeroes most noise bins (|X| ~ 80 sqrt(N) = 1.4e5; no time-domain pre-threshold, which would
+    zero every sample at that level): a hard threshold may flip a borderline bin between two float32 implementations, so the
+    bound is on the energy of the difference (as for the SPEC variants)."""
+    x = synth(2, 2880000, seed=13)
+    a = run(x, 4, thr=1.5e5, wl=True, variant="no_init_thr")
+    b = run(x, 4, thr=1.5e5, wl=False, variant="no_init_thr")
+    y = x.copy(); y[:, -1] = 0
+    d = b - y                                                          # out = y + d: the part the loop adds
+    assert rms(d) > 0.5 * rms(y) and rms(d - y) > 1e-3 * rms(y)          # the tones survive, the threshold really removed something
+    assert float(np.sum(np.square(a - b, dtype=np.float64))) <= 1e-6 * float(np.sum(np.square(b, dtype=np.float64)))
+
+
+def test_two_barrier_kernels_against_the_oracle_and_float64(pack):
+    x = synth(1, 2880000, seed=5)
+    want = ofl.enhance_channels(x, 1, 3, 0.6, normalize=False, autoscale=False)
+    exact = ofl.enhance_channels(x, 1, 3, 0.6, normalize=False, autoscale=False, exact=True)
+    got = run(x, 3, wl=True)
+    old = run(x, 3, wl=False)
+    scale = float(np.max(np.abs(want)))
+    print(f"\nC3 length vs float64: two-barrier kernels max {float(np.max(np.abs(got - exact))):.3e} rms {rms(got - exact):.3e}; stage-by-stage "
+          f"max {float(np.max(np.abs(old - exact))):.3e} rms {rms(old - exact):.3e}; oracle32 max {float(np.max(np.abs(want - exact))):.3e} rms {rms(want - exact):.3e}")
+    assert float(np.max(np.abs(got - want))) <= 2e-5 * scale
+    assert rms(got - exact) <= 2.5 * rms(want - exact) + 1e-9 * scale
+    assert rms(got - exact) <= 1.25 * rms(old - exact) + 1e-9 * scale          # no less accurate than the kernels it replaces
+
+
+def test_two_barrier_kernels_over_200_iterations(pack):
+    """Round-off compounds over the loop: the two kernel families must stay together over a long run."""
+    x = synth(2, 2880000, seed=9)
+    a = run(x, 200, wl=True)
+    b = run(x, 200, wl=False)
+    scale = float(np.max(np.abs(b)))
+    err = float(np.max(np.abs(a - b)))
+    print(f"\n200 iterations: max diff {err / scale:.2e} of the peak, rms {rms(a - b) / scale:.2e}")
+    assert err <= 5e-5 * scale and rms(a - b) <= 5e-6 * scale
+
+
+def test_two_barrier_kernels_inside_a_three_level_plan(pack):
+    """M = 625 x 2 x 2304: the outer column pass and the row pass of a three-level plan take the same kernels (state rows are
+    addressed through (Ma, Mb), 4608 columns); checked against the planner's own two-level plan for that length and the oracle."""
+    n = 2 * 625 * 2 * 2304
+    x = synth(1, n, seed=11)
+    a = run(x, 2, wl=True, split=(625, 2, 2304))
+    b = run(x, 2, wl=True)
+    c = run(x, 2, wl=False, split=(625, 2, 2304))
+    want = ofl.enhance_channels(x, 1, 2, 0.6, normalize=False, autoscale=False)
+    scale = float(np.max(np.abs(want)))
+    assert float(np.max(np.abs(a - c))) <= 4e-6 * scale
+    assert float(np.max(np.abs(a - b))) <= 1e-5 * scale
+    assert float(np.max(np.abs(a - want))) <= 2e-5 * scale
+
+
+INNER = [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 21, 22, 24, 25, 26, 27, 28, 30, 32, 33, 35, 36, 39, 40, 42, 44, 45, 48, 49, 50,
+         52, 54, 55, 56, 60, 63, 64, 72, 80, 90, 96, 100, 120, 144]
+
+
+@pytest.mark.parametrize("inner", INNER)
+def test_one_barrier_inner_pass_of_three_level_plans(pack, inner):
+    """k_colb_wl<LA, LB> serves the inner column pass (length M2) of a three-level plan for every instantiated length: M = 6 x M2 x 50
+    (50 columns: ragged last tile for every tile width) against the oracle, and against the stage-by-stage inner kernels."""
+    n = 2 * 6 * inner * 50
+    x = synth(2, n, seed=1000 + inner)
+    want = ofl.enhance_channels(x, 1, 3, 0.6, normalize=False, autoscale=False)
+    exact = ofl.enhance_channels(x, 1, 3, 0.6, normalize=False, autoscale=False, exact=True)
+    got = run(x, 3, wl=True, split=(6, inner, 50))
+    old = run(x, 3, wl=False, split=(6, inner, 50))
+    scale = float(np.max(np.abs(want)))
+    assert float(np.max(np.abs(got - want))) <= 2e-5 * scale
+    assert float(np.max(np.abs(got - old))) <= 4e-6 * scale
+    assert rms(got - exact) <= 2.5 * rms(want - exact) + 1e-9 * scale

@@ -444,7 +444,8 @@ def test_lowpass_input_vs_torch(pack):
     close(got, want, 2e-4)
     # and the full-size chunk length plans too
     cfgF = A.FlashSRConfig()
-    eF = E.FlashSREngine.__new__(E.FlashSREngine)          # only the pieces lowpass() needs
+    from tools.flashsr_pydriver import PyDriverEngine as PD
+    eF = PD.__new__(PD)          # only the pieces lowpass() needs
     eF.cfg, eF.dev, eF.L = cfgF, torch.device("cuda"), e.L
     eF.window = torch.hann_window(cfgF.n_fft, periodic=True).cuda()
     eF.ldm = ((cfgF.n_fft // 2 + 1 + 15) // 16) * 16

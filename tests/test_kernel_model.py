@@ -46,3 +46,50 @@ def test_ist_three_level_matches_fft_loop(M1, M2, M3, iters):
         d = np.fft.ifft(X).real
     got = km.ist3(km.Plan3(N, M1, M2, M3), y, iters, thr)
     np.testing.assert_allclose(got, d, atol=1e-9 * N)
+
+
+def test_two_barrier_row_kernel_lane_map():
+    """csrc/egr_fatllama_wl.h k_row_wl: the (block, lane, register) a thread holds is X[k1 + 16 (c + 12 d)], the partner L-1-k of the
+    real split sits at (15 - k1, 11 - c, 11 - d) -- the reversed-lane unit of row b -- and the backward steps invert the forward."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(2304) + 1j * rng.standard_normal(2304)
+    regs = km.wl_row_forward(x)
+    X = np.fft.fft(x)
+    for k1 in range(16):
+        for c in range(12):
+            for d in range(12):
+                k = k1 + 16 * (c + 12 * d)
+                assert abs(regs[k1, c, d] - X[k]) < 1e-9
+                p1, pc, pd = km.wl_row_partner(k1, c, d)
+                assert p1 + 16 * (pc + 12 * pd) == 2304 - 1 - k
+    np.testing.assert_allclose(km.wl_row_inverse(regs) / 2304, x, atol=1e-12)
+
+
+def test_two_barrier_column_kernel_needs_no_exchange_between_inverse_and_forward():
+    rng = np.random.default_rng(4)
+    u = rng.standard_normal(625) + 1j * rng.standard_normal(625)
+    t, X = km.wl_col_mid(u)
+    np.testing.assert_allclose(t, np.fft.ifft(u) * 625, atol=1e-9)
+    np.testing.assert_allclose(X, 625 * u, atol=1e-8)
+
+
+@pytest.mark.parametrize("la,lb", [(2, 1), (7, 1), (16, 1), (2, 7), (3, 5), (4, 5), (6, 10), (8, 9), (8, 16), (12, 12)])
+def test_one_barrier_inner_kernel_index_map(la, lb):
+    rng = np.random.default_rng(la * 100 + lb)
+    x = rng.standard_normal(la * lb) + 1j * rng.standard_normal(la * lb)
+    np.testing.assert_allclose(km.wl_inner(x, la, lb, True), np.fft.fft(x), atol=1e-10)
+    np.testing.assert_allclose(km.wl_inner(x, la, lb, False), np.fft.ifft(x) * la * lb, atol=1e-10)
+
+
+def test_planner_prefers_the_two_barrier_kernels_for_whole_minutes_at_48k():
+    """N = 2 x 625 x k x 2304 (k >= 3) plans as 625 x k x 2304 (csrc/egr_plan.cpp): BASELINE configs[4]'s 172.8 M samples -> k = 60."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    from packload import load_pack
+    load_pack()
+    from egregora_amd import fatllama_engine as fe
+    for n, want in ((2880000, (625, 2304, 1)), (5760000, (1125, 2560, 1)), (8640000, (625, 3, 2304)), (28800000, (625, 10, 2304)),
+                    (172800000, (625, 60, 2304)), (86400000, (625, 30, 2304))):
+        i = fe.plan_info(n, 1)
+        assert i["supported"] and (i["M1"], i["M2"], i["M3"]) == want, (n, i)

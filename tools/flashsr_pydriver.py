@@ -526,7 +526,7 @@ class PyDriverEngine(E.FlashSREngine):
     LP_PCT, LP_ORDER, LP_RIPPLE_DB = 0.985, 8, 0.05
 
     def lowpass(self, x):
-        from . import fatllama_engine as fe
+        from egregora_amd import fatllama_engine as fe
         cfg = self.cfg
         B, L = x.shape
         rpad = (cfg.n_fft - cfg.hop) // 2
