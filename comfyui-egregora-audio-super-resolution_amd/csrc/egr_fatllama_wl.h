@@ -35,24 +35,15 @@ namespace egr {
 #define EGR_WL_ROW_S 172                // LDS block stride in elements (144 used; = 12 mod 32: the four units of a wave start 24 banks apart)
 #define EGR_WL_ROW_TS 14                // row stride of the 12 x 12 transpose inside a block (16-byte aligned rows, lane stride 28 banks)
 #define EGR_WL_ROW_LDS (2 * 16 * EGR_WL_ROW_S * 8)
+#ifndef EGR_WL_ROW_WAVES
+#define EGR_WL_ROW_WAVES 1              // __launch_bounds__ minimum waves per SIMD of k_row_wl (register budget)
+#endif
+#ifndef EGR_WL_COL_WAVES
+#define EGR_WL_COL_WAVES 1
+#endif
 #define EGR_WL_COL_THREADS 256          // 25 x 8 = 200 active
 #define EGR_WL_COL_TC 8
 #define EGR_WL_COL_LDS (625 * EGR_WL_COL_TC * 8)
-
-__device__ __forceinline__ void wl_wave_sync() {
-    // orders one wave's LDS accesses for the compiler (the hardware executes a wave's DS instructions in program order)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <int R> __device__ __forceinline__ void wl_bfly_inv(cplx (&v)[R]) {      // unnormalised inverse DFT: swap . forward . swap
-#pragma unroll
-    for (int t = 0; t < R; ++t) v[t] = make_float2(v[t].y, v[t].x);
-    Bfly<R>::run(v);
-#pragma unroll
-    for (int t = 0; t < R; ++t) v[t] = make_float2(v[t].y, v[t].x);
-}
 
 // The default pair hook of k_row (hard threshold on |X|^2; identical arithmetic): Za = Z[k], Zb = Z[M-k], wkd = W_N^k in double.
 __device__ __forceinline__ void wl_pair_hook(const cplx Za, const cplx Zb, const dcplx Wkd, const float thr2, const double scd, cplx& na, cplx& nb) {
@@ -70,7 +61,7 @@ __device__ __forceinline__ void wl_pair_hook(const cplx Za, const cplx Zb, const
     nb = make_float2((float)(scd * (double)(E2.x + O2.y)), -(float)(scd * (double)(E2.y - O2.x)));
 }
 
-__global__ __launch_bounds__(EGR_WL_ROW_THREADS) void k_row_wl(RowP p, WlRowT tb, long long M, cplx* __restrict__ work) {
+__global__ __launch_bounds__(EGR_WL_ROW_THREADS, EGR_WL_ROW_WAVES) void k_row_wl(RowP p, WlRowT tb, long long M, cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     EGR_LDS_CANARY_ARM(smem);
     constexpr int L = 2304, S = EGR_WL_ROW_S, TS = EGR_WL_ROW_TS, RS = 16 * S;
@@ -234,7 +225,7 @@ __global__ __launch_bounds__(EGR_WL_ROW_THREADS) void k_row_wl(RowP p, WlRowT tb
 }
 
 // MODE 1 only (the middle pass of the loop): state -> twiddle^-1 -> IFFT_625 -> FFT_625 -> twiddle -> state, tiles of 8 columns.
-__global__ __launch_bounds__(EGR_WL_COL_THREADS) void k_col_wl(ColP p, WlColT tb, long long M, cplx* __restrict__ work) {
+__global__ __launch_bounds__(EGR_WL_COL_THREADS, EGR_WL_COL_WAVES) void k_col_wl(ColP p, WlColT tb, long long M, cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     EGR_LDS_CANARY_ARM(smem);
     __shared__ cplx t3s[625];

@@ -451,4 +451,23 @@ __device__ __forceinline__ void lds_fft(cplx*& cur, cplx*& alt, const FftDesc& d
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Helpers of the wave-local transforms (egr_fatllama_wl.h, k_pz_rowconv_wl): sub-transforms whose lanes all sit in ONE wave exchange
+// data through LDS without s_barrier.
+__device__ __forceinline__ void wl_wave_sync() {
+    // orders one wave's LDS accesses for the compiler (the hardware executes a wave's DS instructions in program order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int R> __device__ __forceinline__ void wl_bfly_inv(cplx (&v)[R]) {      // unnormalised inverse DFT: swap . forward . swap
+#pragma unroll
+    for (int t = 0; t < R; ++t) v[t] = make_float2(v[t].y, v[t].x);
+    Bfly<R>::run(v);
+#pragma unroll
+    for (int t = 0; t < R; ++t) v[t] = make_float2(v[t].y, v[t].x);
+}
+
+
 }  // namespace egr

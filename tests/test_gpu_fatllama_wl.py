@@ -121,3 +121,4 @@ def test_one_barrier_inner_pass_of_three_level_plans(pack, inner):
     assert float(np.max(np.abs(got - want))) <= 2e-5 * scale
     assert float(np.max(np.abs(got - old))) <= 4e-6 * scale
     assert rms(got - exact) <= 2.5 * rms(want - exact) + 1e-9 * scale
+
