@@ -31,7 +31,10 @@
 
 namespace egr {
 
-#define EGR_WL_ROW_THREADS 320          // 288 cross butterflies (2 rows x 144) on 4.5 waves; local work on 48 lanes of waves 0-3
+#ifndef EGR_WL_ROW_THREADS
+#define EGR_WL_ROW_THREADS 256          // four waves: the local step's 16 units; the 288 cross butterflies (2 rows x 144) take a second
+                                        // round on 32 threads (320 threads = one round measures the same: 28.6 vs 28.8 ms per stage)
+#endif
 #define EGR_WL_ROW_S 172                // LDS block stride in elements (144 used; = 12 mod 32: the four units of a wave start 24 banks apart)
 #define EGR_WL_ROW_TS 14                // row stride of the 12 x 12 transpose inside a block (16-byte aligned rows, lane stride 28 banks)
 #define EGR_WL_ROW_LDS (2 * 16 * EGR_WL_ROW_S * 8)
@@ -78,8 +81,8 @@ __global__ __launch_bounds__(EGR_WL_ROW_THREADS, EGR_WL_ROW_WAVES) void k_row_wl
     cplx* gb = W + (size_t)rbw * L;
     const int tid = threadIdx.x;
     // ---- roles
-    const int xr = tid >= 144 ? 1 : 0, xn2 = tid - 144 * xr;              // cross step: row, n2 (tid < 288)
-    const bool xact = tid < 288 && !(self && xr == 1);
+    constexpr int XIT = (288 + EGR_WL_ROW_THREADS - 1) / EGR_WL_ROW_THREADS;
+    const int xlim = self ? 144 : 288;
     const int wv = tid >> 6, lane = tid & 63, un = lane / 12, l = lane - 12 * un;
     const int k1 = 4 * wv + un;                                            // local step: block k1 of row a, block 15 - k1 of row b
     const bool lact = wv < 4 && lane < 48 && !(self && k1 >= 8);           // a self-paired row: blocks k1 and 15 - k1 of the SAME row
@@ -91,7 +94,11 @@ __global__ __launch_bounds__(EGR_WL_ROW_THREADS, EGR_WL_ROW_WAVES) void k_row_wl
     EGR_STAMP(p, 0);
 
     // ---- cross step, forward: global -> radix 16 -> twiddle -> LDS blocks
-    if (xact) {
+#pragma unroll
+    for (int xi = 0; xi < XIT; ++xi) {          // cross step: row xr, n2 = xn2 (288 butterflies over the workgroup's threads)
+        const int xt = tid + xi * EGR_WL_ROW_THREADS;
+        if (xt >= xlim) break;
+        const int xr = xt >= 144 ? 1 : 0, xn2 = xt - 144 * xr;
         const cplx* g = xr ? gb : ga;
         cplx v[16];
 #pragma unroll
@@ -205,7 +212,11 @@ __global__ __launch_bounds__(EGR_WL_ROW_THREADS, EGR_WL_ROW_WAVES) void k_row_wl
     __syncthreads();
     EGR_STAMP(p, 4);
     // ---- cross step, inverse: LDS blocks -> twiddle^-1 -> inverse radix 16 -> global
-    if (xact) {
+#pragma unroll
+    for (int xi = 0; xi < XIT; ++xi) {
+        const int xt = tid + xi * EGR_WL_ROW_THREADS;
+        if (xt >= xlim) break;
+        const int xr = xt >= 144 ? 1 : 0, xn2 = xt - 144 * xr;
         cplx* g = xr ? gb : ga;
         const float4* tp = (const float4*)(tb.t1 + xn2 * 16);
         const cplx* s = lds + xr * RS + xn2;
