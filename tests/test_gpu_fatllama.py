@@ -26,7 +26,7 @@ pytestmark = pytest.mark.gpu
 # Where the factor > 1 LSD gate applies: bins at least this far above the float32 round-off floor (measured from the float32
 # oracle vs float64).  At the margin a float32 result sits 1e-4 relative = 8.7e-4 dB from float64 -- the north star's bar.
 F32_MARGIN_DB = 80.0
-UNMASKED_LSD_BOUND_DB = 99.0   # placeholder until measured (set from the printed values of a GPU run)
+UNMASKED_LSD_BOUND_DB = 0.3    # unmasked LSD(device, oracle32) for factor > 1: measured 0.03 - 0.10 dB (profiles/r03/pytest_gpu_tail.txt); 3x the largest
 
 
 def synth(C, n, seed, scale=8000.0, integer=True):
