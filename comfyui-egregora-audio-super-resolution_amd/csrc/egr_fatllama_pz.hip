@@ -268,53 +268,107 @@ __global__ __launch_bounds__(F::MAXT, F::MINW1) void k_pzcol(PzP p, float thr, c
     }
 }
 
-// Spectrum pass on a tile pair: right tile = columns rs .. rs + TC - 1, left tile = their mirror images (cDr - c) mod nc in
-// ascending order.  LDS holds both tiles interleaved: element i of right column t at i * 2TC + t, of left column t at
-// i * 2TC + TC + t.  MAXONLY: no write-back; max |X|^2 per channel -> h.max2_out (the relative threshold's reduction).
-template <bool MAXONLY, class F>
-__global__ __launch_bounds__(F::MAXT, F::MINW2) void k_pzpair(PzP p, PzHook h, cplx* __restrict__ work) {
+
+// The crop pass (k_pzcol<1>) with two workgroup barriers -- the scheme of k_col_wl (egr_fatllama_wl.h) for columns of L = LA x LB
+// points, tiles of 8 columns, one thread per (row class, column):
+//   thread (b < LB, col) loads its LA elements i = LB a + b straight from global memory (64-byte row segments per 8 lanes),
+//   x conj W_P^(col i) (a geometric run in double), inverse radix-LA over a, LDS transpose (barrier), thread (c < LA, col):
+//   x conj W_L^(b c), inverse radix-LB over b -> the time-domain points n = c + LA d, crop (positions outside [s, s + D) zeroed) in
+//   registers -- and those are the inputs n = LA a' + b' (b' = c) of its forward radix-LB over a': no exchange between the inverse
+//   and the forward transform.  x W_L^(b' c''), written into the LDS row it has just read, barrier, thread (c'' < LB, col): forward
+//   radix-LA over b', x W_P^(col i), store to the addresses it loaded from.  LDS rows are padded to an odd length (conflict-free
+//   strided accesses); 4 LDS passes per element instead of 14, 2 barriers instead of 13.
+template <int LA, int LB> struct PzColWl {
+    static constexpr int T = LA > LB ? LA : LB;
+    static constexpr int TC = 8;
+    static constexpr int THREADS = ((T * TC + 63) / 64) * 64;
+    static constexpr int LBP = LB | 1;
+    static constexpr int LDS = LA * LBP * TC * 8;
+};
+template <int LA, int LB>
+__global__ __launch_bounds__((PzColWl<LA, LB>::THREADS)) void k_pzcol_wl(PzP p, const cplx* __restrict__ tab, int ntiles, int tiles_per_xcd, cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     EGR_LDS_CANARY_ARM(smem);
-    __shared__ float red[16];
-    const int g = (blockIdx.x & 7) * p.g_per_xcd + (blockIdx.x >> 3);
-    if (g >= p.G) return;
+    using G = PzColWl<LA, LB>;
+    constexpr int TC = G::TC, LBP = G::LBP, L = LA * LB;
+    __shared__ cplx ts[L];
+    const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile >= ntiles) return;
     const int st = blockIdx.y;
-    const int TC = p.TC, lg = p.TClog2, L = p.L, nc = p.nc, TC2 = 2 * TC;
-    cplx* cur = (cplx*)EGR_LDS_BASE(smem);
-    cplx* W = work + (size_t)st * p.P;
+    const int nc = p.nc;
+    cplx* lds = (cplx*)EGR_LDS_BASE(smem);
+    const int tid = threadIdx.x;
+    const int b = tid >> 3, cl = tid & 7, col = tile * TC + cl;
+    cplx* W = work + (size_t)st * p.P + col;
+    for (int e = tid; e < L; e += G::THREADS) ts[e] = tab[e];
     const unsigned long long D = p.D;
     const long long s = p.s;
-    const int rs = (p.c0 + g * TC) % nc;
-    int ls = (p.cDr - rs - TC + 1) % nc;
-    if (ls < 0) ls += nc;
-    // column masks: with an integer reflection centre (D even) column c0 and column c0 + nc / 2 are their own mirror images
-    unsigned rmask = (1u << TC) - 1u, lmask = rmask, selfmask = 0u;
-    if (!p.odd) {
-        if (g == 0) { selfmask = 1u; lmask &= ~(1u << (TC - 1)); }
-        if (g == p.G - 1) { rmask = 1u; selfmask = 1u; lmask = 0u; }
-    }
-    const int nel2 = L * TC2;
-    // this thread's column of the tile pair (the workgroup size is a multiple of 2 TC, at most 8 elements per thread) and its twiddles
-    int tcol;
-    bool tactive;
-    {
-        const int t2 = (int)threadIdx.x & (TC2 - 1);
-        const bool right = t2 < TC;
-        const int t = right ? t2 : t2 - TC;
-        tcol = right ? rs + t : ls + t;
-        if (tcol >= nc) tcol -= nc;
-        tactive = ((right ? rmask : lmask) >> t) & 1u;
-    }
-    PzTwRun<F::NE2> twr;
-    twr.init(p, tcol, (int)threadIdx.x >> (lg + 1), (int)blockDim.x >> (lg + 1));
+    // four-step twiddles W_P^(col (LB a + b)) of this thread's rows (threads b < LB own rows; the same run serves load and store)
+    dcplx w0 = make_double2(1.0, 0.0), wst = w0;
+    cplx v[LA];
+    if (b < LB) {
 #pragma unroll
-    for (int k = 0; k < F::NE2; ++k) {
-        const int e = threadIdx.x + k * blockDim.x;
-        if (e < nel2) cur[e] = tactive ? cmulc(W[(size_t)(e >> (lg + 1)) * nc + tcol], twr.w[k]) : make_float2(0.f, 0.f);
+        for (int a = 0; a < LA; ++a) v[a] = W[(size_t)(LB * a + b) * nc];
+        w0 = tw2d(p.big, (unsigned)col * (unsigned)b);
+        wst = tw2d(p.big, (unsigned)col * (unsigned)LB);
+        dcplx cur = w0;
+#pragma unroll
+        for (int a = 0; a < LA; ++a) {
+            v[a] = cmulc(v[a], make_float2((float)cur.x, (float)cur.y));
+            cur = dcmul(cur, wst);
+        }
+        wl_bfly_inv<LA>(v);                              // v[c] = Z[c][b]
+#pragma unroll
+        for (int c = 0; c < LA; ++c) lds[(c * LBP + b) * TC + cl] = v[c];
     }
     __syncthreads();
-    F::run(cur, p, TC2, lg + 1, true);
+    if (b < LA) {
+        const int c = b;
+        cplx u[LB];
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+            const cplx z = lds[(c * LBP + j) * TC + cl];
+            u[j] = (j && c) ? cmulc(z, ts[j * LA + c]) : z;
+        }
+        wl_bfly_inv<LB>(u);                              // u[d] = t[c + LA d]
+#pragma unroll
+        for (int d = 0; d < LB; ++d) {
+            const long long m = (long long)(c + LA * d) * nc + col - s;
+            if (m < 0 || (unsigned long long)m >= D) u[d] = make_float2(0.f, 0.f);
+        }
+        Bfly<LB>::run(u);                                // forward over a' = d: u[c''] = Z2[c''][b' = c]
+#pragma unroll
+        for (int j = 0; j < LB; ++j) lds[(c * LBP + j) * TC + cl] = (j && c) ? cmul(u[j], ts[j * LA + c]) : u[j];
+    }
+    __syncthreads();
+    if (b < LB) {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) v[j] = lds[(j * LBP + b) * TC + cl];          // Z2[c'' = b][b' = j]
+        Bfly<LA>::run(v);                                // v[d''] = X[c'' + LB d'']
+        dcplx cur = w0;
+#pragma unroll
+        for (int a = 0; a < LA; ++a) {
+            W[(size_t)(LB * a + b) * nc] = cmul(v[a], make_float2((float)cur.x, (float)cur.y));
+            cur = dcmul(cur, wst);
+        }
+    }
+}
+typedef void (*PzColWlFn)(PzP, const cplx*, int, int, cplx*);
+struct PzColWlEntry { int L, la, lb, threads, lds; PzColWlFn fn; };
+#define PZ_COLWL_LIST(X) X(512, 16, 32) X(560, 20, 28) X(600, 24, 25) X(640, 20, 32) X(672, 24, 28) X(720, 24, 30) X(768, 24, 32) X(800, 25, 32) \
+    X(840, 28, 30) X(900, 30, 30) X(960, 30, 32) X(1024, 32, 32)
+#define PZ_COLWL_ENTRY(LEN, A, B) {LEN, A, B, PzColWl<A, B>::THREADS, PzColWl<A, B>::LDS, k_pzcol_wl<A, B>},
+static const PzColWlEntry kPzColWl[] = {PZ_COLWL_LIST(PZ_COLWL_ENTRY)};
 
+// The pair hook of the spectrum pass on natural-order positions p = i nc + c of a tile pair held in LDS; index k = p - s is valid
+// for 0 <= k < D.  at(i, slot): element i of right column t at slot t, of left column t at slot TC + t.  Shared by k_pzpair (stages
+// in place, interleaved tile) and k_pzpair_wl (rows of the thread-per-(row class, column) layout).
+template <bool MAXONLY, class AT>
+__device__ __forceinline__ void pz_pair_hook(const PzP& p, const PzHook& h, AT at, int st, int rs, unsigned rmask, unsigned selfmask,
+                                             float& mxa, float& mxb) {
+    const int TC = p.TC, lg = p.TClog2, L = p.L, nc = p.nc;
+    const unsigned long long D = p.D;
+    const long long s = p.s;
     // ---- pair hook on natural-order positions p = i nc + c; index k = p - s is valid for 0 <= k < D ----
     const int cha = p.kind == 1 ? st : 2 * st, chb = p.kind == 1 ? st : 2 * st + 1;
     const bool hasb = chb < p.C;
@@ -325,7 +379,6 @@ __global__ __launch_bounds__(F::MAXT, F::MINW2) void k_pzpair(PzP p, PzHook h, c
     }
     const double ta2 = ta * ta, tb2 = tb * tb;
     const double sgn = p.odd ? -1.0 : 1.0;          // w[D - k] = (-1)^D w[k]
-    float mxa = 0.f, mxb = 0.f;
     const int nel = L * TC;
 #ifdef EGR_PZ_ABL_NOHOOK
     if (false)
@@ -337,7 +390,7 @@ __global__ __launch_bounds__(F::MAXT, F::MINW2) void k_pzpair(PzP p, PzHook h, c
         const long long pos = (long long)i * nc + c;
         const long long k = pos - s;
         const bool selfcol = (selfmask >> t) & 1u;
-        cplx* pa = cur + (size_t)i * TC2 + t;       // this element
+        cplx* pa = at(i, t);                        // this element
         cplx* pb;                                   // its partner
         bool same = false, valid = k >= 0 && (unsigned long long)k < D;
         unsigned long long kk = valid ? (unsigned long long)k : 0ULL;
@@ -348,16 +401,16 @@ __global__ __launch_bounds__(F::MAXT, F::MINW2) void k_pzpair(PzP p, PzHook h, c
                 const int ip = p.iDr - i - (c > p.cDr ? 1 : 0);
                 if (selfcol) {
                     if (i > ip) continue;           // handled by the partner
-                    pb = cur + (size_t)ip * TC2 + t;
+                    pb = at(ip, t);
                     same = i == ip;
                 } else {
-                    pb = cur + (size_t)ip * TC2 + TC + (TC - 1 - t);
+                    pb = at(ip, TC + (TC - 1 - t));
                 }
             }
         } else if ((unsigned long long)k == D && !selfcol) {
             // position s + D mirrors position s: index 0 sits in the left tile; handle it from here
             const int ip = p.iDr - i - (c > p.cDr ? 1 : 0);
-            cplx* p0 = cur + (size_t)ip * TC2 + TC + (TC - 1 - t);
+            cplx* p0 = at(ip, TC + (TC - 1 - t));
             if (!MAXONLY) *pa = make_float2(0.f, 0.f);
             pa = p0; pb = p0; same = true; valid = true; kk = 0ULL;
         } else {
@@ -419,6 +472,61 @@ __global__ __launch_bounds__(F::MAXT, F::MINW2) void k_pzpair(PzP p, PzHook h, c
             *pb = dmulc_f(Zb2, w, sgn * p.inv_D);
         }
     }
+}
+
+// Spectrum pass on a tile pair: right tile = columns rs .. rs + TC - 1, left tile = their mirror images (cDr - c) mod nc in
+// ascending order.  LDS holds both tiles interleaved: element i of right column t at i * 2TC + t, of left column t at
+// i * 2TC + TC + t.  MAXONLY: no write-back; max |X|^2 per channel -> h.max2_out (the relative threshold's reduction).
+template <bool MAXONLY, class F>
+__global__ __launch_bounds__(F::MAXT, F::MINW2) void k_pzpair(PzP p, PzHook h, cplx* __restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    EGR_LDS_CANARY_ARM(smem);
+    __shared__ float red[16];
+    const int g = (blockIdx.x & 7) * p.g_per_xcd + (blockIdx.x >> 3);
+    if (g >= p.G) return;
+    const int st = blockIdx.y;
+    const int TC = p.TC, lg = p.TClog2, L = p.L, nc = p.nc, TC2 = 2 * TC;
+    cplx* cur = (cplx*)EGR_LDS_BASE(smem);
+    cplx* W = work + (size_t)st * p.P;
+    const unsigned long long D = p.D;
+    const long long s = p.s;
+    const int rs = (p.c0 + g * TC) % nc;
+    int ls = (p.cDr - rs - TC + 1) % nc;
+    if (ls < 0) ls += nc;
+    // column masks: with an integer reflection centre (D even) column c0 and column c0 + nc / 2 are their own mirror images
+    unsigned rmask = (1u << TC) - 1u, lmask = rmask, selfmask = 0u;
+    if (!p.odd) {
+        if (g == 0) { selfmask = 1u; lmask &= ~(1u << (TC - 1)); }
+        if (g == p.G - 1) { rmask = 1u; selfmask = 1u; lmask = 0u; }
+    }
+    const int nel2 = L * TC2;
+    // this thread's column of the tile pair (the workgroup size is a multiple of 2 TC, at most 8 elements per thread) and its twiddles
+    int tcol;
+    bool tactive;
+    {
+        const int t2 = (int)threadIdx.x & (TC2 - 1);
+        const bool right = t2 < TC;
+        const int t = right ? t2 : t2 - TC;
+        tcol = right ? rs + t : ls + t;
+        if (tcol >= nc) tcol -= nc;
+        tactive = ((right ? rmask : lmask) >> t) & 1u;
+    }
+    PzTwRun<F::NE2> twr;
+    twr.init(p, tcol, (int)threadIdx.x >> (lg + 1), (int)blockDim.x >> (lg + 1));
+#pragma unroll
+    for (int k = 0; k < F::NE2; ++k) {
+        const int e = threadIdx.x + k * blockDim.x;
+        if (e < nel2) cur[e] = tactive ? cmulc(W[(size_t)(e >> (lg + 1)) * nc + tcol], twr.w[k]) : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    F::run(cur, p, TC2, lg + 1, true);
+
+    // ---- pair hook (pz_pair_hook) ----
+    const int cha = p.kind == 1 ? st : 2 * st, chb = p.kind == 1 ? st : 2 * st + 1;
+    const bool hasb = chb < p.C;
+    float mxa = 0.f, mxb = 0.f;
+    const int nel = L * TC;
+    pz_pair_hook<MAXONLY>(p, h, [&](int i, int slot) { return cur + (size_t)i * TC2 + slot; }, st, rs, rmask, selfmask, mxa, mxb);
     if (MAXONLY) {
         mxa = block_max(mxa, red);
         if (p.kind == 2 && hasb) mxb = block_max(mxb, red);
@@ -445,6 +553,114 @@ __global__ __launch_bounds__(F::MAXT, F::MINW2) void k_pzpair(PzP p, PzHook h, c
         if (e < nel2 && tactive) W[(size_t)(e >> (lg + 1)) * nc + tcol] = cmul(cur[e], twr.w[k]);
     }
 }
+
+
+// The spectrum pass on a tile pair with four workgroup barriers (the stage-by-stage k_pzpair: 14): the thread-per-(row class,
+// column) scheme of k_pzcol_wl on the pair's 4 + 4 columns.  After the inverse transform thread (c, col) holds the natural-order
+// rows n = c + LA d of its column; it parks them in ITS OWN LDS row (element i of column slot q at ((i % LA) LBP + i / LA) 8 + q),
+// the pair hook runs on that layout (pz_pair_hook), the thread takes its rows back (cropping the left tile), and the forward
+// transform proceeds as in k_pzcol_wl.  One 48 KB buffer, no write-after-read hazard between threads at any point.
+template <int LA, int LB>
+__global__ __launch_bounds__((PzColWl<LA, LB>::THREADS)) void k_pzpair_wl(PzP p, PzHook h, const cplx* __restrict__ tab, cplx* __restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    EGR_LDS_CANARY_ARM(smem);
+    using G = PzColWl<LA, LB>;
+    constexpr int TC = 4, TC2 = 8, LBP = G::LBP, L = LA * LB;
+    __shared__ cplx ts[L];
+    const int g = (blockIdx.x & 7) * p.g_per_xcd + (blockIdx.x >> 3);
+    if (g >= p.G) return;
+    const int st = blockIdx.y;
+    const int nc = p.nc;
+    cplx* lds = (cplx*)EGR_LDS_BASE(smem);
+    const int tid = threadIdx.x;
+    const int b = tid >> 3, cl = tid & 7;
+    for (int e = tid; e < L; e += G::THREADS) ts[e] = tab[e];
+    const unsigned long long D = p.D;
+    const long long s = p.s;
+    const int rs = (p.c0 + g * TC) % nc;
+    int ls = (p.cDr - rs - TC + 1) % nc;
+    if (ls < 0) ls += nc;
+    unsigned rmask = (1u << TC) - 1u, lmask = rmask, selfmask = 0u;
+    if (!p.odd) {
+        if (g == 0) { selfmask = 1u; lmask &= ~(1u << (TC - 1)); }
+        if (g == p.G - 1) { rmask = 1u; selfmask = 1u; lmask = 0u; }
+    }
+    const bool right = cl < TC;
+    const int t = right ? cl : cl - TC;
+    int tcol = right ? rs + t : ls + t;
+    if (tcol >= nc) tcol -= nc;
+    const bool tactive = ((right ? rmask : lmask) >> t) & 1u;
+    cplx* W = work + (size_t)st * p.P + tcol;
+    dcplx w0 = make_double2(1.0, 0.0), wst = w0;
+    cplx v[LA];
+    if (b < LB) {
+        if (tactive) {
+#pragma unroll
+            for (int a = 0; a < LA; ++a) v[a] = W[(size_t)(LB * a + b) * nc];
+            w0 = tw2d(p.big, (unsigned)tcol * (unsigned)b);
+            wst = tw2d(p.big, (unsigned)tcol * (unsigned)LB);
+            dcplx cur = w0;
+#pragma unroll
+            for (int a = 0; a < LA; ++a) {
+                v[a] = cmulc(v[a], make_float2((float)cur.x, (float)cur.y));
+                cur = dcmul(cur, wst);
+            }
+            wl_bfly_inv<LA>(v);
+        } else {
+#pragma unroll
+            for (int a = 0; a < LA; ++a) v[a] = make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < LA; ++c) lds[(c * LBP + b) * TC2 + cl] = v[c];
+    }
+    __syncthreads();
+    cplx u[LB];
+    if (b < LA) {
+        const int c = b;
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+            const cplx z = lds[(c * LBP + j) * TC2 + cl];
+            u[j] = (j && c) ? cmulc(z, ts[j * LA + c]) : z;
+        }
+        wl_bfly_inv<LB>(u);                              // u[d] = row c + LA d of this column, natural order
+#pragma unroll
+        for (int d = 0; d < LB; ++d) lds[(c * LBP + d) * TC2 + cl] = u[d];
+    }
+    __syncthreads();
+    float mxa = 0.f, mxb = 0.f;
+    pz_pair_hook<false>(p, h, [&](int i, int slot) { const int q = i / LA; return lds + ((i - q * LA) * LBP + q) * TC2 + slot; }, st, rs, rmask, selfmask, mxa, mxb);
+    __syncthreads();
+    if (b < LA) {
+        const int c = b;
+#pragma unroll
+        for (int d = 0; d < LB; ++d) {
+            u[d] = lds[(c * LBP + d) * TC2 + cl];
+            if (!right) {                                // left-tile positions outside [s, s + D): nothing pairs with them
+                const long long k = (long long)(c + LA * d) * nc + tcol - s;
+                if (k < 0 || (unsigned long long)k >= D) u[d] = make_float2(0.f, 0.f);
+            }
+        }
+        Bfly<LB>::run(u);
+#pragma unroll
+        for (int j = 0; j < LB; ++j) lds[(c * LBP + j) * TC2 + cl] = (j && c) ? cmul(u[j], ts[j * LA + c]) : u[j];
+    }
+    __syncthreads();
+    if (b < LB && tactive) {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) v[j] = lds[(j * LBP + b) * TC2 + cl];
+        Bfly<LA>::run(v);
+        dcplx cur = w0;
+#pragma unroll
+        for (int a = 0; a < LA; ++a) {
+            W[(size_t)(LB * a + b) * nc] = cmul(v[a], make_float2((float)cur.x, (float)cur.y));
+            cur = dcmul(cur, wst);
+        }
+    }
+}
+typedef void (*PzPairWlFn)(PzP, PzHook, const cplx*, cplx*);
+struct PzPairWlEntry { int L; PzPairWlFn fn; };
+#define PZ_PAIRWL_ENTRY(LEN, A, B) {LEN, k_pzpair_wl<A, B>},
+static const PzPairWlEntry kPzPairWl[] = {PZ_COLWL_LIST(PZ_PAIRWL_ENTRY)};
 
 // One row of length L per workgroup: FFT . x bhat (CONJ: x conj(bhat)) . IFFT, stages in place.  The row's bhat entries are
 // requested before the forward transform (registers), so their latency is off the dependent chain.
@@ -641,6 +857,9 @@ struct PzPlan {
     const cplx* stw_row;         // stage tables of the compile-time row schedule (nullptr: run-time schedule)
     PzRowFn rowconv, rowconv_conj;
     int threads_row;
+    const void* crop_wl;         // PzColWlEntry of the two-barrier crop pass (nullptr: k_pzcol<1>)
+    const void* pair_wl;         // PzPairWlEntry::fn of the four-barrier spectrum pass (nullptr: k_pzpair)
+    const cplx* crop_wl_tab;     // [LB][LA]: W_L^(b c)
     size_t lds_col, lds_pair, lds_row;
 };
 
@@ -747,6 +966,24 @@ int pz_build(egr_fatllama_plan* plan, int kind) {
                 z->threads_pair = e.threads_pair; z->threads_crop = e.threads_crop;
                 z->col_sched = e.L;
             }
+    // the crop pass on the two-barrier kernel where the column length has an instantiation (EGR_PZ_COLWL=0: k_pzcol<1>)
+    z->crop_wl = nullptr; z->crop_wl_tab = nullptr; z->pair_wl = nullptr;
+    if (!(getenv("EGR_PZ_COLWL") && atoi(getenv("EGR_PZ_COLWL")) == 0) && q.nc % 8 == 0 && !(sp.levels == 3))
+        for (const PzColWlEntry& e : kPzColWl)
+            if (e.L == q.L) {
+                std::vector<float2> t((size_t)e.L);
+                const long double two_pi = 6.283185307179586476925286766559L;
+                for (int b = 0; b < e.lb; ++b)
+                    for (int c = 0; c < e.la; ++c) {
+                        const long double ang = -two_pi * (long double)((b * c) % e.L) / (long double)e.L;
+                        t[(size_t)b * e.la + c] = make_float2((float)cosl(ang), (float)sinl(ang));
+                    }
+                if ((rc = fl_upload(plan, t, &z->crop_wl_tab))) return rc;
+                z->crop_wl = &e;
+                // the spectrum pass too, for even/odd packing (kind 1); channel pairs (kind 2, rows of 8192) measure 2 % slower with it
+                if (q.TC == 4 && kind == 1 && !(getenv("EGR_PZ_PAIRWL") && atoi(getenv("EGR_PZ_PAIRWL")) == 0))
+                    for (const PzPairWlEntry& pe : kPzPairWl) if (pe.L == q.L) z->pair_wl = (const void*)pe.fn;
+            }
     z->rowconv = z->rowconv_conj = nullptr;
     z->threads_row = 512;
     if (sched_on)
@@ -836,7 +1073,10 @@ struct PzRun {
         const dim3 g(8 * q.g_per_xcd, ns);
         if (prof && !maxonly) fl_prof_begin(plan, 1, st, slot);
         if (maxonly) hipLaunchKernelGGL(z->pairmax, g, dim3(z->threads_pairmax), z->lds_pair, st, q, h, work);
-        else hipLaunchKernelGGL(z->pair, g, dim3(z->threads_pair), z->lds_pair, st, q, h, work);
+        else if (z->pair_wl) {
+            const PzColWlEntry* e = (const PzColWlEntry*)z->crop_wl;          // same geometry: 8 column slots, max(LA, LB) threads each
+            hipLaunchKernelGGL((PzPairWlFn)z->pair_wl, g, dim3(e->threads), EGR_LDS(e->lds), st, q, h, z->crop_wl_tab, work);
+        } else hipLaunchKernelGGL(z->pair, g, dim3(z->threads_pair), z->lds_pair, st, q, h, work);
         if (prof && !maxonly) fl_prof_end(plan, st, slot);
     }
 };
@@ -897,6 +1137,11 @@ int pz_loop(egr_fatllama_plan* plan, float* out, int max_iter, float thr, float 
             run.conv(true, work, ns, sg, false, &slot);
             if (it + 1 < max_iter) {
                 if (p_it) fl_prof_begin(plan, 2, sg, &slot);
+                if (z->crop_wl) {
+                    const PzColWlEntry* e = (const PzColWlEntry*)z->crop_wl;
+                    const int nt8 = q.nc / 8, tpx8 = ceil_div(nt8, 8);
+                    hipLaunchKernelGGL(e->fn, dim3(8 * tpx8, ns), dim3(e->threads), EGR_LDS(e->lds), sg, qg, z->crop_wl_tab, nt8, tpx8, work);
+                } else
                 hipLaunchKernelGGL(z->crop, gc, dim3(z->threads_crop), z->lds_col, sg, qg, thr, work, og, pk, (const unsigned*)nullptr);
                 if (p_it) fl_prof_end(plan, sg, &slot);
             }

@@ -35,8 +35,12 @@ namespace egr {
 #define EGR_WL_ROW_THREADS 256          // four waves: the local step's 16 units; the 288 cross butterflies (2 rows x 144) take a second
                                         // round on 32 threads (320 threads = one round measures the same: 28.6 vs 28.8 ms per stage)
 #endif
+#ifndef EGR_WL_ROW_S
 #define EGR_WL_ROW_S 172                // LDS block stride in elements (144 used; = 12 mod 32: the four units of a wave start 24 banks apart)
-#define EGR_WL_ROW_TS 14                // row stride of the 12 x 12 transpose inside a block (16-byte aligned rows, lane stride 28 banks)
+#endif
+#ifndef EGR_WL_ROW_TS
+#define EGR_WL_ROW_TS 14                // row stride of the 12 x 12 transpose inside a block (even: 16-byte accesses; odd: 8-byte)
+#endif
 #define EGR_WL_ROW_LDS (2 * 16 * EGR_WL_ROW_S * 8)
 #ifndef EGR_WL_ROW_WAVES
 #define EGR_WL_ROW_WAVES 1              // __launch_bounds__ minimum waves per SIMD of k_row_wl (register budget)
@@ -137,9 +141,14 @@ __global__ __launch_bounds__(EGR_WL_ROW_THREADS, EGR_WL_ROW_WAVES) void k_row_wl
         wl_wave_sync();
 #pragma unroll
         for (int b2 = 0; b2 < 12; b2 += 2) {
-            const float4 x = *(const float4*)(ba + l * TS + b2), y = *(const float4*)(bb + l * TS + b2);
-            A[b2] = make_float2(x.x, x.y); A[b2 + 1] = make_float2(x.z, x.w);
-            B[b2] = make_float2(y.x, y.y); B[b2 + 1] = make_float2(y.z, y.w);
+            if (TS % 2 == 0) {
+                const float4 x = *(const float4*)(ba + l * TS + b2), y = *(const float4*)(bb + l * TS + b2);
+                A[b2] = make_float2(x.x, x.y); A[b2 + 1] = make_float2(x.z, x.w);
+                B[b2] = make_float2(y.x, y.y); B[b2 + 1] = make_float2(y.z, y.w);
+            } else {
+                A[b2] = ba[l * TS + b2]; A[b2 + 1] = ba[l * TS + b2 + 1];
+                B[b2] = bb[l * TS + b2]; B[b2 + 1] = bb[l * TS + b2 + 1];
+            }
         }
         wl_wave_sync();
         Bfly<12>::run(A);          // A[d] = Xa[k1 + 16 (l + 12 d)]
@@ -197,8 +206,13 @@ __global__ __launch_bounds__(EGR_WL_ROW_THREADS, EGR_WL_ROW_WAVES) void k_row_wl
         for (int b2 = 0; b2 < 12; b2 += 2) {
             const cplx a0 = b2 ? cmulc(A[b2], t2[b2]) : A[b2], a1 = cmulc(A[b2 + 1], t2[b2 + 1]);
             const cplx c0 = b2 ? cmulc(B[b2], t2b[b2]) : B[b2], c1 = cmulc(B[b2 + 1], t2b[b2 + 1]);
-            *(float4*)(ba + l * TS + b2) = make_float4(a0.x, a0.y, a1.x, a1.y);
-            *(float4*)(bb + l * TS + b2) = make_float4(c0.x, c0.y, c1.x, c1.y);
+            if (TS % 2 == 0) {
+                *(float4*)(ba + l * TS + b2) = make_float4(a0.x, a0.y, a1.x, a1.y);
+                *(float4*)(bb + l * TS + b2) = make_float4(c0.x, c0.y, c1.x, c1.y);
+            } else {
+                ba[l * TS + b2] = a0; ba[l * TS + b2 + 1] = a1;
+                bb[l * TS + b2] = c0; bb[l * TS + b2 + 1] = c1;
+            }
         }
         wl_wave_sync();
 #pragma unroll

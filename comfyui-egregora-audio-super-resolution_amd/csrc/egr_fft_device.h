@@ -127,6 +127,12 @@ template <> struct Bfly<10> { static __device__ __forceinline__ void run(cplx (&
 template <> struct Bfly<9> { static __device__ __forceinline__ void run(cplx (&v)[9]) { BflyComp<3, 3>::run(v); } };
 template <> struct Bfly<16> { static __device__ __forceinline__ void run(cplx (&v)[16]) { BflyComp<4, 4>::run(v); } };
 template <> struct Bfly<25> { static __device__ __forceinline__ void run(cplx (&v)[25]) { BflyComp<5, 5>::run(v); } };
+// larger composites: register butterflies of the thread-per-(row class, column) column kernels (k_pzcol_wl)
+template <> struct Bfly<20> { static __device__ __forceinline__ void run(cplx (&v)[20]) { BflyComp<4, 5>::run(v); } };
+template <> struct Bfly<24> { static __device__ __forceinline__ void run(cplx (&v)[24]) { BflyComp<4, 6>::run(v); } };
+template <> struct Bfly<28> { static __device__ __forceinline__ void run(cplx (&v)[28]) { BflyComp<4, 7>::run(v); } };
+template <> struct Bfly<30> { static __device__ __forceinline__ void run(cplx (&v)[30]) { BflyComp<5, 6>::run(v); } };
+template <> struct Bfly<32> { static __device__ __forceinline__ void run(cplx (&v)[32]) { BflyComp<4, 8>::run(v); } };
 
 // One radix-R stage over `nseq` sequences.  SEQFAST: sequence index is the fastest thread index
 // (column tiles, nseq = 1<<seq_log2); otherwise nseq is 1 or 2 and the butterfly index is fastest.

@@ -122,3 +122,52 @@ def test_one_barrier_inner_pass_of_three_level_plans(pack, inner):
     assert float(np.max(np.abs(got - old))) <= 4e-6 * scale
     assert rms(got - exact) <= 2.5 * rms(want - exact) + 1e-9 * scale
 
+
+
+def run_pz(x, iters, wl, thr=0.6, **kw):
+    from egregora_amd import fatllama_engine as fe
+    old = os.environ.get("EGR_PZ_COLWL")
+    os.environ["EGR_PZ_COLWL"] = "1" if wl else "0"
+    try:
+        fe.release_plans()
+        y = fe.enhance_device(torch.from_numpy(x).cuda(), 1, iters, thr, **FLAGS, **kw).cpu().numpy()
+        fe.release_plans()
+    finally:
+        if old is None:
+            os.environ.pop("EGR_PZ_COLWL", None)
+        else:
+            os.environ["EGR_PZ_COLWL"] = old
+    return y
+
+
+@pytest.mark.parametrize("n,channels,kw,thr", [
+    (512 * 4096 - 6, 2, {}, 0.6),                      # columns of 512 = 16 x 32
+    (720 * 4096 - 6, 1, {}, 0.6),                      # 720 = 24 x 30, one state
+    (2880001, 3, {}, 0.6),                             # odd length: channel pairs (kind 2), rows of 8192, the last state one channel
+    (600 * 4096 - 6, 2, {"variant": "relative,soft"}, 0.02),     # hook variants run through the same pz_pair_hook
+    (1024 * 4096 - 6, 2, {}, 0.6),                     # 1024 = 32 x 32 on rows of 8192
+])
+def test_column_passes_of_the_chirp_z_path_on_the_thread_per_column_kernels(pack, n, channels, kw, thr):
+    """Lengths without a packed plan: the crop pass and (even lengths) the spectrum pass run k_pzcol_wl / k_pzpair_wl
+    (csrc/egr_fatllama_pz.hip: 2 / 4 workgroup barriers) for every column length with a compile-time schedule; against the
+    stage-by-stage kernels (EGR_PZ_COLWL=0) and, for the shortest, the oracle and float64."""
+    from egregora_amd import fatllama_engine as fe
+    info = fe.plan_info(n, 1)
+    assert info["bluestein"], info
+    scale_in = 8000.0
+    x = synth(channels, n, seed=n % 1000, scale=scale_in)
+    a = run_pz(x, 3, True, thr, **kw)
+    b = run_pz(x, 3, False, thr, **kw)
+    scale = float(np.max(np.abs(b)))
+    err = float(np.max(np.abs(a - b)))
+    print(f"\nchirp-z column passes, n = {n} ({info['M1']} x {info['M2']}): max diff {err / scale:.2e} of the peak, rms {rms(a - b) / scale:.2e}")
+    assert np.isfinite(a).all()
+    if kw:
+        assert float(np.sum(np.square(a - b, dtype=np.float64))) <= 1e-6 * float(np.sum(np.square(b, dtype=np.float64)))
+    else:
+        assert err <= 4e-6 * scale and rms(a - b) <= 4e-7 * scale
+    if n == 512 * 4096 - 6:
+        want = ofl.enhance_channels(x, 1, 3, 0.6, normalize=False, autoscale=False)
+        exact = ofl.enhance_channels(x, 1, 3, 0.6, normalize=False, autoscale=False, exact=True)
+        assert float(np.max(np.abs(a - want))) <= 2e-5 * scale
+        assert rms(a - exact) <= 2.5 * rms(want - exact) + 5e-8 * scale
