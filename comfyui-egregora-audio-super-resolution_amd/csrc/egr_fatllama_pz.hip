@@ -1106,26 +1106,37 @@ int pz_loop(egr_fatllama_plan* plan, float* out, int max_iter, float thr, float 
         EGR_HIP(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
         EGR_HIP(hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming));
     }
-    if (ngroups == 2) {
-        EGR_HIP(hipEventRecord(plan->ev_fork, st));
-        EGR_HIP(hipStreamWaitEvent(plan->side, plan->ev_fork, 0));
-    }
     size_t slot = 0;
     const bool prof = plan->profiling;
-    for (int g = 0; g < ngroups; ++g) {
-        const int s0 = g == 0 ? 0 : ns_all / 2, ns = ngroups == 1 ? ns_all : (g == 0 ? ns_all / 2 : ns_all - ns_all / 2);
-        hipStream_t sg = g == 0 ? st : plan->side;
-        cplx* work = plan->d_work + (size_t)s0 * q.P;
+    auto fork = [&](hipStream_t s0) -> int {
+        if (ngroups == 2) {
+            EGR_HIP(hipEventRecord(plan->ev_fork, s0));
+            EGR_HIP(hipStreamWaitEvent(plan->side, plan->ev_fork, 0));
+        }
+        return EGR_OK;
+    };
+    auto join = [&](hipStream_t s0) -> int {
+        if (ngroups == 2) {
+            EGR_HIP(hipEventRecord(plan->ev_join, plan->side));
+            EGR_HIP(hipStreamWaitEvent(s0, plan->ev_join, 0));
+        }
+        return EGR_OK;
+    };
+    // One group's launches: `first` adds the opening pass, iterations [it0, it1), `last` the closing pass.
+    auto run_group = [&](hipStream_t s0, int g, int it0, int it1, bool first, bool last, bool profiling) {
+        const int sb = g == 0 ? 0 : ns_all / 2, ns = ngroups == 1 ? ns_all : (g == 0 ? ns_all / 2 : ns_all - ns_all / 2);
+        hipStream_t sg = g == 0 ? s0 : plan->side;
+        cplx* work = plan->d_work + (size_t)sb * q.P;
         // the kernels index channels from the state id: shift the per-channel arrays so that state 0 of the group is local state 0
-        const int ch0 = q.kind == 1 ? s0 : 2 * s0;
+        const int ch0 = q.kind == 1 ? sb : 2 * sb;
         PzP qg = q;
         qg.C = C - ch0;
         float* og = out + (size_t)ch0 * q.N;
         unsigned* pk = peak_out + ch0;
         const dim3 gc(8 * q.tiles_per_xcd, ns), bc(z->threads_col);
-        hipLaunchKernelGGL(z->first, gc, bc, z->lds_col, sg, qg, thr0, work, og, pk, thr0_rel ? thr0_rel + ch0 : nullptr);
-        for (int it = 0; it < max_iter; ++it) {
-            const bool p_it = prof && g == 0 && it >= max_iter - 3;      // events around the last iterations of group 0
+        if (first) hipLaunchKernelGGL(z->first, gc, bc, z->lds_col, sg, qg, thr0, work, og, pk, thr0_rel ? thr0_rel + ch0 : nullptr);
+        for (int it = it0; it < it1; ++it) {
+            const bool p_it = profiling && g == 0 && it >= max_iter - 3;      // events around the last iterations of group 0
             run.conv(false, work, ns, sg, p_it, &slot);
             PzHook hg = h;
             if (relative) {
@@ -1146,13 +1157,48 @@ int pz_loop(egr_fatllama_plan* plan, float* out, int max_iter, float thr, float 
                 if (p_it) fl_prof_end(plan, sg, &slot);
             }
         }
-        hipLaunchKernelGGL(z->last, gc, bc, z->lds_col, sg, qg, thr, work, og, pk, (const unsigned*)nullptr);
+        if (last) hipLaunchKernelGGL(z->last, gc, bc, z->lds_col, sg, qg, thr, work, og, pk, (const unsigned*)nullptr);
+    };
+    // The four launches of a middle iteration are the same every iteration and touch the plan's own state only: CH iterations of all
+    // pipelines are captured once into a hipGraph and replayed (as the packed loop does, egr_fatllama.hip); keyed by (threshold,
+    // pipelines, hook kind), never destroyed while a launch of it may be in flight.  Profiling and the relative threshold (a new
+    // reduction slot per iteration) use plain launches.
+    constexpr int CH = 25;
+    // (two pipelines: 113.9 -> 103.4 ms per 800 iterations of 60 s + 2 samples; a single pipeline measures the same either way)
+    const int n_graph = (!prof && plan->use_graph && !relative && ngroups == 2 && max_iter > 2 * CH) ? (max_iter - 1) / CH : 0;
+    int rc = fork(st);
+    if (rc) return rc;
+    for (int g = 0; g < ngroups; ++g) run_group(st, g, 0, 0, true, false, false);
+    if (n_graph > 0) {
+        rc = join(st);
+        if (rc) return rc;
+        if (!(plan->gexec && plan->g_thr == thr && plan->g_groups == ngroups && plan->g_iter_odd == h.soft)) {
+            if (plan->gexec) { EGR_HIP(hipDeviceSynchronize()); EGR_HIP(hipGraphExecDestroy(plan->gexec)); plan->gexec = nullptr; }
+            hipGraph_t graph = nullptr;
+            if (!plan->cap) EGR_HIP(hipStreamCreateWithFlags(&plan->cap, hipStreamNonBlocking));
+            EGR_HIP(hipStreamBeginCapture(plan->cap, hipStreamCaptureModeThreadLocal));
+            rc = fork(plan->cap);
+            if (!rc) for (int g = 0; g < ngroups; ++g) run_group(plan->cap, g, 0, CH, false, false, false);
+            if (!rc) rc = join(plan->cap);
+            hipError_t ce = hipStreamEndCapture(plan->cap, &graph);
+            if (rc || ce != hipSuccess) {
+                if (graph) hipGraphDestroy(graph);
+                hipStreamDestroy(plan->cap);
+                plan->cap = nullptr;
+                if (rc) return rc;
+                EGR_HIP(ce);
+            }
+            hipError_t ie = hipGraphInstantiate(&plan->gexec, graph, nullptr, nullptr, 0);
+            hipGraphDestroy(graph);
+            if (ie != hipSuccess) { plan->gexec = nullptr; EGR_HIP(ie); }
+            plan->g_out = out; plan->g_thr = thr; plan->g_groups = ngroups; plan->g_iter_odd = h.soft;
+        }
+        for (int i = 0; i < n_graph; ++i) EGR_HIP(hipGraphLaunch(plan->gexec, st));
+        rc = fork(st);
+        if (rc) return rc;
     }
-    if (ngroups == 2) {
-        EGR_HIP(hipEventRecord(plan->ev_join, plan->side));
-        EGR_HIP(hipStreamWaitEvent(st, plan->ev_join, 0));
-    }
-    return EGR_OK;
+    for (int g = 0; g < ngroups; ++g) run_group(st, g, n_graph * CH, max_iter, false, true, prof);
+    return join(st);
 }
 
 // y = irfft(rfft(x) * [k >= band_lo]) per channel on a paired chirp-z plan (factor 1): first pass without a threshold, one

@@ -159,3 +159,16 @@ def test_full_size_properties_60s_plus_2_samples(pack):
     exact = ofl.enhance_channels(x[:1], 1, 2, 0.6, normalize=False, autoscale=False, exact=True)
     check(run_gpu(pack, x[:1], 1, 2, 0.6), want, exact, lsd=False)
     assert om.lsd_audio(want[:, :960000], run_gpu(pack, x[:1], 1, 2, 0.6)[:, :960000])[0] <= 1e-3
+
+
+@pytest.mark.parametrize("C,n,iters", [(2, 48002, 77), (4, 4801, 130), (2, 2 * 7919, 51)])
+def test_chirpz_graph_replay_equals_plain_launches(pack, C, n, iters):
+    """Above 50 iterations the chirp-z loop of two state pipelines replays a captured 25-iteration hipGraph (csrc/egr_fatllama_pz.hip
+    pz_loop) plus a remainder; profiling runs use plain stream launches.  Same kernels, same order per state: bit-identical outputs,
+    also from the cached executable graph with another output buffer."""
+    x = synth(C, n, seed=n + iters)
+    a = run_gpu(pack, x, 1, iters, 0.6)
+    b = run_gpu(pack, x, 1, iters, 0.6, profile=True)
+    a2 = run_gpu(pack, x, 1, iters, 0.6)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, a2)
