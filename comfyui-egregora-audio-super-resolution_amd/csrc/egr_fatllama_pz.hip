@@ -764,6 +764,88 @@ __global__ __launch_bounds__(NC / 16) void k_pz_rowconv_s(const cplx* __restrict
     }
 }
 
+
+// Rows of NC = 16 R1 R2 points (1024 = 16 8 8, 2048 = 16 16 8, 4096 = 16 16 16) with the outer stages fused into the memory accesses.
+// Thread tid of NC / 16 owns the residue class {tid + (NC / 16) m, m < 16}: those are the inputs of ITS first radix-16 butterfly
+// (loaded straight from global memory, coalesced), the outputs of ITS last-stage butterflies of the forward transform (so the x Bhat
+// product and the first radix-16 stage of the inverse run on registers, no LDS exchange between the two transforms), and the outputs
+// of ITS last-stage butterflies of the inverse (stored straight to global memory).  Only the middle stage of each transform runs
+// in place in LDS.  8 LDS passes per element instead of 16, 7 barriers instead of 13; same butterflies, tables and arithmetic per
+// element as k_pz_rowconv_s (results agree to round-off; the order of the twiddle products is the same).
+template <bool CONJ, int NC, int R1, int R2>
+__global__ __launch_bounds__(NC / 16) void k_pz_rowconv_f(const cplx* __restrict__ stw, const cplx* __restrict__ bhat, long long P,
+                                                          cplx* __restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    EGR_LDS_CANARY_ARM(smem);
+    constexpr int L = NC, T = NC / 16, PSH = EGR_PZ_ROW_PAD, NB2 = 16 / R2, NS2 = 16 * R1, RS2 = sched_row_stride(R2);
+    static_assert(16 * R1 * R2 == NC && NS2 == NC / R2, "three-stage schedule 16 R1 R2");
+    cplx* cur = (cplx*)EGR_LDS_BASE(smem);
+    cplx* g = work + (size_t)blockIdx.y * P + (size_t)blockIdx.x * L;
+    const cplx* bh = bhat + (size_t)blockIdx.x * L;
+    const cplx* stw2 = stw + 16 * sched_row_stride(R1);          // table of the last stage (lds_fft_sched_inplace's layout)
+    const int tid = threadIdx.x;
+    cplx v[16], bq[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = g[tid + T * m];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) bq[m] = bh[tid + T * m];
+    // ---- forward: stage 0 (radix 16, no twiddles) on registers -> LDS (autosort: butterfly j writes j 16 + t)
+    Bfly<16>::run(v);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) cur[lds_pad<PSH>(tid * 16 + t)] = v[t];
+    __syncthreads();
+    fft_stage_tab_inplace<R1, 16, false, PSH, sched_nbt(L, R1, T), T>(cur, L, stw, 1, 0, 1, lds_pad<PSH>(L), false, false);
+    // ---- forward: last stage (radix R2, Ns = 16 R1 = NC / R2: k = j) LDS -> registers; element index j + t Ns = tid + T (n + NB2 t)
+#pragma unroll
+    for (int n = 0; n < NB2; ++n) {
+        const int j = tid + n * T;
+        cplx u[R2];
+#pragma unroll
+        for (int t = 0; t < R2; ++t) u[t] = cur[lds_pad<PSH>(j + t * NS2)];
+        const float4* tp4 = (const float4*)(stw2 + (size_t)j * RS2);
+#pragma unroll
+        for (int t2 = 0; t2 < RS2 / 2; ++t2) {
+            const float4 w = tp4[t2];
+            if (2 * t2 >= 1 && 2 * t2 < R2) u[2 * t2] = cmul(u[2 * t2], make_float2(w.x, w.y));
+            if (2 * t2 + 1 < R2) u[2 * t2 + 1] = cmul(u[2 * t2 + 1], make_float2(w.z, w.w));
+        }
+        Bfly<R2>::run(u);
+#pragma unroll
+        for (int t = 0; t < R2; ++t) v[n + NB2 * t] = u[t];
+    }
+    // ---- x Bhat, inverse stage 0 (swap . radix 16) on registers
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const cplx b = make_float2(bq[m].x, CONJ ? -bq[m].y : bq[m].y);
+        const cplx x = cmul(v[m], b);
+        v[m] = make_float2(x.y, x.x);
+    }
+    Bfly<16>::run(v);
+    __syncthreads();                                     // every thread has read its last-stage inputs
+#pragma unroll
+    for (int t = 0; t < 16; ++t) cur[lds_pad<PSH>(tid * 16 + t)] = v[t];
+    __syncthreads();
+    fft_stage_tab_inplace<R1, 16, false, PSH, sched_nbt(L, R1, T), T>(cur, L, stw, 1, 0, 1, lds_pad<PSH>(L), false, false);
+    // ---- inverse: last stage -> swap -> global
+#pragma unroll
+    for (int n = 0; n < NB2; ++n) {
+        const int j = tid + n * T;
+        cplx u[R2];
+#pragma unroll
+        for (int t = 0; t < R2; ++t) u[t] = cur[lds_pad<PSH>(j + t * NS2)];
+        const float4* tp4 = (const float4*)(stw2 + (size_t)j * RS2);
+#pragma unroll
+        for (int t2 = 0; t2 < RS2 / 2; ++t2) {
+            const float4 w = tp4[t2];
+            if (2 * t2 >= 1 && 2 * t2 < R2) u[2 * t2] = cmul(u[2 * t2], make_float2(w.x, w.y));
+            if (2 * t2 + 1 < R2) u[2 * t2 + 1] = cmul(u[2 * t2 + 1], make_float2(w.z, w.w));
+        }
+        Bfly<R2>::run(u);
+#pragma unroll
+        for (int t = 0; t < R2; ++t) g[j + t * NS2] = make_float2(u[t].y, u[t].x);
+    }
+}
+
 // ---- plan-time double-precision transform of the chirp sequence ----
 // b[j] = conj(w[|j|]) = exp(+i pi j^2 / D) for |j| < D (cyclic positions j and P - j), zero elsewhere
 __global__ __launch_bounds__(256) void k_pz_chirp_b(unsigned long long D, double inv_2D, long long P, double2* __restrict__ b) {
@@ -995,6 +1077,13 @@ int pz_build(egr_fatllama_plan* plan, int kind) {
                 z->rowconv = e.fn; z->rowconv_conj = e.fn_conj;
                 z->threads_row = e.NC / 16;
             }
+    // three-stage rows (1024 / 2048 / 4096 points): the kernel with the outer stages fused into the memory accesses (EGR_PZ_ROWF=0:
+    // k_pz_rowconv_s); same tables, same LDS footprint
+    if (z->rowconv && !(getenv("EGR_PZ_ROWF") && atoi(getenv("EGR_PZ_ROWF")) == 0)) {
+        if (r.L == 4096) { z->rowconv = k_pz_rowconv_f<false, 4096, 16, 16>; z->rowconv_conj = k_pz_rowconv_f<true, 4096, 16, 16>; }
+        else if (r.L == 2048) { z->rowconv = k_pz_rowconv_f<false, 2048, 16, 8>; z->rowconv_conj = k_pz_rowconv_f<true, 2048, 16, 8>; }
+        else if (r.L == 1024) { z->rowconv = k_pz_rowconv_f<false, 1024, 8, 8>; z->rowconv_conj = k_pz_rowconv_f<true, 1024, 8, 8>; }
+    }
     z->lds_col = EGR_LDS((size_t)q.L * q.TC * sizeof(cplx));
     z->lds_pair = EGR_LDS(2 * (size_t)q.L * q.TC * sizeof(cplx));
     z->lds_row = EGR_LDS(z->stw_row ? (size_t)(r.L + (EGR_PZ_ROW_PAD ? r.L >> EGR_PZ_ROW_PAD : 0)) * sizeof(cplx) : (size_t)r.L * sizeof(cplx));
