@@ -52,22 +52,39 @@ namespace egr {
 #define EGR_WL_COL_TC 8
 #define EGR_WL_COL_LDS (625 * EGR_WL_COL_TC * 8)
 
-// The default pair hook of k_row (hard threshold on |X|^2; identical arithmetic): Za = Z[k], Zb = Z[M-k], wkd = W_N^k in double.
-__device__ __forceinline__ void wl_pair_hook(const cplx Za, const cplx Zb, const dcplx Wkd, const float thr2, const double scd, cplx& na, cplx& nb) {
+// The pair hook of k_row (identical arithmetic): Za = Z[k], Zb = Z[M-k], Wkd = W_N^k in double.
+// HOOK 0: hard threshold against an absolute level (|X|^2 > thr2).  HOOK 1: the SPEC.md section 3 variants -- level tlev (absolute,
+// or thr x the spectrum maximum of this iteration), hard or soft shrink.  HOOK 2: no update; returns max(|X[k]|^2, |X[M-k]|^2).
+template <int HOOK>
+__device__ __forceinline__ float wl_pair_hook(const cplx Za, const cplx Zb, const dcplx Wkd, const float thr2, const float tlev, const int soft,
+                                              const double scd, cplx& na, cplx& nb) {
     const cplx Wk = make_float2((float)Wkd.x, (float)Wkd.y);
     const cplx E = make_float2(0.5f * (Za.x + Zb.x), 0.5f * (Za.y - Zb.y));
     const cplx O = make_float2(0.5f * (Za.y + Zb.y), -0.5f * (Za.x - Zb.x));
     const cplx WO = cmul(Wk, O);
     cplx Xk = cadd(E, WO), Xm = csub(E, WO);
-    if (!(Xk.x * Xk.x + Xk.y * Xk.y > thr2)) Xk = make_float2(0.f, 0.f);
-    if (!(Xm.x * Xm.x + Xm.y * Xm.y > thr2)) Xm = make_float2(0.f, 0.f);
+    if (HOOK == 2) return fmaxf(Xk.x * Xk.x + Xk.y * Xk.y, Xm.x * Xm.x + Xm.y * Xm.y);
+    if (HOOK == 1) {
+        const float mk = sqrtf(Xk.x * Xk.x + Xk.y * Xk.y), mm = sqrtf(Xm.x * Xm.x + Xm.y * Xm.y);
+        float gk = mk > tlev ? 1.f : 0.f, gm = mm > tlev ? 1.f : 0.f;
+        if (soft) {
+            if (mk > tlev) gk = 1.f - tlev / mk;
+            if (mm > tlev) gm = 1.f - tlev / mm;
+        }
+        Xk.x *= gk; Xk.y *= gk; Xm.x *= gm; Xm.y *= gm;
+    } else {
+        if (!(Xk.x * Xk.x + Xk.y * Xk.y > thr2)) Xk = make_float2(0.f, 0.f);
+        if (!(Xm.x * Xm.x + Xm.y * Xm.y > thr2)) Xm = make_float2(0.f, 0.f);
+    }
     const cplx E2 = make_float2(0.5f * (Xk.x + Xm.x), 0.5f * (Xk.y + Xm.y));
     const cplx H = make_float2(0.5f * (Xk.x - Xm.x), 0.5f * (Xk.y - Xm.y));
     const cplx O2 = cmulc(H, Wk);
     na = make_float2((float)(scd * (double)(E2.x - O2.y)), (float)(scd * (double)(E2.y + O2.x)));
     nb = make_float2((float)(scd * (double)(E2.x + O2.y)), -(float)(scd * (double)(E2.y - O2.x)));
+    return 0.f;
 }
 
+template <int HOOK>
 __global__ __launch_bounds__(EGR_WL_ROW_THREADS, EGR_WL_ROW_WAVES) void k_row_wl(RowP p, WlRowT tb, long long M, cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     EGR_LDS_CANARY_ARM(smem);
@@ -155,16 +172,22 @@ __global__ __launch_bounds__(EGR_WL_ROW_THREADS, EGR_WL_ROW_WAVES) void k_row_wl
         Bfly<12>::run(B);          // B[d] = Xb[(15 - k1) + 16 ((11 - l) + 12 d)]
     }
     EGR_STAMP(p, 2);
-    const float thr2 = p.thr2;
+    float thr2 = p.thr2, tlev = p.thr;
+    if (HOOK == 1 && p.max2) {                   // level relative to this iteration's spectrum maximum (written by k_row_wl<2>)
+        tlev = p.thr * sqrtf(__uint_as_float(p.max2[ch]));
+        thr2 = tlev * tlev;
+    }
+    const int soft = p.soft;
     const double scd = p.inv_M_d;
+    float mx2 = 0.f;
     if (!self) {
         if (lact) {
             const dcplx st = make_double2(0.96592582628906828674974319972890, -0.25881904510252076234889883762405);   // W_24
 #pragma unroll
             for (int d = 0; d < 12; ++d) {
                 cplx na, nb;
-                wl_pair_hook(A[d], B[11 - d], wrun, thr2, scd, na, nb);
-                A[d] = na; B[11 - d] = nb;
+                mx2 = fmaxf(mx2, wl_pair_hook<HOOK>(A[d], B[11 - d], wrun, thr2, tlev, soft, scd, na, nb));
+                if (HOOK != 2) { A[d] = na; B[11 - d] = nb; }
                 wrun = dcmul(wrun, st);
             }
         }
@@ -184,18 +207,26 @@ __global__ __launch_bounds__(EGR_WL_ROW_THREADS, EGR_WL_ROW_WAVES) void k_row_wl
             cplx* ea = lds + (k2 & 15) * S + (k2 >> 4);
             cplx* eb = lds + (pb & 15) * S + (pb >> 4);
             cplx na, nb;
-            wl_pair_hook(*ea, *eb, dcmul(wa, p.wk[k2]), thr2, scd, na, nb);
-            *ea = na;
-            if (pb != k2) *eb = nb;
+            mx2 = fmaxf(mx2, wl_pair_hook<HOOK>(*ea, *eb, dcmul(wa, p.wk[k2]), thr2, tlev, soft, scd, na, nb));
+            if (HOOK != 2) {
+                *ea = na;
+                if (pb != k2) *eb = nb;
+            }
         }
         __syncthreads();
-        if (lact) {
+        if (HOOK != 2 && lact) {
 #pragma unroll
             for (int d = 0; d < 12; ++d) { A[d] = ba[l + 12 * d]; B[d] = bb[(11 - l) + 12 * d]; }
             wl_wave_sync();
         }
     }
     EGR_STAMP(p, 3);
+    if (HOOK == 2) {                             // the reduction a threshold RELATIVE to the spectrum's maximum needs: nothing is written back
+        __shared__ float red[16];
+        mx2 = block_max(mx2, red);
+        if (tid == 0) atomicMax(p.max2_out + ch, __float_as_uint(mx2));
+        return;
+    }
     if (lact) {
         // ---- local step, inverse
         const cplx* t2 = tb.t2 + l * 12;             // row a: c = l; W_144^(b c) is symmetric in (b, c)

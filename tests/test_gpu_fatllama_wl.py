@@ -171,3 +171,23 @@ def test_column_passes_of_the_chirp_z_path_on_the_thread_per_column_kernels(pack
         exact = ofl.enhance_channels(x, 1, 3, 0.6, normalize=False, autoscale=False, exact=True)
         assert float(np.max(np.abs(a - want))) <= 2e-5 * scale
         assert rms(a - exact) <= 2.5 * rms(want - exact) + 5e-8 * scale
+
+
+@pytest.mark.parametrize("variant,thr", [("soft", 50.0), ("relative", 0.02), ("relative,soft", 0.02), ("relative,no_init_thr", 0.3)])
+def test_hook_variants_on_the_two_barrier_row_kernel(pack, variant, thr):
+    """SPEC.md section 3 variants at the C3 length: k_row_wl<1> (level from the iteration's spectrum maximum and / or soft shrink) and
+    k_row_wl<2> (the maximum's reduction pass) against the stage-by-stage kernels and the oracle with the matching FatLlamaSpec."""
+    scale_in = 100.0 if variant == "soft" else 8000.0
+    x = synth(2, 2880000, seed=21, scale=scale_in)
+    a = run(x, 3, thr=thr, wl=True, variant=variant)
+    b = run(x, 3, thr=thr, wl=False, variant=variant)
+    eb = float(np.sum(np.square(b, dtype=np.float64)))
+    assert np.isfinite(a).all()
+    assert float(np.sum(np.square(a - b, dtype=np.float64))) <= 1e-6 * eb       # a borderline bin may flip between two float32 runs
+    spec = ofl.FatLlamaSpec(threshold_ref="relative_to_max" if "relative" in variant else "absolute",
+                            threshold_kind="soft" if "soft" in variant else "hard",
+                            init_threshold="none" if "no_init_thr" in variant else "same")
+    want = ofl.enhance_channels(x, 1, 3, thr, normalize=False, autoscale=False, spec=spec)
+    assert float(np.sum(np.square(a - want, dtype=np.float64))) <= 1e-6 * float(np.sum(np.square(want, dtype=np.float64)))
+    y = x.copy(); y[:, -1] = 0
+    assert rms(a - 2 * y) > 1e-4 * rms(y)                                        # the threshold removed something
