@@ -305,6 +305,7 @@ def main():
     el_c2 = None
     arb = {}
     c4_parts = {}
+    c5_len = {}
     if not args.lean:
         x_c2 = x_all[:, :cfg.chunk].contiguous()
         upscale_48k(x_c2, False)
@@ -326,6 +327,26 @@ def main():
                         "P": info["M"], "split": [info["M1"], info["M2"], info["M3"]], "states": states,
                         "k_pz_rowconv_ms": k3["ms"][0], "k_pzpair_ms": k3["ms"][1], "k_pzcol_crop_ms": k3["ms"][2],
                         "states_per_launch": states // groups}
+        # ---- the Fat-Llama stage at BASELINE configs[4]'s length (30 min at 96 kHz: N = 172.8 M samples per channel, stereo, 200
+        # iterations): the state (1.38 GB) leaves the memory-side cache, the passes stream from HBM (plan 625 x 60 x 2304) ----
+        c5_len = {}
+        try:
+            n5 = 172800000
+            g5 = torch.Generator(device="cuda").manual_seed(505)
+            x5 = (0.25 * torch.randn(C, n5, device="cuda", generator=g5)).clamp_(-1.0, 1.0)
+            i5 = fe.plan_info(n5, 1)
+            fe.enhance_device(x5, 1, 4, 0.6, **fl_flags)
+            e5, y5 = timed(lambda: fe.enhance_device(x5, 1, 200, 0.6, **fl_flags), 1)
+            assert bool(torch.isfinite(y5).all())
+            c5_len = {"ms": 1e3 * e5, "samples_per_channel": n5, "iterations": 200, "plan": [i5["M1"], i5["M2"], i5["M3"]],
+                      "state_gb": 8.0 * (n5 // 2) * C / 1e9,
+                      # four passes per iteration, each reading and writing the state once
+                      "hbm_tbs": 200 * 4 * 2 * 8.0 * (n5 // 2) * C / e5 / 1e12, "xrt_at_96k": (n5 / 96000.0) / e5}
+            del x5, y5
+            fe.release_plans()
+            torch.cuda.empty_cache()
+        except Exception as ex:      # noqa: BLE001 -- an extra, never the headline
+            c5_len = {"error": str(ex)[:200]}
         # ---- with N > 1: BASELINE configs[3] as north_star states it (ONE 10-minute stereo file over the N GPUs, strong scaling) ----
         if world > 1 and not c4:
             x_c4 = torch.from_numpy(synth(404, 600 * SR)).cuda()
@@ -404,6 +425,7 @@ def main():
                 "fatllama_arbitrary_length_ms": {k: v["ms"] for k, v in arb.items()} or None,
                 "fatllama_arbitrary_length": arb or None,
                 "chain60_with_arbitrary_length_fatllama_ms": (1e3 * el_fs + arb["60s_plus_2_samples"]["ms"]) if arb else None,
+                "fatllama_configs4_length": c5_len or None,
                 "configs1_flashsr_single_chunk_stereo_xrt": (3 * 5.12 / el_c2) if el_c2 else None,
                 "configs1_ms": (1e3 * el_c2 / 3) if el_c2 else None,
                 "flashsr_flops_per_row": fconv_all / max(1, (len(ag.spans(total)) + world - 1) // world * C),
