@@ -1,4 +1,6 @@
-// Loop kernels of the hot Fat-Llama plan (rows of 2304 points, columns of 625 points) with TWO workgroup barriers each instead
+// The iteration loop of upstream's feed.upscale as the reference calls it (egregora_fat_llama_gpu.py:213-224,
+// egregora_fat_llama_cpu.py:126-134; algorithm: SPEC.md section 3, oracle/fatllama.py) --
+// loop kernels of the hot Fat-Llama plan (rows of 2304 points, columns of 625 points) with TWO workgroup barriers each instead
 // of one or two per radix stage (k_row<false, 1>: 15, k_col<1, 2>: 10 -- 54-67 % of their wave cycles were spent parked at them,
 // profiles/r02/chain60_counters.txt).  Included by egr_fatllama.hip; same state layout, same arithmetic per element (tables rounded
 // once from long double, pair hook and 1/M in double), different factorisation order, so results agree with the stage-by-stage
