@@ -932,11 +932,18 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
                 }
             return fl_upload(p, t, d);
         };
-        if (!off && !p->bluestein && p->row_sched == 1) {
-            if ((rc = table(144, 16, 2304, &p->wl_rt.t1))) return fail(rc);
-            if ((rc = table(12, 12, 144, &p->wl_rt.t2))) return fail(rc);
-            p->wl_row = 1;
-        }
+        p->wl_row_entry = nullptr;
+        if (!off && !p->bluestein)
+            for (const WlRowEntry& e : kWlRows)
+                if (e.L == r.L) {
+                    const int qq = e.q * e.q;
+                    if ((rc = table(qq, e.n1, e.L, &p->wl_rt.t1))) return fail(rc);
+                    if ((rc = table(e.q, e.q, qq, &p->wl_rt.t2))) return fail(rc);
+                    const long double ang = -3.14159265358979323846264338327950288L / (long double)e.q;         // W_(2Q)
+                    p->wl_rt.hook_step = make_double2((double)cosl(ang), (double)sinl(ang));
+                    p->wl_row_entry = &e;
+                    p->wl_row = 1;
+                }
         if (!off && !p->bluestein && a.L == 625 && a.ncols % EGR_WL_COL_TC == 0) {
             if ((rc = table(25, 25, 625, &p->wl_ct.t3))) return fail(rc);
             p->wl_col = 1;
@@ -1222,7 +1229,10 @@ extern "C" int egr_fatllama_trace_once(egr_fatllama_plan* p, void* stream) {
         R.trace = tr; A.trace = tr;
         for (int rep = 0; rep < 3; ++rep) {          // the last repetition's stamps survive
             if (which == 0) {
-                if (p->wl_row) hipLaunchKernelGGL(k_row_wl<0>, grow, dim3(EGR_WL_ROW_THREADS), EGR_LDS(EGR_WL_ROW_LDS), st, R, p->wl_rt, M, p->d_work);
+                if (p->wl_row) {
+                    const WlRowEntry* e = (const WlRowEntry*)p->wl_row_entry;
+                    hipLaunchKernelGGL(e->fn, grow, dim3(e->threads), EGR_LDS(e->lds), st, R, p->wl_rt, M, p->d_work);
+                }
                 else if (p->row_sched == 1) hipLaunchKernelGGL((k_row<false, 1>), grow, blk, EGR_LDS((size_t)2 * (R.L + (EGR_FL_ROW_PAD ? R.L >> EGR_FL_ROW_PAD : 0)) * sizeof(cplx)), st, R, M, p->d_work);
                 else hipLaunchKernelGGL(k_row<false>, grow, blk, EGR_LDS(p->sp.lds_row), st, R, M, p->d_work);
             } else {
@@ -1375,8 +1385,10 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         const dim3 blkc(EGR_FL_COL_THREADS);      // the scheduled column kernels' own workgroup size
         const bool rs1 = p->row_sched == 1 && sched_ok, cs2 = p->col_sched == 2 && sched_ok && !three;
         // the two-barrier kernels serve the default hook (hard threshold against an absolute level) and the middle column pass
-        const bool wlr = p->wl_row != 0, wlc = p->wl_col != 0;
-        const bool wl_variant = relative || R.soft != 0;          // k_row_wl<1>: level from the iteration's maximum and / or soft shrink
+        const WlRowEntry* wle = (const WlRowEntry*)p->wl_row_entry;
+        const bool wl_variant = relative || R.soft != 0;          // k_row_wl<16, 12, 1>: level from the iteration's maximum and / or soft shrink
+        // (the variants are instantiated for rows of 2304 points; other row lengths run them on the stage-by-stage kernels)
+        const bool wlr = p->wl_row != 0 && wle && (!wl_variant || wle->L == 2304), wlc = p->wl_col != 0;
         ColP Awl = A;
         Awl.TC = EGR_WL_COL_TC; Awl.TClog2 = 3; Awl.ntiles = A.ncols / EGR_WL_COL_TC; Awl.tiles_per_xcd = ceil_div(Awl.ntiles, 8);
         // no ping-pong buffer; the row kernel's two rows are padded by one element per 2^EGR_FL_ROW_PAD
@@ -1410,14 +1422,14 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
                 RowP Rg = R;
                 if (relative) {        // this iteration's spectrum maximum first (forward row transforms + split, no write-back)
                     Rg.max2_out = p->d_max2 + (size_t)it * C + c0;
-                    if (wlr) hipLaunchKernelGGL(k_row_wl<2>, growg, dim3(EGR_WL_ROW_THREADS), EGR_LDS(EGR_WL_ROW_LDS), sg, Rg, p->wl_rt, M, wk);
+                    if (wlr) hipLaunchKernelGGL((k_row_wl<16, 12, 2>), growg, dim3(wle->threads), EGR_LDS(wle->lds), sg, Rg, p->wl_rt, M, wk);
                     else if (rs1) hipLaunchKernelGGL((k_row<true, 1>), growg, blk, lrs, sg, Rg, M, wk);
                     else hipLaunchKernelGGL(k_row<true>, growg, blk, lr, sg, Rg, M, wk);
                     Rg.max2 = Rg.max2_out;
                 }
                 if (prof) fl_prof_begin(p, 0, sg, &slot);
-                if (wlr && wl_variant) hipLaunchKernelGGL(k_row_wl<1>, growg, dim3(EGR_WL_ROW_THREADS), EGR_LDS(EGR_WL_ROW_LDS), sg, Rg, p->wl_rt, M, wk);
-                else if (wlr) hipLaunchKernelGGL(k_row_wl<0>, growg, dim3(EGR_WL_ROW_THREADS), EGR_LDS(EGR_WL_ROW_LDS), sg, Rg, p->wl_rt, M, wk);
+                if (wlr && wl_variant) hipLaunchKernelGGL((k_row_wl<16, 12, 1>), growg, dim3(wle->threads), EGR_LDS(wle->lds), sg, Rg, p->wl_rt, M, wk);
+                else if (wlr) hipLaunchKernelGGL(wle->fn, growg, dim3(wle->threads), EGR_LDS(wle->lds), sg, Rg, p->wl_rt, M, wk);
                 else if (rs1) hipLaunchKernelGGL((k_row<false, 1>), growg, blk, lrs, sg, Rg, M, wk);
                 else hipLaunchKernelGGL(k_row<false>, growg, blk, lr, sg, Rg, M, wk);
                 if (prof) fl_prof_end(p, sg, &slot);

@@ -121,8 +121,9 @@ struct RowP {
 
 // tables of the two-barrier loop kernels (egr_fatllama_wl.h)
 struct WlRowT {
-    const cplx* t1;        // [144][16]: W_2304^(n2 k1)
-    const cplx* t2;        // [12][12]:  W_144^(b c)
+    const cplx* t1;        // [Q^2][N1]: W_L^(n2 k1)
+    const cplx* t2;        // [Q][Q]:    W_(Q^2)^(b c)
+    dcplx hook_step;       // W_(2Q): ratio of the pair twiddles between a lane's consecutive registers
 };
 struct WlColT {
     const cplx* t3;        // [25][25]: W_625^(b c)
@@ -199,6 +200,7 @@ struct egr_fatllama_plan {
     int threads;                  // workgroup size of the loop kernels (256 or 512)
     int row_sched, col_sched;     // compile-time schedule ids of the loop kernels (0: run-time schedule)
     int wl_row, wl_col;           // the two-barrier kernels of egr_fatllama_wl.h serve the row / outer column pass of the loop
+    const void* wl_row_entry;     // WlRowEntry of the row length (k_row_wl<N1, Q>)
     int wl_inner;                 // ... and k_colb_wl the inner column pass of a three-level plan
     egr::ColP wl_colB;            // colB with the tile geometry of k_colb_wl
     const egr::cplx* wl_it;       // [LB][LA]: W_L^(b c) of the inner length

@@ -33,20 +33,6 @@
 
 namespace egr {
 
-#ifndef EGR_WL_ROW_THREADS
-#define EGR_WL_ROW_THREADS 256          // four waves: the local step's 16 units; the 288 cross butterflies (2 rows x 144) take a second
-                                        // round on 32 threads (320 threads = one round measures the same: 28.6 vs 28.8 ms per stage)
-#endif
-#ifndef EGR_WL_ROW_S
-#define EGR_WL_ROW_S 172                // LDS block stride in elements (144 used; = 12 mod 32: the four units of a wave start 24 banks apart)
-#endif
-#ifndef EGR_WL_ROW_TS
-#define EGR_WL_ROW_TS 14                // row stride of the 12 x 12 transpose inside a block (even: 16-byte accesses; odd: 8-byte)
-#endif
-#define EGR_WL_ROW_LDS (2 * 16 * EGR_WL_ROW_S * 8)
-#ifndef EGR_WL_ROW_WAVES
-#define EGR_WL_ROW_WAVES 1              // __launch_bounds__ minimum waves per SIMD of k_row_wl (register budget)
-#endif
 #ifndef EGR_WL_COL_WAVES
 #define EGR_WL_COL_WAVES 1
 #endif
@@ -86,11 +72,26 @@ __device__ __forceinline__ float wl_pair_hook(const cplx Za, const cplx Zb, cons
     return 0.f;
 }
 
-template <int HOOK>
-__global__ __launch_bounds__(EGR_WL_ROW_THREADS, EGR_WL_ROW_WAVES) void k_row_wl(RowP p, WlRowT tb, long long M, cplx* __restrict__ work) {
+// Geometry of k_row_wl<N1, Q>: rows of L = N1 Q^2 points (N1 even: cross radix, Q x Q blocks on Q lanes of one wave).
+template <int N1, int Q> struct WlRow {
+    static constexpr int QQ = Q * Q, L = N1 * QQ;
+    static constexpr int TS = Q + 2;                                   // row stride of the Q x Q transpose (even: 16-byte accesses)
+    static constexpr int S = Q * TS + 4;                               // LDS block stride in elements (>= QQ and >= Q TS)
+    static constexpr int RS = N1 * S;
+    static constexpr int LWAVES = (N1 + 64 / Q - 1) / (64 / Q);       // waves of the local step
+    static constexpr int UPW = (N1 + LWAVES - 1) / LWAVES;             // units (block pairs) per wave, balanced
+    static constexpr int THREADS = 64 * (LWAVES < 2 ? 2 : LWAVES);
+    static constexpr int XIT = (2 * QQ + THREADS - 1) / THREADS;       // rounds of the 2 Q^2 cross butterflies
+    static constexpr int LDS = 2 * RS * 8;
+};
+
+template <int N1, int Q, int HOOK>
+__global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRowT tb, long long M, cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     EGR_LDS_CANARY_ARM(smem);
-    constexpr int L = 2304, S = EGR_WL_ROW_S, TS = EGR_WL_ROW_TS, RS = 16 * S;
+    using G = WlRow<N1, Q>;
+    constexpr int L = G::L, QQ = G::QQ, S = G::S, TS = G::TS, RS = G::RS, THREADS = G::THREADS, XIT = G::XIT, UPW = G::UPW;
+    static_assert(N1 % 2 == 0 && S >= QQ && S % 2 == 0, "k_row_wl geometry");
     const int R = p.R;
     const int oa = blockIdx.x;
     const int ob = (R - oa) % R;
@@ -104,37 +105,36 @@ __global__ __launch_bounds__(EGR_WL_ROW_THREADS, EGR_WL_ROW_WAVES) void k_row_wl
     cplx* gb = W + (size_t)rbw * L;
     const int tid = threadIdx.x;
     // ---- roles
-    constexpr int XIT = (288 + EGR_WL_ROW_THREADS - 1) / EGR_WL_ROW_THREADS;
-    const int xlim = self ? 144 : 288;
-    const int wv = tid >> 6, lane = tid & 63, un = lane / 12, l = lane - 12 * un;
-    const int k1 = 4 * wv + un;                                            // local step: block k1 of row a, block 15 - k1 of row b
-    const bool lact = wv < 4 && lane < 48 && !(self && k1 >= 8);           // a self-paired row: blocks k1 and 15 - k1 of the SAME row
-    cplx* ba = lds + k1 * S;
-    cplx* bb = lds + (self ? 0 : RS) + (15 - k1) * S;
-    // the pair twiddles W_N^(o + R k), k = k1 + 16 l + 192 d: a geometric run in double over d (ratio W_(2L)^192 = W_24)
+    const int xlim = self ? QQ : 2 * QQ;
+    const int wv = tid >> 6, lane = tid & 63, un = lane / Q, l = lane - Q * un;
+    const int k1 = UPW * wv + un;                                          // local step: block k1 of row a, block N1 - 1 - k1 of row b
+    const bool lact = un < UPW && k1 < N1 && !(self && k1 >= N1 / 2);      // a self-paired row: blocks k1 and N1 - 1 - k1 of the SAME row
+    cplx* ba = lds + (k1 < N1 ? k1 : 0) * S;
+    cplx* bb = lds + (self ? 0 : RS) + (k1 < N1 ? N1 - 1 - k1 : 0) * S;
+    // the pair twiddles W_N^(o + R k), k = k1 + N1 l + N1 Q d: a geometric run in double over d (ratio W_(2L)^(N1 Q) = W_(2Q))
     dcplx wrun = make_double2(1.0, 0.0);
-    if (lact) wrun = dcmul(tw2d(p.wo, (unsigned)oa), p.wk[k1 + 16 * l]);
+    if (lact) wrun = dcmul(tw2d(p.wo, (unsigned)oa), p.wk[k1 + N1 * l]);
     EGR_STAMP(p, 0);
 
-    // ---- cross step, forward: global -> radix 16 -> twiddle -> LDS blocks
+    // ---- cross step, forward: global -> radix N1 -> twiddle -> LDS blocks
 #pragma unroll
-    for (int xi = 0; xi < XIT; ++xi) {          // cross step: row xr, n2 = xn2 (288 butterflies over the workgroup's threads)
-        const int xt = tid + xi * EGR_WL_ROW_THREADS;
+    for (int xi = 0; xi < XIT; ++xi) {          // cross step: row xr, n2 = xn2 (2 Q^2 butterflies over the workgroup's threads)
+        const int xt = tid + xi * THREADS;
         if (xt >= xlim) break;
-        const int xr = xt >= 144 ? 1 : 0, xn2 = xt - 144 * xr;
+        const int xr = xt >= QQ ? 1 : 0, xn2 = xt - QQ * xr;
         const cplx* g = xr ? gb : ga;
-        cplx v[16];
+        cplx v[N1];
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) v[n1] = g[n1 * 144 + xn2];
-        const float4* tp = (const float4*)(tb.t1 + xn2 * 16);
-        float4 w[8];
+        for (int n1 = 0; n1 < N1; ++n1) v[n1] = g[n1 * QQ + xn2];
+        const float4* tp = (const float4*)(tb.t1 + xn2 * N1);
+        float4 w[N1 / 2];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) w[q] = tp[q];
-        Bfly<16>::run(v);
+        for (int q = 0; q < N1 / 2; ++q) w[q] = tp[q];
+        Bfly<N1>::run(v);
         cplx* d = lds + xr * RS + xn2;
         d[0] = v[0];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < N1 / 2; ++q) {
             if (q > 0) d[(2 * q) * S] = cmul(v[2 * q], make_float2(w[q].x, w[q].y));
             d[(2 * q + 1) * S] = cmul(v[2 * q + 1], make_float2(w[q].z, w[q].w));
         }
@@ -142,40 +142,35 @@ __global__ __launch_bounds__(EGR_WL_ROW_THREADS, EGR_WL_ROW_WAVES) void k_row_wl
     __syncthreads();
     EGR_STAMP(p, 1);
 
-    cplx A[12], B[12];
+    cplx A[Q], B[Q];
     if (lact) {
-        // ---- local step, forward: 144 = 12 x 12 per block, wave-local transposes
-        const cplx* t2 = tb.t2 + l * 12;
+        // ---- local step, forward: Q^2 = Q x Q per block, wave-local transposes
+        const cplx* t2 = tb.t2 + l * Q;
 #pragma unroll
-        for (int a = 0; a < 12; ++a) { A[a] = ba[12 * a + l]; B[a] = bb[12 * a + l]; }
+        for (int a = 0; a < Q; ++a) { A[a] = ba[Q * a + l]; B[a] = bb[Q * a + l]; }
         wl_wave_sync();
-        Bfly<12>::run(A);
-        Bfly<12>::run(B);
+        Bfly<Q>::run(A);
+        Bfly<Q>::run(B);
 #pragma unroll
-        for (int c = 0; c < 12; ++c) {
+        for (int c = 0; c < Q; ++c) {
             const cplx w = t2[c];
             ba[c * TS + l] = c ? cmul(A[c], w) : A[c];
-            bb[(11 - c) * TS + l] = c ? cmul(B[c], w) : B[c];          // row b: lane l will hold c' = 11 - l
+            bb[(Q - 1 - c) * TS + l] = c ? cmul(B[c], w) : B[c];          // row b: lane l will hold c' = Q - 1 - l
         }
         wl_wave_sync();
 #pragma unroll
-        for (int b2 = 0; b2 < 12; b2 += 2) {
-            if (TS % 2 == 0) {
-                const float4 x = *(const float4*)(ba + l * TS + b2), y = *(const float4*)(bb + l * TS + b2);
-                A[b2] = make_float2(x.x, x.y); A[b2 + 1] = make_float2(x.z, x.w);
-                B[b2] = make_float2(y.x, y.y); B[b2 + 1] = make_float2(y.z, y.w);
-            } else {
-                A[b2] = ba[l * TS + b2]; A[b2 + 1] = ba[l * TS + b2 + 1];
-                B[b2] = bb[l * TS + b2]; B[b2 + 1] = bb[l * TS + b2 + 1];
-            }
+        for (int b2 = 0; b2 < Q; b2 += 2) {
+            const float4 x = *(const float4*)(ba + l * TS + b2), y = *(const float4*)(bb + l * TS + b2);
+            A[b2] = make_float2(x.x, x.y); A[b2 + 1] = make_float2(x.z, x.w);
+            B[b2] = make_float2(y.x, y.y); B[b2 + 1] = make_float2(y.z, y.w);
         }
         wl_wave_sync();
-        Bfly<12>::run(A);          // A[d] = Xa[k1 + 16 (l + 12 d)]
-        Bfly<12>::run(B);          // B[d] = Xb[(15 - k1) + 16 ((11 - l) + 12 d)]
+        Bfly<Q>::run(A);           // A[d] = Xa[k1 + N1 (l + Q d)]
+        Bfly<Q>::run(B);           // B[d] = Xb[(N1 - 1 - k1) + N1 ((Q - 1 - l) + Q d)]
     }
     EGR_STAMP(p, 2);
     float thr2 = p.thr2, tlev = p.thr;
-    if (HOOK == 1 && p.max2) {                   // level relative to this iteration's spectrum maximum (written by k_row_wl<2>)
+    if (HOOK == 1 && p.max2) {                   // level relative to this iteration's spectrum maximum (written by k_row_wl<.., 2>)
         tlev = p.thr * sqrtf(__uint_as_float(p.max2[ch]));
         thr2 = tlev * tlev;
     }
@@ -184,12 +179,12 @@ __global__ __launch_bounds__(EGR_WL_ROW_THREADS, EGR_WL_ROW_WAVES) void k_row_wl
     float mx2 = 0.f;
     if (!self) {
         if (lact) {
-            const dcplx st = make_double2(0.96592582628906828674974319972890, -0.25881904510252076234889883762405);   // W_24
+            const dcplx st = tb.hook_step;                                  // W_(2Q)
 #pragma unroll
-            for (int d = 0; d < 12; ++d) {
+            for (int d = 0; d < Q; ++d) {
                 cplx na, nb;
-                mx2 = fmaxf(mx2, wl_pair_hook<HOOK>(A[d], B[11 - d], wrun, thr2, tlev, soft, scd, na, nb));
-                if (HOOK != 2) { A[d] = na; B[11 - d] = nb; }
+                mx2 = fmaxf(mx2, wl_pair_hook<HOOK>(A[d], B[Q - 1 - d], wrun, thr2, tlev, soft, scd, na, nb));
+                if (HOOK != 2) { A[d] = na; B[Q - 1 - d] = nb; }
                 wrun = dcmul(wrun, st);
             }
         }
@@ -197,17 +192,17 @@ __global__ __launch_bounds__(EGR_WL_ROW_THREADS, EGR_WL_ROW_WAVES) void k_row_wl
         // a self-paired row: spectrum to LDS in (block, k2) order, the generic pair loop of k_row, back to registers
         if (lact) {
 #pragma unroll
-            for (int d = 0; d < 12; ++d) { ba[l + 12 * d] = A[d]; bb[(11 - l) + 12 * d] = B[d]; }
+            for (int d = 0; d < Q; ++d) { ba[l + Q * d] = A[d]; bb[(Q - 1 - l) + Q * d] = B[d]; }
         }
         __syncthreads();
         const dcplx wa = tw2d(p.wo, (unsigned)oa);
         int cnt, boff;
         if (oa == 0) { cnt = L / 2 + 1; boff = L; } else { cnt = (L + 1) / 2; boff = L - 1; }
-        for (int k2 = tid; k2 < cnt; k2 += EGR_WL_ROW_THREADS) {
+        for (int k2 = tid; k2 < cnt; k2 += THREADS) {
             int pb = boff - k2;
             if (pb >= L) pb -= L;
-            cplx* ea = lds + (k2 & 15) * S + (k2 >> 4);
-            cplx* eb = lds + (pb & 15) * S + (pb >> 4);
+            cplx* ea = lds + (k2 % N1) * S + (k2 / N1);
+            cplx* eb = lds + (pb % N1) * S + (pb / N1);
             cplx na, nb;
             mx2 = fmaxf(mx2, wl_pair_hook<HOOK>(*ea, *eb, dcmul(wa, p.wk[k2]), thr2, tlev, soft, scd, na, nb));
             if (HOOK != 2) {
@@ -218,7 +213,7 @@ __global__ __launch_bounds__(EGR_WL_ROW_THREADS, EGR_WL_ROW_WAVES) void k_row_wl
         __syncthreads();
         if (HOOK != 2 && lact) {
 #pragma unroll
-            for (int d = 0; d < 12; ++d) { A[d] = ba[l + 12 * d]; B[d] = bb[(11 - l) + 12 * d]; }
+            for (int d = 0; d < Q; ++d) { A[d] = ba[l + Q * d]; B[d] = bb[(Q - 1 - l) + Q * d]; }
             wl_wave_sync();
         }
     }
@@ -231,56 +226,60 @@ __global__ __launch_bounds__(EGR_WL_ROW_THREADS, EGR_WL_ROW_WAVES) void k_row_wl
     }
     if (lact) {
         // ---- local step, inverse
-        const cplx* t2 = tb.t2 + l * 12;             // row a: c = l; W_144^(b c) is symmetric in (b, c)
-        const cplx* t2b = tb.t2 + (11 - l) * 12;     // row b: c' = 11 - l
-        wl_bfly_inv<12>(A);
-        wl_bfly_inv<12>(B);
+        const cplx* t2 = tb.t2 + l * Q;                  // row a: c = l; W_(Q^2)^(b c) is symmetric in (b, c)
+        const cplx* t2b = tb.t2 + (Q - 1 - l) * Q;       // row b: c' = Q - 1 - l
+        wl_bfly_inv<Q>(A);
+        wl_bfly_inv<Q>(B);
 #pragma unroll
-        for (int b2 = 0; b2 < 12; b2 += 2) {
+        for (int b2 = 0; b2 < Q; b2 += 2) {
             const cplx a0 = b2 ? cmulc(A[b2], t2[b2]) : A[b2], a1 = cmulc(A[b2 + 1], t2[b2 + 1]);
             const cplx c0 = b2 ? cmulc(B[b2], t2b[b2]) : B[b2], c1 = cmulc(B[b2 + 1], t2b[b2 + 1]);
-            if (TS % 2 == 0) {
-                *(float4*)(ba + l * TS + b2) = make_float4(a0.x, a0.y, a1.x, a1.y);
-                *(float4*)(bb + l * TS + b2) = make_float4(c0.x, c0.y, c1.x, c1.y);
-            } else {
-                ba[l * TS + b2] = a0; ba[l * TS + b2 + 1] = a1;
-                bb[l * TS + b2] = c0; bb[l * TS + b2 + 1] = c1;
-            }
+            *(float4*)(ba + l * TS + b2) = make_float4(a0.x, a0.y, a1.x, a1.y);
+            *(float4*)(bb + l * TS + b2) = make_float4(c0.x, c0.y, c1.x, c1.y);
         }
         wl_wave_sync();
 #pragma unroll
-        for (int c = 0; c < 12; ++c) { A[c] = ba[c * TS + l]; B[c] = bb[(11 - c) * TS + l]; }
+        for (int c = 0; c < Q; ++c) { A[c] = ba[c * TS + l]; B[c] = bb[(Q - 1 - c) * TS + l]; }
         wl_wave_sync();
-        wl_bfly_inv<12>(A);
-        wl_bfly_inv<12>(B);
+        wl_bfly_inv<Q>(A);
+        wl_bfly_inv<Q>(B);
 #pragma unroll
-        for (int a = 0; a < 12; ++a) { ba[12 * a + l] = A[a]; bb[12 * a + l] = B[a]; }
+        for (int a = 0; a < Q; ++a) { ba[Q * a + l] = A[a]; bb[Q * a + l] = B[a]; }
     }
     __syncthreads();
     EGR_STAMP(p, 4);
-    // ---- cross step, inverse: LDS blocks -> twiddle^-1 -> inverse radix 16 -> global
+    // ---- cross step, inverse: LDS blocks -> twiddle^-1 -> inverse radix N1 -> global
 #pragma unroll
     for (int xi = 0; xi < XIT; ++xi) {
-        const int xt = tid + xi * EGR_WL_ROW_THREADS;
+        const int xt = tid + xi * THREADS;
         if (xt >= xlim) break;
-        const int xr = xt >= 144 ? 1 : 0, xn2 = xt - 144 * xr;
+        const int xr = xt >= QQ ? 1 : 0, xn2 = xt - QQ * xr;
         cplx* g = xr ? gb : ga;
-        const float4* tp = (const float4*)(tb.t1 + xn2 * 16);
+        const float4* tp = (const float4*)(tb.t1 + xn2 * N1);
         const cplx* s = lds + xr * RS + xn2;
-        cplx v[16];
+        cplx v[N1];
         v[0] = s[0];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < N1 / 2; ++q) {
             const float4 w = tp[q];
             if (q > 0) v[2 * q] = cmulc(s[(2 * q) * S], make_float2(w.x, w.y));
             v[2 * q + 1] = cmulc(s[(2 * q + 1) * S], make_float2(w.z, w.w));
         }
-        wl_bfly_inv<16>(v);
+        wl_bfly_inv<N1>(v);
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) g[n1 * 144 + xn2] = v[n1];
+        for (int n1 = 0; n1 < N1; ++n1) g[n1 * QQ + xn2] = v[n1];
     }
     EGR_STAMP(p, 5);
 }
+
+// row lengths with a k_row_wl instantiation: X(L, N1, Q)
+#define EGR_WL_ROW_LIST(X) \
+    X(384, 6, 8) X(576, 4, 12) X(768, 12, 8) X(1152, 8, 12) X(1536, 24, 8) X(1728, 12, 12) X(1920, 30, 8) X(2304, 16, 12) \
+    X(2880, 20, 12) X(3072, 12, 16) X(3456, 24, 12) X(4032, 28, 12) X(4096, 16, 16) X(4608, 32, 12)
+typedef void (*WlRowFn)(RowP, WlRowT, long long, cplx*);
+struct WlRowEntry { int L, n1, q, threads, lds; WlRowFn fn; };
+#define EGR_WL_ROW_ENTRY(LL, A, B) {LL, A, B, WlRow<A, B>::THREADS, WlRow<A, B>::LDS, k_row_wl<A, B, 0>},
+static const WlRowEntry kWlRows[] = {EGR_WL_ROW_LIST(EGR_WL_ROW_ENTRY)};
 
 // MODE 1 only (the middle pass of the loop): state -> twiddle^-1 -> IFFT_625 -> FFT_625 -> twiddle -> state, tiles of 8 columns.
 __global__ __launch_bounds__(EGR_WL_COL_THREADS, EGR_WL_COL_WAVES) void k_col_wl(ColP p, WlColT tb, long long M, cplx* __restrict__ work) {

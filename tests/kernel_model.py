@@ -248,37 +248,40 @@ def _W(T, e):
     return np.exp(-2j * np.pi * (np.asarray(e) % T) / T)
 
 
-def wl_row_forward(x):
-    """k_row_wl, forward half: row of 2304 = 16 x 144 -> regs[k1][lane c][d] = X[k1 + 16 (c + 12 d)] (cross step: one thread per n2,
-    radix 16 over n1 + twiddle W_2304^(n2 k1); local step: 12 lanes per block, radix 12 over a, twiddle W_144^(b c), 12 x 12
-    transpose, radix 12 over b)."""
-    L = 2304
-    F16 = _W(16, np.outer(np.arange(16), np.arange(16)))
-    F12 = _W(12, np.outer(np.arange(12), np.arange(12)))
-    Y = (F16 @ x.reshape(16, 144)) * _W(L, np.outer(np.arange(16), np.arange(144)))          # [k1][n2]
-    regs = np.zeros((16, 12, 12), complex)
-    for k1 in range(16):
-        blk = Y[k1].reshape(12, 12)                        # [a][b]
-        Z = (F12 @ blk) * _W(144, np.outer(np.arange(12), np.arange(12)))      # [c][b]
-        regs[k1] = Z @ F12                                  # [c][d] = sum_b Z[c][b] W_12^(b d)
+def wl_row_forward(x, n1=16, q=12):
+    """k_row_wl<N1, Q>, forward half: row of L = N1 Q^2 -> regs[k1][lane c][d] = X[k1 + N1 (c + Q d)] (cross step: one thread per n2,
+    radix N1 over n1 + twiddle W_L^(n2 k1); local step: Q lanes per block, radix Q over a, twiddle W_(Q^2)^(b c), Q x Q transpose,
+    radix Q over b)."""
+    qq = q * q
+    L = n1 * qq
+    F1 = _W(n1, np.outer(np.arange(n1), np.arange(n1)))
+    Fq = _W(q, np.outer(np.arange(q), np.arange(q)))
+    Y = (F1 @ x.reshape(n1, qq)) * _W(L, np.outer(np.arange(n1), np.arange(qq)))          # [k1][n2]
+    regs = np.zeros((n1, q, q), complex)
+    for k1 in range(n1):
+        blk = Y[k1].reshape(q, q)                          # [a][b]
+        Z = (Fq @ blk) * _W(qq, np.outer(np.arange(q), np.arange(q)))      # [c][b]
+        regs[k1] = Z @ Fq                                   # [c][d] = sum_b Z[c][b] W_Q^(b d)
     return regs
 
 
 def wl_row_inverse(regs):
     """the same steps backwards with conjugate twiddles (unnormalised)."""
-    L = 2304
-    F16 = np.conj(_W(16, np.outer(np.arange(16), np.arange(16))))
-    F12 = np.conj(_W(12, np.outer(np.arange(12), np.arange(12))))
-    Y = np.zeros((16, 144), complex)
-    for k1 in range(16):
-        Z = (regs[k1] @ F12) * np.conj(_W(144, np.outer(np.arange(12), np.arange(12))))      # [c][b]
-        Y[k1] = (F12 @ Z).reshape(144)                       # [a][b] -> n2 = 12 a + b
-    return (F16 @ (Y * np.conj(_W(L, np.outer(np.arange(16), np.arange(144)))))).reshape(L)
+    n1, q, _ = regs.shape
+    qq = q * q
+    L = n1 * qq
+    F1 = np.conj(_W(n1, np.outer(np.arange(n1), np.arange(n1))))
+    Fq = np.conj(_W(q, np.outer(np.arange(q), np.arange(q))))
+    Y = np.zeros((n1, qq), complex)
+    for k1 in range(n1):
+        Z = (regs[k1] @ Fq) * np.conj(_W(qq, np.outer(np.arange(q), np.arange(q))))      # [c][b]
+        Y[k1] = (Fq @ Z).reshape(qq)                         # [a][b] -> n2 = Q a + b
+    return (F1 @ (Y * np.conj(_W(L, np.outer(np.arange(n1), np.arange(qq)))))).reshape(L)
 
 
-def wl_row_partner(k1, c, d):
-    """(block, lane, register) of the real-split partner L - 1 - k of k = k1 + 16 (c + 12 d): what the reversed-lane row-b unit holds."""
-    return 15 - k1, 11 - c, 11 - d
+def wl_row_partner(k1, c, d, n1=16, q=12):
+    """(block, lane, register) of the real-split partner L - 1 - k of k = k1 + N1 (c + Q d): what the reversed-lane row-b unit holds."""
+    return n1 - 1 - k1, q - 1 - c, q - 1 - d
 
 
 def wl_col_mid(u):

@@ -191,3 +191,60 @@ def test_hook_variants_on_the_two_barrier_row_kernel(pack, variant, thr):
     assert float(np.sum(np.square(a - want, dtype=np.float64))) <= 1e-6 * float(np.sum(np.square(want, dtype=np.float64)))
     y = x.copy(); y[:, -1] = 0
     assert rms(a - 2 * y) > 1e-4 * rms(y)                                        # the threshold removed something
+
+
+@pytest.mark.parametrize("n", [480000, 960000, 3600000])
+def test_two_barrier_column_kernel_next_to_the_stage_by_stage_row_kernel(pack, n):
+    """The planner takes columns of 625 points whenever N / 2 has the factor (10 s, 20 s, 75 s at 48 kHz: 625 x 384 / 768 / 2880):
+    k_col_wl serves the column pass, the run-time-schedule k_row the rows.  Against EGR_FL_WL=0 and the oracle."""
+    from egregora_amd import fatllama_engine as fe
+    info = fe.plan_info(n, 1)
+    assert (info["M1"], info["levels"]) == (625, 2), info
+    x = synth(2, n, seed=n % 1013)
+    a = run(x, 3, wl=True)
+    b = run(x, 3, wl=False)
+    scale = float(np.max(np.abs(b)))
+    assert float(np.max(np.abs(a - b))) <= 4e-6 * scale and rms(a - b) <= 4e-7 * scale
+    if n <= 960000:
+        want = ofl.enhance_channels(x, 1, 3, 0.6, normalize=False, autoscale=False)
+        exact = ofl.enhance_channels(x, 1, 3, 0.6, normalize=False, autoscale=False, exact=True)
+        assert float(np.max(np.abs(a - want))) <= 2e-5 * scale
+        assert rms(a - exact) <= 2.5 * rms(want - exact) + 1e-9 * scale
+
+
+ROW_LENGTHS = [384, 576, 768, 1152, 1536, 1728, 1920, 2880, 3072, 3456, 4032, 4096, 4608]
+
+
+@pytest.mark.parametrize("rows", ROW_LENGTHS)
+def test_two_barrier_row_kernel_for_every_instantiated_row_length(pack, rows):
+    """k_row_wl<N1, Q> (rows of N1 Q^2 points) next to k_col_wl: M = 625 x rows -- 10 s ... 106 s at 48 kHz.  Against the
+    stage-by-stage kernels and, for the shorter ones, the oracle and float64."""
+    from egregora_amd import fatllama_engine as fe
+    n = 2 * 625 * rows
+    info = fe.plan_info(n, 1)
+    assert (info["M1"], info["M2"], info["levels"]) == (625, rows, 2), info
+    x = synth(2, n, seed=rows)
+    a = run(x, 3, wl=True)
+    b = run(x, 3, wl=False)
+    scale = float(np.max(np.abs(b)))
+    err = float(np.max(np.abs(a - b)))
+    print(f"\nrows of {rows}: max diff {err / scale:.2e} of the peak, rms {rms(a - b) / scale:.2e}")
+    assert np.isfinite(a).all() and err <= 4e-6 * scale and rms(a - b) <= 4e-7 * scale
+    if n <= 1500000:
+        want = ofl.enhance_channels(x, 1, 3, 0.6, normalize=False, autoscale=False)
+        exact = ofl.enhance_channels(x, 1, 3, 0.6, normalize=False, autoscale=False, exact=True)
+        assert float(np.max(np.abs(a - want))) <= 2e-5 * scale
+        assert rms(a - exact) <= 2.5 * rms(want - exact) + 1e-9 * scale
+
+
+def test_two_barrier_row_kernel_with_an_even_row_count(pack):
+    """M = 320 x 768: an even number of rows has TWO self-paired rows (o = 0 and o = R / 2), both on the LDS hook path of k_row_wl;
+    the columns run the run-time-schedule kernel."""
+    n = 2 * 320 * 768
+    x = synth(2, n, seed=320)
+    a = run(x, 3, wl=True, split=(320, 768, 1))
+    b = run(x, 3, wl=False, split=(320, 768, 1))
+    want = ofl.enhance_channels(x, 1, 3, 0.6, normalize=False, autoscale=False)
+    scale = float(np.max(np.abs(want)))
+    assert float(np.max(np.abs(a - b))) <= 4e-6 * scale
+    assert float(np.max(np.abs(a - want))) <= 2e-5 * scale

@@ -48,21 +48,25 @@ def test_ist_three_level_matches_fft_loop(M1, M2, M3, iters):
     np.testing.assert_allclose(got, d, atol=1e-9 * N)
 
 
-def test_two_barrier_row_kernel_lane_map():
-    """csrc/egr_fatllama_wl.h k_row_wl: the (block, lane, register) a thread holds is X[k1 + 16 (c + 12 d)], the partner L-1-k of the
-    real split sits at (15 - k1, 11 - c, 11 - d) -- the reversed-lane unit of row b -- and the backward steps invert the forward."""
+@pytest.mark.parametrize("n1,q", [(16, 12), (6, 8), (4, 12), (12, 8), (30, 8), (20, 12), (12, 16), (28, 12), (16, 16)])
+def test_two_barrier_row_kernel_lane_map(n1, q):
+    """csrc/egr_fatllama_wl.h k_row_wl<N1, Q>: the (block, lane, register) a thread holds is X[k1 + N1 (c + Q d)], the partner L-1-k
+    of the real split sits at (N1-1 - k1, Q-1 - c, Q-1 - d) -- the reversed-lane unit of row b -- and the backward steps invert the
+    forward; the pair twiddles of a lane's consecutive registers differ by W_(2L)^(N1 Q) = W_(2Q)."""
+    L = n1 * q * q
     rng = np.random.default_rng(3)
-    x = rng.standard_normal(2304) + 1j * rng.standard_normal(2304)
-    regs = km.wl_row_forward(x)
+    x = rng.standard_normal(L) + 1j * rng.standard_normal(L)
+    regs = km.wl_row_forward(x, n1, q)
     X = np.fft.fft(x)
-    for k1 in range(16):
-        for c in range(12):
-            for d in range(12):
-                k = k1 + 16 * (c + 12 * d)
-                assert abs(regs[k1, c, d] - X[k]) < 1e-9
-                p1, pc, pd = km.wl_row_partner(k1, c, d)
-                assert p1 + 16 * (pc + 12 * pd) == 2304 - 1 - k
-    np.testing.assert_allclose(km.wl_row_inverse(regs) / 2304, x, atol=1e-12)
+    for k1 in range(n1):
+        for c in range(q):
+            for d in range(q):
+                k = k1 + n1 * (c + q * d)
+                assert abs(regs[k1, c, d] - X[k]) < 1e-8
+                p1, pc, pd = km.wl_row_partner(k1, c, d, n1, q)
+                assert p1 + n1 * (pc + q * pd) == L - 1 - k
+    np.testing.assert_allclose(km.wl_row_inverse(regs) / L, x, atol=1e-11)
+    assert abs(np.exp(-2j * np.pi * n1 * q / (2 * L)) - np.exp(-1j * np.pi / q)) < 1e-15
 
 
 def test_two_barrier_column_kernel_needs_no_exchange_between_inverse_and_forward():
@@ -89,7 +93,7 @@ def test_planner_prefers_the_two_barrier_kernels_for_whole_minutes_at_48k():
     from packload import load_pack
     load_pack()
     from egregora_amd import fatllama_engine as fe
-    for n, want in ((2880000, (625, 2304, 1)), (5760000, (1125, 2560, 1)), (8640000, (625, 3, 2304)), (28800000, (625, 10, 2304)),
+    for n, want in ((2880000, (625, 2304, 1)), (5760000, (625, 4608, 1)), (960000, (625, 768, 1)), (3600000, (625, 2880, 1)), (8640000, (625, 3, 2304)), (28800000, (625, 10, 2304)),
                     (172800000, (625, 60, 2304)), (86400000, (625, 30, 2304))):
         i = fe.plan_info(n, 1)
         assert i["supported"] and (i["M1"], i["M2"], i["M3"]) == want, (n, i)
