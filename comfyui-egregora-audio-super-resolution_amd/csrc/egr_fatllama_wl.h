@@ -6,7 +6,8 @@
 // once from long double, pair hook and 1/M in double), different factorisation order, so results agree with the stage-by-stage
 // kernels to float32 round-off, not bit for bit.
 //
-// k_row_wl -- a row of L = 2304 = 16 x 144 points as a four-step transform INSIDE the workgroup:
+// k_row_wl<N1, Q> -- a row of L = N1 Q^2 points (14 lengths 384 ... 4608; below: N1 = 16, Q = 12, L = 2304) as a four-step transform
+// INSIDE the workgroup:
 //   n = 144 n1 + n2, k = k1 + 16 k2:  X[k1 + 16 k2] = sum_n2 W_144^(n2 k2) [ W_L^(n2 k1) sum_n1 x[144 n1 + n2] W_16^(n1 k1) ]
 //   "cross" step  (one thread per n2): 16 coalesced global loads -> radix-16 butterfly in registers -> x W_L^(n2 k1) -> LDS block k1
 //                 (the state never sits in LDS in natural order: the load IS the first stage, the store IS the last one)
