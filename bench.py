@@ -383,15 +383,15 @@ def main():
         row_bytes = 8.0 * SEG * C / groups
         dom_ms = max(kt["row_ms"], kt["col_ms"])
         wl = os.environ.get("EGR_FL_WL", "1") != "0"          # the two-barrier loop kernels (csrc/egr_fatllama_wl.h) serve the C3 plan by default
-        dom = ("k_row_wl" if wl else "k_row<false, 1>") if kt["row_ms"] >= kt["col_ms"] else ("k_col_wl" if wl else "k_col<1, 2>")
+        dom = ("k_row_wl<16, 12, 0>" if wl else "k_row<false, 1>") if kt["row_ms"] >= kt["col_ms"] else ("k_col_wl" if wl else "k_col<1, 2>")
         hbm_ach = row_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = conv_traffic = pz_traffic = None
         try:                # HBM bytes per launch from the committed PMC passes (tools/make_traffic_json.py)
             tk = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get("kernels", {})
-            cands = ["k_row_wl", "k_row<false, 1>", "k_row<false, 0>", "k_row<false>"] if dom.startswith("k_row") else ["k_col_wl", "k_col<1, 2>", "k_col<1, 0>", "k_col<1>"]
+            cands = ["k_row_wl<16, 12, 0>", "k_row_wl", "k_row<false, 1>", "k_row<false, 0>", "k_row<false>"] if dom.startswith("k_row") else ["k_col_wl", "k_col<1, 2>", "k_col<1, 0>", "k_col<1>"]
             if not wl:
                 cands = cands[1:]
-            traffic = next((tk[c]["bytes"] for c in cands if c in tk), None)
+            traffic = next((v["bytes"] for c in cands for k, v in tk.items() if k == c or k.startswith(c + "<")), None)
             conv_traffic = tk.get(dom_conv, {}).get("bytes")
             pz_traffic = next((v["bytes"] for k, v in tk.items() if k.startswith("k_pzpair<false")), None)
         except Exception:
