@@ -18,6 +18,9 @@ CONFIGS = [
     ("packed-scheduled-c3-length", 2, 2880000, 1, 3, 0.6, {}),
     ("packed-three-level", 2, 48000, 1, 4, 0.6, {"split": (20, 24, 50)}),
     ("packed-three-level-two-barrier-kernels", 2, 5760000, 1, 2, 0.6, {"split": (625, 2, 2304)}),
+    ("packed-two-barrier-rows-768", 2, 960000, 1, 3, 0.6, {}),                 # 625 x 768: k_row_wl<12, 8> + k_col_wl
+    ("packed-two-barrier-rows-1920", 2, 2400000, 1, 3, 0.6, {}),               # 625 x 1920: k_row_wl<30, 8>
+    ("packed-two-barrier-rows-4608", 1, 5760000, 1, 2, 0.6, {}),               # 625 x 4608: k_row_wl<32, 12>, 88 KB of LDS
     ("packed-relative-soft", 2, 9600, 1, 5, 0.02, {"variant": "relative,soft"}),
     ("chirpz-pairs-odd-centre", 2, 2 * 7919, 1, 4, 0.6, {}),
     ("chirpz-pairs-integer-centre", 2, 4 * 1013, 1, 4, 0.6, {}),
