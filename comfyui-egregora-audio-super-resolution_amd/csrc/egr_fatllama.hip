@@ -1386,9 +1386,8 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         const bool rs1 = p->row_sched == 1 && sched_ok, cs2 = p->col_sched == 2 && sched_ok && !three;
         // the two-barrier kernels serve the default hook (hard threshold against an absolute level) and the middle column pass
         const WlRowEntry* wle = (const WlRowEntry*)p->wl_row_entry;
-        const bool wl_variant = relative || R.soft != 0;          // k_row_wl<16, 12, 1>: level from the iteration's maximum and / or soft shrink
-        // (the variants are instantiated for rows of 2304 points; other row lengths run them on the stage-by-stage kernels)
-        const bool wlr = p->wl_row != 0 && wle && (!wl_variant || wle->L == 2304), wlc = p->wl_col != 0;
+        const bool wl_variant = relative || R.soft != 0;          // k_row_wl<.., 1>: level from the iteration's maximum and / or soft shrink
+        const bool wlr = p->wl_row != 0 && wle, wlc = p->wl_col != 0;
         ColP Awl = A;
         Awl.TC = EGR_WL_COL_TC; Awl.TClog2 = 3; Awl.ntiles = A.ncols / EGR_WL_COL_TC; Awl.tiles_per_xcd = ceil_div(Awl.ntiles, 8);
         // no ping-pong buffer; the row kernel's two rows are padded by one element per 2^EGR_FL_ROW_PAD
@@ -1422,13 +1421,13 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
                 RowP Rg = R;
                 if (relative) {        // this iteration's spectrum maximum first (forward row transforms + split, no write-back)
                     Rg.max2_out = p->d_max2 + (size_t)it * C + c0;
-                    if (wlr) hipLaunchKernelGGL((k_row_wl<16, 12, 2>), growg, dim3(wle->threads), EGR_LDS(wle->lds), sg, Rg, p->wl_rt, M, wk);
+                    if (wlr) hipLaunchKernelGGL(wle->fn_max, growg, dim3(wle->threads), EGR_LDS(wle->lds), sg, Rg, p->wl_rt, M, wk);
                     else if (rs1) hipLaunchKernelGGL((k_row<true, 1>), growg, blk, lrs, sg, Rg, M, wk);
                     else hipLaunchKernelGGL(k_row<true>, growg, blk, lr, sg, Rg, M, wk);
                     Rg.max2 = Rg.max2_out;
                 }
                 if (prof) fl_prof_begin(p, 0, sg, &slot);
-                if (wlr && wl_variant) hipLaunchKernelGGL((k_row_wl<16, 12, 1>), growg, dim3(wle->threads), EGR_LDS(wle->lds), sg, Rg, p->wl_rt, M, wk);
+                if (wlr && wl_variant) hipLaunchKernelGGL(wle->fn_variant, growg, dim3(wle->threads), EGR_LDS(wle->lds), sg, Rg, p->wl_rt, M, wk);
                 else if (wlr) hipLaunchKernelGGL(wle->fn, growg, dim3(wle->threads), EGR_LDS(wle->lds), sg, Rg, p->wl_rt, M, wk);
                 else if (rs1) hipLaunchKernelGGL((k_row<false, 1>), growg, blk, lrs, sg, Rg, M, wk);
                 else hipLaunchKernelGGL(k_row<false>, growg, blk, lr, sg, Rg, M, wk);

@@ -278,8 +278,8 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
     X(384, 6, 8) X(576, 4, 12) X(768, 12, 8) X(1152, 8, 12) X(1536, 24, 8) X(1728, 12, 12) X(1920, 30, 8) X(2304, 16, 12) \
     X(2880, 20, 12) X(3072, 12, 16) X(3456, 24, 12) X(4032, 28, 12) X(4096, 16, 16) X(4608, 32, 12)
 typedef void (*WlRowFn)(RowP, WlRowT, long long, cplx*);
-struct WlRowEntry { int L, n1, q, threads, lds; WlRowFn fn; };
-#define EGR_WL_ROW_ENTRY(LL, A, B) {LL, A, B, WlRow<A, B>::THREADS, WlRow<A, B>::LDS, k_row_wl<A, B, 0>},
+struct WlRowEntry { int L, n1, q, threads, lds; WlRowFn fn, fn_variant, fn_max; };      // hooks 0 / 1 / 2
+#define EGR_WL_ROW_ENTRY(LL, A, B) {LL, A, B, WlRow<A, B>::THREADS, WlRow<A, B>::LDS, k_row_wl<A, B, 0>, k_row_wl<A, B, 1>, k_row_wl<A, B, 2>},
 static const WlRowEntry kWlRows[] = {EGR_WL_ROW_LIST(EGR_WL_ROW_ENTRY)};
 
 // MODE 1 only (the middle pass of the loop): state -> twiddle^-1 -> IFFT_625 -> FFT_625 -> twiddle -> state, tiles of 8 columns.

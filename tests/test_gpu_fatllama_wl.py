@@ -248,3 +248,16 @@ def test_two_barrier_row_kernel_with_an_even_row_count(pack):
     scale = float(np.max(np.abs(want)))
     assert float(np.max(np.abs(a - b))) <= 4e-6 * scale
     assert float(np.max(np.abs(a - want))) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("rows,variant,thr", [(768, "relative,soft", 0.02), (2880, "soft", 50.0), (4608, "relative", 0.02)])
+def test_hook_variants_on_other_row_lengths(pack, rows, variant, thr):
+    """k_row_wl<N1, Q, 1> / <N1, Q, 2> for row lengths other than the C3 plan's, against the stage-by-stage kernels."""
+    n = 2 * 625 * rows
+    x = synth(2, n, seed=rows + 1, scale=100.0 if variant == "soft" else 8000.0)
+    a = run(x, 3, thr=thr, wl=True, variant=variant)
+    b = run(x, 3, thr=thr, wl=False, variant=variant)
+    assert np.isfinite(a).all()
+    assert float(np.sum(np.square(a - b, dtype=np.float64))) <= 1e-6 * float(np.sum(np.square(b, dtype=np.float64)))
+    y = x.copy(); y[:, -1] = 0
+    assert rms(a - 2 * y) > 1e-4 * rms(y)
