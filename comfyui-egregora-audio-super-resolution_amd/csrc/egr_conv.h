@@ -41,6 +41,13 @@ struct ConvP {
     // k_conv_s3: 1 = walk the (row tile, column tile) space XCD-aware -- workgroup L of a z slice sits on XCD L % 8; the
     // workgroups of one XCD take the column tiles of ONE row tile back to back, so the activation tile they share is an L2 hit
     int xcd_remap;
+    // operand scheme of the split kernels: 0 = three bf16 terms (w3 = egr_split3_pack), 1 = two fp16 terms of the pre-scaled
+    // operands (w3 = egr_split2h_pack(w, w_scale); the loader multiplies x by a_scale, both powers of two).  out_scale
+    // (= 1 / (a_scale w_scale), 1 for every other kernel) multiplies the accumulators before bias / residual / activation;
+    // amax: optional slot raised to max |x| over everything the loader split (scheme 1 only).
+    int sch;
+    float a_scale, out_scale;
+    unsigned* amax;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float prm) {
@@ -98,7 +105,7 @@ __device__ __forceinline__ void conv_epilogue_rows_i(const ConvP& p, f32x16 (&ac
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     if (nb + j * 32 < p.Cout) {
-                        float v = acc[i][j][r] + bv[j];
+                        float v = fmaf(acc[i][j][r], p.out_scale, bv[j]);       // out_scale = 1: the plain sum
                         if (bb) v += bb[j * 32];
                         if (RES) v += rv[r][j];
                         yout[o + j * 32] = apply_act(v, p.act, p.act_param);
@@ -136,7 +143,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                     float* row = wz + (size_t)m * p.Cout + n0 + wn0 + col;
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        if (n0 + wn0 + j * 32 + col < p.Cout) row[j * 32] = acc[i][j][r];
+                        if (n0 + wn0 + j * 32 + col < p.Cout) row[j * 32] = acc[i][j][r] * p.out_scale;
                 }
             }
         return;

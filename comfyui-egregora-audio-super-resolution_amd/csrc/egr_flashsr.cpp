@@ -6,6 +6,7 @@
 // launches of the operators in egr_nn_*.hip, with a stream-ordered scratch arena instead of one allocation per operator.
 // The host (Python or C) only supplies named fp32 tensors in torch layouts and calls infer on device pointers.
 #include <math.h>
+#include <cmath>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -150,6 +151,9 @@ struct Ten {                       // an fp32 activation owned by the arena (mov
 struct Wt {                        // one entry of the weight store
     float* w = nullptr;            // raw tensor (norms, biases, snake parameters) or fp32 slab-major pack
     void* w3 = nullptr;            // three-way bf16 split of the pack (egr_split3_pack)
+    void* w2 = nullptr;            // two fp16 terms of w * w_scale (egr_split2h_pack); slot: this contraction's amax slot
+    float w_scale = 1.f;
+    int slot = -1;
     int KH = 0, KW = 0, Cin = 0, Cout = 0;   // logical shape of a packed contraction (Cout = GEMM N)
     int64_t zfloats = 0;           // floats per component of a z-stacked Winograd pack
     int64_t numel = 0;
@@ -194,6 +198,19 @@ struct egr_flashsr {
     std::vector<ProfRec> prof;
     hipStream_t st = nullptr;                         // stream of the forward being enqueued (= cx->st)
     void use(FsrCtx* c) { cx = c; st = c->st; }
+    // Two-term fp16 operand scheme of egr_flashsr_infer (csrc/egr_nn_gemm_s3.hip, scheme 1).  Every split contraction owns a slot
+    // of d_amax; its loader raises the slot to max |x| of what it split.  The scale of a call's activations comes from the
+    // PREVIOUS call's maxima (largest value near 2^12: a factor 16 of headroom below fp16's 65504); after the call the maxima are
+    // read back and a slot whose scaled maximum left the fp16 range sends the whole call through the three-term bf16 kernels
+    // again (which have fp32's range).  The first call of a handle measures the maxima with k_absmax and runs the bf16 kernels.
+    bool h2 = true;                                   // scheme available (off: EGR_FSR_SPLIT_BF16X3, EGREGORA_FLASHSR_SPLIT=bf16x3, f32 MFMA)
+    int h2_mode = -1;                                 // of the forward being enqueued: -1 bf16 terms, 0 bf16 terms + measure, 1 fp16 terms
+    bool h2_cal = false;                              // amax_prev holds a measurement
+    int h2_nslots = 0;
+    unsigned* d_amax = nullptr;
+    float* h_amax = nullptr;                          // pinned
+    std::vector<float> amax_prev, scale_cur, scale_used;   // scale_cur: kept while the scaled maximum stays inside [2^8, 2^14]
+    int64_t h2_reruns = 0, h2_calls = 0;
 
     bool f32_mfma() const { return (flags & EGR_FSR_F32_MFMA) != 0; }
     bool has(const std::string& k) const { return W.find(k) != W.end(); }
@@ -264,6 +281,19 @@ void build_blocks(M* m) {
 int up_kernel(int r) { return 2 * r + (r % 2); }
 
 // ------------------------------------------------------------------------------------------------ weight packing
+constexpr int H2_MAX_SLOTS = 4096;
+
+// power of two that brings a tensor whose largest magnitude is amax to (2^(e-1), 2^e]; 1 for an empty / non-finite measurement
+float h2_scale_for(float amax, int e) {
+    if (!(amax > 0.f) || !std::isfinite(amax)) return 1.f;
+    int ex = 0;
+    const float fr = frexpf(amax, &ex);              // amax = fr 2^ex, fr in [0.5, 1)
+    if (fr == 0.5f) --ex;                            // exact power of two: 2^(ex-1)
+    int k = e - ex;
+    k = std::max(-100, std::min(100, k));
+    return ldexpf(1.f, k);
+}
+
 int split3(M* m, Wt& w) {
     if (m->f32_mfma() || !w.w) return EGR_OK;
     const int64_t ns = w.numel / ((int64_t)w.Cout * 16);
@@ -271,6 +301,28 @@ int split3(M* m, Wt& w) {
     OKR(dev_alloc(m, (size_t)ns * 3 * w.Cout * 16 * 2, &p3));
     OKR(egr_split3_pack(w.w, p3, ns, w.Cout, m->st));
     w.w3 = p3;
+    if (m->h2 && m->h2_nslots < H2_MAX_SLOTS) {      // fp16 terms of w * 2^k, k from the pack's largest magnitude
+        if (!m->d_amax) {
+            if (hipMalloc((void**)&m->d_amax, (H2_MAX_SLOTS + 1) * sizeof(unsigned)) != hipSuccess ||
+                hipHostMalloc((void**)&m->h_amax, (H2_MAX_SLOTS + 1) * sizeof(float)) != hipSuccess) {
+                set_error("hipMalloc(amax slots) failed");
+                return EGR_ERR_ALLOC;
+            }
+            EGR_HIP(hipMemsetAsync(m->d_amax, 0, (H2_MAX_SLOTS + 1) * sizeof(unsigned), m->st));
+        }
+        float* tmp = (float*)(m->d_amax + H2_MAX_SLOTS);
+        float wmax = 0.f;
+        EGR_HIP(hipMemsetAsync(tmp, 0, sizeof(float), m->st));
+        OKR(egr_absmax(w.w, w.numel, tmp, m->st));
+        EGR_HIP(hipMemcpyAsync(&wmax, tmp, sizeof(float), hipMemcpyDeviceToHost, m->st));
+        EGR_HIP(hipStreamSynchronize(m->st));
+        w.w_scale = h2_scale_for(wmax, 13);
+        void* p2 = nullptr;
+        OKR(dev_alloc(m, (size_t)ns * 2 * w.Cout * 16 * 2, &p2));
+        OKR(egr_split2h_pack(w.w, p2, ns, w.Cout, w.w_scale, m->st));
+        w.w2 = p2;
+        w.slot = m->h2_nslots++;
+    }
     return EGR_OK;
 }
 
@@ -285,7 +337,13 @@ int add_packed(M* m, const std::string& key, const float* src, int layout, int K
     w.w = (float*)p;
     OKR(egr_pack_weight(src, w.w, layout, K, N, Ci, Co, KH, KW, m->st));
     w.KH = logical_kh; w.KW = logical_kw; w.Cin = logical_cin; w.Cout = N;
-    if (logical_cin % 16 == 0) OKR(split3(m, w));
+    if (logical_cin % 16 == 0) {
+        const bool keep = m->h2;
+        if (key == "mel_fb") m->h2 = false;          // spectra span > 90 dB and a log follows: the mel projection keeps three bf16 terms
+        const int rc = split3(m, w);
+        m->h2 = keep;
+        OKR(rc);
+    }
     m->W[key] = w;
     return EGR_OK;
 }
@@ -421,6 +479,29 @@ const void* s3_of(const M* m, const Wt* w, int Cin, const float* x) {
     return w->w3;
 }
 
+// One split contraction (egr_conv_s3's argument list; zfloats: floats per z problem of a stacked pack, 0 otherwise) in the operand
+// scheme of the forward being enqueued.  *h2 tells the profiler which kernel family ran.
+int s3_launch(M* m, const Wt* w, const float* x, int64_t x_numel, const float* bias, const float* res, float* y, int B, int H, int W, int Cin,
+              int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t, int pad_l, int up2, int act, float act_param, int osy, int osx,
+              int ooy, int oox, int OHF, int OWF, int nz, int64_t zx, int64_t zfloats, int64_t zy, bool* h2 = nullptr) {
+    const bool can = m->h2 && w->w2 && w->slot >= 0;
+    if (h2) *h2 = can && m->h2_mode == 1;
+    if (can && m->h2_mode == 1) {
+        const float a_scale = m->scale_cur[w->slot] > 0.f ? m->scale_cur[w->slot] : 1.f;
+        m->scale_used[w->slot] = a_scale;
+        return egr_conv_h2(x, w->w2, bias, nullptr, res, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act, act_param, osy,
+                           osx, ooy, oox, OHF, OWF, nz, zx, zfloats * 2 / 8, zy, a_scale, w->w_scale, (float*)(m->d_amax + w->slot), m->st);
+    }
+    if (can && m->h2_mode == 0) OKR(egr_absmax(x, x_numel, (float*)(m->d_amax + w->slot), m->st));
+    return egr_conv_s3(x, w->w3, bias, nullptr, res, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act, act_param, osy, osx,
+                       ooy, oox, OHF, OWF, nz, zx, zfloats * 3 / 8, zy, m->st);
+}
+
+std::string h2_kind(std::string kind, bool h2) {      // "k_conv_s3<128, 256, 1, false>" -> "k_conv_s3<128, 256, 1, false, 1>"
+    if (h2 && !kind.empty() && kind.back() == '>' && kind.rfind("k_conv", 0) == 0) { kind.pop_back(); kind += ", 1>"; }
+    return kind;
+}
+
 // general convolution: weights by key (key + ".weight", bias key + ".bias") or explicit entry `wk`
 int conv(M* m, Ten& y, const Ten& x, const std::string& wkey, int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
          int stride = 1, int dil = 1, int pad_t = 0, int pad_l = 0, int up2 = 0, int act = ACT_NONE, bool bias = true,
@@ -432,9 +513,10 @@ int conv(M* m, Ten& y, const Ten& x, const std::string& wkey, int B, int H, int 
     const double fl = 2.0 * B * OH * OW * Cout * KH * KW * Cin;
     ProfScope ps(m);
     const void* w3 = s3_of(m, w, Cin, x.p);
+    bool h2 = false;
     if (w3) {
-        OKR(egr_conv_s3(x.p, w3, bt, nullptr, res, y.p, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act, act_param, 1, 1,
-                        0, 0, OH, OW, 1, 0, 0, 0, m->st));
+        OKR(s3_launch(m, w, x.p, (int64_t)B * H * W * Cin, bt, res, y.p, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act,
+                      act_param, 1, 1, 0, 0, OH, OW, 1, 0, 0, 0, &h2));
     } else {
         EGR_CHECK(w->w != nullptr, EGR_ERR_ARG, "FlashSR: no fp32 pack for %s", wkey.c_str());
         OKR(egr_conv_nhwc(x.p, w->w, bt, nullptr, res, y.p, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act, act_param,
@@ -449,7 +531,7 @@ int conv(M* m, Ten& y, const Ten& x, const std::string& wkey, int B, int H, int 
             snprintf(buf, sizeof(buf), "k_conv1d_s3<%d, %d>", Cout > 64 ? 128 : (Cout > 32 ? 64 : 32), Cin % 32 == 0 ? 32 : 16);
             kind = buf;
         }
-        ps.end(kind, fl);
+        ps.end(h2_kind(kind, h2), fl);
     }
     if (m->count_flops) m->flops += fl;
     return EGR_OK;
@@ -514,9 +596,10 @@ int conv_winograd(M* m, Ten& y, const Ten& x, const std::string& key, int act, c
     {
         ProfScope ps(m);
         const void* w3 = s3_of(m, wz, Cin, V.p);
+        bool h2 = false;
         if (w3) {
-            OKR(egr_conv_s3(V.p, w3, nullptr, nullptr, nullptr, Mx.p, (int)P, 1, 1, Cin, 1, 1, Cout, 1, 1, 1, 1, 0, 0, 0, 0, 0.0f, 1, 1, 0, 0, 1, 1, nz,
-                            P * Cin, wz->zfloats * 3 / 8, P * Cout, m->st));
+            OKR(s3_launch(m, wz, V.p, (int64_t)nz * P * Cin, nullptr, nullptr, Mx.p, (int)P, 1, 1, Cin, 1, 1, Cout, 1, 1, 1, 1, 0, 0, 0, 0, 0.0f, 1, 1,
+                          0, 0, 1, 1, nz, P * Cin, wz->zfloats, P * Cout, &h2));
         } else {
             EGR_CHECK(wz->w != nullptr, EGR_ERR_ARG, "FlashSR: no fp32 Winograd pack for %s", key.c_str());
             OKR(egr_gemm_zbatched(V.p, wz->w, Mx.p, nz, (int)P, Cin, Cout, P * Cin, wz->zfloats, P * Cout, m->st));
@@ -533,7 +616,7 @@ int conv_winograd(M* m, Ten& y, const Ten& x, const std::string& key, int act, c
                     kind = buf;
                 }
             }
-            ps.end(kind, fl);
+            ps.end(h2_kind(kind, h2), fl);
         }
     }
     if (m->count_flops) m->flops += fl;
@@ -567,13 +650,14 @@ int conv_up2_phases(M* m, Ten& y, const Ten& x, const std::string& key, int act)
             const double fl = 2.0 * B * H * W * Cout * 4 * Cin;
             ProfScope ps(m);
             const void* w3 = s3_of(m, w, Cin, x.p);
+            bool h2 = false;
             if (w3)
-                OKR(egr_conv_s3(x.p, w3, bt, nullptr, nullptr, y.p, B, H, W, Cin, H, W, Cout, 2, 2, 1, 1, 1 - a, 1 - b, 0, act, 0.0f, 2, 2, a, b,
-                                2 * H, 2 * W, 1, 0, 0, 0, m->st));
+                OKR(s3_launch(m, w, x.p, (int64_t)B * H * W * Cin, bt, nullptr, y.p, B, H, W, Cin, H, W, Cout, 2, 2, 1, 1, 1 - a, 1 - b, 0, act, 0.0f, 2, 2,
+                              a, b, 2 * H, 2 * W, 1, 0, 0, 0, &h2));
             else
                 OKR(egr_conv_nhwc_placed(x.p, w->w, bt, nullptr, nullptr, y.p, B, H, W, Cin, H, W, Cout, 2, 2, 1, 1, 1 - a, 1 - b, 0, act, 0.0f, 2, 2,
                                          a, b, 2 * H, 2 * W, m->st));
-            if (ps.on) ps.end(kind_of((long long)B * H * W, Cin, Cout, w3 != nullptr, Cin % 16 == 0, 4LL * Cin), fl);
+            if (ps.on) ps.end(h2_kind(kind_of((long long)B * H * W, Cin, Cout, w3 != nullptr, Cin % 16 == 0, 4LL * Cin), h2), fl);
             if (m->count_flops) m->flops += fl;
         }
     return EGR_OK;
@@ -1098,6 +1182,8 @@ extern "C" int egr_flashsr_destroy(egr_flashsr* m) {
     }
     if (m->ev_fork) hipEventDestroy(m->ev_fork);
     for (auto& r : m->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    if (m->d_amax) hipFree(m->d_amax);
+    if (m->h_amax) hipHostFree(m->h_amax);
     delete m;
     return EGR_OK;
 }
@@ -1121,6 +1207,8 @@ extern "C" int egr_flashsr_create(egr_flashsr** out, const egr_flashsr_config* c
     hipGetDevice(&m->device);
     if (const char* e = getenv("EGREGORA_FLASHSR_STREAMS")) { const int g = atoi(e); if (g >= 1 && g <= 4) m->max_groups = g; }
     if (const char* e = getenv("EGREGORA_FLASHSR_WINOGRAD_MIN_CH")) m->wino_min_ch = atoi(e);
+    m->h2 = !(flags & (EGR_FSR_F32_MFMA | EGR_FSR_SPLIT_BF16X3));
+    if (const char* e = getenv("EGREGORA_FLASHSR_SPLIT")) { if (!strcmp(e, "bf16x3")) m->h2 = false; }
     if (const char* e = getenv("EGREGORA_FLASHSR_ROWS")) { const int r = atoi(e); if (r >= 1) m->rows_per_pass = r; }
     build_blocks(m);
     const int down = 1 << (cfg->vae_levels - 1);
@@ -1173,6 +1261,7 @@ extern "C" int egr_flashsr_forward(egr_flashsr* m, const float* x, const float* 
     m->ctxs[0]->st = (hipStream_t)stream;
     m->use(m->ctxs[0].get());
     ForwardGuard guard(m->device, m->st);
+    m->h2_mode = -1;                                  // the introspection walk stays on the three-term kernels (bit-equal to the operator API)
     return forward(m, x, noise, rows, lowpass, y, stages);
 }
 
@@ -1223,9 +1312,74 @@ static int ensure_side_streams(egr_flashsr* m, hipStream_t caller, int want) {
 // A pass of >= 2 * min_group_rows rows is split into up to max_groups contiguous ROW GROUPS that run as concurrent forwards on the
 // handle's verified side streams, each with its own scratch arena (fork / join by events around the pass): one group's
 // matrix-bound kernels overlap another's HBM-bound ones and fill each other's tails (26 rows: 260 ms in one forward).
+static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uint64_t seed, const int64_t* row_ids, float* y, void* stream);
+
 extern "C" int egr_flashsr_infer(egr_flashsr* m, const float* x, int rows, int lowpass, uint64_t seed, const int64_t* row_ids, float* y,
                                  void* stream) {
     EGR_CHECK(m && x && y && rows >= 1, EGR_ERR_ARG, "egr_flashsr_infer: null / empty argument");
+    hipStream_t st0 = (hipStream_t)stream;
+    if (!m->h2 || m->h2_nslots == 0 || m->count_flops) {
+        m->h2_mode = -1;
+        return infer_once(m, x, rows, lowpass, seed, row_ids, y, stream);
+    }
+    // operand scheme bookkeeping (see the h2 fields of the handle): measure -> scale -> verify, re-run on the bf16 terms if a value
+    // left fp16's range.  The read-back makes the call synchronous with the host (one 16 KiB copy).
+    const int n = m->h2_nslots;
+    m->amax_prev.resize(n, 0.f);
+    m->scale_cur.resize(n, 0.f);
+    m->scale_used.assign(n, 0.f);
+    ++m->h2_calls;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        m->h2_mode = (m->h2_cal && attempt == 0) ? 1 : 0;
+        EGR_HIP(hipMemsetAsync(m->d_amax, 0, (size_t)n * sizeof(unsigned), st0));
+        const int rc = infer_once(m, x, rows, lowpass, seed, row_ids, y, stream);
+        const int mode = m->h2_mode;
+        m->h2_mode = -1;
+        if (rc != EGR_OK) return rc;
+        EGR_HIP(hipMemcpyAsync(m->h_amax, m->d_amax, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st0));
+        EGR_HIP(hipStreamSynchronize(st0));
+        bool overflow = false;
+        for (int i = 0; i < n; ++i) {
+            const float a = m->h_amax[i];
+            if (mode == 1 && m->scale_used[i] > 0.f && !(a * m->scale_used[i] < 60000.f)) overflow = true;     // also catches inf / nan bits
+            if (a > 0.f && std::isfinite(a)) {
+                m->amax_prev[i] = a;
+                // a scale is kept while the new maximum sits between 2^8 and 2^14 under it (same scale -> same bits for the same
+                // data, whatever the calls in between); otherwise it is re-centred at 2^12
+                const float sc = a * m->scale_cur[i];
+                if (!(m->scale_cur[i] > 0.f) || sc > 16384.f || sc < 256.f) m->scale_cur[i] = h2_scale_for(a, 12);
+            }
+        }
+        m->h2_cal = true;
+        if (!overflow) break;
+        ++m->h2_reruns;
+    }
+    return EGR_OK;
+}
+
+// 0: scheme off for this handle, 1: on.  calls / reruns: egr_flashsr_infer calls on the scheme and how many were sent through the
+// bf16 kernels again after a range check failed; calibrated: the next call will use the fp16 terms.
+extern "C" int egr_flashsr_split_info(egr_flashsr* m, int* enabled, int* calibrated, int* slots, int64_t* calls, int64_t* reruns) {
+    EGR_CHECK(m != nullptr, EGR_ERR_ARG, "handle is null");
+    if (enabled) *enabled = m->h2 && m->h2_nslots > 0;
+    if (calibrated) *calibrated = m->h2_cal;
+    if (slots) *slots = m->h2_nslots;
+    if (calls) *calls = m->h2_calls;
+    if (reruns) *reruns = m->h2_reruns;
+    return EGR_OK;
+}
+
+// scheme: 0 = three bf16 terms always, 1 = two fp16 terms with measured scales (needs a handle created with the scheme available)
+extern "C" int egr_flashsr_set_split(egr_flashsr* m, int scheme) {
+    EGR_CHECK(m && (scheme == 0 || scheme == 1), EGR_ERR_ARG, "bad argument");
+    EGR_CHECK(scheme == 0 || m->h2_nslots > 0, EGR_ERR_UNSUPPORTED, "this handle holds no fp16 weight terms");
+    m->h2 = scheme == 1;
+    m->h2_cal = false;
+    m->scale_cur.assign(m->scale_cur.size(), 0.f);
+    return EGR_OK;
+}
+
+static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uint64_t seed, const int64_t* row_ids, float* y, void* stream) {
     hipStream_t st0 = (hipStream_t)stream;
     m->ctxs[0]->st = st0;
     m->use(m->ctxs[0].get());
@@ -1327,6 +1481,7 @@ extern "C" int egr_flashsr_flop_count(egr_flashsr* m, int rows, double* flops, v
     EGR_HIP(hipMemsetAsync(x.p, 0, x.bytes, m->st));
     OKR(egr_randn(nz.p, (int64_t)m->lat_h * m->lat_w * c.z_ch, rows, 0, nullptr, m->st));
     m->count_flops = true; m->flops = 0.0;
+    m->h2_mode = -1;
     const int rc = forward(m, x.p, nz.p, rows, 0, y.p, nullptr);
     m->count_flops = false;
     EGR_HIP(hipStreamSynchronize(m->st));

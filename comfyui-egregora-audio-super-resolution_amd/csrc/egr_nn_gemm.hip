@@ -481,7 +481,8 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
                        int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t,
                        int pad_l, int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF,
                        int nz, long long zx, long long zw, long long zy, const float* gn_scale, const float* gn_shift,
-                       int gn_silu, void* stream, const void* w3 = nullptr);
+                       int gn_silu, void* stream, const void* w3 = nullptr, int sch = 0, float a_scale = 1.f, float w_scale = 1.f,
+                       float* amax = nullptr);
 
 extern "C" int egr_conv_nhwc(const float* x, const float* w, const float* bias, const float* bias_b, const float* res,
                              float* y, int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
@@ -528,12 +529,27 @@ extern "C" int egr_conv_s3(const float* x, const void* w3, const float* bias, co
                        act_param, osy, osx, ooy, oox, OHF, OWF, nz, zx, zw3, zy, nullptr, nullptr, 0, stream, w3);
 }
 
+// The same on two fp16 terms per operand (csrc/egr_nn_gemm_s3.hip, scheme 1): w2 = egr_split2h_pack(w, w_scale); the loader
+// multiplies x by a_scale (both powers of two) and raises *amax (optional; bits of a float, zeroed by the caller) to max |x|.
+extern "C" int egr_conv_h2(const float* x, const void* w2, const float* bias, const float* bias_b, const float* res, float* y,
+                           int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil,
+                           int pad_t, int pad_l, int up2, int act, float act_param, int osy, int osx, int ooy, int oox,
+                           int OHF, int OWF, int nz, int64_t zx, int64_t zw2, int64_t zy, float a_scale, float w_scale,
+                           float* amax, void* stream) {
+    EGR_CHECK(w2, EGR_ERR_ARG, "null w2");
+    EGR_CHECK(nz >= 1 && nz <= 65535, EGR_ERR_ARG, "bad nz");
+    return conv_launch(x, nullptr, bias, bias_b, res, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act,
+                       act_param, osy, osx, ooy, oox, OHF, OWF, nz, zx, zw2, zy, nullptr, nullptr, 0, stream, w2, 1, a_scale,
+                       w_scale, amax);
+}
+
 static int conv_launch(const float* x, const float* w, const float* bias, const float* bias_b, const float* res, float* y,
                        int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t,
                        int pad_l, int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF,
                        int nz, long long zx, long long zw, long long zy, const float* gn_scale, const float* gn_shift,
-                       int gn_silu, void* stream, const void* w3) {
+                       int gn_silu, void* stream, const void* w3, int sch, float a_scale, float w_scale, float* amax) {
     EGR_CHECK(x && (w || w3) && y, EGR_ERR_ARG, "null x/w/y");
+    EGR_CHECK(sch == 0 || (w3 && a_scale > 0.f && w_scale > 0.f), EGR_ERR_ARG, "bad operand scheme / scales");
     EGR_CHECK(!w3 || ((Cin % BK) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)w3) & 15) == 0 && !gn_scale), EGR_ERR_ARG,
               "split-bf16 conv needs Cin %% 16 == 0, 16-byte aligned x / w3 and no fused input affine");
     EGR_CHECK(!gn_scale || (gn_shift && (Cin % BK) == 0 && (((uintptr_t)x) & 15) == 0), EGR_ERR_ARG,
@@ -549,6 +565,7 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW;
     p.stride = stride; p.dil = dil; p.pad_t = pad_t; p.pad_l = pad_l; p.up2 = up2; p.act = act; p.act_param = act_param;
     p.M = (int)M; p.K = KH * KW * Cin;
+    p.sch = sch; p.a_scale = a_scale; p.out_scale = sch ? 1.0f / (a_scale * w_scale) : 1.0f; p.amax = sch ? (unsigned*)amax : nullptr;
     EGR_CHECK(osy >= 1 && osx >= 1 && ooy >= 0 && oox >= 0 && (OH - 1) * osy + ooy < OHF && (OW - 1) * osx + oox < OWF,
               EGR_ERR_ARG, "bad output placement");
     p.osy = osy; p.osx = osx; p.ooy = ooy; p.oox = oox; p.OHF = OHF; p.OWF = OWF;
@@ -570,7 +587,7 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
     { int zrc = zero_page(&p.zeros); if (zrc) return zrc; }
     p.nz = nz; p.zs_nzb = 0;
     if (nz > 1) grid.z = nz;
-    if (w3 && nz > 1 && KH == 1 && KW == 1 && H == 1 && W == 1 && stride == 1 && zw == (long long)(p.K / BK) * Cout * 6 &&
+    if (w3 && nz > 1 && KH == 1 && KW == 1 && H == 1 && W == 1 && stride == 1 && zw == (long long)(p.K / BK) * Cout * (sch ? 4 : 6) &&
         !bias && !bias_b && !res && act == 0 && osy == 1 && osx == 1 && OHF == OH && OWF == OW) {
         p.zs_nzb = s3_zs_nzb(M, Cout, 128, bn, nz, p.K);          // Winograd GEMMs: stream several z per workgroup
         if (p.zs_nzb > 0) {                                       // (128-row tiles: the 256-row variant would spill)

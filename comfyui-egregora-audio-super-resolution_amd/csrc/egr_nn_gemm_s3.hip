@@ -51,6 +51,102 @@ __device__ __forceinline__ void split3_x8(const float4& u, const float4& v, uint
     split3_pair(v.z, v.w, q0.w, q1.w, q2.w);
 }
 
+// ---- scheme 1: two fp16 terms of the pre-scaled operand (x s = h0 + h1, h0 = f16(x s), h1 = f16(x s - h0); s a power of two that
+// brings the tensor's largest magnitude near 2^12, so every element down to 2^-15 of it keeps 22 significand bits and smaller ones
+// an absolute error of 2^-37 of the maximum).  f16 x f16 products are exact in fp32, so  a0 b0 + a0 b1 + a1 b0  carries the fp32
+// product up to a1 b1 and the two term roundings (each < 2^-22 |a b|) with HALF the matrix instructions of the bf16 scheme and
+// one third fewer LDS operand bytes; fewer accumulator roundings per 16 k (3 instead of 6) make the measured error against
+// float64 no larger (tests/test_gpu_split_h2.py).  The loader also records max |x| of everything it splits (one atomic per wave
+// that raises the slot) so that the host can choose the next call's scale and detect a value beyond fp16's range (csrc/egr_flashsr.cpp).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split2h_pair(float a, float b, float s, uint32_t& p0, uint32_t& p1) {
+    const float as = a * s, bs = b * s;
+    const f32x2 v = {as, bs};
+    const f16x2 hi = __builtin_convertvector(v, f16x2);                // RNE (v_cvt_pk_f16_f32)
+    p0 = __builtin_bit_cast(uint32_t, hi);
+    const f32x2 r = {as - (float)hi[0], bs - (float)hi[1]};            // exact
+    p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+}
+
+__device__ __forceinline__ void split2h_x8(const float4& u, const float4& v, float s, uint4& q0, uint4& q1) {
+    split2h_pair(u.x, u.y, s, q0.x, q1.x);
+    split2h_pair(u.z, u.w, s, q0.y, q1.y);
+    split2h_pair(v.x, v.y, s, q0.z, q1.z);
+    split2h_pair(v.z, v.w, s, q0.w, q1.w);
+}
+
+__device__ __forceinline__ float absmax8(const float4& u, const float4& v, float m) {
+    m = fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), m);
+    m = fmaxf(fmaxf(fabsf(u.z), fabsf(u.w)), m);
+    m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), m);
+    return fmaxf(fmaxf(fabsf(v.z), fabsf(v.w)), m);
+}
+
+// raises *slot (the bits of a non-negative float, which order like unsigned integers) to the wave's maximum
+__device__ __forceinline__ void amax_commit(unsigned* slot, float m) {
+    if (!slot) return;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const unsigned bits = __float_as_uint(m);
+    if ((threadIdx.x & 63) == 0 && bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+}
+
+// the operand split of scheme SCH into its NP planes q[0..NP)
+template <int SCH>
+__device__ __forceinline__ void split_x8(const float4& u, const float4& v, float s, uint4 (&q)[3]) {
+    if constexpr (SCH == 0) split3_x8(u, v, q[0], q[1], q[2]);
+    else split2h_x8(u, v, s, q[0], q[1]);
+}
+
+// the partial products of one 32x32x16 block, smallest terms first
+template <int SCH>
+__device__ __forceinline__ void mma_split(const uint4 (&a)[3], const uint4 (&b)[3], f32x16& acc) {
+    if constexpr (SCH == 0) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[2]), __builtin_bit_cast(bf16x8, b[0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[2]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, b[1]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, b[0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[1]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]), acc, 0, 0, 0);
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[1]), __builtin_bit_cast(f16x8, b[0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[1]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[0]), acc, 0, 0, 0);
+    }
+}
+
+// packed fp32 weights -> [slab][2][Cout][16] f16 terms of w * scale
+__global__ __launch_bounds__(256) void k_split2h_pack(const float* __restrict__ w, uint4* __restrict__ w2, long long nslabs, int Cout,
+                                                      float scale) {
+    const long long total = nslabs * Cout * 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int half = (int)(i & 1);
+        const long long rn = i >> 1;
+        const long long slab = rn / Cout;
+        const int n = (int)(rn - slab * Cout);
+        const float4* src = (const float4*)(w + (rn * 16 + half * 8));
+        uint4 q0, q1;
+        split2h_x8(src[0], src[1], scale, q0, q1);
+        uint4* dst = w2 + ((slab * 2) * Cout + n) * 2 + half;
+        dst[0] = q0;
+        dst[(size_t)Cout * 2] = q1;
+    }
+}
+
+// max |x| over n floats into *slot (bits of a non-negative float); the host zeroes the slot
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, long long n, unsigned* __restrict__ slot) {
+    float m = 0.f;
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = ((const float4*)x)[i];
+        m = fmaxf(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))), m);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+    amax_commit(slot, m);
+}
+
 __global__ __launch_bounds__(256) void k_split3_pack(const float* __restrict__ w, uint4* __restrict__ w3, long long nslabs,
                                                      int Cout) {
     // one thread per (slab, n, half): 8 consecutive k of one output channel
@@ -80,11 +176,12 @@ template <> struct S3Cfg<128, 64> { static constexpr int WM = 2, WN = 2, TM = 2,
 template <> struct S3Cfg<128, 32> { static constexpr int WM = 4, WN = 1, TM = 1, TN = 1; };
 
 __device__ __forceinline__ bf16x8 as_bf(const uint4& v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ f16x8 as_hf(const uint4& v) { return __builtin_bit_cast(f16x8, v); }
 
 // plain tile store (z-streamed GEMMs have no bias / residual / activation / placement)
 template <int TM, int TN>
 __device__ __forceinline__ void store_tile_plain(f32x16 (&acc)[TM][TN], float* __restrict__ y, int M, int Cout, int m0, int n0,
-                                                 int wm0, int wn0) {
+                                                 int wm0, int wn0, float os) {
     const int lane = threadIdx.x & 63, col = lane & 31, rhalf = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -95,18 +192,21 @@ __device__ __forceinline__ void store_tile_plain(f32x16 (&acc)[TM][TN], float* _
                 float* row = y + (size_t)m * Cout + n0 + wn0 + col;
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    if (n0 + wn0 + j * 32 + col < Cout) row[j * 32] = acc[i][j][r];
+                    if (n0 + wn0 + j * 32 + col < Cout) row[j * 32] = acc[i][j][r] * os;
             }
         }
 }
 
-template <int BM, int BN, int PF, bool ZS = false>
+template <int BM, int BN, int PF, bool ZS = false, int SCH = 0>
 __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
     typedef S3Cfg<BM, BN> TC;
     constexpr int TM = TC::TM, TN = TC::TN;
     constexpr int AP = BM / 128;                                  // A chunks (8 k of one row) per thread per slab
-    __shared__ uint4 As[2][3][BM * 2];
-    __shared__ uint4 Bs[2][3][BN * 2];
+    constexpr int NP = SCH ? 2 : 3;                               // operand planes (terms of the split)
+    __shared__ uint4 As[2][NP][BM * 2];
+    __shared__ uint4 Bs[2][NP][BN * 2];
+    const float a_scale = p.a_scale;
+    float amax = 0.f;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm0 = (wave / TC::WN) * (BM / TC::WM), wn0 = (wave % TC::WN) * (BN / TC::WN);
     int bx = blockIdx.x, by = blockIdx.y;
@@ -194,9 +294,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
     set_tap(tap);
     const int a_slot = ar * 2 + (ah ^ ((ar >> 3) & 1));          // row ar + 128 lands 256 slots further
 
-    // ---- B: 6*BN 16-byte chunks per slab (3 planes x BN channels x 2 halves), up to 3 per thread ----
-    constexpr int NBQ = 6 * BN;
-    const size_t b_slab = (size_t)p.Cout * 6;                    // uint4 per slab
+    // ---- B: 2*NP*BN 16-byte chunks per slab (NP planes x BN channels x 2 halves), up to 6 per thread ----
+    constexpr int NBQ = 2 * NP * BN;
+    const size_t b_slab = (size_t)p.Cout * 2 * NP;               // uint4 per slab
 #define S3_BSETUP(I, PTR, STEP, SLOT)                                                                                \
     const uint4* PTR;                                                                                                \
     unsigned STEP;                                                                                                   \
@@ -237,13 +337,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
         r.b0 = *bptr0;
         if (256 < NBQ) r.b1 = *bptr1;
         if (512 < NBQ) r.b2 = *bptr2;
-        if (768 < NBQ) { r.b3 = *bptr3; r.b4 = *bptr4; r.b5 = *bptr5; }
+        if (768 < NBQ) r.b3 = *bptr3;
+        if (1024 < NBQ) { r.b4 = *bptr4; r.b5 = *bptr5; }
     };
     auto load_tile_advance = [&]() {                  // pointer bookkeeping; the tap change is the only branch
         bptr0 += bstep0;
         if (256 < NBQ) bptr1 += bstep1;
         if (512 < NBQ) bptr2 += bstep2;
-        if (768 < NBQ) { bptr3 += bstep3; bptr4 += bstep4; bptr5 += bstep5; }
+        if (768 < NBQ) bptr3 += bstep3;
+        if (1024 < NBQ) { bptr4 += bstep4; bptr5 += bstep5; }
         c0 += S3_BK;
         if (c0 >= p.Cin) { c0 = 0; ++tap; set_tap(tap); }
     };
@@ -255,32 +357,32 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
         load_tile_advance();
     };
     auto store_tile = [&](const Stage& r, int buf) {
-        uint4 q0, q1, q2;
+        uint4 q[3];
 #ifdef S3_ABL_NOSPLIT
-        q0 = q1 = q2 = make_uint4(__float_as_uint(r.a0.x), __float_as_uint(r.a0.y), __float_as_uint(r.a1.x), __float_as_uint(r.a1.y));
+        q[0] = q[1] = q[2] = make_uint4(__float_as_uint(r.a0.x), __float_as_uint(r.a0.y), __float_as_uint(r.a1.x), __float_as_uint(r.a1.y));
 #else
-        split3_x8(r.a0, r.a1, q0, q1, q2);
+        split_x8<SCH>(r.a0, r.a1, a_scale, q);
+        if (SCH) amax = absmax8(r.a0, r.a1, amax);
 #endif
 #ifdef S3_ABL_NOSTORE
         if (buf > 1)
 #endif
         {
-            As[buf][0][a_slot] = q0;
-            As[buf][1][a_slot] = q1;
-            As[buf][2][a_slot] = q2;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) As[buf][pl][a_slot] = q[pl];
             if (AP > 1) {
 #ifndef S3_ABL_NOSPLIT
-                split3_x8(r.a2, r.a3, q0, q1, q2);
+                split_x8<SCH>(r.a2, r.a3, a_scale, q);
+                if (SCH) amax = absmax8(r.a2, r.a3, amax);
 #endif
-                As[buf][0][a_slot + 256] = q0;
-                As[buf][1][a_slot + 256] = q1;
-                As[buf][2][a_slot + 256] = q2;
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) As[buf][pl][a_slot + 256] = q[pl];
             }
             if (tid < NBQ) Bs[buf][0][bslot0] = r.b0;
             if (tid + 256 < NBQ) Bs[buf][0][bslot1] = r.b1;
             if (tid + 512 < NBQ) Bs[buf][0][bslot2] = r.b2;
-            if (768 < NBQ) {
-                Bs[buf][0][bslot3] = r.b3;
+            if (768 < NBQ) Bs[buf][0][bslot3] = r.b3;
+            if (1024 < NBQ) {
                 Bs[buf][0][bslot4] = r.b4;
                 Bs[buf][0][bslot5] = r.b5;
             }
@@ -304,14 +406,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
 #pragma unroll
             for (int j = 0; j < TNH; ++j)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) b[j][q] = Bs[cur][q][(wn0 + (j0 + j) * 32) * 2 + o_slot];
+                for (int q = 0; q < NP; ++q) b[j][q] = Bs[cur][q][(wn0 + (j0 + j) * 32) * 2 + o_slot];
 #pragma unroll
             for (int i0 = 0; i0 < TM; i0 += TH) {
                 uint4 a[TH][3];
 #pragma unroll
                 for (int i = 0; i < TH; ++i)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) a[i][q] = As[cur][q][(wm0 + (i0 + i) * 32) * 2 + o_slot];
+                    for (int q = 0; q < NP; ++q) a[i][q] = As[cur][q][(wm0 + (i0 + i) * 32) * 2 + o_slot];
                 if (i0 == 0 && j0 == 0) {
                     if (FULL) {
                         store_tile(sn, cur ^ 1);
@@ -321,17 +423,27 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
                         if (kt + 1 + PF < kt_end) load_tile(sn);
                     }
                 }
-                // smallest terms first
+                // SCH 0: the six bf16 products term by term over the sub-tiles (smallest terms first); SCH 1: three f16 products
+                if constexpr (SCH == 0) {
 #define S3_MMA(QA, QB)                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < TH; ++i) _Pragma("unroll") for (int j = 0; j < TNH; ++j) acc[i0 + i][j0 + j] =  \
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[i][QA]), as_bf(b[j][QB]), acc[i0 + i][j0 + j], 0, 0, 0);
-                S3_MMA(2, 0)
-                S3_MMA(0, 2)
-                S3_MMA(1, 1)
-                S3_MMA(1, 0)
-                S3_MMA(0, 1)
-                S3_MMA(0, 0)
+                    S3_MMA(2, 0)
+                    S3_MMA(0, 2)
+                    S3_MMA(1, 1)
+                    S3_MMA(1, 0)
+                    S3_MMA(0, 1)
+                    S3_MMA(0, 0)
 #undef S3_MMA
+                } else {
+#define S3_MMA(QA, QB)                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TH; ++i) _Pragma("unroll") for (int j = 0; j < TNH; ++j) acc[i0 + i][j0 + j] =  \
+        __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(a[i][QA]), as_hf(b[j][QB]), acc[i0 + i][j0 + j], 0, 0, 0);
+                    S3_MMA(1, 0)
+                    S3_MMA(0, 1)
+                    S3_MMA(0, 0)
+#undef S3_MMA
+                }
             }
         }
         if (FULL) load_tile_advance();
@@ -339,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
             const int done = kt + 1;
             const int zl = done / ktiles_all;
             if (done - zl * ktiles_all == 0) {
-                store_tile_plain<TM, TN>(acc, p.y + (size_t)(zl - 1) * p.zy, p.M, p.Cout, m0, n0, wm0, wn0);
+                store_tile_plain<TM, TN>(acc, p.y + (size_t)(zl - 1) * p.zy, p.M, p.Cout, m0, n0, wm0, wn0, p.out_scale);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -377,6 +489,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
         }
         if (kt < kt_end) slab(kt, 0, s0, TailT());
     }
+    if (SCH) amax_commit(p.amax, amax);
     if (!ZS) conv_epilogue<TM, TN>(p, acc, m0, n0, wm0, wn0);
 }
 
@@ -412,6 +525,17 @@ void launch_conv_s3(int bm, int bn, dim3 grid, hipStream_t st, const ConvP& p_in
     static const bool remap = !(getenv("EGR_S3_XCD") && atoi(getenv("EGR_S3_XCD")) == 0);
     ConvP p = p_in;
     p.xcd_remap = (remap && grid.y > 1 && ((grid.x * grid.y) & 7) == 0) ? 1 : 0;
+    if (p.sch) {                                  // two-term fp16 scheme (PF = 1 only)
+        if (p.zs_nzb > 0) {
+            if (bn == 256) hipLaunchKernelGGL((k_conv_s3<128, 256, 1, true, 1>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((k_conv_s3<128, 128, 1, true, 1>), grid, dim3(256), 0, st, p);
+        } else if (bn == 256) hipLaunchKernelGGL((k_conv_s3<128, 256, 1, false, 1>), grid, dim3(256), 0, st, p);
+        else if (bm == 256) hipLaunchKernelGGL((k_conv_s3<256, 128, 1, false, 1>), grid, dim3(256), 0, st, p);
+        else if (bn == 128) hipLaunchKernelGGL((k_conv_s3<128, 128, 1, false, 1>), grid, dim3(256), 0, st, p);
+        else if (bn == 64) hipLaunchKernelGGL((k_conv_s3<128, 64, 1, false, 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_conv_s3<128, 32, 1, false, 1>), grid, dim3(256), 0, st, p);
+        return;
+    }
     if (p.zs_nzb > 0) {
         if (bn == 256) hipLaunchKernelGGL((k_conv_s3<128, 256, 1, true>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((k_conv_s3<128, 128, 1, true>), grid, dim3(256), 0, st, p);
@@ -430,6 +554,27 @@ void launch_conv_s3(int bm, int bn, dim3 grid, hipStream_t st, const ConvP& p_in
 }  // namespace egr
 
 using namespace egr;
+
+extern "C" int egr_split2h_pack(const float* w_packed, void* w2, int64_t nslabs, int Cout, float scale, void* stream) {
+    EGR_CHECK(w_packed && w2 && nslabs >= 1 && Cout >= 1 && scale > 0.f, EGR_ERR_ARG, "bad split2h pack argument");
+    EGR_CHECK((((uintptr_t)w_packed) & 15) == 0 && (((uintptr_t)w2) & 15) == 0, EGR_ERR_ARG, "split2h pack needs 16-byte alignment");
+    long long nb = (nslabs * Cout * 2 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_split2h_pack, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w_packed, (uint4*)w2,
+                       (long long)nslabs, Cout, scale);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_absmax(const float* x, int64_t n, float* slot, void* stream) {
+    EGR_CHECK(x && slot && n >= 1 && (((uintptr_t)x) & 15) == 0, EGR_ERR_ARG, "bad absmax argument");
+    long long nb = (n / 4 + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_absmax, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, (long long)n, (unsigned*)slot);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
 
 extern "C" int egr_split3_pack(const float* w_packed, void* w3, int64_t nslabs, int Cout, void* stream) {
     EGR_CHECK(w_packed && w3 && nslabs >= 1 && Cout >= 1, EGR_ERR_ARG, "bad split3 pack argument");
@@ -451,12 +596,15 @@ extern "C" int egr_split3_pack(const float* w_packed, void* w3, int64_t nslabs, 
 // ds_read_b128 for any row offset (brute-forced over all offsets for NCH = 2, 4).
 namespace egr {
 
-template <int BN, int CC>
+template <int BN, int CC, int SCH = 0>
 __global__ __launch_bounds__(256, 2) void k_conv1d_s3(ConvP p) {
     typedef S3Cfg<128, BN> TC;
     constexpr int TM = TC::TM, TN = TC::TN, NCH = CC / 8, NSL = CC / 16, RMAX = 128 + 50;
-    __shared__ uint4 As[3][RMAX * NCH];
-    __shared__ uint4 Bs[2][3][BN * 2];
+    constexpr int NP = SCH ? 2 : 3;
+    __shared__ uint4 As[NP][RMAX * NCH];
+    __shared__ uint4 Bs[2][NP][BN * 2];
+    const float a_scale = p.a_scale;
+    float amax = 0.f;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm0 = (wave / TC::WN) * (128 / TC::WM), wn0 = (wave % TC::WN) * (BN / TC::WN);
     const int L = p.W, b = blockIdx.z, l0 = blockIdx.x * 128, n0 = blockIdx.y * BN;
@@ -471,9 +619,9 @@ __global__ __launch_bounds__(256, 2) void k_conv1d_s3(ConvP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // B tiles: 6*BN chunks per slab, up to 3 per thread (as in k_conv_s3)
-    constexpr int NBQ = 6 * BN;
-    const size_t b_slab = (size_t)p.Cout * 6;
+    // B tiles: 2*NP*BN chunks per slab, up to 3 per thread (as in k_conv_s3)
+    constexpr int NBQ = 2 * NP * BN;
+    const size_t b_slab = (size_t)p.Cout * 2 * NP;
     const int cpt = p.Cin / 16;                  // slabs per tap in the weight pack
 #define C1_BSETUP(I, OFF, SLOT, OK)                                                                               \
     size_t OFF;                                                                                                      \
@@ -522,17 +670,31 @@ __global__ __launch_bounds__(256, 2) void k_conv1d_s3(ConvP p) {
         const int cc = sg / spc, s = sg - cc * spc, tap = s / NSL, cs = s - tap * NSL;
         if (s == 0) {                            // new channel chunk: split its halo tile into LDS (all waves are past the
             const int c0 = cc * CC;              // previous chunk: the barrier that ended its last slab)
-            for (int e = tid; e < R * NCH; e += 256) {
+            // every load of the tile is requested before the first one is consumed (a run-time trip count would make each
+            // round wait for its own HBM round trip: two or three serial latencies at the head of every workgroup)
+            constexpr int NIT = (RMAX * NCH + 255) / 256;
+            float4 hu[NIT], hv[NIT];
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int e = tid + 256 * i;
                 const int r = e / NCH, ch = e - r * NCH, pos = pos0 + r;
-                const bool ok = (unsigned)pos < (unsigned)L;
+                const bool ok = e < R * NCH && (unsigned)pos < (unsigned)L;
                 const float* src = ok ? xb + (size_t)pos * p.Cin + c0 + ch * 8 : p.zeros;
-                const float4 u = *(const float4*)src, v = *(const float4*)(src + 4);
-                uint4 q0, q1, q2;
-                split3_x8(u, v, q0, q1, q2);
-                const int slot = r * NCH + (ch ^ ((r / (16 / NCH)) & (NCH - 1)));
-                As[0][slot] = q0;
-                As[1][slot] = q1;
-                As[2][slot] = q2;
+                hu[i] = *(const float4*)src;
+                hv[i] = *(const float4*)(src + 4);
+            }
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int e = tid + 256 * i;
+                if (e < R * NCH) {
+                    const int r = e / NCH, ch = e - r * NCH;
+                    uint4 q[3];
+                    split_x8<SCH>(hu[i], hv[i], a_scale, q);
+                    if (SCH) amax = absmax8(hu[i], hv[i], amax);
+                    const int slot = r * NCH + (ch ^ ((r / (16 / NCH)) & (NCH - 1)));
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) As[pl][slot] = q[pl];
+                }
             }
         }
         __syncthreads();                         // B tile `cur` (stored one iteration ago) and the halo tile are visible
@@ -540,7 +702,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1d_s3(ConvP p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) bq[j][q] = Bs[cur][q][(wn0 + j * 32) * 2 + ob_slot];
+            for (int q = 0; q < NP; ++q) bq[j][q] = Bs[cur][q][(wn0 + j * 32) * 2 + ob_slot];
         uint4 aq[TM][3];
         const int ch = cs * 2 + lk;
 #pragma unroll
@@ -548,20 +710,30 @@ __global__ __launch_bounds__(256, 2) void k_conv1d_s3(ConvP p) {
             const int r = wm0 + i * 32 + li + tap * p.dil;
             const int slot = r * NCH + (ch ^ ((r / (16 / NCH)) & (NCH - 1)));
 #pragma unroll
-            for (int q = 0; q < 3; ++q) aq[i][q] = As[q][slot];
+            for (int q = 0; q < NP; ++q) aq[i][q] = As[q][slot];
         }
         if (sg + 1 < stotal) store_b(cur ^ 1, nx);   // buffer cur^1 was last read in iteration sg-1, before this barrier
         if (sg + 5 < stotal) load_b(sg + 5, nx);
+        if constexpr (SCH == 0) {
 #define C1_MMA(QA, QB)                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =            \
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(aq[i][QA]), as_bf(bq[j][QB]), acc[i][j], 0, 0, 0);
-        C1_MMA(2, 0)
-        C1_MMA(0, 2)
-        C1_MMA(1, 1)
-        C1_MMA(1, 0)
-        C1_MMA(0, 1)
-        C1_MMA(0, 0)
+            C1_MMA(2, 0)
+            C1_MMA(0, 2)
+            C1_MMA(1, 1)
+            C1_MMA(1, 0)
+            C1_MMA(0, 1)
+            C1_MMA(0, 0)
 #undef C1_MMA
+        } else {
+#define C1_MMA(QA, QB)                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =            \
+        __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(aq[i][QA]), as_hf(bq[j][QB]), acc[i][j], 0, 0, 0);
+            C1_MMA(1, 0)
+            C1_MMA(0, 1)
+            C1_MMA(0, 0)
+#undef C1_MMA
+        }
         if (s + 1 == spc) __syncthreads();       // last slab of the chunk: everyone is done with the halo tile
     };
 
@@ -581,6 +753,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1d_s3(ConvP p) {
     if (sg < stotal) slab(sg, s1);
     if (sg + 1 < stotal) slab(sg + 1, s2);
     if (sg + 2 < stotal) slab(sg + 2, s3);
+    if (SCH) amax_commit(p.amax, amax);
     conv_epilogue<TM, TN>(p, acc, b * L + l0, n0, wm0, wn0);
 }
 
@@ -594,15 +767,18 @@ bool launch_conv1d_s3(const ConvP& p, hipStream_t st) {
     const int bn = p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32);
     const dim3 grid(p.W / 128, (p.Cout + bn - 1) / bn, p.B);
     if (p.B > 65535) return false;
-    if (p.Cin % 32 == 0) {
-        if (bn == 128) hipLaunchKernelGGL((k_conv1d_s3<128, 32>), grid, dim3(256), 0, st, p);
-        else if (bn == 64) hipLaunchKernelGGL((k_conv1d_s3<64, 32>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((k_conv1d_s3<32, 32>), grid, dim3(256), 0, st, p);
-    } else {
-        if (bn == 128) hipLaunchKernelGGL((k_conv1d_s3<128, 16>), grid, dim3(256), 0, st, p);
-        else if (bn == 64) hipLaunchKernelGGL((k_conv1d_s3<64, 16>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((k_conv1d_s3<32, 16>), grid, dim3(256), 0, st, p);
+#define C1_LAUNCH(SCH_)                                                                                   \
+    if (p.Cin % 32 == 0) {                                                                                \
+        if (bn == 128) hipLaunchKernelGGL((k_conv1d_s3<128, 32, SCH_>), grid, dim3(256), 0, st, p);       \
+        else if (bn == 64) hipLaunchKernelGGL((k_conv1d_s3<64, 32, SCH_>), grid, dim3(256), 0, st, p);    \
+        else hipLaunchKernelGGL((k_conv1d_s3<32, 32, SCH_>), grid, dim3(256), 0, st, p);                  \
+    } else {                                                                                              \
+        if (bn == 128) hipLaunchKernelGGL((k_conv1d_s3<128, 16, SCH_>), grid, dim3(256), 0, st, p);       \
+        else if (bn == 64) hipLaunchKernelGGL((k_conv1d_s3<64, 16, SCH_>), grid, dim3(256), 0, st, p);    \
+        else hipLaunchKernelGGL((k_conv1d_s3<32, 16, SCH_>), grid, dim3(256), 0, st, p);                  \
     }
+    if (p.sch) { C1_LAUNCH(1) } else { C1_LAUNCH(0) }
+#undef C1_LAUNCH
     return true;
 }
 

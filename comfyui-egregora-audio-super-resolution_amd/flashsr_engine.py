@@ -37,6 +37,10 @@ class FlashSREngine:
     # dense contractions run on the bf16 matrix pipe with fp32-grade results ("bf16x3": exact three-way split of both
     # operands, six partial products accumulated in fp32, csrc/egr_nn_gemm_s3.hip) or on v_mfma_f32_32x32x2_f32 ("f32").
     MFMA_MODE = os.environ.get("EGREGORA_FLASHSR_MFMA", "bf16x3")
+    # operand scheme of egr_flashsr_infer's split contractions: "f16x2" = two fp16 terms with scales measured on the previous call
+    # (first call and range-check failures run the bf16 terms; include/egregora_amd.h egr_flashsr_set_split), "bf16x3" = always
+    # three bf16 terms.  egr_flashsr_forward / the operator API always use the bf16 terms.
+    SPLIT = os.environ.get("EGREGORA_FLASHSR_SPLIT", "f16x2")
     # F(2x2,3x3) paid from 256 channels (its transforms move 4x the tensor); F(4x4,3x3) moves 2.25x and pays from 128
     WINO_MIN_CH = int(os.environ.get("EGREGORA_FLASHSR_WINOGRAD_MIN_CH", "128"))
     WINO_F4 = os.environ.get("EGREGORA_FLASHSR_WINOGRAD_F4", "1") != "0"   # F(4x4,3x3) where H and W are multiples of 4
@@ -92,6 +96,7 @@ class FlashSREngine:
         f |= 0 if self.GN_PARTIALS else native.FSR_NO_GN_PARTIALS
         f |= 0 if self.thin else native.FSR_NO_THIN_ENDS
         f |= native.FSR_NO_FUSE_GN if self.FUSE_GN == "0" else 0
+        f |= native.FSR_SPLIT_BF16X3 if self.SPLIT == "bf16x3" else 0
         return f
 
     @property
@@ -158,6 +163,16 @@ class FlashSREngine:
                                               _p(row_ids.contiguous()) if row_ids is not None else None, _p(y), self._st()),
                      "egr_flashsr_infer")
         return y
+
+    def set_split(self, scheme: str):
+        """"bf16x3" or "f16x2" for the following c_infer calls (the latter needs an engine built with SPLIT = "f16x2")."""
+        native.check(self.L.egr_flashsr_set_split(C.c_void_p(self.handle), 1 if scheme == "f16x2" else 0), "egr_flashsr_set_split")
+
+    def split_info(self) -> dict:
+        en, cal, sl, calls, rr = C.c_int(), C.c_int(), C.c_int(), C.c_int64(), C.c_int64()
+        native.check(self.L.egr_flashsr_split_info(C.c_void_p(self.handle), C.byref(en), C.byref(cal), C.byref(sl), C.byref(calls), C.byref(rr)),
+                     "egr_flashsr_split_info")
+        return dict(enabled=bool(en.value), calibrated=bool(cal.value), slots=sl.value, calls=calls.value, reruns=rr.value)
 
     def c_profile(self, fn) -> dict:
         """{kernel instantiation: (launches, flops, ms)} of the MFMA contraction launches the handle made while fn() ran."""

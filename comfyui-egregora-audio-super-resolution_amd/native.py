@@ -14,7 +14,7 @@ EGR_OK = 0
 FL_NORMALIZE, FL_AUTOSCALE, FL_PCM_IN, FL_NODE_POST = 0x1, 0x2, 0x4, 0x8
 FL_THR_RELATIVE, FL_THR_SOFT, FL_NO_INIT_THR, FL_ZERO_STUFF, FL_INTERP_LINSPACE = 0x10, 0x20, 0x40, 0x80, 0x100      # SPEC.md section 3
 FL_INFO_LEN = 48
-ABI_VERSION = 2          # include/egregora_amd.h EGR_ABI_VERSION
+ABI_VERSION = 3          # include/egregora_amd.h EGR_ABI_VERSION
 
 # name -> (restype, argtypes); must list every symbol of include/egregora_amd.h
 _vp, _i, _i64, _f, _u = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint
@@ -65,6 +65,9 @@ SIGNATURES = {
     "egr_conv_nhwc_placed": (_i, [_vp] * 6 + [_i] * 15 + [_f] + [_i] * 6 + [_vp]),
     "egr_split3_pack": (_i, [_vp, _vp, _i64, _i, _vp]),
     "egr_conv_s3": (_i, [_vp] * 6 + [_i] * 15 + [_f] + [_i] * 7 + [_i64] * 3 + [_vp]),
+    "egr_split2h_pack": (_i, [_vp, _vp, _i64, _i, _f, _vp]),
+    "egr_absmax": (_i, [_vp, _i64, _vp, _vp]),
+    "egr_conv_h2": (_i, [_vp] * 6 + [_i] * 15 + [_f] + [_i] * 7 + [_i64] * 3 + [_f, _f, _vp, _vp]),
     "egr_winograd_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "egr_groupnorm_coeff": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "egr_conv_nhwc_gn": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
@@ -104,6 +107,8 @@ SIGNATURES = {
     "egr_flashsr_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "egr_flashsr_set_rows_per_pass": (_i, [_vp, _i]),
     "egr_flashsr_set_streams": (_i, [_vp, _i, _i]),
+    "egr_flashsr_set_split": (_i, [_vp, _i]),
+    "egr_flashsr_split_info": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "egr_flashsr_set_profiling": (_i, [_vp, _i]),
     "egr_flashsr_profile": (_i, [_vp, _i, C.c_char_p, C.c_size_t, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                  C.POINTER(_i)]),
@@ -116,6 +121,7 @@ SIGNATURES = {
 
 FSR_MAX = 8
 FSR_F32_MFMA, FSR_NO_WINOGRAD, FSR_NO_WINO_F4, FSR_NO_GN_PARTIALS, FSR_NO_THIN_ENDS, FSR_NO_FUSE_GN = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
+FSR_SPLIT_BF16X3 = 0x40
 
 
 class FlashSRConfigC(C.Structure):

@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 /* 2: paired chirp-z plans (egr_fatllama_plan_create_chirpz, info[40..41], egr_fatllama_kernel_times3), model handle, DFN / null-test entry points */
-#define EGR_ABI_VERSION 2
+#define EGR_ABI_VERSION 3
 
 #define EGR_OK 0
 #define EGR_ERR_ARG 1          /* bad argument */
@@ -276,6 +276,24 @@ int egr_conv_nhwc_placed(const float* x, const float* w, const float* bias, cons
  *   egr_conv_s3     : egr_conv_nhwc_placed on w3; requires Cin % 16 == 0.  nz > 1 runs nz independent problems along
  *                     blockIdx.z with offsets zx / zy (floats) and zw3 (16-byte units of w3), as egr_gemm_zbatched does. */
 int egr_split3_pack(const float* w_packed, void* w3, int64_t nslabs, int Cout, void* stream);
+
+/* The same contraction on TWO fp16 terms per operand (scheme 1 of csrc/egr_nn_gemm_s3.hip): x s = h0 + h1 with h0 = f16(x s),
+ * h1 = f16(x s - h0), s a power of two chosen by the caller so that the tensor's largest magnitude sits near 2^12 (fp16 tops out
+ * at 65504); three exact products h0 h0 + h0 h1 + h1 h0 accumulated in fp32 by v_mfma_f32_32x32x16_f16 -- half the matrix
+ * instructions of the three-term bf16 scheme, 22 significand bits per operand for every element within 2^-15 of the tensor's
+ * maximum (absolute error 2^-37 of the maximum below that), measured error vs float64 <= the bf16 scheme's
+ * (tests/test_gpu_split_h2.py).  An operand beyond the fp16 range after scaling gives inf / nan: the caller checks *amax.
+ *   egr_split2h_pack : packed fp32 weights [nslabs][Cout][16] -> w2 [nslabs][2][Cout][16] f16 terms of w * w_scale
+ *   egr_absmax       : raises *slot (a float the caller zeroed) to max |x[i]|, i < n  (x 16-byte aligned)
+ *   egr_conv_h2      : egr_conv_s3 on w2; the loader multiplies x by a_scale, the epilogue divides by a_scale * w_scale (both
+ *                      powers of two) and, when amax is not null, *amax (zeroed by the caller) is raised to max |x| of
+ *                      everything the loader read.  zw2 counts 16-byte units of w2. */
+int egr_split2h_pack(const float* w_packed, void* w2, int64_t nslabs, int Cout, float w_scale, void* stream);
+int egr_absmax(const float* x, int64_t n, float* slot, void* stream);
+int egr_conv_h2(const float* x, const void* w2, const float* bias, const float* bias_b, const float* res, float* y, int B,
+                int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t, int pad_l,
+                int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF, int nz, int64_t zx,
+                int64_t zw2, int64_t zy, float a_scale, float w_scale, float* amax, void* stream);
 int egr_conv_s3(const float* x, const void* w3, const float* bias, const float* bias_b, const float* res, float* y, int B,
                 int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t, int pad_l,
                 int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF, int nz, int64_t zx,
@@ -410,6 +428,7 @@ typedef struct egr_tensor_desc {
 #define EGR_FSR_NO_GN_PARTIALS 0x08u
 #define EGR_FSR_NO_THIN_ENDS   0x10u
 #define EGR_FSR_NO_FUSE_GN     0x20u
+#define EGR_FSR_SPLIT_BF16X3   0x40u /* egr_flashsr_infer never uses the two-term fp16 operand scheme (no fp16 weight terms are kept) */
 int egr_flashsr_default_config(egr_flashsr_config* cfg);       /* the declared full-size table */
 int egr_flashsr_create(egr_flashsr** out, const egr_flashsr_config* cfg, const egr_tensor_desc* tensors, int n_tensors,
                        unsigned flags, void* stream);           /* repacks on `stream`, synchronises before returning */
@@ -427,6 +446,15 @@ int egr_flashsr_infer(egr_flashsr* h, const float* x, int rows, int lowpass_inpu
 int egr_flashsr_forward(egr_flashsr* h, const float* x, const float* noise, int rows, int lowpass_input, float* y, float* const* stages,
                         void* stream);
 int egr_flashsr_set_rows_per_pass(egr_flashsr* h, int rows);
+/* Operand scheme of egr_flashsr_infer's split contractions.  Default (scheme 1): the FIRST call of a handle runs the three-term
+ * bf16 kernels and measures max |x| of every contraction's input; later calls run the two-term fp16 kernels (egr_conv_h2) with each
+ * input scaled from the previous call's maximum (16x headroom), read the new maxima back when the call's work is done (the call
+ * is synchronous with the host from then on) and, if a scaled value left fp16's range, run the whole call again on the bf16
+ * kernels -- so the result never depends on the range of fp16, only the time does.  egr_flashsr_set_split(h, 0) or creation flag
+ * EGR_FSR_SPLIT_BF16X3 or EGREGORA_FLASHSR_SPLIT=bf16x3 keep every call on the bf16 kernels; egr_flashsr_forward always is.
+ * egr_flashsr_split_info: enabled, calibrated (next call uses fp16 terms), contraction slots, infer calls on the scheme, re-runs. */
+int egr_flashsr_set_split(egr_flashsr* h, int scheme);
+int egr_flashsr_split_info(egr_flashsr* h, int* enabled, int* calibrated, int* slots, int64_t* calls, int64_t* reruns);
 /* Concurrent row groups inside egr_flashsr_infer: a pass of >= 2 * min_group_rows rows is split into up to max_groups (1..4,
  * default 2; EGREGORA_FLASHSR_STREAMS) contiguous groups run as simultaneous forwards on side streams the handle creates and
  * verifies to sit on other hardware queues than the caller's; fork / join by events, so the call still looks single-stream. */
