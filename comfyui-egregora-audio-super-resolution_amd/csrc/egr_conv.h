@@ -158,6 +158,114 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
     else conv_epilogue_rows<TM, TN, false>(p, acc, bv, yout, m0, n0, wm0, wn0);
 }
 
+// TRANSPOSED accumulator tiles (kernels that issue mfma(weights, activations): D[i][j] = sum_k w[n = i][k] x[m = j][k]): register r of
+// lane l holds output channel (r&3) + 8*(r>>2) + 4*(l>>5) of pixel l&31, i.e. four CONSECUTIVE channels of one pixel per register
+// quad -- the tile leaves as 16-byte stores (32 per thread at 64 x 128 per wave instead of 128 four-byte ones; bias / residual reads
+// are 16 bytes too).  acc[i][j]: pixels wm0 + 32 i .., channels wn0 + 32 j ..  Cout % 4 != 0 falls back to element stores.
+template <int TM, int TN>
+__device__ __forceinline__ void store_tile_plain_t(f32x16 (&acc)[TM][TN], float* __restrict__ y, int M, int Cout, int m0, int n0, int wm0,
+                                                   int wn0, float os);
+template <int TM, int TN, bool VEC, bool RES>
+__device__ __forceinline__ void conv_epilogue_t_rows(const ConvP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0) {
+    const int lane = threadIdx.x & 63, px = lane & 31, ch4 = 4 * (lane >> 5);
+    const float os = p.out_scale;
+    const bool ident = (p.osy == 1 && p.osx == 1 && p.OHF == p.OH && p.OWF == p.OW);
+    const bool decode = !ident || p.bias_b;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm0 + i * 32 + px;
+        if (m < p.M) {
+            size_t mo = (size_t)m;
+            int b = 0;
+            if (decode) {
+                const int ox = m % p.OW, t = m / p.OW, oy = t % p.OH;
+                b = t / p.OH;
+                if (!ident) mo = ((size_t)b * p.OHF + (size_t)oy * p.osy + p.ooy) * p.OWF + (size_t)ox * p.osx + p.oox;
+            }
+            const size_t rowo = mo * p.Cout;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float4 rv[4];
+                if (RES && VEC) {                    // the residual reads of a 32-channel block go out before any is consumed
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = n0 + wn0 + j * 32 + 8 * g + ch4;
+                        rv[g] = *(const float4*)(p.res + (n < p.Cout ? rowo + n : 0));
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn0 + j * 32 + 8 * g + ch4;
+                    if (VEC) {
+                        if (n < p.Cout) {
+                            float4 v = make_float4(acc[i][j][4 * g] * os, acc[i][j][4 * g + 1] * os, acc[i][j][4 * g + 2] * os, acc[i][j][4 * g + 3] * os);
+                            if (p.bias) { const float4 t = *(const float4*)(p.bias + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                            if (p.bias_b) { const float4 t = *(const float4*)(p.bias_b + (size_t)b * p.Cout + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                            if (RES) { v.x += rv[g].x; v.y += rv[g].y; v.z += rv[g].z; v.w += rv[g].w; }
+                            v.x = apply_act(v.x, p.act, p.act_param); v.y = apply_act(v.y, p.act, p.act_param);
+                            v.z = apply_act(v.z, p.act, p.act_param); v.w = apply_act(v.w, p.act, p.act_param);
+                            *(float4*)(p.y + rowo + n) = v;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.Cout) {
+                                float v = acc[i][j][4 * g + e] * os;
+                                if (p.bias) v += p.bias[n + e];
+                                if (p.bias_b) v += p.bias_b[(size_t)b * p.Cout + n + e];
+                                if (RES) v += p.res[rowo + n + e];
+                                p.y[rowo + n + e] = apply_act(v, p.act, p.act_param);
+                            }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_t(const ConvP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0) {
+    const bool vec = (p.Cout & 3) == 0;
+    if (p.ksplit > 1) {        // raw partial sums; bias / residual / activation are applied by k_splitk_reduce
+        store_tile_plain_t<TM, TN>(acc, p.ws + (size_t)blockIdx.z * p.M * p.Cout, p.M, p.Cout, m0, n0, wm0, wn0, p.out_scale);
+        return;
+    }
+    if (vec) {
+        if (p.res) conv_epilogue_t_rows<TM, TN, true, true>(p, acc, m0, n0, wm0, wn0);
+        else conv_epilogue_t_rows<TM, TN, true, false>(p, acc, m0, n0, wm0, wn0);
+    } else {
+        if (p.res) conv_epilogue_t_rows<TM, TN, false, true>(p, acc, m0, n0, wm0, wn0);
+        else conv_epilogue_t_rows<TM, TN, false, false>(p, acc, m0, n0, wm0, wn0);
+    }
+}
+
+// plain transposed tile store (z-streamed GEMMs: no bias / residual / activation / placement)
+template <int TM, int TN>
+__device__ __forceinline__ void store_tile_plain_t(f32x16 (&acc)[TM][TN], float* __restrict__ y, int M, int Cout, int m0, int n0, int wm0,
+                                                   int wn0, float os) {
+    const int lane = threadIdx.x & 63, px = lane & 31, ch4 = 4 * (lane >> 5);
+    const bool vec = (Cout & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm0 + i * 32 + px;
+        if (m >= M) continue;
+        float* row = y + (size_t)m * Cout;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn0 + j * 32 + 8 * g + ch4;
+                if (vec) {
+                    if (n < Cout) *(float4*)(row + n) = make_float4(acc[i][j][4 * g] * os, acc[i][j][4 * g + 1] * os, acc[i][j][4 * g + 2] * os, acc[i][j][4 * g + 3] * os);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < Cout) row[n + e] = acc[i][j][4 * g + e] * os;
+                }
+            }
+    }
+}
+
 // egr_nn_gemm.hip: 4 KiB of zeros on the current device (created on first use, one per device)
 int zero_page(const float** out);
 

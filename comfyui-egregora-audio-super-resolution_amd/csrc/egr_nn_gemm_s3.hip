@@ -400,6 +400,41 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
         constexpr bool FULL = decltype(full_tag)::value;
         constexpr int TH = TM > 2 ? 1 : TM;                       // A sub-tiles in flight (register budget)
         constexpr int TNH = TN > 2 ? 1 : TN;                      // B sub-tiles in flight
+        if constexpr (SCH == 1 && TM <= 2) {
+            // fp16 scheme: half the matrix instructions per slab make the LDS operand reads the scarce resource (the loop above re-reads
+            // the A operands for every column sub-tile: 24 ds_read_b128 per wave and slab at TN = 4).  Here the wave's A operands are
+            // read ONCE per slab and stay in registers, the B operands of column sub-tile j + 1 are fetched while j multiplies.
+            uint4 a[TM][2], b[2][2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) a[i][q] = As[cur][q][(wm0 + i * 32) * 2 + o_slot];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) b[0][q] = Bs[cur][q][wn0 * 2 + o_slot];
+            if (FULL) {
+                store_tile(sn, cur ^ 1);
+                load_tile_issue(sn);
+            } else {
+                if (kt + 1 < kt_end) store_tile(sn, cur ^ 1);
+                if (kt + 1 + PF < kt_end) load_tile(sn);
+            }
+            // the machine scheduler otherwise sinks the global loads below the MFMAs (two instructions before the barrier), which
+            // leaves them the first few hundred cycles of the NEXT slab to land instead of a whole slab
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (j + 1 < TN) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) b[(j + 1) & 1][q] = Bs[cur][q][(wn0 + (j + 1) * 32) * 2 + o_slot];
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(a[i][1]), as_hf(b[j & 1][0]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(a[i][0]), as_hf(b[j & 1][1]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(a[i][0]), as_hf(b[j & 1][0]), acc[i][j], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int j0 = 0; j0 < TN; j0 += TNH) {
             uint4 b[TNH][3];
@@ -422,6 +457,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
                         if (kt + 1 < kt_end) store_tile(sn, cur ^ 1);
                         if (kt + 1 + PF < kt_end) load_tile(sn);
                     }
+                    // keeps the global loads above the MFMAs (see the fp16 path); the bf16 kernels spill with it (36 bytes per lane
+                    // at 128 x 256) and stay as they were
+                    if constexpr (SCH == 1) __builtin_amdgcn_sched_barrier(0);
                 }
                 // SCH 0: the six bf16 products term by term over the sub-tiles (smallest terms first); SCH 1: three f16 products
                 if constexpr (SCH == 0) {
@@ -446,6 +484,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
                 }
             }
         }
+        }
         if (FULL) load_tile_advance();
         if (ZS) {                                   // last slab of a z problem: store its tile, restart the accumulators
             const int done = kt + 1;
@@ -465,6 +504,148 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
 #endif
     };
 
+    if constexpr (SCH == 1 && TM <= 2 && BM == 128) {
+        // fp16 scheme, 128-row tiles: with half the matrix work per slab the loop was bound by the latency of the activation loads
+        // (every A line is read by one workgroup only -- an HBM / MALL miss -- and had one slab to arrive).  Here the A tile is
+        // requested TWO slabs ahead through two alternating register sets (8 registers each) and the weight tile, an L2 hit shared
+        // by every row tile, one slab ahead; B is issued before A so that the wait for B (vmcnt counts in order) leaves the newer A
+        // request in flight.
+        struct SA { float4 a0, a1; };
+        struct SB { uint4 b0, b1, b2, b3; };
+        static_assert(NBQ <= 1024, "four weight chunks per thread");
+        SA sa0, sa1;
+        SB sb;
+        sb.b0 = sb.b1 = sb.b2 = sb.b3 = make_uint4(0, 0, 0, 0);
+        auto a_issue = [&](SA& r) {
+#ifdef S3_ABL_NOGLOBAL
+            if (c0 > 0 || tap > 0) return;
+#endif
+            const float* sp = aptr0 + astep0 * c0;
+            r.a0 = *(const float4*)sp;
+            r.a1 = *(const float4*)(sp + 4);
+        };
+        auto a_adv = [&]() {
+            c0 += S3_BK;
+            if (c0 >= p.Cin) { c0 = 0; ++tap; set_tap(tap); }
+        };
+        auto b_issue = [&](SB& r) {
+#ifdef S3_ABL_NOGLOBAL
+            if (c0 > S3_BK || tap > 0) return;
+#endif
+            r.b0 = *bptr0;
+            if (256 < NBQ) r.b1 = *bptr1;
+            if (512 < NBQ) r.b2 = *bptr2;
+            if (768 < NBQ) r.b3 = *bptr3;
+        };
+        auto b_adv = [&]() {
+            bptr0 += bstep0;
+            if (256 < NBQ) bptr1 += bstep1;
+            if (512 < NBQ) bptr2 += bstep2;
+            if (768 < NBQ) bptr3 += bstep3;
+        };
+        auto store2 = [&](const SA& ra, const SB& rb, int buf) {
+            uint4 q[3];
+#ifdef S3_ABL_NOSPLIT
+            q[0] = q[1] = make_uint4(__float_as_uint(ra.a0.x), __float_as_uint(ra.a0.y), __float_as_uint(ra.a1.x), __float_as_uint(ra.a1.y));
+#else
+            split_x8<1>(ra.a0, ra.a1, a_scale, q);
+            amax = absmax8(ra.a0, ra.a1, amax);
+#endif
+#ifdef S3_ABL_NOSTORE
+            if (buf > 1)
+#endif
+            {
+            As[buf][0][a_slot] = q[0];
+            As[buf][1][a_slot] = q[1];
+            if (NBQ >= 256 || tid < NBQ) Bs[buf][0][bslot0] = rb.b0;
+            if (NBQ >= 512 || tid + 256 < NBQ) Bs[buf][0][bslot1] = rb.b1;
+            if (NBQ >= 768 || tid + 512 < NBQ) Bs[buf][0][bslot2] = rb.b2;
+            if (768 < NBQ) Bs[buf][0][bslot3] = rb.b3;
+            }
+        };
+        // slab t (local index): MFMAs on LDS buffer cur; tile t+1 = (ra, sb) -> LDS buffer cur^1; B(t+2) -> sb, A(t+3) -> ra
+        auto slab2 = [&](int t, int cur, SA& ra, auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            const int n = kt_end - kt_begin;
+            // the weight tile is the FIRST MFMA operand: accumulator registers run along the output channels (conv_epilogue_t)
+            uint4 a[TM][2], b[2][2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) a[i][q] = As[cur][q][(wm0 + i * 32) * 2 + o_slot];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) b[0][q] = Bs[cur][q][wn0 * 2 + o_slot];
+            if (FULL) {
+                store2(ra, sb, cur ^ 1);
+                b_issue(sb);
+                __builtin_amdgcn_sched_barrier(0);    // B before A in program order: the next slab's wait for B leaves A in flight
+                a_issue(ra);
+            } else {
+                if (t + 1 < n) store2(ra, sb, cur ^ 1);
+                if (t + 2 < n) b_issue(sb);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 3 < n) a_issue(ra);
+            }
+            __builtin_amdgcn_sched_barrier(0);        // the requests stay above the MFMAs
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (j + 1 < TN) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) b[(j + 1) & 1][q] = Bs[cur][q][(wn0 + (j + 1) * 32) * 2 + o_slot];
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(b[j & 1][0]), as_hf(a[i][1]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(b[j & 1][1]), as_hf(a[i][0]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(b[j & 1][0]), as_hf(a[i][0]), acc[i][j], 0, 0, 0);
+            }
+            if (FULL || t + 2 < n) b_adv();
+            if (FULL || t + 3 < n) a_adv();
+            if (ZS) {                                   // last slab of a z problem: store its tile, restart the accumulators
+                const int done = kt_begin + t + 1;
+                const int zl = done / ktiles_all;
+                if (done - zl * ktiles_all == 0) {
+                    store_tile_plain_t<TM, TN>(acc, p.y + (size_t)(zl - 1) * p.zy, p.M, p.Cout, m0, n0, wm0, wn0, p.out_scale);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                }
+            }
+#ifndef S3_ABL_NOBARRIER
+            __syncthreads();
+#endif
+        };
+        typedef std::integral_constant<bool, true> FullT;
+        typedef std::integral_constant<bool, false> TailT;
+        const int n = kt_end - kt_begin;
+        a_issue(sa0); a_adv();
+        b_issue(sb); b_adv();
+        store2(sa0, sb, 0);
+        __syncthreads();
+        sa1 = sa0;
+        if (1 < n) { b_issue(sb); b_adv(); __builtin_amdgcn_sched_barrier(0); a_issue(sa1); a_adv(); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (2 < n) { a_issue(sa0); a_adv(); }
+        int t = 0;
+        for (; t + 4 < n; t += 2) {                  // tile t+1 lives in sa1 for even t, in sa0 for odd t
+            slab2(t, 0, sa1, FullT());
+            slab2(t + 1, 1, sa0, FullT());
+        }
+        if (t < n) { slab2(t, 0, sa1, TailT()); ++t; }
+        if (t < n) { slab2(t, 1, sa0, TailT()); ++t; }
+        if (t < n) { slab2(t, 0, sa1, TailT()); ++t; }
+        if (t < n) { slab2(t, 1, sa0, TailT()); ++t; }
+        amax_commit(p.amax, amax);
+#ifdef S3_ABL_NOEPI
+        if (acc[0][0][0] == 123.456f)
+#endif
+        if (!ZS) conv_epilogue_t<TM, TN>(p, acc, m0, n0, wm0, wn0);
+        return;
+    }
     Stage s0, s1;
     s0.a2 = s0.a3 = s1.a0 = s1.a1 = s1.a2 = s1.a3 = make_float4(0.f, 0.f, 0.f, 0.f);
     s0.b0 = s0.b1 = s0.b2 = s1.b0 = s1.b1 = s1.b2 = make_uint4(0, 0, 0, 0);

@@ -58,7 +58,9 @@ CASES = [(2, 16, 12, 128, 128, 3), (1, 9, 7, 256, 96, 3), (3, 8, 8, 512, 40, 1),
          (2, 8, 4, 640, 640, 3),         # small M, long K: split-K
          (1, 5, 3, 16, 20, 3),
          (1, 24, 16, 64, 512, 3),        # 128 x 256 tile
-         (2, 8, 8, 48, 256, 1)]
+         (2, 8, 8, 48, 256, 1),
+         (2, 6, 6, 32, 30, 3),           # Cout % 4 != 0: element stores
+         (1, 40, 40, 128, 512, 3)]       # ragged M on the 128 x 256 tile
 
 
 @pytest.mark.parametrize("mag", [1.0, 1e-4, 1e4])

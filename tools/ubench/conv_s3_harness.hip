@@ -19,11 +19,15 @@ int main(int argc, char** argv) {
     std::vector<float> h(M * Ci); const bool zero = getenv("S3_ZERO") != nullptr;
     for (auto& v : h) v = zero ? 0.f : (float)rand() / RAND_MAX - 0.5f; hipMemcpy(x, h.data(), M * Ci * 4, hipMemcpyHostToDevice);
     std::vector<float> hw(ns * Co * 16); for (auto& v : hw) v = zero ? 0.f : ((float)rand() / RAND_MAX - 0.5f) * 0.05f; hipMemcpy(wp, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+    const int sch = getenv("S3_SCH") ? atoi(getenv("S3_SCH")) : 0;
+    if (sch) egr_split2h_pack(wp, w3, ns, Co, 8192.f, nullptr); else
     egr_split3_pack(wp, w3, ns, Co, nullptr);
     egr::ConvP p; memset(&p, 0, sizeof(p));
     p.x = x; p.w3 = (const uint4*)w3; p.y = y; p.B = B; p.H = H; p.W = W; p.Cin = Ci; p.OH = H; p.OW = W; p.Cout = Co; p.KH = k; p.KW = k;
     p.stride = 1; p.dil = 1; p.pad_t = k / 2; p.pad_l = k / 2; p.M = (int)M; p.K = (int)K; p.osy = p.osx = 1; p.OHF = H; p.OWF = W;
     p.ksplit = 1; p.kt_per = (int)ns; p.zeros = zeros;
+    p.sch = sch; p.a_scale = sch ? 4096.f : 1.f; p.out_scale = sch ? 1.f / (4096.f * 8192.f) : 1.f; p.amax = nullptr;
+    if (getenv("S3_XCD")) p.xcd_remap = 1;
     const int bn = getenv("S3_BN") ? atoi(getenv("S3_BN")) : (Co > 64 ? 128 : (Co > 32 ? 64 : 32));
     const int bm = getenv("S3_BM") ? atoi(getenv("S3_BM")) : egr::s3_bm(M, Co, bn);
     dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)((Co + bn - 1) / bn));
