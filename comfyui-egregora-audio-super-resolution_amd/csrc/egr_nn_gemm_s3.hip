@@ -400,41 +400,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
         constexpr bool FULL = decltype(full_tag)::value;
         constexpr int TH = TM > 2 ? 1 : TM;                       // A sub-tiles in flight (register budget)
         constexpr int TNH = TN > 2 ? 1 : TN;                      // B sub-tiles in flight
-        if constexpr (SCH == 1 && TM <= 2) {
-            // fp16 scheme: half the matrix instructions per slab make the LDS operand reads the scarce resource (the loop above re-reads
-            // the A operands for every column sub-tile: 24 ds_read_b128 per wave and slab at TN = 4).  Here the wave's A operands are
-            // read ONCE per slab and stay in registers, the B operands of column sub-tile j + 1 are fetched while j multiplies.
-            uint4 a[TM][2], b[2][2];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) a[i][q] = As[cur][q][(wm0 + i * 32) * 2 + o_slot];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) b[0][q] = Bs[cur][q][wn0 * 2 + o_slot];
-            if (FULL) {
-                store_tile(sn, cur ^ 1);
-                load_tile_issue(sn);
-            } else {
-                if (kt + 1 < kt_end) store_tile(sn, cur ^ 1);
-                if (kt + 1 + PF < kt_end) load_tile(sn);
-            }
-            // the machine scheduler otherwise sinks the global loads below the MFMAs (two instructions before the barrier), which
-            // leaves them the first few hundred cycles of the NEXT slab to land instead of a whole slab
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if (j + 1 < TN) {
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) b[(j + 1) & 1][q] = Bs[cur][q][(wn0 + (j + 1) * 32) * 2 + o_slot];
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(a[i][1]), as_hf(b[j & 1][0]), acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(a[i][0]), as_hf(b[j & 1][1]), acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(a[i][0]), as_hf(b[j & 1][0]), acc[i][j], 0, 0, 0);
-            }
-        } else {
 #pragma unroll
         for (int j0 = 0; j0 < TN; j0 += TNH) {
             uint4 b[TNH][3];
@@ -483,7 +448,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
 #undef S3_MMA
                 }
             }
-        }
         }
         if (FULL) load_tile_advance();
         if (ZS) {                                   // last slab of a z problem: store its tile, restart the accumulators
@@ -567,7 +531,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
         auto slab2 = [&](int t, int cur, SA& ra, auto full_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
             const int n = kt_end - kt_begin;
-            // the weight tile is the FIRST MFMA operand: accumulator registers run along the output channels (conv_epilogue_t)
+            // the wave's A operands are read ONCE per slab and stay in registers, the B operands of column sub-tile j + 1 are fetched
+            // while j multiplies (12 ds_read_b128 per wave and slab at TN = 4; the generic loop below re-reads A per sub-tile: 24).
+            // The weight tile is the FIRST MFMA operand: accumulator registers run along the output channels (conv_epilogue_t)
             uint4 a[TM][2], b[2][2];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -907,9 +873,10 @@ __global__ __launch_bounds__(256, 2) void k_conv1d_s3(ConvP p) {
             C1_MMA(0, 0)
 #undef C1_MMA
         } else {
+            // weights as the first operand: transposed accumulators, 16-byte stores (conv_epilogue_t)
 #define C1_MMA(QA, QB)                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =            \
-        __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(aq[i][QA]), as_hf(bq[j][QB]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(bq[j][QB]), as_hf(aq[i][QA]), acc[i][j], 0, 0, 0);
             C1_MMA(1, 0)
             C1_MMA(0, 1)
             C1_MMA(0, 0)
@@ -934,8 +901,12 @@ __global__ __launch_bounds__(256, 2) void k_conv1d_s3(ConvP p) {
     if (sg < stotal) slab(sg, s1);
     if (sg + 1 < stotal) slab(sg + 1, s2);
     if (sg + 2 < stotal) slab(sg + 2, s3);
-    if (SCH) amax_commit(p.amax, amax);
-    conv_epilogue<TM, TN>(p, acc, b * L + l0, n0, wm0, wn0);
+    if (SCH) {
+        amax_commit(p.amax, amax);
+        conv_epilogue_t<TM, TN>(p, acc, b * L + l0, n0, wm0, wn0);
+    } else {
+        conv_epilogue<TM, TN>(p, acc, b * L + l0, n0, wm0, wn0);
+    }
 }
 
 // true when the input-stationary 1-D kernel applies; launches it
