@@ -376,8 +376,11 @@ def main():
         conv_tfs = fconv / (tconv * 1e-3) / 1e12 if tconv > 0 else 0.0      # fp32-equivalent (algorithmic) rate
         # k_conv_s3 executes SIX bf16 MFMA products per fp32 multiply-add: its roofline is the dense bf16 peak and
         # `achieved` counts the executed bf16 flops (6 x algorithmic)
+        # (the two-term fp16 scheme -- kernel names ending in ", 1>" -- executes THREE f16 products; same dense peak)
         s3 = dom_conv.startswith("k_conv_s3") or dom_conv.startswith("k_conv1d_s3")
-        mfma_mult, mfma_peak = (6.0, MFMA_BF16_PEAK_TFS) if s3 else (1.0, MFMA_F32_PEAK_TFS)
+        h2 = s3 and dom_conv.endswith(", 1>")
+        split = eng.split_info() if eng.mfma != "f32" else {"enabled": False}
+        mfma_mult, mfma_peak = ((3.0 if h2 else 6.0), MFMA_BF16_PEAK_TFS) if s3 else (1.0, MFMA_F32_PEAK_TFS)
         # the loop runs the channels as two concurrent pipelines (one launch = C/2 channels) unless EGR_FL_STREAMS=1
         groups = 2 if (C >= 2 and os.environ.get("EGR_FL_STREAMS", "2") != "1") else 1
         row_bytes = 8.0 * SEG * C / groups
@@ -400,7 +403,7 @@ def main():
         out = {
             "metric": METRIC, "value": args.steps * audio_s / el, "unit": "audio-sec/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
-            "scaling": "strong" if c4 else "weak", "vs_baseline": None, "dtype": "f32" if eng.mfma == "f32" else "f32(bf16x3)",
+            "scaling": "strong" if c4 else "weak", "vs_baseline": None, "dtype": "f32" if eng.mfma == "f32" else ("f32(f16x2)" if split.get("enabled") else "f32(bf16x3)"),
             "data": "synthetic",
             "config": {"workload": ("c4: BASELINE configs[3], ONE 10 min stereo 48 kHz file, FlashSR (5.12 s chunks, hop 4.62 s, "
                                     "student_ldm 1-step + VAE + sr_vocoder, declared architecture, synthetic weights) chunk-sharded over "
@@ -413,10 +416,15 @@ def main():
                                    + (f" [only={args.only}]" if args.only and not c4 else ""),
                        "flashsr_executor": "egr_flashsr_infer (C ABI, csrc/egr_flashsr.cpp)",
                        "lsd_800_vs_1_iteration_db": lsd_iters[0],
-                       "mfma": ("fp32 operands split exactly into three bf16 terms, six partial products on "
-                                "v_mfma_f32_32x32x16_bf16 with fp32 accumulation: error vs float64 <= the f32-MFMA kernel's "
-                                "(tests/test_gpu_flashsr.py::test_split3_conv_error_vs_float64)") if eng.mfma != "f32"
+                       "mfma": (("fp32 operands as two fp16 terms of the operand scaled from the previous call's measured maximum, three "
+                                 "partial products on v_mfma_f32_32x32x16_f16 with fp32 accumulation, range verified after every call "
+                                 "(re-run on the bf16 terms otherwise): error vs float64 <= 1.25x the f32-MFMA kernel's "
+                                 "(tests/test_gpu_split_h2.py); first call of a handle: ") if split.get("enabled") else "") +
+                                ("fp32 operands split exactly into three bf16 terms, six partial products on "
+                                 "v_mfma_f32_32x32x16_bf16 with fp32 accumulation: error vs float64 <= the f32-MFMA kernel's "
+                                 "(tests/test_gpu_flashsr.py::test_split3_conv_error_vs_float64)") if eng.mfma != "f32"
                        else "v_mfma_f32_32x32x2_f32",
+                       "flashsr_split": split,
                        "arch": arch, "chunks": n_chunks, "rows_per_pass": E.ROWS_PER_PASS,
                        "fatllama_split": [info["M1"], info["M2"]]},
             "parts": {
@@ -437,7 +445,7 @@ def main():
             # dominant kernel of the step: the implicit-GEMM convolution (all dense contractions of FlashSR)
             "roofline": {"bound": "mfma", "kernel": dom_conv, "achieved": conv_tfs * mfma_mult, "peak": mfma_peak,
                          "unit": "TFLOP/s", "frac": conv_tfs * mfma_mult / mfma_peak, "traffic": conv_traffic,
-                         "mfma_dtype": "bf16 (6 executed products per fp32 multiply-add)" if s3 else "f32",
+                         "mfma_dtype": ("f16 (3 executed products per fp32 multiply-add)" if h2 else "bf16 (6 executed products per fp32 multiply-add)") if s3 else "f32",
                          "fp32_equivalent_tflops": conv_tfs, "vs_f32_mfma_peak": conv_tfs / MFMA_F32_PEAK_TFS,
                          "launches": nconv, "flops_total": fconv, "ms_total": tconv,
                          "avg_flops_per_launch": fconv / max(1, nconv), "avg_launch_ms": tconv / max(1, nconv)},

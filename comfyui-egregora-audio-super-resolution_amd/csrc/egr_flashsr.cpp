@@ -206,6 +206,7 @@ struct egr_flashsr {
     bool h2 = true;                                   // scheme available (off: EGR_FSR_SPLIT_BF16X3, EGREGORA_FLASHSR_SPLIT=bf16x3, f32 MFMA)
     int h2_mode = -1;                                 // of the forward being enqueued: -1 bf16 terms, 0 bf16 terms + measure, 1 fp16 terms
     bool h2_cal = false;                              // amax_prev holds a measurement
+    bool h2_fwd = false;                              // egr_flashsr_forward too runs the fp16 terms once measured (set_split 2: stage taps for tests)
     int h2_nslots = 0;
     unsigned* d_amax = nullptr;
     float* h_amax = nullptr;                          // pinned
@@ -1261,8 +1262,13 @@ extern "C" int egr_flashsr_forward(egr_flashsr* m, const float* x, const float* 
     m->ctxs[0]->st = (hipStream_t)stream;
     m->use(m->ctxs[0].get());
     ForwardGuard guard(m->device, m->st);
-    m->h2_mode = -1;                                  // the introspection walk stays on the three-term kernels (bit-equal to the operator API)
-    return forward(m, x, noise, rows, lowpass, y, stages);
+    // the introspection walk stays on the three-term kernels (bit-equal to the operator API) unless egr_flashsr_set_split(h, 2) asked
+    // for the scales of the last egr_flashsr_infer call (no range verification here: stage taps for the tests)
+    m->h2_mode = (m->h2 && m->h2_fwd && m->h2_cal && m->h2_nslots > 0 && (int)m->scale_cur.size() == m->h2_nslots) ? 1 : -1;
+    if (m->h2_mode == 1) m->scale_used.assign(m->h2_nslots, 0.f);
+    const int rc = forward(m, x, noise, rows, lowpass, y, stages);
+    m->h2_mode = -1;
+    return rc;
 }
 
 // x [rows][chunk] -> y [rows][chunk]; rows = chunks x channels ride the batch dimension (reference :366-368) and are processed
@@ -1369,11 +1375,14 @@ extern "C" int egr_flashsr_split_info(egr_flashsr* m, int* enabled, int* calibra
     return EGR_OK;
 }
 
-// scheme: 0 = three bf16 terms always, 1 = two fp16 terms with measured scales (needs a handle created with the scheme available)
+// scheme: 0 = three bf16 terms always, 1 = two fp16 terms with measured scales (needs a handle created with the scheme available),
+// 2 = as 1 and egr_flashsr_forward uses the scales of the last egr_flashsr_infer call as well (unverified: stage taps for tests)
 extern "C" int egr_flashsr_set_split(egr_flashsr* m, int scheme) {
-    EGR_CHECK(m && (scheme == 0 || scheme == 1), EGR_ERR_ARG, "bad argument");
+    EGR_CHECK(m && scheme >= 0 && scheme <= 2, EGR_ERR_ARG, "bad argument");
     EGR_CHECK(scheme == 0 || m->h2_nslots > 0, EGR_ERR_UNSUPPORTED, "this handle holds no fp16 weight terms");
+    if (scheme == 2) { m->h2 = true; m->h2_fwd = true; return EGR_OK; }     // keeps the measured scales
     m->h2 = scheme == 1;
+    m->h2_fwd = false;
     m->h2_cal = false;
     m->scale_cur.assign(m->scale_cur.size(), 0.f);
     return EGR_OK;

@@ -166,7 +166,8 @@ class FlashSREngine:
 
     def set_split(self, scheme: str):
         """"bf16x3" or "f16x2" for the following c_infer calls (the latter needs an engine built with SPLIT = "f16x2")."""
-        native.check(self.L.egr_flashsr_set_split(C.c_void_p(self.handle), 1 if scheme == "f16x2" else 0), "egr_flashsr_set_split")
+        code = {"bf16x3": 0, "f16x2": 1, "f16x2+forward": 2}[scheme]     # the last: c_forward too uses the measured fp16 scales (tests)
+        native.check(self.L.egr_flashsr_set_split(C.c_void_p(self.handle), code), "egr_flashsr_set_split")
 
     def split_info(self) -> dict:
         en, cal, sl, calls, rr = C.c_int(), C.c_int(), C.c_int(), C.c_int64(), C.c_int64()

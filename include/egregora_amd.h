@@ -452,6 +452,8 @@ int egr_flashsr_set_rows_per_pass(egr_flashsr* h, int rows);
  * is synchronous with the host from then on) and, if a scaled value left fp16's range, run the whole call again on the bf16
  * kernels -- so the result never depends on the range of fp16, only the time does.  egr_flashsr_set_split(h, 0) or creation flag
  * EGR_FSR_SPLIT_BF16X3 or EGREGORA_FLASHSR_SPLIT=bf16x3 keep every call on the bf16 kernels; egr_flashsr_forward always is.
+ * egr_flashsr_set_split(h, 2): as scheme 1, and egr_flashsr_forward runs the fp16 kernels too with the scales of the last
+ * egr_flashsr_infer call (no range verification: per-stage taps of the fp16 path for the tests).
  * egr_flashsr_split_info: enabled, calibrated (next call uses fp16 terms), contraction slots, infer calls on the scheme, re-runs. */
 int egr_flashsr_set_split(egr_flashsr* h, int scheme);
 int egr_flashsr_split_info(egr_flashsr* h, int* enabled, int* calibrated, int* slots, int64_t* calls, int64_t* reruns);

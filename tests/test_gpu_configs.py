@@ -53,8 +53,18 @@ def test_c4_ten_minutes_stereo_long_form(pack, full_engine):
     assert tuple(y.shape) == (1, 2, total) and out["sample_rate"] == 48000 and y.dtype == torch.float32
     assert bool(torch.isfinite(y).all()) and float(y.abs().max()) > 0
     assert float(y[0, :, 0].abs().max()) == 0.0                       # Q1: Hann endpoint
+    # the first call of a handle runs the three-term bf16 kernels and measures the operand scales, later calls the two-term fp16
+    # kernels (include/egregora_amd.h egr_flashsr_set_split): calls 2 and 3 are bit-identical, call 1 sits fp32 round-off away
     (out2,) = node.run(A, False, "48000")
-    assert torch.equal(out2["waveform"], y)                           # deterministic
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    (out2b,) = node.run(A, False, "48000")
+    dt2 = time.perf_counter() - t0
+    print(f"C4 on one MI355X, steady state (fp16 operand terms): 600 s stereo in {dt2:.2f} s = {600 / dt2:.0f} xRT")
+    assert torch.equal(out2b["waveform"], out2["waveform"])           # deterministic
+    d12 = float((out2["waveform"] - y).abs().max())
+    print(f"C4: max |difference| between the measuring call and the calls after it {d12:.2e} (peak {float(y.abs().max()):.3f}); {full_engine.split_info()}")
+    assert d12 <= 2e-4 * float(y.abs().max())
     old = E.ROWS_PER_PASS
     try:
         E.ROWS_PER_PASS = 14                                          # 19 passes instead of 9, different pass boundaries

@@ -573,6 +573,26 @@ def test_full_size_engine_vs_torch_reference_one_row(pack):
         gt = got_st[k].permute(0, 3, 1, 2)
         assert rel_l2(gt, want_st[k]) <= 5e-4, (k, rel_l2(gt, want_st[k]))
     assert rel_l2(y, want) <= 2e-3, rel_l2(y, want)
+    # The same gates on the PRODUCT call's steady state: egr_flashsr_infer, first call = the walk above (three bf16 terms, measures the
+    # operand maxima), second call = two fp16 terms per operand scaled from those maxima (csrc/egr_nn_gemm_s3.hip scheme 1).
+    ids = torch.zeros(1, dtype=torch.int64, device="cuda")
+    y_first = e.c_infer(x.cuda(), ids, 0)
+    assert torch.equal(y_first, y) and e.split_info()["calibrated"]
+    y_h = e.c_infer(x.cuda(), ids, 0)
+    assert e.split_info()["reruns"] == 0 and not torch.equal(y_h, y)
+    e.set_split("f16x2+forward")
+    h_st = {}
+    y_hf = e.c_forward(x.cuda(), nz, h_st)
+    assert torch.equal(y_hf, y_h)                              # the stage taps below belong to the fp16-term run
+    lsd_h = om.lsd_audio(exact.numpy(), y_h.cpu().numpy())
+    print("fp16 operand terms (steady state of egr_flashsr_infer) vs float64:")
+    for k in ("mel", "z_cond", "v", "z0", "mel_hat", "y"):
+        gt = h_st[k].permute(0, 3, 1, 2).cpu() if h_st[k].dim() == 4 else h_st[k].cpu()
+        eg = rms(gt.double() - ex_st[k])
+        print(f"  {k:8s} {eg:.3e} ratio to torch32 {eg / max(report[k][1], 1e-300):.2f}")
+        assert eg <= 3.0 * report[k][1] + 1e-9 * report[k][3] and eg <= 1e-5 * report[k][3], (k, eg, report[k])
+    print(f"  LSD(HIP fp16 terms, f64) mean/p95 = {lsd_h[0]:.3e} / {lsd_h[1]:.3e} dB")
+    assert lsd_h[0] <= 1e-3 and lsd_h[1] <= 1e-3, lsd_h
 
 
 def test_full_size_engine_shapes_and_determinism(pack):

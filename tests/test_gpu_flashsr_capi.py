@@ -27,7 +27,14 @@ def tiny(pack):
     from egregora_amd import flashsr_arch as A, flashsr_engine as E
     cfg = A.tiny_config()
     P = A.init_params(cfg, 0)
-    e = PyDriverEngine(cfg, P)
+    # bit-for-bit comparisons between egr_flashsr_infer and the operator walk need both on the same kernels: the handle of this
+    # fixture keeps every call on the three-term bf16 kernels (the fp16 scheme of egr_flashsr_infer: tests/test_gpu_split_h2.py)
+    old = E.FlashSREngine.SPLIT
+    E.FlashSREngine.SPLIT = "bf16x3"
+    try:
+        e = PyDriverEngine(cfg, P)
+    finally:
+        E.FlashSREngine.SPLIT = old
     yield e, cfg, P
     e.close()
 
