@@ -15,10 +15,10 @@ grep '^{' $OUT/bench_stats.log | tail -1 > $OUT/bench_stats.json
 # (egr_flashsr_set_profiling runs one group), so the per-kernel averages of this pass are the ones that must agree with it
 EGREGORA_FLASHSR_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_g1 -o chain -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --lean > $OUT/bench_stats_g1.log 2>&1
 grep '^{' $OUT/bench_stats_g1.log | tail -1 > $OUT/bench_stats_g1.json
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o chain -- python bench.py --steps 1 --warmup 0 --iters 20 --no-cpu-baseline --lean > $OUT/bench_pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o chain -- python bench.py --steps 1 --warmup 0 --iters 20 --no-cpu-baseline --lean > $OUT/bench_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o chain -- python bench.py --steps 1 --warmup 1 --iters 20 --no-cpu-baseline --lean > $OUT/bench_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o chain -- python bench.py --steps 1 --warmup 1 --iters 20 --no-cpu-baseline --lean > $OUT/bench_pmc_write.log 2>&1
 # matrix-pipe occupancy of the contraction kernels (north_star: "MFMA-busy counters") and the wait / LDS picture of the Fat-Llama loop
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_mfma -o chain -- python bench.py --steps 1 --warmup 0 --iters 20 --no-cpu-baseline --lean > $OUT/bench_pmc_mfma.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_mfma -o chain -- python bench.py --steps 1 --warmup 1 --iters 20 --no-cpu-baseline --lean > $OUT/bench_pmc_mfma.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc_wait -o chain -- python bench.py --only fatllama --steps 1 --warmup 0 --iters 60 --no-cpu-baseline --lean > $OUT/bench_pmc_wait.log 2>&1
 python tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 python tools/summarize_counters.py $OUT > $OUT/counters.txt 2>&1
