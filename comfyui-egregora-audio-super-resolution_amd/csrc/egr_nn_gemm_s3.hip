@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
             if (512 < NBQ) bptr2 += bstep2;
             if (768 < NBQ) bptr3 += bstep3;
         };
-        auto store2 = [&](const SA& ra, const SB& rb, int buf) {
+        auto storeA = [&](const SA& ra, int buf) {
             uint4 q[3];
 #ifdef S3_ABL_NOSPLIT
             q[0] = q[1] = make_uint4(__float_as_uint(ra.a0.x), __float_as_uint(ra.a0.y), __float_as_uint(ra.a1.x), __float_as_uint(ra.a1.y));
@@ -521,6 +521,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
             {
             As[buf][0][a_slot] = q[0];
             As[buf][1][a_slot] = q[1];
+            }
+        };
+        auto storeB = [&](const SB& rb, int buf) {
+#ifdef S3_ABL_NOSTORE
+            if (buf > 1)
+#endif
+            {
             if (NBQ >= 256 || tid < NBQ) Bs[buf][0][bslot0] = rb.b0;
             if (NBQ >= 512 || tid + 256 < NBQ) Bs[buf][0][bslot1] = rb.b1;
             if (NBQ >= 768 || tid + 512 < NBQ) Bs[buf][0][bslot2] = rb.b2;
@@ -541,18 +548,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
                 for (int q = 0; q < 2; ++q) a[i][q] = As[cur][q][(wm0 + i * 32) * 2 + o_slot];
 #pragma unroll
             for (int q = 0; q < 2; ++q) b[0][q] = Bs[cur][q][wn0 * 2 + o_slot];
+            // The weight tile needs no arithmetic: it goes to LDS and its successor is requested before anything else (pinned: the
+            // machine scheduler otherwise sinks the requests below the MFMAs).  The activation tile's split, its LDS stores and the
+            // request for A(t+3) are left to the scheduler to spread over the MFMAs: that request has two slabs to land, so it may
+            // sit anywhere in this one, and it stays behind B's in program order (the next slab's wait for B leaves it in flight).
             if (FULL) {
-                store2(ra, sb, cur ^ 1);
+                storeB(sb, cur ^ 1);
                 b_issue(sb);
-                __builtin_amdgcn_sched_barrier(0);    // B before A in program order: the next slab's wait for B leaves A in flight
+                __builtin_amdgcn_sched_barrier(0);
+                storeA(ra, cur ^ 1);
                 a_issue(ra);
             } else {
-                if (t + 1 < n) store2(ra, sb, cur ^ 1);
+                if (t + 1 < n) storeB(sb, cur ^ 1);
                 if (t + 2 < n) b_issue(sb);
                 __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < n) storeA(ra, cur ^ 1);
                 if (t + 3 < n) a_issue(ra);
             }
-            __builtin_amdgcn_sched_barrier(0);        // the requests stay above the MFMAs
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if (j + 1 < TN) {
@@ -590,7 +602,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
         const int n = kt_end - kt_begin;
         a_issue(sa0); a_adv();
         b_issue(sb); b_adv();
-        store2(sa0, sb, 0);
+        storeA(sa0, 0);
+        storeB(sb, 0);
         __syncthreads();
         sa1 = sa0;
         if (1 < n) { b_issue(sb); b_adv(); __builtin_amdgcn_sched_barrier(0); a_issue(sa1); a_adv(); }
