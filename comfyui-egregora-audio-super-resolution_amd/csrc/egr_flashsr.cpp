@@ -206,6 +206,7 @@ struct egr_flashsr {
     bool h2 = true;                                   // scheme available (off: EGR_FSR_SPLIT_BF16X3, EGREGORA_FLASHSR_SPLIT=bf16x3, f32 MFMA)
     int h2_mode = -1;                                 // of the forward being enqueued: -1 bf16 terms, 0 bf16 terms + measure, 1 fp16 terms
     bool h2_cal = false;                              // amax_prev holds a measurement
+    int h2_cal_rows = 6;                              // rows of the measuring call (EGREGORA_FLASHSR_CAL_ROWS); the others of that call run fp16 terms
     bool h2_fwd = false;                              // egr_flashsr_forward too runs the fp16 terms once measured (set_split 2: stage taps for tests)
     int h2_nslots = 0;
     unsigned* d_amax = nullptr;
@@ -1210,6 +1211,7 @@ extern "C" int egr_flashsr_create(egr_flashsr** out, const egr_flashsr_config* c
     if (const char* e = getenv("EGREGORA_FLASHSR_WINOGRAD_MIN_CH")) m->wino_min_ch = atoi(e);
     m->h2 = !(flags & (EGR_FSR_F32_MFMA | EGR_FSR_SPLIT_BF16X3));
     if (const char* e = getenv("EGREGORA_FLASHSR_SPLIT")) { if (!strcmp(e, "bf16x3")) m->h2 = false; }
+    if (const char* e = getenv("EGREGORA_FLASHSR_CAL_ROWS")) { const int r = atoi(e); if (r >= 1) m->h2_cal_rows = r; }
     if (const char* e = getenv("EGREGORA_FLASHSR_ROWS")) { const int r = atoi(e); if (r >= 1) m->rows_per_pass = r; }
     build_blocks(m);
     const int down = 1 << (cfg->vae_levels - 1);
@@ -1318,7 +1320,8 @@ static int ensure_side_streams(egr_flashsr* m, hipStream_t caller, int want) {
 // A pass of >= 2 * min_group_rows rows is split into up to max_groups contiguous ROW GROUPS that run as concurrent forwards on the
 // handle's verified side streams, each with its own scratch arena (fork / join by events around the pass): one group's
 // matrix-bound kernels overlap another's HBM-bound ones and fill each other's tails (26 rows: 260 ms in one forward).
-static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uint64_t seed, const int64_t* row_ids, float* y, void* stream);
+static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uint64_t seed, const int64_t* row_ids, int64_t id_base, float* y,
+                      void* stream);
 
 extern "C" int egr_flashsr_infer(egr_flashsr* m, const float* x, int rows, int lowpass, uint64_t seed, const int64_t* row_ids, float* y,
                                  void* stream) {
@@ -1326,7 +1329,7 @@ extern "C" int egr_flashsr_infer(egr_flashsr* m, const float* x, int rows, int l
     hipStream_t st0 = (hipStream_t)stream;
     if (!m->h2 || m->h2_nslots == 0 || m->count_flops) {
         m->h2_mode = -1;
-        return infer_once(m, x, rows, lowpass, seed, row_ids, y, stream);
+        return infer_once(m, x, rows, lowpass, seed, row_ids, 0, y, stream);
     }
     // operand scheme bookkeeping (see the h2 fields of the handle): measure -> scale -> verify, re-run on the bf16 terms if a value
     // left fp16's range.  The read-back makes the call synchronous with the host (one 16 KiB copy).
@@ -1335,19 +1338,20 @@ extern "C" int egr_flashsr_infer(egr_flashsr* m, const float* x, int rows, int l
     m->scale_cur.resize(n, 0.f);
     m->scale_used.assign(n, 0.f);
     ++m->h2_calls;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        m->h2_mode = (m->h2_cal && attempt == 0) ? 1 : 0;
-        EGR_HIP(hipMemsetAsync(m->d_amax, 0, (size_t)n * sizeof(unsigned), st0));
-        const int rc = infer_once(m, x, rows, lowpass, seed, row_ids, y, stream);
-        const int mode = m->h2_mode;
+    const int64_t chunk = m->cfg.chunk;
+    // rows [lo, lo + cnt) in `mode`; reads the maxima back, updates the scales, returns 1 when a scaled value left the fp16 range
+    auto run = [&](int lo, int cnt, int mode) -> int {
+        m->h2_mode = mode;
+        if (hipMemsetAsync(m->d_amax, 0, (size_t)n * sizeof(unsigned), st0) != hipSuccess) return -EGR_ERR_HIP;
+        const int rc = infer_once(m, x + (size_t)lo * chunk, cnt, lowpass, seed, row_ids ? row_ids + lo : nullptr, lo, y + (size_t)lo * chunk, stream);
         m->h2_mode = -1;
-        if (rc != EGR_OK) return rc;
-        EGR_HIP(hipMemcpyAsync(m->h_amax, m->d_amax, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st0));
-        EGR_HIP(hipStreamSynchronize(st0));
-        bool overflow = false;
+        if (rc != EGR_OK) return -rc;
+        if (hipMemcpyAsync(m->h_amax, m->d_amax, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st0) != hipSuccess ||
+            hipStreamSynchronize(st0) != hipSuccess) { set_error("egr_flashsr_infer: reading the operand maxima back failed"); return -EGR_ERR_HIP; }
+        int overflow = 0;
         for (int i = 0; i < n; ++i) {
             const float a = m->h_amax[i];
-            if (mode == 1 && m->scale_used[i] > 0.f && !(a * m->scale_used[i] < 60000.f)) overflow = true;     // also catches inf / nan bits
+            if (mode == 1 && m->scale_used[i] > 0.f && !(a * m->scale_used[i] < 60000.f)) overflow = 1;     // also catches inf / nan bits
             if (a > 0.f && std::isfinite(a)) {
                 m->amax_prev[i] = a;
                 // a scale is kept while the new maximum sits between 2^8 and 2^14 under it (same scale -> same bits for the same
@@ -1357,8 +1361,23 @@ extern "C" int egr_flashsr_infer(egr_flashsr* m, const float* x, int rows, int l
             }
         }
         m->h2_cal = true;
-        if (!overflow) break;
-        ++m->h2_reruns;
+        return overflow;
+    };
+    int lo = 0;
+    if (!m->h2_cal) {            // measuring call: the first h2_cal_rows rows on the bf16 kernels (rows are independent of each other)
+        const int cnt = std::min(rows, std::max(1, m->h2_cal_rows));
+        const int r = run(0, cnt, 0);
+        if (r < 0) return -r;
+        lo = cnt;
+    }
+    if (lo < rows) {
+        int r = run(lo, rows - lo, 1);
+        if (r < 0) return -r;
+        if (r == 1) {            // a value left the fp16 range: these rows again on the bf16 kernels
+            ++m->h2_reruns;
+            r = run(lo, rows - lo, 0);
+            if (r < 0) return -r;
+        }
     }
     return EGR_OK;
 }
@@ -1388,7 +1407,9 @@ extern "C" int egr_flashsr_set_split(egr_flashsr* m, int scheme) {
     return EGR_OK;
 }
 
-static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uint64_t seed, const int64_t* row_ids, float* y, void* stream) {
+// rows of one call; row_ids NULL: implicit ids id_base .. id_base + rows - 1
+static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uint64_t seed, const int64_t* row_ids, int64_t id_base, float* y,
+                      void* stream) {
     hipStream_t st0 = (hipStream_t)stream;
     m->ctxs[0]->st = st0;
     m->use(m->ctxs[0].get());
@@ -1401,9 +1422,9 @@ static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uin
     else
         groups_max = 1;
     Ten ids;                                                      // implicit ids 0 .. rows-1 as a device array (groups need offsets)
-    if (!row_ids && (rows > m->rows_per_pass || groups_max > 1)) {
+    if (!row_ids && (rows > m->rows_per_pass || groups_max > 1 || id_base != 0)) {
         std::vector<int64_t> h(rows);
-        for (int i = 0; i < rows; ++i) h[i] = i;
+        for (int i = 0; i < rows; ++i) h[i] = id_base + i;
         OKR(new_ten(m, ids, {2 * (int64_t)rows}));
         EGR_HIP(hipMemcpyAsync(ids.p, h.data(), (size_t)rows * 8, hipMemcpyHostToDevice, st0));
         EGR_HIP(hipStreamSynchronize(st0));

@@ -244,4 +244,17 @@ def test_handle_scheme_measure_scale_verify(pack):
     assert bool(torch.isfinite(yl2).all())
     eh.set_split("bf16x3")
     assert torch.equal(eh.c_infer(x, None, 4), yb)
+    # A first call with more rows than the measuring part takes (6): rows 0..5 are the bf16 walk bit for bit, the rest of the SAME call
+    # already runs the fp16 terms (ids continue: implicit ids 6..9 = the explicit ones).
+    eh.set_split("f16x2")
+    assert not eh.split_info()["calibrated"]
+    x10 = (0.05 * torch.randn(10, cfg.chunk, generator=g)).cuda()
+    yb10 = eb.c_infer(x10, None, 4)
+    yh10 = eh.c_infer(x10, None, 4)
+    assert torch.equal(yh10[:6], eb.c_infer(x10[:6].contiguous(), None, 4)) and eh.split_info()["calibrated"]
+    assert not torch.equal(yh10[6:], yb10[6:])
+    assert float((yh10 - yb10).double().norm() / yb10.double().norm()) < 2e-4       # (tile choices follow the row count of a forward)
+    yh10e = eh.c_infer(x10, torch.arange(10, dtype=torch.int64, device="cuda"), 4)
+    assert float((yh10e - yb10).double().norm() / yb10.double().norm()) < 2e-4
+    assert torch.equal(yh10e, eh.c_infer(x10, None, 4))
     eh.close(); eb.close()
