@@ -27,7 +27,7 @@ e.set_split("bf16x3")
 yb, tb = timed()
 print("bf16x3: %.1f ms per call" % tb)
 prof_b = e.c_profile(lambda: e.c_infer(x, None, 1))
-print("bit-equal(call 1, bf16x3):", bool(torch.equal(y0, yb)))
+print("bit-equal(rows 0..5 of call 1 = the measuring part, bf16x3):", bool(torch.equal(y0[:6], e.c_infer(x[:6].contiguous(), None, 1))))
 rel = float((yh - yb).double().norm() / yb.double().norm())
 print("rel L2 (f16x2 vs bf16x3) %.3e  max %.3e of peak" % (rel, float((yh - yb).abs().max() / yb.abs().max())))
 l = [OM.lsd_audio(yh[i].cpu().numpy()[None], yb[i].cpu().numpy()[None]) for i in range(4)]
