@@ -1432,8 +1432,11 @@ static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uin
     }
     if (groups_max > 1 && !m->ev_fork) EGR_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     int rc = EGR_OK;
-    for (int lo = 0; lo < rows && rc == EGR_OK; lo += m->rows_per_pass) {
-        const int n = std::min(m->rows_per_pass, rows - lo);
+    // passes of equal size (260 rows at 32 per pass: nine passes of 29 / 28 rows instead of eight of 32 and one of 4)
+    const int npass = (rows + m->rows_per_pass - 1) / m->rows_per_pass;
+    const int per = (rows + npass - 1) / npass;
+    for (int lo = 0; lo < rows && rc == EGR_OK; lo += per) {
+        const int n = std::min(per, rows - lo);
         const int G = std::max(1, std::min(groups_max, n / m->min_group_rows));
         if (G > 1) EGR_HIP(hipEventRecord(m->ev_fork, st0));
         int done_rows = 0;

@@ -258,3 +258,21 @@ def test_handle_scheme_measure_scale_verify(pack):
     assert float((yh10e - yb10).double().norm() / yb10.double().norm()) < 2e-4
     assert torch.equal(yh10e, eh.c_infer(x10, None, 4))
     eh.close(); eb.close()
+
+
+def test_fp16_calls_repeat_bit_for_bit_with_concurrent_row_groups(pack):
+    """The bug class a flaky test found in round 2 (a rare race in shared scratch): 14 rows = two concurrent 7-row groups on side
+    streams, fp16 operand terms with the loaders' atomic maxima, 20 repetitions -- every repetition must give the same bits, and
+    the maxima the handle keeps must not drift (no re-run, scales kept)."""
+    from egregora_amd import flashsr_arch as A, flashsr_engine as E, native
+    cfg = A.tiny_config()
+    e = E.FlashSREngine(cfg, A.init_params(cfg, 0))
+    native.check(e.L.egr_flashsr_set_streams(C.c_void_p(e.handle), 2, 6), "set_streams")
+    x = (0.1 * torch.randn(14, cfg.chunk, generator=torch.Generator().manual_seed(21))).cuda()
+    e.c_infer(x, None, 5)                            # measuring part + the first fp16 rows
+    ref = e.c_infer(x, None, 5)
+    for _ in range(20):
+        assert torch.equal(e.c_infer(x, None, 5), ref)
+    info = e.split_info()
+    assert info["reruns"] == 0 and info["calls"] == 22
+    e.close()
