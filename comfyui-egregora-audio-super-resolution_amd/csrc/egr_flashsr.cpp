@@ -1352,6 +1352,9 @@ extern "C" int egr_flashsr_infer(egr_flashsr* m, const float* x, int rows, int l
         for (int i = 0; i < n; ++i) {
             const float a = m->h_amax[i];
             if (mode == 1 && m->scale_used[i] > 0.f && !(a * m->scale_used[i] < 60000.f)) overflow = 1;     // also catches inf / nan bits
+            // the other end: a tensor whose scaled maximum fell below 1 (4096x quieter than what the scale was measured on, or a
+            // scale measured on silence) would keep fewer than fp32's bits relative to its own maximum
+            if (mode == 1 && m->scale_used[i] > 0.f && a > 0.f && a * m->scale_used[i] < 1.0f) overflow = 1;
             if (a > 0.f && std::isfinite(a)) {
                 m->amax_prev[i] = a;
                 // a scale is kept while the new maximum sits between 2^8 and 2^14 under it (same scale -> same bits for the same

@@ -449,7 +449,7 @@ int egr_flashsr_set_rows_per_pass(egr_flashsr* h, int rows);
 /* Operand scheme of egr_flashsr_infer's split contractions.  Default (scheme 1): the first rows (6; EGREGORA_FLASHSR_CAL_ROWS) of a
  * handle's FIRST call run the three-term bf16 kernels and measure max |x| of every contraction's input; the other rows of that call
  * and all later calls run the two-term fp16 kernels (egr_conv_h2) with each input scaled from the last measured maximum (16x headroom), read the new maxima back when the call's work is done (the call
- * is synchronous with the host from then on) and, if a scaled value left fp16's range, run those rows again on the bf16
+ * is synchronous with the host from then on) and, if a scaled value left fp16's range (or a tensor's scaled maximum fell below 1), run those rows again on the bf16
  * kernels -- so the result never depends on the range of fp16, only the time does.  egr_flashsr_set_split(h, 0) or creation flag
  * EGR_FSR_SPLIT_BF16X3 or EGREGORA_FLASHSR_SPLIT=bf16x3 keep every call on the bf16 kernels; egr_flashsr_forward always is.
  * egr_flashsr_set_split(h, 2): as scheme 1, and egr_flashsr_forward runs the fp16 kernels too with the scales of the last

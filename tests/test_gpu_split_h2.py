@@ -242,6 +242,19 @@ def test_handle_scheme_measure_scale_verify(pack):
     assert eh.split_info()["reruns"] == info["reruns"]
     assert float((yl2 - ybl).double().norm() / ybl.double().norm()) < 2e-5
     assert bool(torch.isfinite(yl2).all())
+    # the other end of the range: silence (all maxima zero: scales kept, nothing to verify) and an input 100 dB below the one the
+    # scales were measured on (re-run on the bf16 kernels unless the model's own normalisation keeps the activations in range)
+    yz = eh.c_infer(torch.zeros_like(x), None, 4)
+    ybz = eb.c_infer(torch.zeros_like(x), None, 4)            # (not silence at the output: the diffusion noise drives the model)
+    assert bool(torch.isfinite(yz).all()) and float((yz - ybz).double().norm() / ybz.double().norm()) < 2e-5
+    xq = 1e-5 * xl
+    ybq = eb.c_infer(xq, None, 4)
+    before = eh.split_info()["reruns"]
+    yq = eh.c_infer(xq, None, 4)
+    if eh.split_info()["reruns"] > before:
+        assert torch.equal(yq, ybq)
+    else:
+        assert float((yq - ybq).double().norm() / (ybq.double().norm() + 1e-30)) < 2e-5
     eh.set_split("bf16x3")
     assert torch.equal(eh.c_infer(x, None, 4), yb)
     # A first call with more rows than the measuring part takes (6): rows 0..5 are the bf16 walk bit for bit, the rest of the SAME call
