@@ -42,13 +42,32 @@ struct ConvP {
     // workgroups of one XCD take the column tiles of ONE row tile back to back, so the activation tile they share is an L2 hit
     int xcd_remap;
     // operand scheme of the split kernels: 0 = three bf16 terms (w3 = egr_split3_pack), 1 = two fp16 terms of the pre-scaled
-    // operands (w3 = egr_split2h_pack(w, w_scale); the loader multiplies x by a_scale, both powers of two).  out_scale
-    // (= 1 / (a_scale w_scale), 1 for every other kernel) multiplies the accumulators before bias / residual / activation;
-    // amax: optional slot raised to max |x| over everything the loader split (scheme 1 only).
+    // operands (w3 = egr_split2h_pack(w, w_scale)).  Scheme 1 scales every BATCH ROW of x by its own power of two, derived in the
+    // kernel from row_amax[m / rows_div] (bits of that row's max |x|, written by the producer or by k_absmax_rows): the scaled
+    // maximum lands in [2^14, 2^15), whatever the level of the row, and the result of a row depends on that row alone.
+    // out_scale (1 / w_scale; 1 for every other kernel) and the row's inverse scale multiply the accumulators before bias /
+    // residual / activation.
     int sch;
-    float a_scale, out_scale;
-    unsigned* amax;
+    float out_scale;
+    const unsigned* row_amax;
+    int rows_div;
+    // scheme 1, optional: out_amax[m / rows_div] is raised to max |y| over the GEMM rows of each batch row (after bias / residual /
+    // activation) -- the row maxima of y for the NEXT split contraction that reads it, without a pass over y.  Not with split-K.
+    unsigned* out_amax;
 };
+
+// scheme 1: the power of two that brings a row whose largest magnitude has the bits `amax_bits` into [2^14, 2^15), and its
+// inverse (both normal floats for every row: the biased exponent e of the maximum is clamped to [15, 254], i.e. rows below 2^-112
+// are treated as 2^-112 -- they are zero for every purpose of the graph -- and inf / nan maxima get a scale that lets them
+// propagate as they would in fp32).  The epilogue applies the inverse and 1 / w_scale as two exact multiplications.
+__device__ __forceinline__ float h2_row_scale(unsigned amax_bits) {
+    const int e = min(max((int)((amax_bits >> 23) & 0xffu), 15), 254);
+    return __uint_as_float((unsigned)(268 - e) << 23);
+}
+__device__ __forceinline__ float h2_row_inv(unsigned amax_bits) {
+    const int e = min(max((int)((amax_bits >> 23) & 0xffu), 15), 254);
+    return __uint_as_float((unsigned)(e - 14) << 23);
+}
 
 __device__ __forceinline__ float apply_act(float v, int act, float prm) {
     switch (act) {
@@ -62,9 +81,10 @@ __device__ __forceinline__ float apply_act(float v, int act, float prm) {
 
 // Output rows of one thread: (i, r) -> pixel m.  RES is compile-time so that the residual loads of a 32-row sub-tile are
 // issued back to back before any of them is consumed (a run-time `if (p.res)` between them serialises the round trips).
-template <int I, int TM, int TN, bool RES>
+// os_tab (OST): per-row output scales of the block tile in LDS, indexed by m - m0 (scheme 1 of the split kernels)
+template <int I, int TM, int TN, bool RES, bool OST>
 __device__ __forceinline__ void conv_epilogue_rows_i(const ConvP& p, f32x16 (&acc)[TM][TN], const float (&bv)[TN], float* yout,
-                                                     int m0, int n0, int wm0, int wn0) {
+                                                     int m0, int n0, int wm0, int wn0, const float* os_tab, unsigned* om_tab = nullptr) {
     const int lane = threadIdx.x & 63, col = lane & 31, rhalf = lane >> 5;
     const bool ident = (p.osy == 1 && p.osx == 1 && p.OHF == p.OH && p.OWF == p.OW);
     const bool decode = !ident || p.bias_b;
@@ -102,34 +122,39 @@ __device__ __forceinline__ void conv_epilogue_rows_i(const ConvP& p, f32x16 (&ac
                 int b;
                 const size_t o = place(m, b);
                 const float* bb = p.bias_b ? p.bias_b + (size_t)b * p.Cout + nb : nullptr;
+                const float os = OST ? os_tab[m - m0] : 1.0f;
+                float vm = 0.f;
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     if (nb + j * 32 < p.Cout) {
-                        float v = fmaf(acc[i][j][r], p.out_scale, bv[j]);       // out_scale = 1: the plain sum
+                        float v = fmaf(OST ? acc[i][j][r] * os : acc[i][j][r], p.out_scale, bv[j]);   // out_scale = 1: the plain sum
                         if (bb) v += bb[j * 32];
                         if (RES) v += rv[r][j];
-                        yout[o + j * 32] = apply_act(v, p.act, p.act_param);
+                        v = apply_act(v, p.act, p.act_param);
+                        yout[o + j * 32] = v;
+                        vm = fmaxf(vm, fabsf(v));
                     }
+                if (OST && om_tab) atomicMax(&om_tab[m / p.rows_div - m0 / p.rows_div], __float_as_uint(vm));
             }
         }
     }
 }
 
-template <int TM, int TN, bool RES>
+template <int TM, int TN, bool RES, bool OST>
 __device__ __forceinline__ void conv_epilogue_rows(const ConvP& p, f32x16 (&acc)[TM][TN], const float (&bv)[TN], float* yout,
-                                                   int m0, int n0, int wm0, int wn0) {
-    conv_epilogue_rows_i<0, TM, TN, RES>(p, acc, bv, yout, m0, n0, wm0, wn0);
-    if constexpr (TM > 1) conv_epilogue_rows_i<1, TM, TN, RES>(p, acc, bv, yout, m0, n0, wm0, wn0);
-    if constexpr (TM > 2) conv_epilogue_rows_i<2, TM, TN, RES>(p, acc, bv, yout, m0, n0, wm0, wn0);
-    if constexpr (TM > 3) conv_epilogue_rows_i<3, TM, TN, RES>(p, acc, bv, yout, m0, n0, wm0, wn0);
+                                                   int m0, int n0, int wm0, int wn0, const float* os_tab, unsigned* om_tab) {
+    conv_epilogue_rows_i<0, TM, TN, RES, OST>(p, acc, bv, yout, m0, n0, wm0, wn0, os_tab, om_tab);
+    if constexpr (TM > 1) conv_epilogue_rows_i<1, TM, TN, RES, OST>(p, acc, bv, yout, m0, n0, wm0, wn0, os_tab, om_tab);
+    if constexpr (TM > 2) conv_epilogue_rows_i<2, TM, TN, RES, OST>(p, acc, bv, yout, m0, n0, wm0, wn0, os_tab, om_tab);
+    if constexpr (TM > 3) conv_epilogue_rows_i<3, TM, TN, RES, OST>(p, acc, bv, yout, m0, n0, wm0, wn0, os_tab, om_tab);
     static_assert(TM <= 4, "add more rows");
 }
 
 // Accumulator layout of every 32x32 MFMA tile: register r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
 // Writes raw split-K partials, or bias + per-row bias + residual + activation at the (possibly strided) output place.
-template <int TM, int TN>
+template <int TM, int TN, bool OST = false>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0,
-                                              float* yb = nullptr) {
+                                              float* yb = nullptr, const float* os_tab = nullptr, unsigned* om_tab = nullptr) {
     float* const yout = yb ? yb : p.y;
     const int lane = threadIdx.x & 63, col = lane & 31, rhalf = lane >> 5;
     if (p.ksplit > 1) {        // raw partial sums; bias / residual / activation are applied by k_splitk_reduce
@@ -141,9 +166,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
                 if (m < p.M) {
                     float* row = wz + (size_t)m * p.Cout + n0 + wn0 + col;
+                    const float os = OST ? os_tab[m - m0] : 1.0f;
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        if (n0 + wn0 + j * 32 + col < p.Cout) row[j * 32] = acc[i][j][r] * p.out_scale;
+                        if (n0 + wn0 + j * 32 + col < p.Cout) row[j * 32] = (OST ? acc[i][j][r] * os : acc[i][j][r]) * p.out_scale;
                 }
             }
         return;
@@ -154,8 +180,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         const int n = n0 + wn0 + j * 32 + col;
         bv[j] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
     }
-    if (p.res) conv_epilogue_rows<TM, TN, true>(p, acc, bv, yout, m0, n0, wm0, wn0);
-    else conv_epilogue_rows<TM, TN, false>(p, acc, bv, yout, m0, n0, wm0, wn0);
+    if (p.res) conv_epilogue_rows<TM, TN, true, OST>(p, acc, bv, yout, m0, n0, wm0, wn0, os_tab, om_tab);
+    else conv_epilogue_rows<TM, TN, false, OST>(p, acc, bv, yout, m0, n0, wm0, wn0, os_tab, om_tab);
 }
 
 // TRANSPOSED accumulator tiles (kernels that issue mfma(weights, activations): D[i][j] = sum_k w[n = i][k] x[m = j][k]): register r of
@@ -164,17 +190,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
 // are 16 bytes too).  acc[i][j]: pixels wm0 + 32 i .., channels wn0 + 32 j ..  Cout % 4 != 0 falls back to element stores.
 template <int TM, int TN>
 __device__ __forceinline__ void store_tile_plain_t(f32x16 (&acc)[TM][TN], float* __restrict__ y, int M, int Cout, int m0, int n0, int wm0,
-                                                   int wn0, float os);
+                                                   int wn0, const float* os_tab, float osw);
 template <int TM, int TN, bool VEC, bool RES>
-__device__ __forceinline__ void conv_epilogue_t_rows(const ConvP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0) {
+__device__ __forceinline__ void conv_epilogue_t_rows(const ConvP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0,
+                                                     const float* os_tab, unsigned* om_tab) {
     const int lane = threadIdx.x & 63, px = lane & 31, ch4 = 4 * (lane >> 5);
-    const float os = p.out_scale;
     const bool ident = (p.osy == 1 && p.osx == 1 && p.OHF == p.OH && p.OWF == p.OW);
     const bool decode = !ident || p.bias_b;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm0 + i * 32 + px;
         if (m < p.M) {
+            const float os = os_tab[wm0 + i * 32 + px], osw = p.out_scale;
             size_t mo = (size_t)m;
             int b = 0;
             if (decode) {
@@ -183,6 +210,7 @@ __device__ __forceinline__ void conv_epilogue_t_rows(const ConvP& p, f32x16 (&ac
                 if (!ident) mo = ((size_t)b * p.OHF + (size_t)oy * p.osy + p.ooy) * p.OWF + (size_t)ox * p.osx + p.oox;
             }
             const size_t rowo = mo * p.Cout;
+            float vm = 0.f;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float4 rv[4];
@@ -198,57 +226,65 @@ __device__ __forceinline__ void conv_epilogue_t_rows(const ConvP& p, f32x16 (&ac
                     const int n = n0 + wn0 + j * 32 + 8 * g + ch4;
                     if (VEC) {
                         if (n < p.Cout) {
-                            float4 v = make_float4(acc[i][j][4 * g] * os, acc[i][j][4 * g + 1] * os, acc[i][j][4 * g + 2] * os, acc[i][j][4 * g + 3] * os);
+                            float4 v = make_float4(acc[i][j][4 * g] * os * osw, acc[i][j][4 * g + 1] * os * osw, acc[i][j][4 * g + 2] * os * osw,
+                                                   acc[i][j][4 * g + 3] * os * osw);
                             if (p.bias) { const float4 t = *(const float4*)(p.bias + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
                             if (p.bias_b) { const float4 t = *(const float4*)(p.bias_b + (size_t)b * p.Cout + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
                             if (RES) { v.x += rv[g].x; v.y += rv[g].y; v.z += rv[g].z; v.w += rv[g].w; }
                             v.x = apply_act(v.x, p.act, p.act_param); v.y = apply_act(v.y, p.act, p.act_param);
                             v.z = apply_act(v.z, p.act, p.act_param); v.w = apply_act(v.w, p.act, p.act_param);
                             *(float4*)(p.y + rowo + n) = v;
+                            vm = fmaxf(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))), vm);
                         }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (n + e < p.Cout) {
-                                float v = acc[i][j][4 * g + e] * os;
+                                float v = acc[i][j][4 * g + e] * os * osw;
                                 if (p.bias) v += p.bias[n + e];
                                 if (p.bias_b) v += p.bias_b[(size_t)b * p.Cout + n + e];
                                 if (RES) v += p.res[rowo + n + e];
-                                p.y[rowo + n + e] = apply_act(v, p.act, p.act_param);
+                                v = apply_act(v, p.act, p.act_param);
+                                p.y[rowo + n + e] = v;
+                                vm = fmaxf(vm, fabsf(v));
                             }
                     }
                 }
             }
+            if (om_tab) atomicMax(&om_tab[m / p.rows_div - m0 / p.rows_div], __float_as_uint(vm));
         }
     }
 }
 
+// om_tab (optional, LDS, zeroed, one word per batch row the block tile touches): raised to max |y| per batch row
 template <int TM, int TN>
-__device__ __forceinline__ void conv_epilogue_t(const ConvP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0) {
+__device__ __forceinline__ void conv_epilogue_t(const ConvP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0,
+                                                const float* os_tab, unsigned* om_tab = nullptr) {
     const bool vec = (p.Cout & 3) == 0;
     if (p.ksplit > 1) {        // raw partial sums; bias / residual / activation are applied by k_splitk_reduce
-        store_tile_plain_t<TM, TN>(acc, p.ws + (size_t)blockIdx.z * p.M * p.Cout, p.M, p.Cout, m0, n0, wm0, wn0, p.out_scale);
+        store_tile_plain_t<TM, TN>(acc, p.ws + (size_t)blockIdx.z * p.M * p.Cout, p.M, p.Cout, m0, n0, wm0, wn0, os_tab, p.out_scale);
         return;
     }
     if (vec) {
-        if (p.res) conv_epilogue_t_rows<TM, TN, true, true>(p, acc, m0, n0, wm0, wn0);
-        else conv_epilogue_t_rows<TM, TN, true, false>(p, acc, m0, n0, wm0, wn0);
+        if (p.res) conv_epilogue_t_rows<TM, TN, true, true>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab);
+        else conv_epilogue_t_rows<TM, TN, true, false>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab);
     } else {
-        if (p.res) conv_epilogue_t_rows<TM, TN, false, true>(p, acc, m0, n0, wm0, wn0);
-        else conv_epilogue_t_rows<TM, TN, false, false>(p, acc, m0, n0, wm0, wn0);
+        if (p.res) conv_epilogue_t_rows<TM, TN, false, true>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab);
+        else conv_epilogue_t_rows<TM, TN, false, false>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab);
     }
 }
 
 // plain transposed tile store (z-streamed GEMMs: no bias / residual / activation / placement)
 template <int TM, int TN>
 __device__ __forceinline__ void store_tile_plain_t(f32x16 (&acc)[TM][TN], float* __restrict__ y, int M, int Cout, int m0, int n0, int wm0,
-                                                   int wn0, float os) {
+                                                   int wn0, const float* os_tab, float osw) {
     const int lane = threadIdx.x & 63, px = lane & 31, ch4 = 4 * (lane >> 5);
     const bool vec = (Cout & 3) == 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm0 + i * 32 + px;
         if (m >= M) continue;
+        const float os = os_tab[wm0 + i * 32 + px];
         float* row = y + (size_t)m * Cout;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -256,13 +292,26 @@ __device__ __forceinline__ void store_tile_plain_t(f32x16 (&acc)[TM][TN], float*
             for (int g = 0; g < 4; ++g) {
                 const int n = n0 + wn0 + j * 32 + 8 * g + ch4;
                 if (vec) {
-                    if (n < Cout) *(float4*)(row + n) = make_float4(acc[i][j][4 * g] * os, acc[i][j][4 * g + 1] * os, acc[i][j][4 * g + 2] * os, acc[i][j][4 * g + 3] * os);
+                    if (n < Cout) *(float4*)(row + n) = make_float4(acc[i][j][4 * g] * os * osw, acc[i][j][4 * g + 1] * os * osw, acc[i][j][4 * g + 2] * os * osw,
+                                                                    acc[i][j][4 * g + 3] * os * osw);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (n + e < Cout) row[n + e] = acc[i][j][4 * g + e] * os;
+                        if (n + e < Cout) row[n + e] = acc[i][j][4 * g + e] * os * osw;
                 }
             }
+    }
+}
+
+// after the epilogue: the block tile's per-batch-row output maxima (LDS, nrows words) go to out_amax[b_first ...] -- one checked
+// atomic per batch row the tile touches.  Every thread of the workgroup must arrive.
+__device__ __forceinline__ void out_amax_commit(const ConvP& p, const unsigned* om_tab, int m0, int bm) {
+    __syncthreads();
+    const int b_first = m0 / p.rows_div, b_last = min(m0 + bm - 1, p.M - 1) / p.rows_div;
+    for (int t = threadIdx.x; t <= b_last - b_first; t += blockDim.x) {
+        const unsigned bits = om_tab[t];
+        unsigned* slot = p.out_amax + (size_t)(b_first + t) * EGR_ROW_AMAX_STRIDE;
+        if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
     }
 }
 

@@ -128,6 +128,9 @@ struct Ten {                       // an fp32 activation owned by the arena (mov
     int64_t d[4] = {0, 0, 0, 0};
     std::shared_ptr<Ten> part;     // GroupNorm partial sums left by the F(4x4) output transform (egr_winograd4_output_stats)
     int part_tiles = 0;
+    // per-batch-row max |x| (bits; a slice of the context's pool, valid until the end of the forward): written by the producer of
+    // the tensor or by the first split contraction that reads it (row_amax_of), reused by every later one
+    mutable unsigned* rs = nullptr;
     Ten() {}
     Ten(const Ten&) = delete;
     Ten& operator=(const Ten&) = delete;
@@ -136,24 +139,24 @@ struct Ten {                       // an fp32 activation owned by the arena (mov
         if (this != &o) {
             release();
             a = o.a; p = o.p; bytes = o.bytes; nd = o.nd; memcpy(d, o.d, sizeof(d)); part = std::move(o.part); part_tiles = o.part_tiles;
+            rs = o.rs; o.rs = nullptr;
             o.a = nullptr; o.p = nullptr; o.bytes = 0;
         }
         return *this;
     }
     ~Ten() { release(); }
-    void release() { if (a && p) a->put(p, bytes); p = nullptr; a = nullptr; part.reset(); }
+    void release() { if (a && p) a->put(p, bytes); p = nullptr; a = nullptr; part.reset(); rs = nullptr; }
     int64_t numel() const { int64_t n = 1; for (int i = 0; i < nd; ++i) n *= d[i]; return n; }
     // non-owning view of the same storage (the owner must outlive it); keeps the GroupNorm partials the owner carries
-    Ten alias() const { Ten v; v.nd = nd; memcpy(v.d, d, sizeof(d)); v.p = p; v.part = part; v.part_tiles = part_tiles; return v; }
+    Ten alias() const { Ten v; v.nd = nd; memcpy(v.d, d, sizeof(d)); v.p = p; v.part = part; v.part_tiles = part_tiles; v.rs = rs; return v; }
     void view(std::initializer_list<int64_t> s) { nd = 0; for (int64_t v : s) d[nd++] = v; }
 };
 
 struct Wt {                        // one entry of the weight store
     float* w = nullptr;            // raw tensor (norms, biases, snake parameters) or fp32 slab-major pack
     void* w3 = nullptr;            // three-way bf16 split of the pack (egr_split3_pack)
-    void* w2 = nullptr;            // two fp16 terms of w * w_scale (egr_split2h_pack); slot: this contraction's amax slot
+    void* w2 = nullptr;            // two fp16 terms of w * w_scale (egr_split2h_pack)
     float w_scale = 1.f;
-    int slot = -1;
     int KH = 0, KW = 0, Cin = 0, Cout = 0;   // logical shape of a packed contraction (Cout = GEMM N)
     int64_t zfloats = 0;           // floats per component of a z-stacked Winograd pack
     int64_t numel = 0;
@@ -172,6 +175,10 @@ struct FsrCtx {
     size_t gn_ws_bytes = 0;
     std::map<int, egr_fatllama_plan*> lp_plans;       // input low-pass: spectral-gain plans per row count
     hipEvent_t done = nullptr;
+    // per-row operand maxima of the forward in flight (fp16 operand scheme): one R-entry slice per measured tensor, zeroed as a
+    // whole when a forward starts
+    unsigned* rs_pool = nullptr;
+    size_t rs_cap = 0, rs_used = 0;
 };
 
 struct egr_flashsr {
@@ -191,6 +198,7 @@ struct egr_flashsr {
     float* window = nullptr; float* filt = nullptr;
     int ldm = 0, lat_h = 0, lat_w = 0;
     float alpha = 0.f, sigma = 0.f;
+    float* d_wmax = nullptr;                          // one float: weight maxima at pack time
     int rows_per_pass = 32;
     int wino_min_ch = 128;
     double flops = 0.0; bool count_flops = false;
@@ -198,21 +206,21 @@ struct egr_flashsr {
     std::vector<ProfRec> prof;
     hipStream_t st = nullptr;                         // stream of the forward being enqueued (= cx->st)
     void use(FsrCtx* c) { cx = c; st = c->st; }
-    // Two-term fp16 operand scheme of egr_flashsr_infer (csrc/egr_nn_gemm_s3.hip, scheme 1).  Every split contraction owns a slot
-    // of d_amax; its loader raises the slot to max |x| of what it split.  The scale of a call's activations comes from the
-    // PREVIOUS call's maxima (largest value near 2^12: a factor 16 of headroom below fp16's 65504); after the call the maxima are
-    // read back and a slot whose scaled maximum left the fp16 range sends the whole call through the three-term bf16 kernels
-    // again (which have fp32's range).  The first call of a handle measures the maxima with k_absmax and runs the bf16 kernels.
+    // Two-term fp16 operand scheme of egr_flashsr_infer (csrc/egr_nn_gemm_s3.hip, scheme 1).  Every batch row of every split
+    // contraction's input is scaled by its own power of two, which the kernel derives from that row's max |x|; the maxima are
+    // written on the device by the tensor's producer (Winograd input transforms) or by one k_absmax_rows pass the first time a
+    // tensor feeds a split contraction (row_amax_of).  Nothing about the scales passes through the host or survives the call:
+    // the result of a row is a function of (weights, that row's input, seed, row id) and of the row count of its forward only
+    // through tile choices; no value can leave fp16's range (the scale comes from the row's own maximum), so there is nothing to
+    // verify or re-run, and the call is as asynchronous as the bf16 one.
     bool h2 = true;                                   // scheme available (off: EGR_FSR_SPLIT_BF16X3, EGREGORA_FLASHSR_SPLIT=bf16x3, f32 MFMA)
-    int h2_mode = -1;                                 // of the forward being enqueued: -1 bf16 terms, 0 bf16 terms + measure, 1 fp16 terms
-    bool h2_cal = false;                              // amax_prev holds a measurement
-    int h2_cal_rows = 6;                              // rows of the measuring call (EGREGORA_FLASHSR_CAL_ROWS); the others of that call run fp16 terms
-    bool h2_fwd = false;                              // egr_flashsr_forward too runs the fp16 terms once measured (set_split 2: stage taps for tests)
-    int h2_nslots = 0;
-    unsigned* d_amax = nullptr;
-    float* h_amax = nullptr;                          // pinned
-    std::vector<float> amax_prev, scale_cur, scale_used;   // scale_cur: kept while the scaled maximum stays inside [2^8, 2^14]
-    int64_t h2_reruns = 0, h2_calls = 0;
+    int h2_mode = -1;                                 // of the forward being enqueued: -1 bf16 terms, 1 fp16 terms
+    bool h2_fwd = false;                              // egr_flashsr_forward too runs the fp16 terms (set_split 2: stage taps for tests)
+    int h2_nweights = 0;                              // contraction weights that hold fp16 terms
+    int R = 1;                                        // batch rows of the forward being enqueued
+    bool out_amax_on = true;                          // contraction epilogues leave the row maxima of their outputs (EGREGORA_FLASHSR_OUT_AMAX=0: off)
+    bool next_out_ra = false;                         // set by a call site whose output feeds another split contraction directly; consumed by the next conv()
+    int64_t h2_calls = 0;
 
     bool f32_mfma() const { return (flags & EGR_FSR_F32_MFMA) != 0; }
     bool has(const std::string& k) const { return W.find(k) != W.end(); }
@@ -283,8 +291,6 @@ void build_blocks(M* m) {
 int up_kernel(int r) { return 2 * r + (r % 2); }
 
 // ------------------------------------------------------------------------------------------------ weight packing
-constexpr int H2_MAX_SLOTS = 4096;
-
 // power of two that brings a tensor whose largest magnitude is amax to (2^(e-1), 2^e]; 1 for an empty / non-finite measurement
 float h2_scale_for(float amax, int e) {
     if (!(amax > 0.f) || !std::isfinite(amax)) return 1.f;
@@ -292,7 +298,7 @@ float h2_scale_for(float amax, int e) {
     const float fr = frexpf(amax, &ex);              // amax = fr 2^ex, fr in [0.5, 1)
     if (fr == 0.5f) --ex;                            // exact power of two: 2^(ex-1)
     int k = e - ex;
-    k = std::max(-100, std::min(100, k));
+    k = std::max(-60, std::min(60, k));
     return ldexpf(1.f, k);
 }
 
@@ -303,27 +309,19 @@ int split3(M* m, Wt& w) {
     OKR(dev_alloc(m, (size_t)ns * 3 * w.Cout * 16 * 2, &p3));
     OKR(egr_split3_pack(w.w, p3, ns, w.Cout, m->st));
     w.w3 = p3;
-    if (m->h2 && m->h2_nslots < H2_MAX_SLOTS) {      // fp16 terms of w * 2^k, k from the pack's largest magnitude
-        if (!m->d_amax) {
-            if (hipMalloc((void**)&m->d_amax, (H2_MAX_SLOTS + 1) * sizeof(unsigned)) != hipSuccess ||
-                hipHostMalloc((void**)&m->h_amax, (H2_MAX_SLOTS + 1) * sizeof(float)) != hipSuccess) {
-                set_error("hipMalloc(amax slots) failed");
-                return EGR_ERR_ALLOC;
-            }
-            EGR_HIP(hipMemsetAsync(m->d_amax, 0, (H2_MAX_SLOTS + 1) * sizeof(unsigned), m->st));
-        }
-        float* tmp = (float*)(m->d_amax + H2_MAX_SLOTS);
+    if (m->h2) {                                      // fp16 terms of w * 2^k, k from the pack's largest magnitude
+        if (!m->d_wmax && hipMalloc((void**)&m->d_wmax, sizeof(float)) != hipSuccess) { set_error("hipMalloc(weight maximum) failed"); return EGR_ERR_ALLOC; }
         float wmax = 0.f;
-        EGR_HIP(hipMemsetAsync(tmp, 0, sizeof(float), m->st));
-        OKR(egr_absmax(w.w, w.numel, tmp, m->st));
-        EGR_HIP(hipMemcpyAsync(&wmax, tmp, sizeof(float), hipMemcpyDeviceToHost, m->st));
+        EGR_HIP(hipMemsetAsync(m->d_wmax, 0, sizeof(float), m->st));
+        OKR(egr_absmax(w.w, w.numel, m->d_wmax, m->st));
+        EGR_HIP(hipMemcpyAsync(&wmax, m->d_wmax, sizeof(float), hipMemcpyDeviceToHost, m->st));
         EGR_HIP(hipStreamSynchronize(m->st));
         w.w_scale = h2_scale_for(wmax, 13);
         void* p2 = nullptr;
         OKR(dev_alloc(m, (size_t)ns * 2 * w.Cout * 16 * 2, &p2));
         OKR(egr_split2h_pack(w.w, p2, ns, w.Cout, w.w_scale, m->st));
         w.w2 = p2;
-        w.slot = m->h2_nslots++;
+        ++m->h2_nweights;
     }
     return EGR_OK;
 }
@@ -483,18 +481,57 @@ const void* s3_of(const M* m, const Wt* w, int Cin, const float* x) {
 
 // One split contraction (egr_conv_s3's argument list; zfloats: floats per z problem of a stacked pack, 0 otherwise) in the operand
 // scheme of the forward being enqueued.  *h2 tells the profiler which kernel family ran.
-int s3_launch(M* m, const Wt* w, const float* x, int64_t x_numel, const float* bias, const float* res, float* y, int B, int H, int W, int Cin,
+// R-entry slice of the context's pool of per-row maxima (zero at the start of the forward)
+unsigned* rs_take(M* m) {
+    FsrCtx* c = m->cx;
+    if (c->rs_used + (size_t)m->R * EGR_ROW_AMAX_STRIDE > c->rs_cap) { set_error("FlashSR: pool of per-row operand maxima exhausted (%zu entries)", c->rs_cap); return nullptr; }
+    unsigned* p = c->rs_pool + c->rs_used;
+    c->rs_used += (size_t)m->R * EGR_ROW_AMAX_STRIDE;
+    return p;
+}
+
+// slice for the row maxima of a tensor an element-wise producer is about to write (null outside the fp16 scheme)
+int rs_for_output(M* m, Ten& y, float** ra) {
+    *ra = nullptr;
+    if (!(m->h2 && m->h2_mode == 1 && m->out_amax_on) || y.numel() % m->R != 0) return EGR_OK;
+    y.rs = rs_take(m);
+    if (!y.rs) return EGR_ERR_ALLOC;
+    *ra = (float*)y.rs;
+    return EGR_OK;
+}
+
+// per-batch-row max |x| of a tensor whose leading dimension runs over the R rows of the forward (nz > 1: nz blocks zx floats
+// apart, the Winograd V layout); measured once per tensor, reused by every later contraction that reads it
+int row_amax_of(M* m, const float* x, int64_t numel, int nz, int64_t zx, unsigned** slot) {
+    if (*slot) return EGR_OK;
+    EGR_CHECK(numel % m->R == 0, EGR_ERR_ARG, "FlashSR: a tensor of %lld elements does not split into %d batch rows", (long long)numel, m->R);
+    unsigned* p = rs_take(m);
+    if (!p) return EGR_ERR_ALLOC;
+    OKR(egr_absmax_rows(x, m->R, numel / m->R, nz, zx, (float*)p, m->st));
+    *slot = p;
+    return EGR_OK;
+}
+
+// y_rs (optional): the launch leaves the per-row maxima of y there (fp16 scheme, nz == 1; a fresh slice is taken when *y_rs is null
+// -- the four phase launches of an up-sampling convolution share one)
+int s3_launch(M* m, const Wt* w, const float* x, int64_t x_numel, unsigned** x_rs, const float* bias, const float* res, float* y, int B, int H, int W, int Cin,
               int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t, int pad_l, int up2, int act, float act_param, int osy, int osx,
-              int ooy, int oox, int OHF, int OWF, int nz, int64_t zx, int64_t zfloats, int64_t zy, bool* h2 = nullptr) {
-    const bool can = m->h2 && w->w2 && w->slot >= 0;
-    if (h2) *h2 = can && m->h2_mode == 1;
-    if (can && m->h2_mode == 1) {
-        const float a_scale = m->scale_cur[w->slot] > 0.f ? m->scale_cur[w->slot] : 1.f;
-        m->scale_used[w->slot] = a_scale;
+              int ooy, int oox, int OHF, int OWF, int nz, int64_t zx, int64_t zfloats, int64_t zy, bool* h2 = nullptr, unsigned** y_rs = nullptr) {
+    const bool use = m->h2 && w->w2 && m->h2_mode == 1 && ((int64_t)B * OH * OW) % m->R == 0;
+    if (h2) *h2 = use;
+    if (use) {
+        unsigned* local = nullptr;
+        if (!x_rs) x_rs = &local;
+        OKR(row_amax_of(m, x, nz > 1 ? x_numel / nz : x_numel, nz, zx, x_rs));
+        float* out_ra = nullptr;
+        if (y_rs && nz == 1 && m->out_amax_on) {
+            if (!*y_rs) *y_rs = rs_take(m);
+            if (!*y_rs) return EGR_ERR_ALLOC;
+            out_ra = (float*)*y_rs;
+        }
         return egr_conv_h2(x, w->w2, bias, nullptr, res, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act, act_param, osy,
-                           osx, ooy, oox, OHF, OWF, nz, zx, zfloats * 2 / 8, zy, a_scale, w->w_scale, (float*)(m->d_amax + w->slot), m->st);
+                           osx, ooy, oox, OHF, OWF, nz, zx, zfloats * 2 / 8, zy, w->w_scale, (const float*)*x_rs, m->R, out_ra, m->st);
     }
-    if (can && m->h2_mode == 0) OKR(egr_absmax(x, x_numel, (float*)(m->d_amax + w->slot), m->st));
     return egr_conv_s3(x, w->w3, bias, nullptr, res, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act, act_param, osy, osx,
                        ooy, oox, OHF, OWF, nz, zx, zfloats * 3 / 8, zy, m->st);
 }
@@ -509,6 +546,8 @@ int conv(M* m, Ten& y, const Ten& x, const std::string& wkey, int B, int H, int 
          int stride = 1, int dil = 1, int pad_t = 0, int pad_l = 0, int up2 = 0, int act = ACT_NONE, bool bias = true,
          const float* bias_t = nullptr, const float* res = nullptr, float act_param = 0.f, const Wt* wk = nullptr) {
     OKR(new_ten(m, y, {B, OH, OW, Cout}));
+    const bool want_out_amax = m->next_out_ra;
+    m->next_out_ra = false;
     const Wt* w = wk ? wk : m->get(wkey + ".weight");
     EGR_CHECK(w != nullptr, EGR_ERR_ARG, "FlashSR: weight %s.weight missing", wkey.c_str());
     const float* bt = bias_t ? bias_t : (bias && !wk ? m->ptr(wkey + ".bias") : nullptr);
@@ -517,8 +556,8 @@ int conv(M* m, Ten& y, const Ten& x, const std::string& wkey, int B, int H, int 
     const void* w3 = s3_of(m, w, Cin, x.p);
     bool h2 = false;
     if (w3) {
-        OKR(s3_launch(m, w, x.p, (int64_t)B * H * W * Cin, bt, res, y.p, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act,
-                      act_param, 1, 1, 0, 0, OH, OW, 1, 0, 0, 0, &h2));
+        OKR(s3_launch(m, w, x.p, (int64_t)B * H * W * Cin, &x.rs, bt, res, y.p, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act,
+                      act_param, 1, 1, 0, 0, OH, OW, 1, 0, 0, 0, &h2, want_out_amax ? &y.rs : nullptr));
     } else {
         EGR_CHECK(w->w != nullptr, EGR_ERR_ARG, "FlashSR: no fp32 pack for %s", wkey.c_str());
         OKR(egr_conv_nhwc(x.p, w->w, bt, nullptr, res, y.p, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act, act_param,
@@ -560,7 +599,9 @@ int groupnorm(M* m, Ten& y, const Ten& x, const std::string& key, float eps, boo
     y.p = (float*)m->cx->arena.get(y.bytes);
     if (!y.p) return EGR_ERR_ALLOC;
     y.a = &m->cx->arena;
-    return egr_groupnorm_nhwc(x.p, m->ptr(key + ".weight"), m->ptr(key + ".bias"), y.p, B, HW, Cc, G, eps, silu ? 1 : 0, m->cx->gn_ws, m->st);
+    float* ra = nullptr;
+    if (B == m->R) OKR(rs_for_output(m, y, &ra));
+    return egr_groupnorm_nhwc_ra(x.p, m->ptr(key + ".weight"), m->ptr(key + ".bias"), y.p, B, HW, Cc, G, eps, silu ? 1 : 0, m->cx->gn_ws, ra, m->st);
 }
 
 int gn_coeff(M* m, Ten& sc, Ten& sh, const Ten& x, const std::string& key, float eps) {
@@ -591,7 +632,13 @@ int conv_winograd(M* m, Ten& y, const Ten& x, const std::string& key, int act, c
     const int64_t P = (int64_t)B * TH * TW;
     Ten V, Mx;
     OKR(new_ten(m, V, {nz, P, Cin}));
-    if (f4) OKR(egr_winograd4_input(x.p, gsc, gsh, gsilu, B, H, W, Cin, V.p, m->st));
+    // fp16 operand scheme: the F(4x4) input transform leaves the per-row maxima of V as it writes it
+    const bool v_h2 = m->h2 && m->h2_mode == 1 && wz && wz->w2 && Cin % 16 == 0 && B == m->R;
+    if (f4 && v_h2) {
+        V.rs = rs_take(m);
+        if (!V.rs) return EGR_ERR_ALLOC;
+        OKR(egr_winograd4_input_ra(x.p, gsc, gsh, gsilu, B, H, W, Cin, V.p, (float*)V.rs, m->st));
+    } else if (f4) OKR(egr_winograd4_input(x.p, gsc, gsh, gsilu, B, H, W, Cin, V.p, m->st));
     else OKR(egr_winograd_input(x.p, gsc, gsh, gsilu, B, H, W, Cin, V.p, m->st));
     OKR(new_ten(m, Mx, {nz, P, Cout}));
     const double fl = nz * 2.0 * (double)P * Cin * Cout;
@@ -600,7 +647,7 @@ int conv_winograd(M* m, Ten& y, const Ten& x, const std::string& key, int act, c
         const void* w3 = s3_of(m, wz, Cin, V.p);
         bool h2 = false;
         if (w3) {
-            OKR(s3_launch(m, wz, V.p, (int64_t)nz * P * Cin, nullptr, nullptr, Mx.p, (int)P, 1, 1, Cin, 1, 1, Cout, 1, 1, 1, 1, 0, 0, 0, 0, 0.0f, 1, 1,
+            OKR(s3_launch(m, wz, V.p, (int64_t)nz * P * Cin, &V.rs, nullptr, nullptr, Mx.p, (int)P, 1, 1, Cin, 1, 1, Cout, 1, 1, 1, 1, 0, 0, 0, 0, 0.0f, 1, 1,
                           0, 0, 1, 1, nz, P * Cin, wz->zfloats, P * Cout, &h2));
         } else {
             EGR_CHECK(wz->w != nullptr, EGR_ERR_ARG, "FlashSR: no fp32 Winograd pack for %s", key.c_str());
@@ -627,14 +674,21 @@ int conv_winograd(M* m, Ten& y, const Ten& x, const std::string& key, int act, c
     const float* bt = bias_t ? bias_t : m->ptr(key + ".bias");
     const int G = m->cfg.gn_groups;
     const int silu = act == ACT_SILU ? 1 : 0;
+    // fp16 operand scheme: the output transform leaves the per-row maxima of y (it may feed a 1x1 / strided / phase convolution)
+    float* y_ra = nullptr;
+    if (f4 && m->h2 && m->h2_mode == 1 && B == m->R) {
+        y.rs = rs_take(m);
+        if (!y.rs) return EGR_ERR_ALLOC;
+        y_ra = (float*)y.rs;
+    }
     if (f4 && !(m->flags & EGR_FSR_NO_GN_PARTIALS) && Cout % G == 0 && (Cout / G) % 4 == 0) {
         auto part = std::make_shared<Ten>();
         OKR(new_ten(m, *part, {P, Cout / 4, 2}));
-        OKR(egr_winograd4_output_stats(Mx.p, bt, res, y.p, B, H, W, Cout, silu, part->p, m->st));
+        OKR(egr_winograd4_output_ra(Mx.p, bt, res, y.p, B, H, W, Cout, silu, part->p, y_ra, m->st));
         y.part = part;
         y.part_tiles = TH * TW;
     } else if (f4) {
-        OKR(egr_winograd4_output(Mx.p, bt, res, y.p, B, H, W, Cout, silu, m->st));
+        OKR(egr_winograd4_output_ra(Mx.p, bt, res, y.p, B, H, W, Cout, silu, nullptr, y_ra, m->st));
     } else {
         OKR(egr_winograd_output(Mx.p, bt, res, y.p, B, H, W, Cout, silu, m->st));
     }
@@ -654,8 +708,8 @@ int conv_up2_phases(M* m, Ten& y, const Ten& x, const std::string& key, int act)
             const void* w3 = s3_of(m, w, Cin, x.p);
             bool h2 = false;
             if (w3)
-                OKR(s3_launch(m, w, x.p, (int64_t)B * H * W * Cin, bt, nullptr, y.p, B, H, W, Cin, H, W, Cout, 2, 2, 1, 1, 1 - a, 1 - b, 0, act, 0.0f, 2, 2,
-                              a, b, 2 * H, 2 * W, 1, 0, 0, 0, &h2));
+                OKR(s3_launch(m, w, x.p, (int64_t)B * H * W * Cin, &x.rs, bt, nullptr, y.p, B, H, W, Cin, H, W, Cout, 2, 2, 1, 1, 1 - a, 1 - b, 0, act, 0.0f, 2, 2,
+                              a, b, 2 * H, 2 * W, 1, 0, 0, 0, &h2, &y.rs));
             else
                 OKR(egr_conv_nhwc_placed(x.p, w->w, bt, nullptr, nullptr, y.p, B, H, W, Cin, H, W, Cout, 2, 2, 1, 1, 1 - a, 1 - b, 0, act, 0.0f, 2, 2,
                                          a, b, 2 * H, 2 * W, m->st));
@@ -671,6 +725,8 @@ int conv3(M* m, Ten& y, const Ten& x, const std::string& key, int stride = 1, in
     const Wt* wb = m->get(key + ".weight");
     EGR_CHECK(wb != nullptr, EGR_ERR_ARG, "FlashSR: weight %s.weight missing", key.c_str());
     const int Cout = wb->Cout;
+    const bool want_ra = m->next_out_ra;            // only the generic path below hands it to conv(); the other paths track on their own
+    m->next_out_ra = false;
     if (up2 && m->has(key + ".weight.ph00") && stride == 1 && pad == 1 && !res && !bias_t) return conv_up2_phases(m, y, x, key, act);
     if (m->has(key + ".weight.wino") && !up2 && stride == 1 && pad == 1 && (act == ACT_NONE || act == ACT_SILU) && H % 2 == 0 && W % 2 == 0 &&
         Cin % 16 == 0)
@@ -691,6 +747,7 @@ int conv3(M* m, Ten& y, const Ten& x, const std::string& key, int stride = 1, in
         return EGR_OK;
     }
     const int LH = up2 ? 2 * H : H, LW = up2 ? 2 * W : W;
+    m->next_out_ra = want_ra;
     return conv(m, y, x, key, B, H, W, Cin, LH / stride, LW / stride, Cout, 3, 3, stride, 1, pad, pad, up2, act, true, bias_t, res);
 }
 
@@ -736,17 +793,23 @@ int gn_conv3(M* m, Ten& y, const Ten& x, const std::string& norm_key, float eps,
 
 int layernorm(M* m, Ten& y, const Ten& x2, const std::string& key) {
     OKR(new_ten(m, y, {x2.d[0], x2.d[1]}));
-    return egr_layernorm_rows(x2.p, m->ptr(key + ".weight"), m->ptr(key + ".bias"), y.p, x2.d[0], (int)x2.d[1], 1e-5f, m->st);
+    float* ra = nullptr;
+    if (x2.d[0] % m->R == 0) OKR(rs_for_output(m, y, &ra));
+    if (!ra) return egr_layernorm_rows(x2.p, m->ptr(key + ".weight"), m->ptr(key + ".bias"), y.p, x2.d[0], (int)x2.d[1], 1e-5f, m->st);
+    return egr_layernorm_rows_ra(x2.p, m->ptr(key + ".weight"), m->ptr(key + ".bias"), y.p, x2.d[0], (int)x2.d[1], 1e-5f, m->R, ra, m->st);
 }
 
-int eltwise(M* m, Ten& y, const Ten& a, const float* b, int op, float s0 = 0.f, float s1 = 0.f) {
+int eltwise(M* m, Ten& y, const Ten& a, const float* b, int op, float s0 = 0.f, float s1 = 0.f, bool want_ra = false) {
     y.release();
     y.nd = a.nd; memcpy(y.d, a.d, sizeof(y.d));
     y.bytes = (size_t)y.numel() * 4;
     y.p = (float*)m->cx->arena.get(y.bytes);
     if (!y.p) return EGR_ERR_ALLOC;
     y.a = &m->cx->arena;
-    return egr_eltwise(a.p, b, y.p, a.numel(), op, s0, s1, m->st);
+    float* ra = nullptr;
+    if (want_ra) OKR(rs_for_output(m, y, &ra));
+    if (!ra) return egr_eltwise(a.p, b, y.p, a.numel(), op, s0, s1, m->st);
+    return egr_eltwise_ra(a.p, b, y.p, a.numel(), op, s0, s1, m->R, ra, m->st);
 }
 
 // q, k, v [B*T][C] -> [B*T][C]: softmax(q k^T / sqrt(d)) v per head
@@ -782,13 +845,22 @@ int attention(M* m, Ten& o, const Ten& q, const Ten& k, const Ten& v, int B, int
 
 int snake(M* m, Ten& y, const Ten& x, const std::string& akey, const std::string& bkey) {
     OKR(new_ten(m, y, {x.d[0], x.d[1], x.d[2]}));
-    return egr_snake_aa(x.p, m->ptr(akey), m->ptr(bkey), m->filt, y.p, (int)x.d[0], (int)x.d[1], (int)x.d[2], m->cfg.aa_taps, m->st);
+    float* ra = nullptr;                           // fp16 operand scheme: y feeds a 1-D convolution; its row maxima ride along
+    if (m->h2 && m->h2_mode == 1 && (int)x.d[0] == m->R) {
+        y.rs = rs_take(m);
+        if (!y.rs) return EGR_ERR_ALLOC;
+        ra = (float*)y.rs;
+    }
+    return egr_snake_aa_ra(x.p, m->ptr(akey), m->ptr(bkey), m->filt, y.p, (int)x.d[0], (int)x.d[1], (int)x.d[2], m->cfg.aa_taps, ra, m->st);
 }
 
 int concat(M* m, Ten& y, const Ten& a, const Ten& b) {
     const int64_t rows = a.d[0] * a.d[1] * a.d[2];
     OKR(new_ten(m, y, {a.d[0], a.d[1], a.d[2], a.d[3] + b.d[3]}));
-    return egr_concat_channels(a.p, b.p, y.p, rows, (int)a.d[3], (int)b.d[3], m->st);
+    float* ra = nullptr;
+    if ((int)a.d[0] == m->R) OKR(rs_for_output(m, y, &ra));
+    if (!ra) return egr_concat_channels(a.p, b.p, y.p, rows, (int)a.d[3], (int)b.d[3], m->st);
+    return egr_concat_channels_ra(a.p, b.p, y.p, rows, (int)a.d[3], (int)b.d[3], m->R, ra, m->st);
 }
 
 // ------------------------------------------------------------------------------------------------ constant sub-graph
@@ -871,6 +943,7 @@ int vae_attn(M* m, Ten& y, const Ten& x, const std::string& name) {
     OKR(conv1x1(m, v, h, name + ".v"));
     OKR(attention(m, o, q, k, v, B, H * W, Cc, 1));
     o.view({B, H, W, Cc});
+    m->next_out_ra = true;
     return conv1x1(m, y, o, name + ".proj_out", x.p);
 }
 
@@ -884,6 +957,7 @@ int vae_encode(M* m, Ten& z, const Ten& mel) {
             h = std::move(t);
         }
         if (lv != c.vae_levels - 1) {
+            m->next_out_ra = true;
             OKR(conv3(m, t, h, "vae.encoder.down." + std::to_string(lv) + ".downsample.conv", 2, 0, ACT_NONE, nullptr, 0));
             h = std::move(t);
         }
@@ -905,6 +979,7 @@ int vae_encode(M* m, Ten& z, const Ten& mel) {
 int vae_decode(M* m, Ten& y, const Ten& z) {
     const egr_flashsr_config& c = m->cfg;
     Ten h, t;
+    m->next_out_ra = true;
     OKR(conv1x1(m, t, z, "vae.post_quant_conv"));
     OKR(conv3(m, h, t, "vae.decoder.conv_in"));
     OKR(vae_res(m, t, h, "vae.decoder.mid.block_1")); h = std::move(t);
@@ -955,9 +1030,16 @@ int unet_block(M* m, Ten& y, const Ten& x, const std::string& base, bool has_att
     OKR(layernorm(m, ln, t, base + ".st.ff_ln"));
     OKR(linear(m, u, ln, base + ".st.ff.geglu"));
     OKR(new_ten(m, g, {(int64_t)B * T, 4 * Cc}));
-    OKR(egr_geglu(u.p, g.p, (int64_t)B * T, 4 * Cc, m->st));
+    {
+        float* ra = nullptr;
+        if (B == m->R) OKR(rs_for_output(m, g, &ra));
+        if (ra) OKR(egr_geglu_ra(u.p, g.p, (int64_t)B * T, 4 * Cc, m->R, ra, m->st));
+        else OKR(egr_geglu(u.p, g.p, (int64_t)B * T, 4 * Cc, m->st));
+    }
+    m->next_out_ra = true;
     OKR(linear(m, t3, g, base + ".st.ff.out", t.p));
     t3.view({B, H, W, Cc});
+    m->next_out_ra = true;
     return conv1x1(m, y, t3, base + ".st.proj_out", r.p);
 }
 
@@ -975,6 +1057,7 @@ int unet(M* m, Ten& out, Ten&& x0) {
             skips.push_back(std::move(t));
             h = std::move(cp);
         } else if (kind == "down") {
+            m->next_out_ra = true;
             OKR(conv3(m, t, h, base + ".conv", 2, 0, ACT_NONE, nullptr, 1));
             Ten cp = t.alias();
             skips.push_back(std::move(t));
@@ -1030,10 +1113,10 @@ int amp(M* m, Ten& y, Ten&& h, int j) {
             OKR(eltwise(m, s, acc, x.p, EW_ADD));
             acc = std::move(s);
         } else {                                   // last branch: the mean's scale rides on the last add
-            return eltwise(m, y, acc, x.p, EW_ADD_SCALE, 1.0f / c.voc_n_kernels);
+            return eltwise(m, y, acc, x.p, EW_ADD_SCALE, 1.0f / c.voc_n_kernels, 0.f, true);   // feeds the next stage's up-sampling GEMM
         }
     }
-    return eltwise(m, y, acc, nullptr, EW_SCALE, 1.0f / c.voc_n_kernels);
+    return eltwise(m, y, acc, nullptr, EW_SCALE, 1.0f / c.voc_n_kernels, 0.f, true);
 }
 
 int vocoder(M* m, Ten& y, const Ten& mel_hat, const float* wave, int B) {
@@ -1048,6 +1131,7 @@ int vocoder(M* m, Ten& y, const Ten& mel_hat, const float* wave, int B) {
         const Ten* e = &e0;
         for (int i = 0; i < n; ++i) {
             const int r = c.voc_rates[n - 1 - i];
+            m->next_out_ra = i + 1 < n;                 // feeds the next strided convolution of the encoder
             OKR(conv1d(m, feats[i], *e, "voc.wave_enc." + std::to_string(i), 2 * r + 1, r, 1, r, ACT_LEAKY));
             e = &feats[i];
         }
@@ -1056,6 +1140,7 @@ int vocoder(M* m, Ten& y, const Ten& mel_hat, const float* wave, int B) {
     mh.view({B, T, Fm});
     mh.p = mel_hat.p;
     Ten h;
+    m->next_out_ra = true;
     OKR(conv1d(m, h, mh, "voc.conv_pre", 7, 1, 1, 3, ACT_NONE, feats[n - 1].p));
     feats[n - 1].release();
     for (int j = 0; j < n; ++j) {
@@ -1067,6 +1152,7 @@ int vocoder(M* m, Ten& y, const Ten& mel_hat, const float* wave, int B) {
         Ten Y, out, hx;
         hx.view({(int64_t)Bc * Lin, 1, 1, Ci});
         hx.p = h.p;
+        hx.rs = h.rs;                                  // (a view: the row maxima of h are its own)
         OKR(conv(m, Y, hx, "voc.ups." + std::to_string(j), Bc * Lin, 1, 1, Ci, 1, 1, kt * Co, 1, 1, 1, 1, 0, 0, 0, ACT_NONE, false, nullptr, nullptr, 0.f, wt));
         OKR(new_ten(m, out, {Bc, (int64_t)Lin * r, Co}));
         const float* add = (j <= n - 2) ? feats[n - 2 - j].p : nullptr;
@@ -1094,6 +1180,18 @@ int copy_out(M* m, float* dst, const Ten& t) {
 int forward(M* m, const float* x_in, const float* noise, int R, int lowpass_on, float* y_out, float* const* stages) {
     const egr_flashsr_config& c = m->cfg;
     const float* x = x_in;
+    m->R = R;
+    if (m->h2_mode == 1) {                         // per-row operand maxima of this forward: one zeroed pool per context
+        FsrCtx* cx = m->cx;
+        const size_t need = (size_t)(2 * m->h2_nweights + 64) * (size_t)R * EGR_ROW_AMAX_STRIDE;
+        if (cx->rs_cap < need) {
+            if (cx->rs_pool) { hipStreamSynchronize(m->st); hipFree(cx->rs_pool); cx->rs_pool = nullptr; cx->rs_cap = 0; }
+            if (hipMalloc((void**)&cx->rs_pool, need * sizeof(unsigned)) != hipSuccess) { set_error("hipMalloc(row maxima pool) failed"); return EGR_ERR_ALLOC; }
+            cx->rs_cap = need;
+        }
+        EGR_HIP(hipMemsetAsync(cx->rs_pool, 0, cx->rs_cap * sizeof(unsigned), m->st));
+        cx->rs_used = 0;
+    }
     Ten xl;
     if (lowpass_on) { OKR(lowpass(m, xl, x_in, R, c.chunk)); x = xl.p; }
     Ten mel, z_c, v, z0, mel_hat, y;
@@ -1179,13 +1277,13 @@ extern "C" int egr_flashsr_destroy(egr_flashsr* m) {
         FsrCtx* c = m->ctxs[i].get();
         for (auto& kv : c->lp_plans) egr_fatllama_plan_destroy(kv.second);
         if (c->gn_ws) hipFree(c->gn_ws);
+        if (c->rs_pool) hipFree(c->rs_pool);
         if (c->done) hipEventDestroy(c->done);
         if (i > 0 && c->st) hipStreamDestroy(c->st);
     }
     if (m->ev_fork) hipEventDestroy(m->ev_fork);
     for (auto& r : m->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
-    if (m->d_amax) hipFree(m->d_amax);
-    if (m->h_amax) hipHostFree(m->h_amax);
+    if (m->d_wmax) hipFree(m->d_wmax);
     delete m;
     return EGR_OK;
 }
@@ -1211,8 +1309,8 @@ extern "C" int egr_flashsr_create(egr_flashsr** out, const egr_flashsr_config* c
     if (const char* e = getenv("EGREGORA_FLASHSR_WINOGRAD_MIN_CH")) m->wino_min_ch = atoi(e);
     m->h2 = !(flags & (EGR_FSR_F32_MFMA | EGR_FSR_SPLIT_BF16X3));
     if (const char* e = getenv("EGREGORA_FLASHSR_SPLIT")) { if (!strcmp(e, "bf16x3")) m->h2 = false; }
-    if (const char* e = getenv("EGREGORA_FLASHSR_CAL_ROWS")) { const int r = atoi(e); if (r >= 1) m->h2_cal_rows = r; }
     if (const char* e = getenv("EGREGORA_FLASHSR_ROWS")) { const int r = atoi(e); if (r >= 1) m->rows_per_pass = r; }
+    if (const char* e = getenv("EGREGORA_FLASHSR_OUT_AMAX")) m->out_amax_on = atoi(e) != 0;
     build_blocks(m);
     const int down = 1 << (cfg->vae_levels - 1);
     m->lat_h = cfg->n_frames / down; m->lat_w = cfg->n_mels / down;
@@ -1265,9 +1363,8 @@ extern "C" int egr_flashsr_forward(egr_flashsr* m, const float* x, const float* 
     m->use(m->ctxs[0].get());
     ForwardGuard guard(m->device, m->st);
     // the introspection walk stays on the three-term kernels (bit-equal to the operator API) unless egr_flashsr_set_split(h, 2) asked
-    // for the scales of the last egr_flashsr_infer call (no range verification here: stage taps for the tests)
-    m->h2_mode = (m->h2 && m->h2_fwd && m->h2_cal && m->h2_nslots > 0 && (int)m->scale_cur.size() == m->h2_nslots) ? 1 : -1;
-    if (m->h2_mode == 1) m->scale_used.assign(m->h2_nslots, 0.f);
+    // for the fp16 operand terms here too (stage taps for the tests)
+    m->h2_mode = (m->h2 && m->h2_fwd && m->h2_nweights > 0) ? 1 : -1;
     const int rc = forward(m, x, noise, rows, lowpass, y, stages);
     m->h2_mode = -1;
     return rc;
@@ -1295,6 +1392,7 @@ static int ensure_side_streams(egr_flashsr* m, hipStream_t caller, int want) {
             hipStreamSynchronize(m->ctxs[i]->st);
             for (auto& kv : m->ctxs[i]->lp_plans) egr_fatllama_plan_destroy(kv.second);
             if (m->ctxs[i]->gn_ws) hipFree(m->ctxs[i]->gn_ws);
+            if (m->ctxs[i]->rs_pool) hipFree(m->ctxs[i]->rs_pool);
             if (m->ctxs[i]->done) hipEventDestroy(m->ctxs[i]->done);
             hipStreamDestroy(m->ctxs[i]->st);
             m->ctxs.erase(m->ctxs.begin() + i);
@@ -1326,87 +1424,33 @@ static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uin
 extern "C" int egr_flashsr_infer(egr_flashsr* m, const float* x, int rows, int lowpass, uint64_t seed, const int64_t* row_ids, float* y,
                                  void* stream) {
     EGR_CHECK(m && x && y && rows >= 1, EGR_ERR_ARG, "egr_flashsr_infer: null / empty argument");
-    hipStream_t st0 = (hipStream_t)stream;
-    if (!m->h2 || m->h2_nslots == 0 || m->count_flops) {
-        m->h2_mode = -1;
-        return infer_once(m, x, rows, lowpass, seed, row_ids, 0, y, stream);
-    }
-    // operand scheme bookkeeping (see the h2 fields of the handle): measure -> scale -> verify, re-run on the bf16 terms if a value
-    // left fp16's range.  The read-back makes the call synchronous with the host (one 16 KiB copy).
-    const int n = m->h2_nslots;
-    m->amax_prev.resize(n, 0.f);
-    m->scale_cur.resize(n, 0.f);
-    m->scale_used.assign(n, 0.f);
-    ++m->h2_calls;
-    const int64_t chunk = m->cfg.chunk;
-    // rows [lo, lo + cnt) in `mode`; reads the maxima back, updates the scales, returns 1 when a scaled value left the fp16 range
-    auto run = [&](int lo, int cnt, int mode) -> int {
-        m->h2_mode = mode;
-        if (hipMemsetAsync(m->d_amax, 0, (size_t)n * sizeof(unsigned), st0) != hipSuccess) return -EGR_ERR_HIP;
-        const int rc = infer_once(m, x + (size_t)lo * chunk, cnt, lowpass, seed, row_ids ? row_ids + lo : nullptr, lo, y + (size_t)lo * chunk, stream);
-        m->h2_mode = -1;
-        if (rc != EGR_OK) return -rc;
-        if (hipMemcpyAsync(m->h_amax, m->d_amax, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st0) != hipSuccess ||
-            hipStreamSynchronize(st0) != hipSuccess) { set_error("egr_flashsr_infer: reading the operand maxima back failed"); return -EGR_ERR_HIP; }
-        int overflow = 0;
-        for (int i = 0; i < n; ++i) {
-            const float a = m->h_amax[i];
-            if (mode == 1 && m->scale_used[i] > 0.f && !(a * m->scale_used[i] < 60000.f)) overflow = 1;     // also catches inf / nan bits
-            // the other end: a tensor whose scaled maximum fell below 1 (4096x quieter than what the scale was measured on, or a
-            // scale measured on silence) would keep fewer than fp32's bits relative to its own maximum
-            if (mode == 1 && m->scale_used[i] > 0.f && a > 0.f && a * m->scale_used[i] < 1.0f) overflow = 1;
-            if (a > 0.f && std::isfinite(a)) {
-                m->amax_prev[i] = a;
-                // a scale is kept while the new maximum sits between 2^8 and 2^14 under it (same scale -> same bits for the same
-                // data, whatever the calls in between); otherwise it is re-centred at 2^12
-                const float sc = a * m->scale_cur[i];
-                if (!(m->scale_cur[i] > 0.f) || sc > 16384.f || sc < 256.f) m->scale_cur[i] = h2_scale_for(a, 12);
-            }
-        }
-        m->h2_cal = true;
-        return overflow;
-    };
-    int lo = 0;
-    if (!m->h2_cal) {            // measuring call: the first h2_cal_rows rows on the bf16 kernels (rows are independent of each other)
-        const int cnt = std::min(rows, std::max(1, m->h2_cal_rows));
-        const int r = run(0, cnt, 0);
-        if (r < 0) return -r;
-        lo = cnt;
-    }
-    if (lo < rows) {
-        int r = run(lo, rows - lo, 1);
-        if (r < 0) return -r;
-        if (r == 1) {            // a value left the fp16 range: these rows again on the bf16 kernels
-            ++m->h2_reruns;
-            r = run(lo, rows - lo, 0);
-            if (r < 0) return -r;
-        }
-    }
-    return EGR_OK;
+    // operand scheme of this call's forwards: two fp16 terms with per-row device-side scales (see the h2 fields of the handle), or
+    // three bf16 terms.  Either way the call only enqueues work: no read-back, no host synchronisation.
+    m->h2_mode = (m->h2 && m->h2_nweights > 0 && !m->count_flops) ? 1 : -1;
+    if (m->h2_mode == 1) ++m->h2_calls;
+    const int rc = infer_once(m, x, rows, lowpass, seed, row_ids, 0, y, stream);
+    m->h2_mode = -1;
+    return rc;
 }
 
-// 0: scheme off for this handle, 1: on.  calls / reruns: egr_flashsr_infer calls on the scheme and how many were sent through the
-// bf16 kernels again after a range check failed; calibrated: the next call will use the fp16 terms.
-extern "C" int egr_flashsr_split_info(egr_flashsr* m, int* enabled, int* calibrated, int* slots, int64_t* calls, int64_t* reruns) {
+// enabled: egr_flashsr_infer runs the fp16 operand terms on this handle; weights: contraction weights that hold fp16 terms;
+// calls: egr_flashsr_infer calls made on the scheme.  (ABI 3 reported a calibration state and re-run count here: the scheme has
+// neither any more -- scales are per row and per call, derived on the device.)
+extern "C" int egr_flashsr_split_info(egr_flashsr* m, int* enabled, int* weights, int64_t* calls) {
     EGR_CHECK(m != nullptr, EGR_ERR_ARG, "handle is null");
-    if (enabled) *enabled = m->h2 && m->h2_nslots > 0;
-    if (calibrated) *calibrated = m->h2_cal;
-    if (slots) *slots = m->h2_nslots;
+    if (enabled) *enabled = m->h2 && m->h2_nweights > 0;
+    if (weights) *weights = m->h2_nweights;
     if (calls) *calls = m->h2_calls;
-    if (reruns) *reruns = m->h2_reruns;
     return EGR_OK;
 }
 
-// scheme: 0 = three bf16 terms always, 1 = two fp16 terms with measured scales (needs a handle created with the scheme available),
-// 2 = as 1 and egr_flashsr_forward uses the scales of the last egr_flashsr_infer call as well (unverified: stage taps for tests)
+// scheme: 0 = three bf16 terms always, 1 = two fp16 terms with per-row device-side scales in egr_flashsr_infer (needs a handle
+// created with the scheme available), 2 = as 1 and egr_flashsr_forward runs the fp16 terms as well (stage taps for tests)
 extern "C" int egr_flashsr_set_split(egr_flashsr* m, int scheme) {
     EGR_CHECK(m && scheme >= 0 && scheme <= 2, EGR_ERR_ARG, "bad argument");
-    EGR_CHECK(scheme == 0 || m->h2_nslots > 0, EGR_ERR_UNSUPPORTED, "this handle holds no fp16 weight terms");
-    if (scheme == 2) { m->h2 = true; m->h2_fwd = true; return EGR_OK; }     // keeps the measured scales
-    m->h2 = scheme == 1;
-    m->h2_fwd = false;
-    m->h2_cal = false;
-    m->scale_cur.assign(m->scale_cur.size(), 0.f);
+    EGR_CHECK(scheme == 0 || m->h2_nweights > 0, EGR_ERR_UNSUPPORTED, "this handle holds no fp16 weight terms");
+    m->h2 = scheme >= 1;
+    m->h2_fwd = scheme == 2;
     return EGR_OK;
 }
 
@@ -1424,15 +1468,6 @@ static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uin
         groups_max = std::min(m->max_groups, 1 + ensure_side_streams(m, st0, groups_max - 1));   // side contexts of an earlier, wider setting stay idle
     else
         groups_max = 1;
-    Ten ids;                                                      // implicit ids 0 .. rows-1 as a device array (groups need offsets)
-    if (!row_ids && (rows > m->rows_per_pass || groups_max > 1 || id_base != 0)) {
-        std::vector<int64_t> h(rows);
-        for (int i = 0; i < rows; ++i) h[i] = id_base + i;
-        OKR(new_ten(m, ids, {2 * (int64_t)rows}));
-        EGR_HIP(hipMemcpyAsync(ids.p, h.data(), (size_t)rows * 8, hipMemcpyHostToDevice, st0));
-        EGR_HIP(hipStreamSynchronize(st0));
-        row_ids = (const int64_t*)ids.p;
-    }
     if (groups_max > 1 && !m->ev_fork) EGR_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     int rc = EGR_OK;
     // passes of equal size (260 rows at 32 per pass: nine passes of 29 / 28 rows instead of eight of 32 and one of 4)
@@ -1451,7 +1486,7 @@ static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uin
             m->use(cx);
             Ten nz;
             rc = new_ten(m, nz, {ng, per_row});
-            if (rc == EGR_OK) rc = egr_randn(nz.p, per_row, ng, seed, row_ids ? row_ids + glo : nullptr, m->st);
+            if (rc == EGR_OK) rc = egr_randn_base(nz.p, per_row, ng, seed, row_ids ? row_ids + glo : nullptr, id_base + glo, m->st);
             if (rc == EGR_OK) rc = forward(m, x + (size_t)glo * c.chunk, nz.p, ng, lowpass, y + (size_t)glo * c.chunk, nullptr);
             if (g > 0) {                                          // join even after an error: nothing may outlive the call unordered
                 hipEventRecord(cx->done, cx->st);

@@ -306,7 +306,16 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
 }
 
 // y[place(m)][n] = act(sum_z ws[z][m][n] + bias[n] + bias_b[b][n] + res[place(m)][n])   (fixed summation order)
+// AMX: p.out_amax[m / rows_div] is raised to max |y| per batch row (LDS table of up to 1024 batch rows per workgroup, then one
+// checked atomic per batch row the workgroup touched)
+template <bool AMX>
 __global__ __launch_bounds__(256) void k_splitk_reduce(ConvP p) {
+    __shared__ unsigned om[AMX ? 1024 : 1];
+    const int nbr = AMX ? (p.M + p.rows_div - 1) / p.rows_div : 0;
+    if (AMX) {
+        for (int t = threadIdx.x; t < nbr; t += 256) om[t] = 0u;
+        __syncthreads();
+    }
     const long long total = (long long)p.M * p.Cout;
     const bool ident = (p.osy == 1 && p.osx == 1 && p.OHF == p.OH && p.OWF == p.OW);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -320,7 +329,17 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(ConvP p) {
         if (!ident) mo = ((size_t)b * p.OHF + (size_t)oy * p.osy + p.ooy) * p.OWF + (size_t)ox * p.osx + p.oox;
         if (p.bias_b) v += p.bias_b[(size_t)b * p.Cout + n];
         if (p.res) v += p.res[mo * p.Cout + n];
-        p.y[mo * p.Cout + n] = apply_act(v, p.act, p.act_param);
+        v = apply_act(v, p.act, p.act_param);
+        p.y[mo * p.Cout + n] = v;
+        if (AMX) atomicMax(&om[m / p.rows_div], __float_as_uint(fabsf(v)));
+    }
+    if (AMX) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < nbr; t += 256) {
+            const unsigned bits = om[t];
+            unsigned* slot = p.out_amax + (size_t)t * EGR_ROW_AMAX_STRIDE;
+            if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+        }
     }
 }
 
@@ -481,8 +500,8 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
                        int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t,
                        int pad_l, int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF,
                        int nz, long long zx, long long zw, long long zy, const float* gn_scale, const float* gn_shift,
-                       int gn_silu, void* stream, const void* w3 = nullptr, int sch = 0, float a_scale = 1.f, float w_scale = 1.f,
-                       float* amax = nullptr);
+                       int gn_silu, void* stream, const void* w3 = nullptr, int sch = 0, float w_scale = 1.f,
+                       const float* row_amax = nullptr, int batch_rows = 0, float* out_amax = nullptr);
 
 extern "C" int egr_conv_nhwc(const float* x, const float* w, const float* bias, const float* bias_b, const float* res,
                              float* y, int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
@@ -529,27 +548,32 @@ extern "C" int egr_conv_s3(const float* x, const void* w3, const float* bias, co
                        act_param, osy, osx, ooy, oox, OHF, OWF, nz, zx, zw3, zy, nullptr, nullptr, 0, stream, w3);
 }
 
-// The same on two fp16 terms per operand (csrc/egr_nn_gemm_s3.hip, scheme 1): w2 = egr_split2h_pack(w, w_scale); the loader
-// multiplies x by a_scale (both powers of two) and raises *amax (optional; bits of a float, zeroed by the caller) to max |x|.
+// The same on two fp16 terms per operand (csrc/egr_nn_gemm_s3.hip, scheme 1): w2 = egr_split2h_pack(w, w_scale).  The GEMM rows
+// (B * OH * OW of them) belong to `batch_rows` equal consecutive groups -- the rows of the batch -- and every group is scaled by its
+// own power of two, derived in the kernel from row_amax[group] (bits of the group's max |x|: egr_absmax_rows, or the producer of
+// x); nothing about the scale travels through the host.  out_amax (optional, [batch_rows] floats the caller zeroed): raised to
+// max |y| per batch row by the epilogue (not when the launch takes the split-K path: the caller checks with egr_conv_h2_splits_k).
 extern "C" int egr_conv_h2(const float* x, const void* w2, const float* bias, const float* bias_b, const float* res, float* y,
                            int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil,
                            int pad_t, int pad_l, int up2, int act, float act_param, int osy, int osx, int ooy, int oox,
-                           int OHF, int OWF, int nz, int64_t zx, int64_t zw2, int64_t zy, float a_scale, float w_scale,
-                           float* amax, void* stream) {
-    EGR_CHECK(w2, EGR_ERR_ARG, "null w2");
+                           int OHF, int OWF, int nz, int64_t zx, int64_t zw2, int64_t zy, float w_scale, const float* row_amax,
+                           int batch_rows, float* out_amax, void* stream) {
+    EGR_CHECK(w2 && row_amax, EGR_ERR_ARG, "null w2 / row_amax");
     EGR_CHECK(nz >= 1 && nz <= 65535, EGR_ERR_ARG, "bad nz");
     return conv_launch(x, nullptr, bias, bias_b, res, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, pad_t, pad_l, up2, act,
-                       act_param, osy, osx, ooy, oox, OHF, OWF, nz, zx, zw2, zy, nullptr, nullptr, 0, stream, w2, 1, a_scale,
-                       w_scale, amax);
+                       act_param, osy, osx, ooy, oox, OHF, OWF, nz, zx, zw2, zy, nullptr, nullptr, 0, stream, w2, 1, w_scale, row_amax,
+                       batch_rows, out_amax);
 }
 
 static int conv_launch(const float* x, const float* w, const float* bias, const float* bias_b, const float* res, float* y,
                        int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t,
                        int pad_l, int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF,
                        int nz, long long zx, long long zw, long long zy, const float* gn_scale, const float* gn_shift,
-                       int gn_silu, void* stream, const void* w3, int sch, float a_scale, float w_scale, float* amax) {
+                       int gn_silu, void* stream, const void* w3, int sch, float w_scale, const float* row_amax, int batch_rows,
+                       float* out_amax) {
     EGR_CHECK(x && (w || w3) && y, EGR_ERR_ARG, "null x/w/y");
-    EGR_CHECK(sch == 0 || (w3 && a_scale > 0.f && w_scale > 0.f), EGR_ERR_ARG, "bad operand scheme / scales");
+    EGR_CHECK(sch == 0 || (w3 && w_scale > 0.f && row_amax && batch_rows >= 1 && ((long long)B * OH * OW) % batch_rows == 0), EGR_ERR_ARG,
+              "bad operand scheme: needs w_scale > 0, row_amax and a batch row count that divides the GEMM rows");
     EGR_CHECK(!w3 || ((Cin % BK) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)w3) & 15) == 0 && !gn_scale), EGR_ERR_ARG,
               "split-bf16 conv needs Cin %% 16 == 0, 16-byte aligned x / w3 and no fused input affine");
     EGR_CHECK(!gn_scale || (gn_shift && (Cin % BK) == 0 && (((uintptr_t)x) & 15) == 0), EGR_ERR_ARG,
@@ -565,7 +589,9 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW;
     p.stride = stride; p.dil = dil; p.pad_t = pad_t; p.pad_l = pad_l; p.up2 = up2; p.act = act; p.act_param = act_param;
     p.M = (int)M; p.K = KH * KW * Cin;
-    p.sch = sch; p.a_scale = a_scale; p.out_scale = sch ? 1.0f / (a_scale * w_scale) : 1.0f; p.amax = sch ? (unsigned*)amax : nullptr;
+    p.sch = sch; p.out_scale = sch ? 1.0f / w_scale : 1.0f; p.row_amax = sch ? (const unsigned*)row_amax : nullptr;
+    p.rows_div = sch ? (int)(M / batch_rows) : 1;
+    p.out_amax = (sch && nz == 1) ? (unsigned*)out_amax : nullptr;
     EGR_CHECK(osy >= 1 && osx >= 1 && ooy >= 0 && oox >= 0 && (OH - 1) * osy + ooy < OHF && (OW - 1) * osx + oox < OWF,
               EGR_ERR_ARG, "bad output placement");
     p.osy = osy; p.osx = osx; p.ooy = ooy; p.oox = oox; p.OHF = OHF; p.OWF = OWF;
@@ -608,6 +634,8 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
             if (rc) return rc;
             p.ksplit = S; p.kt_per = per; p.ws = ws;
             grid.z = S;
+            // (with out_amax: the reduction kernel writes y and tracks the row maxima)
+            EGR_CHECK(!p.out_amax || batch_rows <= 1024, EGR_ERR_UNSUPPORTED, "out_amax with split-K serves up to 1024 batch rows");
         }
     }
 #define LAUNCH(BN_, V_) hipLaunchKernelGGL((k_conv_igemm<BN_, V_>), grid, dim3(256), 0, st, p)
@@ -625,7 +653,8 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
     if (p.ksplit > 1) {
         long long nb = (M * Cout + 255) / 256;
         if (nb > 2048) nb = 2048;
-        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)nb), dim3(256), 0, st, p);
+        if (p.out_amax) hipLaunchKernelGGL(k_splitk_reduce<true>, dim3((unsigned)nb), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(k_splitk_reduce<false>, dim3((unsigned)nb), dim3(256), 0, st, p);
     }
     EGR_HIP(hipGetLastError());
     return EGR_OK;

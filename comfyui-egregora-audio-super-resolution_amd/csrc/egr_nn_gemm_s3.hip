@@ -56,8 +56,10 @@ __device__ __forceinline__ void split3_x8(const float4& u, const float4& v, uint
 // an absolute error of 2^-37 of the maximum).  f16 x f16 products are exact in fp32, so  a0 b0 + a0 b1 + a1 b0  carries the fp32
 // product up to a1 b1 and the two term roundings (each < 2^-22 |a b|) with HALF the matrix instructions of the bf16 scheme and
 // one third fewer LDS operand bytes; fewer accumulator roundings per 16 k (3 instead of 6) make the measured error against
-// float64 no larger (tests/test_gpu_split_h2.py).  The loader also records max |x| of everything it splits (one atomic per wave
-// that raises the slot) so that the host can choose the next call's scale and detect a value beyond fp16's range (csrc/egr_flashsr.cpp).
+// float64 no larger (tests/test_gpu_split_h2.py).  s is per BATCH ROW and comes from the device: row_amax[b] holds the bits of
+// max |x| of row b (left there by the tensor's producer, or by k_absmax_rows), and h2_row_scale turns its exponent into the power
+// of two that puts the row's maximum in [2^14, 2^15) -- no host round trip, no history, and a quiet row next to a loud one keeps
+// its own 22 bits (csrc/egr_conv.h, csrc/egr_flashsr.cpp).
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -75,13 +77,6 @@ __device__ __forceinline__ void split2h_x8(const float4& u, const float4& v, flo
     split2h_pair(u.z, u.w, s, q0.y, q1.y);
     split2h_pair(v.x, v.y, s, q0.z, q1.z);
     split2h_pair(v.z, v.w, s, q0.w, q1.w);
-}
-
-__device__ __forceinline__ float absmax8(const float4& u, const float4& v, float m) {
-    m = fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), m);
-    m = fmaxf(fmaxf(fabsf(u.z), fabsf(u.w)), m);
-    m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), m);
-    return fmaxf(fmaxf(fabsf(v.z), fabsf(v.w)), m);
 }
 
 // raises *slot (the bits of a non-negative float, which order like unsigned integers) to the wave's maximum
@@ -147,6 +142,38 @@ __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, lon
     amax_commit(slot, m);
 }
 
+// out[r] (bits of a non-negative float, zeroed by the caller) raised to max |x| over row r of x: nz segments of `per_row` floats
+// at x + z * zx + r * per_row (nz = 1: one contiguous run; the Winograd V tensor: one segment per component).  grid (blocks, R, nz)
+__global__ __launch_bounds__(256) void k_absmax_rows(const float* __restrict__ x, long long per_row, long long zx, unsigned* __restrict__ out) {
+    const float* xr = x + (size_t)blockIdx.z * zx + (size_t)blockIdx.y * per_row;
+    float m = 0.f;
+    const long long n4 = per_row >> 2;
+    // four independent 16-byte loads in flight per thread
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long st = (long long)gridDim.x * blockDim.x;
+    for (; i + 3 * st < n4; i += 4 * st) {
+        const float4 a = ((const float4*)xr)[i], b = ((const float4*)xr)[i + st], c = ((const float4*)xr)[i + 2 * st], d = ((const float4*)xr)[i + 3 * st];
+        m = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))), m);
+        m = fmaxf(fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))), m);
+        m = fmaxf(fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))), m);
+        m = fmaxf(fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w))), m);
+    }
+    for (; i < n4; i += st) {
+        const float4 a = ((const float4*)xr)[i];
+        m = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))), m);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (per_row & 3)) m = fmaxf(m, fabsf(xr[(n4 << 2) + threadIdx.x]));
+    amax_commit(out + (size_t)blockIdx.y * EGR_ROW_AMAX_STRIDE, m);
+}
+
+// the same for rows that are not 16-byte aligned (element loads)
+__global__ __launch_bounds__(256) void k_absmax_rows_scalar(const float* __restrict__ x, long long per_row, long long zx, unsigned* __restrict__ out) {
+    const float* xr = x + (size_t)blockIdx.z * zx + (size_t)blockIdx.y * per_row;
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per_row; i += (long long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(xr[i]));
+    amax_commit(out + (size_t)blockIdx.y * EGR_ROW_AMAX_STRIDE, m);
+}
+
 __global__ __launch_bounds__(256) void k_split3_pack(const float* __restrict__ w, uint4* __restrict__ w3, long long nslabs,
                                                      int Cout) {
     // one thread per (slab, n, half): 8 consecutive k of one output channel
@@ -179,9 +206,9 @@ __device__ __forceinline__ bf16x8 as_bf(const uint4& v) { return __builtin_bit_c
 __device__ __forceinline__ f16x8 as_hf(const uint4& v) { return __builtin_bit_cast(f16x8, v); }
 
 // plain tile store (z-streamed GEMMs have no bias / residual / activation / placement)
-template <int TM, int TN>
+template <int TM, int TN, bool OST = false>
 __device__ __forceinline__ void store_tile_plain(f32x16 (&acc)[TM][TN], float* __restrict__ y, int M, int Cout, int m0, int n0,
-                                                 int wm0, int wn0, float os) {
+                                                 int wm0, int wn0, float os_u, const float* os_tab = nullptr) {
     const int lane = threadIdx.x & 63, col = lane & 31, rhalf = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -190,6 +217,7 @@ __device__ __forceinline__ void store_tile_plain(f32x16 (&acc)[TM][TN], float* _
             const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
             if (m < M) {
                 float* row = y + (size_t)m * Cout + n0 + wn0 + col;
+                const float os = OST ? os_tab[m - m0] * os_u : os_u;
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     if (n0 + wn0 + j * 32 + col < Cout) row[j * 32] = acc[i][j][r] * os;
@@ -205,8 +233,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
     constexpr int NP = SCH ? 2 : 3;                               // operand planes (terms of the split)
     __shared__ uint4 As[2][NP][BM * 2];
     __shared__ uint4 Bs[2][NP][BN * 2];
-    const float a_scale = p.a_scale;
-    float amax = 0.f;
+    __shared__ float os_tab[SCH ? BM : 1];                        // scheme 1: output scale of every row of the block tile
+    __shared__ unsigned om_tab[SCH ? BM : 1];                     // scheme 1: max |y| per batch row of the block tile (p.out_amax)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm0 = (wave / TC::WN) * (BM / TC::WM), wn0 = (wave % TC::WN) * (BN / TC::WN);
     int bx = blockIdx.x, by = blockIdx.y;
@@ -242,6 +270,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
     // ---- A: thread owns 8 consecutive k (half ah) of tile rows ar (and ar + 128 when BM = 256) ----
     // (plain scalars on purpose: arrays captured by the lambdas below end up in scratch)
     const int ar = tid >> 1, ah = tid & 1;
+    float a_scale0 = 1.f, a_scale1 = 1.f;                         // scheme 1: the operand scales of this thread's rows
+    if constexpr (SCH == 1) {
+        for (int r = tid; r < BM; r += 256) {
+            os_tab[r] = h2_row_inv(p.row_amax[(size_t)(min(m0 + r, p.M - 1) / p.rows_div) * EGR_ROW_AMAX_STRIDE]);
+            om_tab[r] = 0u;
+        }
+        a_scale0 = h2_row_scale(p.row_amax[(size_t)(min(m0 + ar, p.M - 1) / p.rows_div) * EGR_ROW_AMAX_STRIDE]);
+        if (AP > 1) a_scale1 = h2_row_scale(p.row_amax[(size_t)(min(m0 + ar + 128, p.M - 1) / p.rows_div) * EGR_ROW_AMAX_STRIDE]);
+    }
     int a_iy0, a_ix0, a_iy1 = 0, a_ix1 = 0;
     size_t a_base0, a_base1 = 0;
     bool a_ok0, a_ok1 = false;
@@ -361,8 +398,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
 #ifdef S3_ABL_NOSPLIT
         q[0] = q[1] = q[2] = make_uint4(__float_as_uint(r.a0.x), __float_as_uint(r.a0.y), __float_as_uint(r.a1.x), __float_as_uint(r.a1.y));
 #else
-        split_x8<SCH>(r.a0, r.a1, a_scale, q);
-        if (SCH) amax = absmax8(r.a0, r.a1, amax);
+        split_x8<SCH>(r.a0, r.a1, a_scale0, q);
 #endif
 #ifdef S3_ABL_NOSTORE
         if (buf > 1)
@@ -372,8 +408,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
             for (int pl = 0; pl < NP; ++pl) As[buf][pl][a_slot] = q[pl];
             if (AP > 1) {
 #ifndef S3_ABL_NOSPLIT
-                split_x8<SCH>(r.a2, r.a3, a_scale, q);
-                if (SCH) amax = absmax8(r.a2, r.a3, amax);
+                split_x8<SCH>(r.a2, r.a3, a_scale1, q);
 #endif
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) As[buf][pl][a_slot + 256] = q[pl];
@@ -454,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
             const int done = kt + 1;
             const int zl = done / ktiles_all;
             if (done - zl * ktiles_all == 0) {
-                store_tile_plain<TM, TN>(acc, p.y + (size_t)(zl - 1) * p.zy, p.M, p.Cout, m0, n0, wm0, wn0, p.out_scale);
+                store_tile_plain<TM, TN, SCH == 1>(acc, p.y + (size_t)(zl - 1) * p.zy, p.M, p.Cout, m0, n0, wm0, wn0, p.out_scale, os_tab);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -512,8 +547,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
 #ifdef S3_ABL_NOSPLIT
             q[0] = q[1] = make_uint4(__float_as_uint(ra.a0.x), __float_as_uint(ra.a0.y), __float_as_uint(ra.a1.x), __float_as_uint(ra.a1.y));
 #else
-            split_x8<1>(ra.a0, ra.a1, a_scale, q);
-            amax = absmax8(ra.a0, ra.a1, amax);
+            split_x8<1>(ra.a0, ra.a1, a_scale0, q);
 #endif
 #ifdef S3_ABL_NOSTORE
             if (buf > 1)
@@ -584,7 +618,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
                 const int done = kt_begin + t + 1;
                 const int zl = done / ktiles_all;
                 if (done - zl * ktiles_all == 0) {
-                    store_tile_plain_t<TM, TN>(acc, p.y + (size_t)(zl - 1) * p.zy, p.M, p.Cout, m0, n0, wm0, wn0, p.out_scale);
+                    store_tile_plain_t<TM, TN>(acc, p.y + (size_t)(zl - 1) * p.zy, p.M, p.Cout, m0, n0, wm0, wn0, os_tab, p.out_scale);
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -618,11 +652,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
         if (t < n) { slab2(t, 1, sa0, TailT()); ++t; }
         if (t < n) { slab2(t, 0, sa1, TailT()); ++t; }
         if (t < n) { slab2(t, 1, sa0, TailT()); ++t; }
-        amax_commit(p.amax, amax);
 #ifdef S3_ABL_NOEPI
         if (acc[0][0][0] == 123.456f)
 #endif
-        if (!ZS) conv_epilogue_t<TM, TN>(p, acc, m0, n0, wm0, wn0);
+        unsigned* const om = (!ZS && p.out_amax && p.ksplit <= 1) ? om_tab : nullptr;
+        if (!ZS) conv_epilogue_t<TM, TN>(p, acc, m0, n0, wm0, wn0, os_tab, om);
+        if (om) out_amax_commit(p, om_tab, m0, BM);
         return;
     }
     Stage s0, s1;
@@ -649,8 +684,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
         }
         if (kt < kt_end) slab(kt, 0, s0, TailT());
     }
-    if (SCH) amax_commit(p.amax, amax);
-    if (!ZS) conv_epilogue<TM, TN>(p, acc, m0, n0, wm0, wn0);
+    unsigned* const om = (SCH == 1 && !ZS && p.out_amax && p.ksplit <= 1) ? om_tab : nullptr;
+    if (!ZS) conv_epilogue<TM, TN, SCH == 1>(p, acc, m0, n0, wm0, wn0, nullptr, os_tab, om);
+    if (om) out_amax_commit(p, om_tab, m0, BM);
 }
 
 // block-tile height for a problem: 256 rows when that still leaves >= 2 full rounds of workgroups on the 256 CUs
@@ -736,6 +772,26 @@ extern "C" int egr_absmax(const float* x, int64_t n, float* slot, void* stream) 
     return EGR_OK;
 }
 
+// row_amax[r] = bits of max |x| over batch row r (rows x per_row floats, contiguous; nz > 1: nz such blocks zx floats apart, the
+// maximum taken over all of them).  row_amax must be zeroed by the caller (maxima of several tensors may share it).  16-byte
+// aligned rows (per_row % 4 == 0, zx % 4 == 0) take the vector kernel.  Feeds egr_conv_h2.
+extern "C" int egr_absmax_rows(const float* x, int rows, int64_t per_row, int nz, int64_t zx, float* row_amax, void* stream) {
+    EGR_CHECK(x && row_amax && rows >= 1 && rows <= 65535 && per_row >= 1 && nz >= 1 && nz <= 65535, EGR_ERR_ARG, "bad absmax_rows argument");
+    const bool vec = (((uintptr_t)x) & 15) == 0 && per_row % 4 == 0 && (nz == 1 || zx % 4 == 0);
+    long long nb = vec ? (per_row / 4 + 1023) / 1024 : (per_row + 1023) / 1024;              // 4 loads per thread per round
+    const long long cap = std::max(1LL, 4096LL / ((long long)rows * nz));
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    if (vec)
+        hipLaunchKernelGGL(k_absmax_rows, dim3((unsigned)nb, (unsigned)rows, (unsigned)nz), dim3(256), 0, (hipStream_t)stream, x, (long long)per_row,
+                           (long long)zx, (unsigned*)row_amax);
+    else
+        hipLaunchKernelGGL(k_absmax_rows_scalar, dim3((unsigned)nb, (unsigned)rows, (unsigned)nz), dim3(256), 0, (hipStream_t)stream, x,
+                           (long long)per_row, (long long)zx, (unsigned*)row_amax);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
 extern "C" int egr_split3_pack(const float* w_packed, void* w3, int64_t nslabs, int Cout, void* stream) {
     EGR_CHECK(w_packed && w3 && nslabs >= 1 && Cout >= 1, EGR_ERR_ARG, "bad split3 pack argument");
     EGR_CHECK((((uintptr_t)w_packed) & 15) == 0 && (((uintptr_t)w3) & 15) == 0, EGR_ERR_ARG, "split3 pack needs 16-byte alignment");
@@ -763,11 +819,18 @@ __global__ __launch_bounds__(256, 2) void k_conv1d_s3(ConvP p) {
     constexpr int NP = SCH ? 2 : 3;
     __shared__ uint4 As[NP][RMAX * NCH];
     __shared__ uint4 Bs[2][NP][BN * 2];
-    const float a_scale = p.a_scale;
-    float amax = 0.f;
+    __shared__ float os_tab[SCH ? 128 : 1];
+    __shared__ unsigned om_tab[1];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm0 = (wave / TC::WN) * (128 / TC::WM), wn0 = (wave % TC::WN) * (BN / TC::WN);
     const int L = p.W, b = blockIdx.z, l0 = blockIdx.x * 128, n0 = blockIdx.y * BN;
+    float a_scale = 1.f;                         // scheme 1: the tile lies inside ONE batch row (launch_conv1d_s3: rows_div % 128 == 0)
+    if constexpr (SCH == 1) {
+        const unsigned bits = p.row_amax[(size_t)((b * L + l0) / p.rows_div) * EGR_ROW_AMAX_STRIDE];
+        a_scale = h2_row_scale(bits);
+        if (tid < 128) os_tab[tid] = h2_row_inv(bits);
+        if (tid == 0) om_tab[0] = 0u;
+    }
     const int R = 128 + p.dil * (p.KW - 1), pos0 = l0 - p.pad_l;
     const float* xb = p.x + (size_t)b * L * p.Cin;
 
@@ -850,7 +913,6 @@ __global__ __launch_bounds__(256, 2) void k_conv1d_s3(ConvP p) {
                     const int r = e / NCH, ch = e - r * NCH;
                     uint4 q[3];
                     split_x8<SCH>(hu[i], hv[i], a_scale, q);
-                    if (SCH) amax = absmax8(hu[i], hv[i], amax);
                     const int slot = r * NCH + (ch ^ ((r / (16 / NCH)) & (NCH - 1)));
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl) As[pl][slot] = q[pl];
@@ -915,8 +977,9 @@ __global__ __launch_bounds__(256, 2) void k_conv1d_s3(ConvP p) {
     if (sg + 1 < stotal) slab(sg + 1, s2);
     if (sg + 2 < stotal) slab(sg + 2, s3);
     if (SCH) {
-        amax_commit(p.amax, amax);
-        conv_epilogue_t<TM, TN>(p, acc, b * L + l0, n0, wm0, wn0);
+        unsigned* const om = p.out_amax ? om_tab : nullptr;          // the tile lies in one batch row: one word
+        conv_epilogue_t<TM, TN>(p, acc, b * L + l0, n0, wm0, wn0, os_tab, om);
+        if (om) out_amax_commit(p, om_tab, b * L + l0, 128);
     } else {
         conv_epilogue<TM, TN>(p, acc, b * L + l0, n0, wm0, wn0);
     }
@@ -927,7 +990,7 @@ bool launch_conv1d_s3(const ConvP& p, hipStream_t st) {
     static const bool off = getenv("EGR_S3_CONV1D") && atoi(getenv("EGR_S3_CONV1D")) == 0;
     if (off || !p.w3 || p.H != 1 || p.KH != 1 || p.KW < 2 || p.stride != 1 || p.up2 || p.OW != p.W || (p.W % 128) != 0 ||
         p.dil * (p.KW - 1) > 50 || 2 * p.pad_l != p.dil * (p.KW - 1) || (p.Cin % 16) != 0 || p.ksplit > 1 || p.zs_nzb > 0 ||
-        p.nz > 1 || p.osy != 1 || p.osx != 1 || p.OHF != p.OH || p.OWF != p.OW)
+        p.nz > 1 || p.osy != 1 || p.osx != 1 || p.OHF != p.OH || p.OWF != p.OW || (p.sch && (p.rows_div % 128) != 0))
         return false;
     const int bn = p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32);
     const dim3 grid(p.W / 128, (p.Cout + bn - 1) / bn, p.B);

@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include "egr_common.h"
+#include "egr_rowmax.h"
 #include "egr_fft_device.h"
 #include "egr_plan.h"
 
@@ -106,15 +107,17 @@ __global__ void k_gn_coeff(const double* __restrict__ stats, const float* __rest
     shift[i] = (float)((double)beta[c] - mean * sc);
 }
 
+// grid (chunks, B): a workgroup loops over the quads of image b = blockIdx.y; row_amax (optional): row_amax[b] raised to max |y|
 __global__ __launch_bounds__(256) void k_affine_c(const float* __restrict__ x, const float* __restrict__ scale,
                                                    const float* __restrict__ shift, float* __restrict__ y,
-                                                   long long n4, int HW, int C, int silu) {
+                                                   long long n4_img, int HW, int C, int silu, unsigned* __restrict__ row_amax) {
     // vectorised over 4 channels; C % 4 == 0
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+    const int b = blockIdx.y;
+    float ym = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4_img;
          i += (long long)gridDim.x * blockDim.x) {
-        const long long e = i * 4;
+        const long long e = ((long long)b * n4_img + i) * 4;
         const int c = (int)(e % C);
-        const int b = (int)(e / ((long long)HW * C));
         const float4 v = *(const float4*)(x + e);
         const float4 sc = *(const float4*)(scale + (size_t)b * C + c);
         const float4 sh = *(const float4*)(shift + (size_t)b * C + c);
@@ -124,15 +127,21 @@ __global__ __launch_bounds__(256) void k_affine_c(const float* __restrict__ x, c
             o.z = o.z / (1.f + __expf(-o.z)); o.w = o.w / (1.f + __expf(-o.w));
         }
         *(float4*)(y + e) = o;
+        ym = amax4(o, ym);
     }
+    if (row_amax) row_amax_commit_wg(row_amax + (size_t)b * EGR_ROW_AMAX_STRIDE, ym);
 }
 
 // ---------------------------------------------------------------- LayerNorm over rows of C (one wave per row)
+// grid (chunks, batch rows): the waves of a workgroup loop over the `per_b` token rows of batch row blockIdx.y;
+// row_amax (optional): row_amax[batch row] raised to max |y|
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ g,
-                                                    const float* __restrict__ b, float* __restrict__ y, int rows,
-                                                    int C, float eps) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= rows) return;
+                                                    const float* __restrict__ b, float* __restrict__ y, int per_b,
+                                                    int C, float eps, unsigned* __restrict__ row_amax) {
+    const int lane = threadIdx.x & 63;
+    float ym = 0.f;
+    for (int rb = blockIdx.x * 4 + (threadIdx.x >> 6); rb < per_b; rb += gridDim.x * 4) {
+    const size_t row = (size_t)blockIdx.y * per_b + rb;
     const float* xr = x + (size_t)row * C;
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += xr[c];
@@ -145,7 +154,9 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     const float rstd = rsqrtf(v / C + eps);
     float* yr = y + (size_t)row * C;
-    for (int c = lane; c < C; c += 64) yr[c] = (xr[c] - mean) * rstd * g[c] + b[c];
+    for (int c = lane; c < C; c += 64) { const float o = (xr[c] - mean) * rstd * g[c] + b[c]; yr[c] = o; ym = fmaxf(ym, fabsf(o)); }
+    }
+    if (row_amax) row_amax_commit_wg(row_amax + (size_t)blockIdx.y * EGR_ROW_AMAX_STRIDE, ym);
 }
 
 // ---------------------------------------------------------------- row softmax in place (one workgroup per row)
@@ -173,8 +184,14 @@ __global__ __launch_bounds__(256) void k_softmax(float* __restrict__ x, int cols
 
 // ---------------------------------------------------------------- element-wise
 enum { EW_ADD = 0, EW_AXPBY = 1, EW_SILU = 2, EW_SCALE = 3, EW_COPY = 4, EW_ADD_SCALE = 5 };
+// grid (chunks, rows): a workgroup loops over the `n` elements of row blockIdx.y; row_amax (optional): max |y| per row
 __global__ __launch_bounds__(256) void k_eltwise(const float* __restrict__ a, const float* __restrict__ b,
-                                                  float* __restrict__ y, long long n, int op, float s0, float s1) {
+                                                  float* __restrict__ y, long long n, int op, float s0, float s1,
+                                                  unsigned* __restrict__ row_amax) {
+    const size_t ro = (size_t)blockIdx.y * n;
+    a += ro; y += ro;
+    if (b) b += ro;
+    float ym = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         float v;
@@ -187,32 +204,50 @@ __global__ __launch_bounds__(256) void k_eltwise(const float* __restrict__ a, co
             default: v = a[i]; break;
         }
         y[i] = v;
+        ym = fmaxf(ym, fabsf(v));
     }
+    if (row_amax) row_amax_commit_wg(row_amax + (size_t)blockIdx.y * EGR_ROW_AMAX_STRIDE, ym);
 }
 
 // GEGLU: u [rows][2*D] -> y [rows][D] = u[:, :D] * gelu(u[:, D:])   (exact erf GELU)
-__global__ __launch_bounds__(256) void k_geglu(const float* __restrict__ u, float* __restrict__ y, long long rows, int D) {
+// grid (chunks, batch rows): `rows` token rows per batch row; row_amax (optional): max |y| per batch row
+__global__ __launch_bounds__(256) void k_geglu(const float* __restrict__ u, float* __restrict__ y, long long rows, int D,
+                                                unsigned* __restrict__ row_amax) {
     const long long n = rows * D;
+    u += (size_t)blockIdx.y * n * 2;
+    y += (size_t)blockIdx.y * n;
+    float ym = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         const long long r = i / D;
         const int d = (int)(i - r * D);
         const float a = u[r * 2 * D + d], g = u[r * 2 * D + D + d];
-        y[i] = a * (0.5f * g * (1.0f + erff(g * 0.70710678118654752f)));
+        const float o = a * (0.5f * g * (1.0f + erff(g * 0.70710678118654752f)));
+        y[i] = o;
+        ym = fmaxf(ym, fabsf(o));
     }
+    if (row_amax) row_amax_commit_wg(row_amax + (size_t)blockIdx.y * EGR_ROW_AMAX_STRIDE, ym);
 }
 
 // channel concat: y[m][0..C1) = a[m], y[m][C1..C1+C2) = b[m]
+// grid (chunks, batch rows): M pixel rows per batch row; row_amax (optional): max |y| per batch row
 __global__ __launch_bounds__(256) void k_concat(const float* __restrict__ a, const float* __restrict__ b,
-                                                 float* __restrict__ y, long long M, int C1, int C2) {
+                                                 float* __restrict__ y, long long M, int C1, int C2, unsigned* __restrict__ row_amax) {
     const int C = C1 + C2;
     const long long n = M * C;
+    a += (size_t)blockIdx.y * M * C1;
+    b += (size_t)blockIdx.y * M * C2;
+    y += (size_t)blockIdx.y * n;
+    float ym = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         const long long m = i / C;
         const int c = (int)(i - m * C);
-        y[i] = c < C1 ? a[m * C1 + c] : b[m * C2 + (c - C1)];
+        const float o = c < C1 ? a[m * C1 + c] : b[m * C2 + (c - C1)];
+        y[i] = o;
+        ym = fmaxf(ym, fabsf(o));
     }
+    if (row_amax) row_amax_commit_wg(row_amax + (size_t)blockIdx.y * EGR_ROW_AMAX_STRIDE, ym);
 }
 
 // [B][C][H][W] <-> [B][H][W][C] style permutes are done by the host once (weights, tiny tensors); the only
@@ -330,12 +365,16 @@ __global__ __launch_bounds__(256) void k_snake_aa_tiled(const float* __restrict_
 template <int J>
 __global__ __launch_bounds__(256) void k_snake_aa_reg(const float* __restrict__ x, const float* __restrict__ alpha,
                                                       const float* __restrict__ beta, const float* __restrict__ filt,
-                                                      float* __restrict__ y, int L, int C, int nruns, long long total) {
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= total) return;
+                                                      float* __restrict__ y, int L, int C, int nruns,
+                                                      unsigned* __restrict__ row_amax) {
+    // grid (row chunks, B): a workgroup loops over the (run, channel) items of batch row b = blockIdx.y.
+    // row_amax (optional): row_amax[b] raised to max |y| of batch row b (the 1-D convolution that reads y scales each row from it)
+    const int b = blockIdx.y;
+    const long long per_row = (long long)nruns * C;
+    float ymax = 0.f;
+    for (long long gid = (long long)blockIdx.x * 256 + threadIdx.x; gid < per_row; gid += (long long)gridDim.x * 256) {
     const int c = (int)(gid % C);
-    const long long rr = gid / C;
-    const int run = (int)(rr % nruns), b = (int)(rr / nruns);
+    const int run = (int)(gid / C);
     const int l0 = run * J;
     float f[12];
 #pragma unroll
@@ -380,8 +419,13 @@ __global__ __launch_bounds__(256) void k_snake_aa_reg(const float* __restrict__ 
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < 12; ++k) acc += f[k] * sv[2 * jj + k];
-        if (l0 + jj < L) yb[(size_t)(l0 + jj) * C] = acc;
+        if (l0 + jj < L) { yb[(size_t)(l0 + jj) * C] = acc; ymax = fmaxf(ymax, fabsf(acc)); }
     }
+    }
+    // (measured inside the forward, 91 launches: 146 us per launch without the maxima; with them 156 us at <= 8192 workgroups and one
+    // checked commit per workgroup, 181 us at 32768, 165 - 202 us with per-wave or unchecked commits; one commit per workgroup of a
+    // 100 k-workgroup grid: 2.7 ms -- same-line atomics serialise at ~25 ns)
+    if (row_amax) row_amax_commit_wg(row_amax + (size_t)b * EGR_ROW_AMAX_STRIDE, ymax);          // (uniform branch: every thread arrives)
 }
 
 // ---------------------------------------------------------------- ConvTranspose1d overlap-add (gather form)
@@ -466,14 +510,14 @@ __device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigne
 }
 
 __global__ __launch_bounds__(256) void k_randn(float* __restrict__ out, long long per_row, int rows,
-                                                unsigned long long seed, const long long* __restrict__ row_ids) {
+                                                unsigned long long seed, const long long* __restrict__ row_ids, long long id_base) {
     const long long quads = (per_row + 3) / 4;
     const long long n = quads * rows;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(i / quads);
         const long long q = i - (long long)r * quads;
-        const unsigned long long rid = row_ids ? (unsigned long long)row_ids[r] : (unsigned long long)r;
+        const unsigned long long rid = row_ids ? (unsigned long long)row_ids[r] : (unsigned long long)(id_base + r);
         unsigned c0 = (unsigned)q, c1 = (unsigned)(q >> 32), c2 = (unsigned)rid, c3 = (unsigned)(rid >> 32);
         unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
 #pragma unroll
@@ -747,9 +791,18 @@ static inline int grid1d(long long n) {
 
 using namespace egr;
 
+extern "C" int egr_groupnorm_nhwc_ra(const float* x, const float* gamma, const float* beta, float* y, int B, int HW, int C,
+                                     int G, float eps, int silu, void* workspace, float* row_amax, void* stream);
 extern "C" int egr_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, float* y, int B, int HW, int C,
                                   int G, float eps, int silu, void* workspace, void* stream) {
-    EGR_CHECK(x && gamma && beta && y && workspace, EGR_ERR_ARG, "null argument");
+    return egr_groupnorm_nhwc_ra(x, gamma, beta, y, B, HW, C, G, eps, silu, workspace, nullptr, stream);
+}
+
+// The `_ra` forms of the element-wise operators: same outputs, and row_amax[b] (optional; floats the caller zeroed) is raised to
+// max |y| over batch row b -- the operand maxima of the split contraction that reads y (egr_conv_h2) without a pass over y.
+extern "C" int egr_groupnorm_nhwc_ra(const float* x, const float* gamma, const float* beta, float* y, int B, int HW, int C,
+                                     int G, float eps, int silu, void* workspace, float* row_amax, void* stream) {
+    EGR_CHECK(x && gamma && beta && y && workspace && B <= 65535, EGR_ERR_ARG, "null argument");
     EGR_CHECK(B >= 1 && HW >= 1 && C >= 4 && G >= 1 && C % G == 0 && C % 4 == 0, EGR_ERR_ARG, "bad groupnorm geometry");
     hipStream_t st = (hipStream_t)stream;
     // workspace layout: double stats[B*G*2] | float scale[B*C] | float shift[B*C]
@@ -768,8 +821,9 @@ extern "C" int egr_groupnorm_nhwc(const float* x, const float* gamma, const floa
         hipLaunchKernelGGL(k_gn_stats, dim3(nslab, B), dim3(C < 256 ? ((C + 63) / 64) * 64 : 256), 0, st, x, HW, C, G, stats, slab);
     hipLaunchKernelGGL(k_gn_coeff, dim3((B * C + 255) / 256), dim3(256), 0, st, stats, gamma, beta, scale, shift, B, C, G,
                        (double)HW * (C / G), eps);
-    const long long n4 = (long long)B * HW * C / 4;
-    hipLaunchKernelGGL(k_affine_c, dim3(grid1d(n4)), dim3(256), 0, st, x, scale, shift, y, n4, HW, C, silu);
+    const long long n4 = (long long)HW * C / 4;
+    hipLaunchKernelGGL(k_affine_c, dim3(row_grid_x(n4, B, 8192, 2), (unsigned)B), dim3(256), 0, st, x, scale, shift, y, n4, HW, C, silu,
+                       (unsigned*)row_amax);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }
@@ -813,13 +867,26 @@ extern "C" size_t egr_groupnorm_workspace_bytes(int B, int C, int G) {
     return sizeof(double) * (size_t)B * G * 2 + sizeof(float) * 2 * (size_t)B * C + 64;
 }
 
-extern "C" int egr_layernorm_rows(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C,
-                                  float eps, void* stream) {
-    EGR_CHECK(x && gamma && beta && y && rows >= 1 && C >= 1, EGR_ERR_ARG, "bad argument");
-    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
-                       (int)rows, C, eps);
+// batch_rows equal consecutive groups of the `rows` token rows (1: no grouping)
+extern "C" int egr_layernorm_rows_ra(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C,
+                                     float eps, int batch_rows, float* row_amax, void* stream) {
+    EGR_CHECK(x && gamma && beta && y && rows >= 1 && C >= 1 && batch_rows >= 1 && batch_rows <= 65535 && rows % batch_rows == 0, EGR_ERR_ARG,
+              "bad argument");
+    const long long per_b = rows / batch_rows;
+    long long nx = (per_b + 3) / 4, cap = std::max<long long>(1, 16384 / batch_rows);
+    if (nx > cap) nx = cap;
+    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)nx, (unsigned)batch_rows), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+                       (int)per_b, C, eps, (unsigned*)row_amax);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
+}
+
+extern "C" int egr_layernorm_rows(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C,
+                                  float eps, void* stream) {
+    // (as many groups as keep the grid fine: the grouping does not change any value)
+    int g = 1;
+    for (int c : {64, 32, 16, 8, 4, 2}) if (rows % c == 0) { g = c; break; }
+    return egr_layernorm_rows_ra(x, gamma, beta, y, rows, C, eps, g, nullptr, stream);
 }
 
 extern "C" int egr_softmax_rows(float* x, int64_t rows, int cols, void* stream) {
@@ -829,20 +896,39 @@ extern "C" int egr_softmax_rows(float* x, int64_t rows, int cols, void* stream) 
     return EGR_OK;
 }
 
-extern "C" int egr_eltwise(const float* a, const float* b, float* y, int64_t n, int op, float s0, float s1, void* stream) {
-    EGR_CHECK(a && y && n >= 0 && op >= 0 && op <= 5, EGR_ERR_ARG, "bad argument");
+// n elements = batch_rows equal consecutive runs
+extern "C" int egr_eltwise_ra(const float* a, const float* b, float* y, int64_t n, int op, float s0, float s1, int batch_rows,
+                              float* row_amax, void* stream) {
+    EGR_CHECK(a && y && n >= 0 && op >= 0 && op <= 5 && batch_rows >= 1 && batch_rows <= 65535 && n % batch_rows == 0, EGR_ERR_ARG, "bad argument");
     EGR_CHECK(b || (op != EW_ADD && op != EW_AXPBY && op != EW_ADD_SCALE), EGR_ERR_ARG, "binary op needs b");
     if (n == 0) return EGR_OK;
-    hipLaunchKernelGGL(k_eltwise, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, (long long)n, op, s0, s1);
+    const long long per = n / batch_rows;
+    hipLaunchKernelGGL(k_eltwise, dim3(row_grid_x(per, batch_rows, 8192, 4), (unsigned)batch_rows), dim3(256), 0, (hipStream_t)stream, a, b, y, per,
+                       op, s0, s1, (unsigned*)row_amax);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_eltwise(const float* a, const float* b, float* y, int64_t n, int op, float s0, float s1, void* stream) {
+    int g = 1;
+    for (int c : {64, 32, 16, 8, 4, 2}) if (n % c == 0) { g = c; break; }
+    return egr_eltwise_ra(a, b, y, n, op, s0, s1, g, nullptr, stream);
+}
+
+// rows token rows = batch_rows equal consecutive groups
+extern "C" int egr_geglu_ra(const float* u, float* y, int64_t rows, int D, int batch_rows, float* row_amax, void* stream) {
+    EGR_CHECK(u && y && rows >= 1 && D >= 1 && batch_rows >= 1 && batch_rows <= 65535 && rows % batch_rows == 0, EGR_ERR_ARG, "bad argument");
+    const long long per = rows / batch_rows;
+    hipLaunchKernelGGL(k_geglu, dim3(row_grid_x(per * D, batch_rows, 8192, 4), (unsigned)batch_rows), dim3(256), 0, (hipStream_t)stream, u, y, per, D,
+                       (unsigned*)row_amax);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }
 
 extern "C" int egr_geglu(const float* u, float* y, int64_t rows, int D, void* stream) {
-    EGR_CHECK(u && y && rows >= 1 && D >= 1, EGR_ERR_ARG, "bad argument");
-    hipLaunchKernelGGL(k_geglu, dim3(grid1d(rows * D)), dim3(256), 0, (hipStream_t)stream, u, y, (long long)rows, D);
-    EGR_HIP(hipGetLastError());
-    return EGR_OK;
+    int g = 1;
+    for (int c : {64, 32, 16, 8, 4, 2}) if (rows % c == 0) { g = c; break; }
+    return egr_geglu_ra(u, y, rows, D, g, nullptr, stream);
 }
 
 extern "C" int egr_tap_gather(const float* P, const float* bias, float* y, int B, int H, int W, int KH, int KW, int Cout, int pad_t,
@@ -872,12 +958,21 @@ extern "C" int egr_conv_cin1(const float* x, const float* w_packed, const float*
     return EGR_OK;
 }
 
-extern "C" int egr_concat_channels(const float* a, const float* b, float* y, int64_t M, int C1, int C2, void* stream) {
-    EGR_CHECK(a && b && y && M >= 1 && C1 >= 1 && C2 >= 1, EGR_ERR_ARG, "bad argument");
-    hipLaunchKernelGGL(k_concat, dim3(grid1d(M * (C1 + C2))), dim3(256), 0, (hipStream_t)stream, a, b, y, (long long)M, C1,
-                       C2);
+// M pixel rows = batch_rows equal consecutive groups
+extern "C" int egr_concat_channels_ra(const float* a, const float* b, float* y, int64_t M, int C1, int C2, int batch_rows, float* row_amax,
+                                      void* stream) {
+    EGR_CHECK(a && b && y && M >= 1 && C1 >= 1 && C2 >= 1 && batch_rows >= 1 && batch_rows <= 65535 && M % batch_rows == 0, EGR_ERR_ARG, "bad argument");
+    const long long per = M / batch_rows;
+    hipLaunchKernelGGL(k_concat, dim3(row_grid_x(per * (C1 + C2), batch_rows, 8192, 4), (unsigned)batch_rows), dim3(256), 0, (hipStream_t)stream, a, b, y,
+                       per, C1, C2, (unsigned*)row_amax);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
+}
+
+extern "C" int egr_concat_channels(const float* a, const float* b, float* y, int64_t M, int C1, int C2, void* stream) {
+    int g = 1;
+    for (int c : {64, 32, 16, 8, 4, 2}) if (M % c == 0) { g = c; break; }
+    return egr_concat_channels_ra(a, b, y, M, C1, C2, g, nullptr, stream);
 }
 
 extern "C" int egr_transpose_batched(const float* x, float* y, int batch, int R, int Cc, void* stream) {
@@ -888,8 +983,16 @@ extern "C" int egr_transpose_batched(const float* x, float* y, int batch, int R,
     return EGR_OK;
 }
 
+extern "C" int egr_snake_aa_ra(const float* x, const float* alpha, const float* beta, const float* filt, float* y, int B,
+                               int L, int C, int K, float* row_amax, void* stream);
 extern "C" int egr_snake_aa(const float* x, const float* alpha, const float* beta, const float* filt, float* y, int B,
                             int L, int C, int K, void* stream) {
+    return egr_snake_aa_ra(x, alpha, beta, filt, y, B, L, C, K, nullptr, stream);
+}
+
+// same, and row_amax[b] (optional; floats the caller zeroed) is raised to max |y| of batch row b
+extern "C" int egr_snake_aa_ra(const float* x, const float* alpha, const float* beta, const float* filt, float* y, int B,
+                               int L, int C, int K, float* row_amax, void* stream) {
     EGR_CHECK(x && alpha && beta && filt && y && B >= 1 && B <= 65535 && L >= 1 && C >= 1 && K >= 2 && K <= 32 && K % 2 == 0,
               EGR_ERR_ARG, "bad argument");
     hipStream_t st = (hipStream_t)stream;
@@ -897,9 +1000,10 @@ extern "C" int egr_snake_aa(const float* x, const float* alpha, const float* bet
     if (K == 12 && !tiled) {
         constexpr int J = 16;
         const int nruns = (L + J - 1) / J;
-        const long long total = (long long)B * nruns * C;
-        hipLaunchKernelGGL((k_snake_aa_reg<J>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, alpha, beta, filt, y, L, C,
-                           nruns, total);
+        static const int max_wg = getenv("EGR_SNAKE_WG") ? atoi(getenv("EGR_SNAKE_WG")) : 8192;
+        hipLaunchKernelGGL((k_snake_aa_reg<J>), dim3(row_grid_x((long long)nruns * C, B, max_wg), (unsigned)B), dim3(256), 0, st, x, alpha, beta, filt, y, L, C,
+                           nruns, (unsigned*)row_amax);
+        row_amax = nullptr;                      // done in the kernel
     } else if (K == 12 && C % 64 == 0)
         hipLaunchKernelGGL((k_snake_aa_tiled<64, 32>), dim3(C / 64, (L + 31) / 32, B), dim3(256), 0, st, x, alpha, beta, filt, y, L, C);
     else if (K == 12 && C % 32 == 0)
@@ -909,6 +1013,7 @@ extern "C" int egr_snake_aa(const float* x, const float* alpha, const float* bet
     else
         hipLaunchKernelGGL(k_snake_aa, dim3((C + 63) / 64, (L + 3) / 4, B), dim3(256), 0, st, x, alpha, beta, filt, y, L, C, K);
     EGR_HIP(hipGetLastError());
+    if (row_amax) return egr_absmax_rows(y, B, (int64_t)L * C, 1, 0, row_amax, stream);      // the other kernels: a pass over y
     return EGR_OK;
 }
 
@@ -939,13 +1044,18 @@ extern "C" int egr_stft_frames(const float* x, int B, int L, int n_fft, int hop,
     return EGR_OK;
 }
 
-extern "C" int egr_randn(float* out, int64_t per_row, int rows, uint64_t seed, const int64_t* row_ids, void* stream) {
+// row r of out is a function of (seed, id of row r) only: id = row_ids[r] (device array) or, without one, id_base + r
+extern "C" int egr_randn_base(float* out, int64_t per_row, int rows, uint64_t seed, const int64_t* row_ids, int64_t id_base, void* stream) {
     EGR_CHECK(out && per_row >= 1 && rows >= 1, EGR_ERR_ARG, "bad argument");
     const long long n = ((per_row + 3) / 4) * rows;
     hipLaunchKernelGGL(k_randn, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, out, (long long)per_row, rows,
-                       (unsigned long long)seed, (const long long*)row_ids);
+                       (unsigned long long)seed, (const long long*)row_ids, (long long)id_base);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
+}
+
+extern "C" int egr_randn(float* out, int64_t per_row, int rows, uint64_t seed, const int64_t* row_ids, void* stream) {
+    return egr_randn_base(out, per_row, rows, seed, row_ids, 0, stream);
 }
 
 extern "C" int egr_lowpass_gain(const float* mag, int B, int T, int ldm, int nb, float pct, float sr, int order,

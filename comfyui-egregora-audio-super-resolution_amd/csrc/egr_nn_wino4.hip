@@ -12,6 +12,7 @@
 //   G row p     : [1, p, p^2] / N_p,  N_0 = a^2 b^2, N_+-a = 2 a^2 (a^2-b^2), N_+-b = 2 b^2 (b^2-a^2);  G row inf : [0, 0, 1]
 //   A^T[i][p]   : p^i (i < 4), plus 1 at [3][inf]
 #include "egr_common.h"
+#include "egr_rowmax.h"
 
 namespace egr {
 
@@ -62,17 +63,25 @@ __device__ __forceinline__ void at6(const float4 (&m)[6], float4 (&s)[4]) {
 // V[6 i + j][t][c] = (B^T d B)[i][j] of the 6x6 input tile whose origin is (4 ty - 1, 4 tx - 1); t = (b, ty, tx).
 // GN / SILU are compile-time so that the 36 tile loads are issued back to back (a run-time branch between them made the
 // compiler wait for every load separately: 36 serialized round trips per thread).
+// row_amax (optional): row_amax[b] is raised to the bits of max |V| over image b's tiles and all 36 components -- the operand
+// scale of the GEMMs that read V (scheme 1 of csrc/egr_nn_gemm_s3.hip) without another pass over V.
 template <bool GN, bool SILU>
 __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, int B, int H, int W, int C, int TH, int TW,
                                                    const float* __restrict__ gsc, const float* __restrict__ gsh,
-                                                   float* __restrict__ V) {
+                                                   float* __restrict__ V, unsigned* __restrict__ row_amax) {
     const int C4 = C >> 2;
-    const long long P = (long long)B * TH * TW, total = P * C4;
+    const long long P = (long long)B * TH * TW;
     const size_t zs = (size_t)P * C;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        const long long t = i / C4;
-        const int tx = (int)(t % TW), ty = (int)((t / TW) % TH), b = (int)(t / ((long long)TW * TH));
+    // grid (row chunks, B): a workgroup loops over the (tile, channel quad) items of image b = blockIdx.y
+    const int b = blockIdx.y;
+    const long long per_img = (long long)TH * TW * C4;
+    float vmax = 0.f;
+    for (long long ii = (long long)blockIdx.x * blockDim.x + threadIdx.x; ii < per_img; ii += (long long)gridDim.x * blockDim.x) {
+        {
+        const int c4 = (int)(ii % C4);
+        const int tl = (int)(ii / C4);
+        const int tx = tl % TW, ty = tl / TW;
+        const long long t = (long long)b * TH * TW + tl;
         float4 d[6][6];                                   // d[r][q]: row r, column q of the tile
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
@@ -129,26 +138,39 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float* __restrict__ x, i
             float4 row[6];
             bt6(d[r], row);
 #pragma unroll
-            for (int q = 0; q < 6; ++q) st_f4(o + (size_t)(6 * r + q) * zs, row[q]);
+            for (int q = 0; q < 6; ++q) {
+                st_f4(o + (size_t)(6 * r + q) * zs, row[q]);
+                vmax = amax4(row[q], vmax);
+            }
+        }
         }
     }
+    if (row_amax) row_amax_commit(row_amax + (size_t)b * EGR_ROW_AMAX_STRIDE, vmax);                  // once per wave, every lane arrives together
 }
 
 // y[b][4ty+a][4tx+c][n] = act((A^T M A)[a][c] + bias[n] + res[...]),  M[6 i + j][t][n].  RES / SILU are compile-time (loads
 // of the residual are then hoisted above the arithmetic instead of being waited for one by one).
 // STATS: each thread also writes (sum, sum of squares) of its 64 outputs to part[t][n4] -- the GroupNorm statistics of y are
 // then a reduction over 1/32 of the tensor's bytes instead of another pass over y (egr_groupnorm_coeff_from_partials).
+// row_amax (optional): row_amax[b] raised to max |y| of image b (the tensor feeds 1x1 / strided / phase convolutions directly).
 template <bool RES, bool SILU, bool STATS>
 __global__ __launch_bounds__(256) void k_wino4_out(const float* __restrict__ Mx, const float* __restrict__ bias,
                                                     const float* __restrict__ res, int B, int H, int W, int N, int TH, int TW,
-                                                    float* __restrict__ y, float2* __restrict__ part) {
+                                                    float* __restrict__ y, float2* __restrict__ part, unsigned* __restrict__ row_amax) {
     const int N4 = N >> 2;
-    const long long P = (long long)B * TH * TW, total = P * N4;
+    const long long P = (long long)B * TH * TW;
     const size_t zs = (size_t)P * N;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int n4 = (int)(i % N4);
-        const long long t = i / N4;
-        const int tx = (int)(t % TW), ty = (int)((t / TW) % TH), b = (int)(t / ((long long)TW * TH));
+    // grid (row chunks, B): a workgroup loops over the (tile, channel quad) items of image b = blockIdx.y
+    const int b = blockIdx.y;
+    const long long per_img = (long long)TH * TW * N4;
+    float ymax = 0.f;
+    for (long long ii = (long long)blockIdx.x * blockDim.x + threadIdx.x; ii < per_img; ii += (long long)gridDim.x * blockDim.x) {
+        {
+        const int n4 = (int)(ii % N4);
+        const int tl = (int)(ii / N4);
+        const int tx = tl % TW, ty = tl / TW;
+        const long long t = (long long)b * TH * TW + tl;
+        const long long i = t * N4 + n4;
         const float* mi = Mx + (size_t)t * N + 4 * n4;
         float4 s[4][6];                                   // s[a][q] = (A^T m)[a][q]
 #pragma unroll
@@ -183,6 +205,7 @@ __global__ __launch_bounds__(256) void k_wino4_out(const float* __restrict__ Mx,
                     v.z = v.z / (1.f + __expf(-v.z)); v.w = v.w / (1.f + __expf(-v.w));
                 }
                 *(float4*)(y + off + (size_t)c * N) = v;
+                ymax = amax4(v, ymax);
                 if (STATS) {
                     ps += (v.x + v.y) + (v.z + v.w);
                     pq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
@@ -190,7 +213,9 @@ __global__ __launch_bounds__(256) void k_wino4_out(const float* __restrict__ Mx,
             }
         }
         if (STATS) part[i] = make_float2(ps, pq);
+        }
     }
+    if (row_amax) row_amax_commit(row_amax + (size_t)b * EGR_ROW_AMAX_STRIDE, ymax);
 }
 
 // stats[b][g] = (sum, sum of squares) over image b's tiles and group g's channel quads of part[t][n4]; one workgroup per (g, b),
@@ -245,27 +270,36 @@ extern "C" int egr_winograd4_g(double* g18) {
     return EGR_OK;
 }
 
+extern "C" int egr_winograd4_input_ra(const float* x, const float* gn_scale, const float* gn_shift, int gn_silu, int B, int H,
+                                      int W, int C, float* V, float* row_amax, void* stream);
 extern "C" int egr_winograd4_input(const float* x, const float* gn_scale, const float* gn_shift, int gn_silu, int B, int H,
                                    int W, int C, float* V, void* stream) {
+    return egr_winograd4_input_ra(x, gn_scale, gn_shift, gn_silu, B, H, W, C, V, nullptr, stream);
+}
+
+// same, and row_amax[b] (optional; bits of a non-negative float, zeroed by the caller) is raised to max |V| of image b
+extern "C" int egr_winograd4_input_ra(const float* x, const float* gn_scale, const float* gn_shift, int gn_silu, int B, int H,
+                                      int W, int C, float* V, float* row_amax, void* stream) {
     EGR_CHECK(x && V && B >= 1 && H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0 && C >= 4 && C % 4 == 0 &&
                   (!gn_scale || gn_shift), EGR_ERR_ARG, "F(4x4,3x3) input transform needs H, W, C multiples of 4");
     const int TH = H / 4, TW = W / 4;
-    const long long n = (long long)B * TH * TW * (C / 4);
-    const dim3 g(grid1d(n)), blk(256);
+    EGR_CHECK(B <= 65535, EGR_ERR_ARG, "too many images");
+    const dim3 g(row_grid_x((long long)TH * TW * (C / 4), B), (unsigned)B), blk(256);
     hipStream_t st = (hipStream_t)stream;
-    if (!gn_scale) hipLaunchKernelGGL((k_wino4_in<false, false>), g, blk, 0, st, x, B, H, W, C, TH, TW, gn_scale, gn_shift, V);
-    else if (gn_silu) hipLaunchKernelGGL((k_wino4_in<true, true>), g, blk, 0, st, x, B, H, W, C, TH, TW, gn_scale, gn_shift, V);
-    else hipLaunchKernelGGL((k_wino4_in<true, false>), g, blk, 0, st, x, B, H, W, C, TH, TW, gn_scale, gn_shift, V);
+    unsigned* ra = (unsigned*)row_amax;
+    if (!gn_scale) hipLaunchKernelGGL((k_wino4_in<false, false>), g, blk, 0, st, x, B, H, W, C, TH, TW, gn_scale, gn_shift, V, ra);
+    else if (gn_silu) hipLaunchKernelGGL((k_wino4_in<true, true>), g, blk, 0, st, x, B, H, W, C, TH, TW, gn_scale, gn_shift, V, ra);
+    else hipLaunchKernelGGL((k_wino4_in<true, false>), g, blk, 0, st, x, B, H, W, C, TH, TW, gn_scale, gn_shift, V, ra);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }
 
 static int wino4_out_launch(const float* M, const float* bias, const float* res, float* y, int B, int H, int W, int N, int act,
-                            float2* part, hipStream_t st) {
+                            float2* part, unsigned* row_amax, hipStream_t st) {
     const int TH = H / 4, TW = W / 4;
-    const long long n = (long long)B * TH * TW * (N / 4);
-    const dim3 g(grid1d(n)), blk(256);
-#define W4O(R_, S_, T_) hipLaunchKernelGGL((k_wino4_out<R_, S_, T_>), g, blk, 0, st, M, bias, res, B, H, W, N, TH, TW, y, part)
+    EGR_CHECK(B <= 65535, EGR_ERR_ARG, "too many images");
+    const dim3 g(row_grid_x((long long)TH * TW * (N / 4), B), (unsigned)B), blk(256);
+#define W4O(R_, S_, T_) hipLaunchKernelGGL((k_wino4_out<R_, S_, T_>), g, blk, 0, st, M, bias, res, B, H, W, N, TH, TW, y, part, row_amax)
     if (part) {
         if (res && act) W4O(true, true, true); else if (res) W4O(true, false, true);
         else if (act) W4O(false, true, true); else W4O(false, false, true);
@@ -282,7 +316,7 @@ extern "C" int egr_winograd4_output(const float* M, const float* bias, const flo
                                     int act, void* stream) {
     EGR_CHECK(M && y && B >= 1 && H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0 && N >= 4 && N % 4 == 0 &&
                   (act == 0 || act == 1), EGR_ERR_ARG, "F(4x4,3x3) output transform needs H, W, N multiples of 4");
-    return wino4_out_launch(M, bias, res, y, B, H, W, N, act, nullptr, (hipStream_t)stream);
+    return wino4_out_launch(M, bias, res, y, B, H, W, N, act, nullptr, nullptr, (hipStream_t)stream);
 }
 
 // same, and part[B*(H/4)*(W/4)][N/4] float2 receives every thread's (sum, sum of squares) of its 4 x 4 x 4 outputs
@@ -290,7 +324,15 @@ extern "C" int egr_winograd4_output_stats(const float* M, const float* bias, con
                                           int N, int act, void* part, void* stream) {
     EGR_CHECK(M && y && part && B >= 1 && H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0 && N >= 4 && N % 4 == 0 &&
                   (act == 0 || act == 1), EGR_ERR_ARG, "F(4x4,3x3) output transform needs H, W, N multiples of 4");
-    return wino4_out_launch(M, bias, res, y, B, H, W, N, act, (float2*)part, (hipStream_t)stream);
+    return wino4_out_launch(M, bias, res, y, B, H, W, N, act, (float2*)part, nullptr, (hipStream_t)stream);
+}
+
+// both output transforms with row_amax[b] (optional; floats the caller zeroed) raised to max |y| of image b; part may be null
+extern "C" int egr_winograd4_output_ra(const float* M, const float* bias, const float* res, float* y, int B, int H, int W, int N,
+                                       int act, void* part, float* row_amax, void* stream) {
+    EGR_CHECK(M && y && B >= 1 && H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0 && N >= 4 && N % 4 == 0 &&
+                  (act == 0 || act == 1), EGR_ERR_ARG, "F(4x4,3x3) output transform needs H, W, N multiples of 4");
+    return wino4_out_launch(M, bias, res, y, B, H, W, N, act, (float2*)part, (unsigned*)row_amax, (hipStream_t)stream);
 }
 
 // stats[B][G][2] (double: sum, sum of squares per image and group) from the partials of egr_winograd4_output_stats;

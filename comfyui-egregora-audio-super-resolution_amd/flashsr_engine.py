@@ -37,9 +37,9 @@ class FlashSREngine:
     # dense contractions run on the bf16 matrix pipe with fp32-grade results ("bf16x3": exact three-way split of both
     # operands, six partial products accumulated in fp32, csrc/egr_nn_gemm_s3.hip) or on v_mfma_f32_32x32x2_f32 ("f32").
     MFMA_MODE = os.environ.get("EGREGORA_FLASHSR_MFMA", "bf16x3")
-    # operand scheme of egr_flashsr_infer's split contractions: "f16x2" = two fp16 terms with scales measured on the previous call
-    # (first call and range-check failures run the bf16 terms; include/egregora_amd.h egr_flashsr_set_split), "bf16x3" = always
-    # three bf16 terms.  egr_flashsr_forward / the operator API always use the bf16 terms.
+    # operand scheme of egr_flashsr_infer's split contractions: "f16x2" = two fp16 terms, one power-of-two scale per (tensor, batch
+    # row) derived on the device from that row's own maximum (include/egregora_amd.h egr_flashsr_set_split), "bf16x3" = always
+    # three bf16 terms.  egr_flashsr_forward / the operator API use the bf16 terms.
     SPLIT = os.environ.get("EGREGORA_FLASHSR_SPLIT", "f16x2")
     # F(2x2,3x3) paid from 256 channels (its transforms move 4x the tensor); F(4x4,3x3) moves 2.25x and pays from 128
     WINO_MIN_CH = int(os.environ.get("EGREGORA_FLASHSR_WINOGRAD_MIN_CH", "128"))
@@ -166,14 +166,15 @@ class FlashSREngine:
 
     def set_split(self, scheme: str):
         """"bf16x3" or "f16x2" for the following c_infer calls (the latter needs an engine built with SPLIT = "f16x2")."""
-        code = {"bf16x3": 0, "f16x2": 1, "f16x2+forward": 2}[scheme]     # the last: c_forward too uses the measured fp16 scales (tests)
+        code = {"bf16x3": 0, "f16x2": 1, "f16x2+forward": 2}[scheme]     # the last: c_forward too runs the fp16 operand terms (tests)
         native.check(self.L.egr_flashsr_set_split(C.c_void_p(self.handle), code), "egr_flashsr_set_split")
 
     def split_info(self) -> dict:
-        en, cal, sl, calls, rr = C.c_int(), C.c_int(), C.c_int(), C.c_int64(), C.c_int64()
-        native.check(self.L.egr_flashsr_split_info(C.c_void_p(self.handle), C.byref(en), C.byref(cal), C.byref(sl), C.byref(calls), C.byref(rr)),
-                     "egr_flashsr_split_info")
-        return dict(enabled=bool(en.value), calibrated=bool(cal.value), slots=sl.value, calls=calls.value, reruns=rr.value)
+        """enabled: c_infer runs two fp16 terms per operand with per-row scales derived on the device; weights: contraction weights that
+        hold fp16 terms; calls: c_infer calls made on the scheme (include/egregora_amd.h egr_flashsr_set_split)."""
+        en, nw, calls = C.c_int(), C.c_int(), C.c_int64()
+        native.check(self.L.egr_flashsr_split_info(C.c_void_p(self.handle), C.byref(en), C.byref(nw), C.byref(calls)), "egr_flashsr_split_info")
+        return dict(enabled=bool(en.value), weights=nw.value, calls=calls.value)
 
     def c_profile(self, fn) -> dict:
         """{kernel instantiation: (launches, flops, ms)} of the MFMA contraction launches the handle made while fn() ran."""

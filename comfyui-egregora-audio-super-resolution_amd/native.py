@@ -14,7 +14,7 @@ EGR_OK = 0
 FL_NORMALIZE, FL_AUTOSCALE, FL_PCM_IN, FL_NODE_POST = 0x1, 0x2, 0x4, 0x8
 FL_THR_RELATIVE, FL_THR_SOFT, FL_NO_INIT_THR, FL_ZERO_STUFF, FL_INTERP_LINSPACE = 0x10, 0x20, 0x40, 0x80, 0x100      # SPEC.md section 3
 FL_INFO_LEN = 48
-ABI_VERSION = 3          # include/egregora_amd.h EGR_ABI_VERSION
+ABI_VERSION = 4          # include/egregora_amd.h EGR_ABI_VERSION
 
 # name -> (restype, argtypes); must list every symbol of include/egregora_amd.h
 _vp, _i, _i64, _f, _u = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint
@@ -67,7 +67,8 @@ SIGNATURES = {
     "egr_conv_s3": (_i, [_vp] * 6 + [_i] * 15 + [_f] + [_i] * 7 + [_i64] * 3 + [_vp]),
     "egr_split2h_pack": (_i, [_vp, _vp, _i64, _i, _f, _vp]),
     "egr_absmax": (_i, [_vp, _i64, _vp, _vp]),
-    "egr_conv_h2": (_i, [_vp] * 6 + [_i] * 15 + [_f] + [_i] * 7 + [_i64] * 3 + [_f, _f, _vp, _vp]),
+    "egr_absmax_rows": (_i, [_vp, _i, _i64, _i, _i64, _vp, _vp]),
+    "egr_conv_h2": (_i, [_vp] * 6 + [_i] * 15 + [_f] + [_i] * 7 + [_i64] * 3 + [_f, _vp, _i, _vp, _vp]),
     "egr_winograd_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "egr_groupnorm_coeff": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "egr_conv_nhwc_gn": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
@@ -75,14 +76,21 @@ SIGNATURES = {
     "egr_winograd_output": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "egr_winograd4_g": (_i, [C.POINTER(C.c_double)]),
     "egr_winograd4_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "egr_winograd4_input_ra": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "egr_winograd4_output": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "egr_winograd4_output_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "egr_winograd4_output_ra": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "egr_groupnorm_stats_from_partials": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "egr_groupnorm_coeff_from_stats": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "egr_bgemm_nt_s3": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_i64] * 6 + [_f, _vp]),
     "egr_bgemm": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_i64] * 6 + [_i, _f, _vp]),
     "egr_groupnorm_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "egr_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "egr_groupnorm_nhwc_ra": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "egr_layernorm_rows_ra": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _i, _vp, _vp]),
+    "egr_eltwise_ra": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _i, _vp, _vp]),
+    "egr_geglu_ra": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
+    "egr_concat_channels_ra": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "egr_layernorm_rows": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
     "egr_softmax_rows": (_i, [_vp, _i64, _i, _vp]),
     "egr_eltwise": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _vp]),
@@ -95,10 +103,12 @@ SIGNATURES = {
     "egr_concat_channels": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "egr_transpose_batched": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "egr_snake_aa": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "egr_snake_aa_ra": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "egr_col2im_convtr1d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "egr_stft_frames": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "egr_lowpass_gain": (_i, [_vp, _i, _i, _i, _i, _f, _f, _i, _f, _i64, _vp, _vp, _vp]),
     "egr_randn": (_i, [_vp, _i64, _i, C.c_uint64, _vp, _vp]),
+    "egr_randn_base": (_i, [_vp, _i64, _i, C.c_uint64, _vp, _i64, _vp]),
     "egr_flashsr_default_config": (_i, [_vp]),
     "egr_flashsr_create": (_i, [C.POINTER(_vp), _vp, _vp, _i, _u, _vp]),
     "egr_flashsr_create_from_file": (_i, [C.POINTER(_vp), C.c_char_p, _u, _vp]),
@@ -108,7 +118,7 @@ SIGNATURES = {
     "egr_flashsr_set_rows_per_pass": (_i, [_vp, _i]),
     "egr_flashsr_set_streams": (_i, [_vp, _i, _i]),
     "egr_flashsr_set_split": (_i, [_vp, _i]),
-    "egr_flashsr_split_info": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "egr_flashsr_split_info": (_i, [_vp, _vp, _vp, _vp]),
     "egr_flashsr_set_profiling": (_i, [_vp, _i]),
     "egr_flashsr_profile": (_i, [_vp, _i, C.c_char_p, C.c_size_t, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                  C.POINTER(_i)]),

@@ -23,8 +23,12 @@
 extern "C" {
 #endif
 
-/* 2: paired chirp-z plans (egr_fatllama_plan_create_chirpz, info[40..41], egr_fatllama_kernel_times3), model handle, DFN / null-test entry points */
-#define EGR_ABI_VERSION 3
+/* 2: paired chirp-z plans (egr_fatllama_plan_create_chirpz, info[40..41], egr_fatllama_kernel_times3), model handle, DFN / null-test entry points
+ * 3: two-term fp16 operand scheme (egr_split2h_pack, egr_absmax, egr_conv_h2, egr_flashsr_set_split / _split_info)
+ * 4: the fp16 scheme's scales are per batch row and derived on the device: egr_conv_h2 takes (w_scale, row_amax, batch_rows)
+ *    instead of (a_scale, w_scale, amax); egr_absmax_rows, egr_winograd4_input_ra / _output_ra, egr_snake_aa_ra, egr_randn_base added; egr_flashsr_split_info
+ *    reports (enabled, weights, calls); egr_flashsr_infer no longer measures, verifies, re-runs or synchronises */
+#define EGR_ABI_VERSION 4
 
 #define EGR_OK 0
 #define EGR_ERR_ARG 1          /* bad argument */
@@ -278,22 +282,32 @@ int egr_conv_nhwc_placed(const float* x, const float* w, const float* bias, cons
 int egr_split3_pack(const float* w_packed, void* w3, int64_t nslabs, int Cout, void* stream);
 
 /* The same contraction on TWO fp16 terms per operand (scheme 1 of csrc/egr_nn_gemm_s3.hip): x s = h0 + h1 with h0 = f16(x s),
- * h1 = f16(x s - h0), s a power of two chosen by the caller so that the tensor's largest magnitude sits near 2^12 (fp16 tops out
- * at 65504); three exact products h0 h0 + h0 h1 + h1 h0 accumulated in fp32 by v_mfma_f32_32x32x16_f16 -- half the matrix
- * instructions of the three-term bf16 scheme, 22 significand bits per operand for every element within 2^-15 of the tensor's
- * maximum (absolute error 2^-37 of the maximum below that), measured error vs float64 <= the bf16 scheme's
- * (tests/test_gpu_split_h2.py).  An operand beyond the fp16 range after scaling gives inf / nan: the caller checks *amax.
+ * h1 = f16(x s - h0); three exact products h0 h0 + h0 h1 + h1 h0 accumulated in fp32 by v_mfma_f32_32x32x16_f16 -- half the matrix
+ * instructions of the three-term bf16 scheme; measured error vs float64 <= the bf16 scheme's (tests/test_gpu_split_h2.py).
+ * s is a power of two PER BATCH ROW, derived inside the kernel from that row's max |x| so that the row's scaled maximum lies in
+ * [2^14, 2^15): no operand can leave fp16's range, every element within 2^-29 of ITS ROW's maximum keeps 22 significand bits
+ * (absolute error 2^-40 of the row maximum below that), and a row's result does not depend on the other rows of the batch.
  *   egr_split2h_pack : packed fp32 weights [nslabs][Cout][16] -> w2 [nslabs][2][Cout][16] f16 terms of w * w_scale
  *   egr_absmax       : raises *slot (a float the caller zeroed) to max |x[i]|, i < n  (x 16-byte aligned)
- *   egr_conv_h2      : egr_conv_s3 on w2; the loader multiplies x by a_scale, the epilogue divides by a_scale * w_scale (both
- *                      powers of two) and, when amax is not null, *amax (zeroed by the caller) is raised to max |x| of
- *                      everything the loader read.  zw2 counts 16-byte units of w2. */
+ *   egr_absmax_rows  : row_amax[r] (floats the caller zeroed) raised to max |x| over batch row r: `rows` contiguous runs of per_row
+ *                      floats; nz > 1: nz such blocks zx floats apart (the Winograd V layout [nz][rows * tiles][C]), one maximum
+ *                      per row over all of them.  per_row % 4 == 0, x 16-byte aligned.
+ *   egr_conv_h2      : egr_conv_s3 on w2.  The B * OH * OW GEMM rows form batch_rows equal consecutive groups; group g is scaled
+ *                      by the power of two derived from row_amax[g] (device floats: egr_absmax_rows of x, or what the producer
+ *                      of x left: egr_winograd4_input_ra) and the epilogue undoes it together with w_scale.  zw2 counts 16-byte
+ *                      units of w2.  out_amax (optional, [batch_rows] floats the caller zeroed; nz == 1): raised to max |y| per
+ *                      batch row -- the row_amax of the NEXT contraction that reads y.  Nothing about the scales passes through
+ *                      the host. */
+/* Layout of every row_amax / out_amax array: the maximum of batch row r is the float at index r * EGR_ROW_AMAX_STRIDE (one 128-byte
+ * line per row: atomic commits to different rows do not serialise in the L2; the other floats of a line are unused). */
+#define EGR_ROW_AMAX_STRIDE 32
 int egr_split2h_pack(const float* w_packed, void* w2, int64_t nslabs, int Cout, float w_scale, void* stream);
 int egr_absmax(const float* x, int64_t n, float* slot, void* stream);
+int egr_absmax_rows(const float* x, int rows, int64_t per_row, int nz, int64_t zx, float* row_amax, void* stream);
 int egr_conv_h2(const float* x, const void* w2, const float* bias, const float* bias_b, const float* res, float* y, int B,
                 int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t, int pad_l,
                 int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF, int nz, int64_t zx,
-                int64_t zw2, int64_t zy, float a_scale, float w_scale, float* amax, void* stream);
+                int64_t zw2, int64_t zy, float w_scale, const float* row_amax, int batch_rows, float* out_amax, void* stream);
 int egr_conv_s3(const float* x, const void* w3, const float* bias, const float* bias_b, const float* res, float* y, int B,
                 int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t, int pad_l,
                 int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF, int nz, int64_t zx,
@@ -326,6 +340,10 @@ int egr_bgemm_nt_s3(const float* a, const float* b, float* c, int nb1, int nb2, 
 int egr_winograd4_g(double* g18);
 int egr_winograd4_input(const float* x, const float* gn_scale, const float* gn_shift, int gn_silu, int B, int H, int W, int C,
                         float* V, void* stream);
+/* same, and row_amax[b] (optional; floats the caller zeroed) is raised to max |V| over image b -- the operand maxima egr_conv_h2
+ * wants for the 36 GEMMs that read V, without another pass over V */
+int egr_winograd4_input_ra(const float* x, const float* gn_scale, const float* gn_shift, int gn_silu, int B, int H, int W, int C,
+                           float* V, float* row_amax, void* stream);
 int egr_winograd4_output(const float* M, const float* bias, const float* res, float* y, int B, int H, int W, int N, int act,
                          void* stream);
 /* GroupNorm statistics of y without another pass over it: egr_winograd4_output_stats also writes every thread's (sum, sum of
@@ -334,6 +352,10 @@ int egr_winograd4_output(const float* M, const float* bias, const float* res, fl
  * egr_groupnorm_coeff_from_stats turns statistics into the per-(b, c) scale / shift the consumer applies. */
 int egr_winograd4_output_stats(const float* M, const float* bias, const float* res, float* y, int B, int H, int W, int N,
                                int act, void* part, void* stream);
+/* either output transform (part may be NULL) with row_amax[b] (optional; floats the caller zeroed) raised to max |y| of image b:
+ * the operand maxima egr_conv_h2 wants when y feeds a 1x1 / strided / phase convolution directly */
+int egr_winograd4_output_ra(const float* M, const float* bias, const float* res, float* y, int B, int H, int W, int N, int act,
+                            void* part, float* row_amax, void* stream);
 int egr_groupnorm_stats_from_partials(const void* part, int B, int tiles_per_image, int C, int G, double* stats, void* stream);
 int egr_groupnorm_coeff_from_stats(const double* stats, const float* gamma, const float* beta, int B, int HW, int C, int G,
                                    float eps, float* scale, float* shift, void* stream);
@@ -362,6 +384,18 @@ int egr_softmax_rows(float* x, int64_t rows, int cols, void* stream);
 /* op: 0 a+b, 1 s0*a+s1*b, 2 silu(a), 3 s0*a, 4 copy, 5 s0*(a+b) */
 int egr_eltwise(const float* a, const float* b, float* y, int64_t n, int op, float s0, float s1, void* stream);
 int egr_geglu(const float* u, float* y, int64_t rows, int D, void* stream);
+/* The `_ra` forms of the element-wise operators (ABI 4): same outputs; the tensor is `batch_rows` equal consecutive runs (the rows of
+ * the batch) and row_amax[b] (optional; floats the caller zeroed) is raised to max |y| over run b -- the operand maxima of the
+ * split contraction that reads y (egr_conv_h2) without a pass over y. */
+int egr_groupnorm_nhwc_ra(const float* x, const float* gamma, const float* beta, float* y, int B, int HW, int C, int G, float eps,
+                          int silu, void* workspace, float* row_amax, void* stream);
+int egr_layernorm_rows_ra(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C, float eps,
+                          int batch_rows, float* row_amax, void* stream);
+int egr_eltwise_ra(const float* a, const float* b, float* y, int64_t n, int op, float s0, float s1, int batch_rows, float* row_amax,
+                   void* stream);
+int egr_geglu_ra(const float* u, float* y, int64_t rows, int D, int batch_rows, float* row_amax, void* stream);
+int egr_concat_channels_ra(const float* a, const float* b, float* y, int64_t M, int C1, int C2, int batch_rows, float* row_amax,
+                           void* stream);
 /* Wall time (us) of two spin_us-long busy kernels launched back to back on streams a and b: about spin_us when the two streams
  * run concurrently (different hardware queues), about twice that when the runtime multiplexes them onto one queue.  The FlashSR
  * engine uses it once per process to pick side streams that really overlap with the caller's stream. */
@@ -379,6 +413,9 @@ int egr_transpose_batched(const float* x, float* y, int batch, int R, int Cc, vo
 /* Anti-aliased snake over [B][L][C]: 2x up (K-tap FIR, replicate pad) . x + sin^2(e^alpha x)/(e^beta+1e-9) . 2x down. */
 int egr_snake_aa(const float* x, const float* alpha, const float* beta, const float* filt, float* y, int B, int L, int C,
                  int K, void* stream);
+/* same, and row_amax[b] (optional; floats the caller zeroed) is raised to max |y| of batch row b */
+int egr_snake_aa_ra(const float* x, const float* alpha, const float* beta, const float* filt, float* y, int B, int L, int C,
+                    int K, float* row_amax, void* stream);
 /* ConvTranspose1d as GEMM + gather: Y [B][Lin][K][Co] -> out [B][Lout][Co] (+bias, + optional add). */
 int egr_col2im_convtr1d(const float* Y, const float* bias, const float* add, float* out, int B, int Lin, int Lout, int Co,
                         int K, int r, int pad, void* stream);
@@ -392,6 +429,8 @@ int egr_lowpass_gain(const float* mag, int B, int T, int ldm, int nb, float pct,
                      int64_t nbins, int* cut_out, float* gain, void* stream);
 /* Standard normals: element e of row r is a function of (seed, row_ids[r] or r, e) only (Philox4x32-10). */
 int egr_randn(float* out, int64_t per_row, int rows, uint64_t seed, const int64_t* row_ids, void* stream);
+/* same; without row_ids the id of row r is id_base + r */
+int egr_randn_base(float* out, int64_t per_row, int rows, uint64_t seed, const int64_t* row_ids, int64_t id_base, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * FlashSR model handle -- the inner boundary of SURVEY.md section 8(b).
@@ -446,17 +485,23 @@ int egr_flashsr_infer(egr_flashsr* h, const float* x, int rows, int lowpass_inpu
 int egr_flashsr_forward(egr_flashsr* h, const float* x, const float* noise, int rows, int lowpass_input, float* y, float* const* stages,
                         void* stream);
 int egr_flashsr_set_rows_per_pass(egr_flashsr* h, int rows);
-/* Operand scheme of egr_flashsr_infer's split contractions.  Default (scheme 1): the first rows (6; EGREGORA_FLASHSR_CAL_ROWS) of a
- * handle's FIRST call run the three-term bf16 kernels and measure max |x| of every contraction's input; the other rows of that call
- * and all later calls run the two-term fp16 kernels (egr_conv_h2) with each input scaled from the last measured maximum (16x headroom), read the new maxima back when the call's work is done (the call
- * is synchronous with the host from then on) and, if a scaled value left fp16's range (or a tensor's scaled maximum fell below 1), run those rows again on the bf16
- * kernels -- so the result never depends on the range of fp16, only the time does.  egr_flashsr_set_split(h, 0) or creation flag
- * EGR_FSR_SPLIT_BF16X3 or EGREGORA_FLASHSR_SPLIT=bf16x3 keep every call on the bf16 kernels; egr_flashsr_forward always is.
- * egr_flashsr_set_split(h, 2): as scheme 1, and egr_flashsr_forward runs the fp16 kernels too with the scales of the last
- * egr_flashsr_infer call (no range verification: per-stage taps of the fp16 path for the tests).
- * egr_flashsr_split_info: enabled, calibrated (next call uses fp16 terms), contraction slots, infer calls on the scheme, re-runs. */
+/* Operand scheme of egr_flashsr_infer's split contractions.  Default (scheme 1): two fp16 terms per operand (egr_conv_h2) with
+ * one power-of-two scale per (tensor, batch row), derived on the device from that row's own maximum (left by the tensor's
+ * producer, or measured by egr_absmax_rows when the tensor first feeds a split contraction).  Consequences: the output row r is a
+ * function of (weights, x[r], seed, id of r) -- not of the handle's history, of the other rows of the call, or of how rows are
+ * spread over ranks (tile / split-K choices still follow the row count of a forward: fp32 round-off only); no operand can leave
+ * fp16's range, so nothing is verified or run twice; a quiet row next to a loud one keeps its own precision.
+ * egr_flashsr_set_split(h, 0) or creation flag EGR_FSR_SPLIT_BF16X3 or EGREGORA_FLASHSR_SPLIT=bf16x3 keep every call on the
+ * three-term bf16 kernels; egr_flashsr_forward always is, unless egr_flashsr_set_split(h, 2) (stage taps of the fp16 path for
+ * the tests).  The mel projection and the attention products always run on bf16 terms.
+ * egr_flashsr_split_info: enabled, contraction weights holding fp16 terms, egr_flashsr_infer calls made on the scheme.
+ *
+ * WHEN egr_flashsr_infer BLOCKS THE HOST: it does not, in the steady state -- all work is enqueued on `stream` (and on the
+ * handle's side streams, forked from and joined to `stream` by events).  The FIRST call with a given (row count, lowpass) shape
+ * allocates scratch (hipMalloc, which synchronises the device), creates the low-pass plans and, once per caller stream, times
+ * two spin kernels to verify its side streams (~1 ms).  x and y must stay valid until the work has run, as for any kernel. */
 int egr_flashsr_set_split(egr_flashsr* h, int scheme);
-int egr_flashsr_split_info(egr_flashsr* h, int* enabled, int* calibrated, int* slots, int64_t* calls, int64_t* reruns);
+int egr_flashsr_split_info(egr_flashsr* h, int* enabled, int* weights, int64_t* calls);
 /* Concurrent row groups inside egr_flashsr_infer: a pass of >= 2 * min_group_rows rows is split into up to max_groups (1..4,
  * default 2; EGREGORA_FLASHSR_STREAMS) contiguous groups run as simultaneous forwards on side streams the handle creates and
  * verifies to sit on other hardware queues than the caller's; fork / join by events, so the call still looks single-stream. */

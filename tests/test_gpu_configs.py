@@ -53,8 +53,9 @@ def test_c4_ten_minutes_stereo_long_form(pack, full_engine):
     assert tuple(y.shape) == (1, 2, total) and out["sample_rate"] == 48000 and y.dtype == torch.float32
     assert bool(torch.isfinite(y).all()) and float(y.abs().max()) > 0
     assert float(y[0, :, 0].abs().max()) == 0.0                       # Q1: Hann endpoint
-    # the first call of a handle runs the three-term bf16 kernels and measures the operand scales, later calls the two-term fp16
-    # kernels (include/egregora_amd.h egr_flashsr_set_split): calls 2 and 3 are bit-identical, call 1 sits fp32 round-off away
+    # every call runs the two-term fp16 kernels with per-row device-side scales (include/egregora_amd.h egr_flashsr_set_split):
+    # the result does not depend on the handle's history, so calls 1, 2 and 3 are bit-identical; the first also pays the scratch
+    # arena's allocations
     (out2,) = node.run(A, False, "48000")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -63,8 +64,8 @@ def test_c4_ten_minutes_stereo_long_form(pack, full_engine):
     print(f"C4 on one MI355X, steady state (fp16 operand terms): 600 s stereo in {dt2:.2f} s = {600 / dt2:.0f} xRT")
     assert torch.equal(out2b["waveform"], out2["waveform"])           # deterministic
     d12 = float((out2["waveform"] - y).abs().max())
-    print(f"C4: max |difference| between the measuring call and the calls after it {d12:.2e} (peak {float(y.abs().max()):.3f}); {full_engine.split_info()}")
-    assert d12 <= 2e-4 * float(y.abs().max())
+    print(f"C4: max |difference| between the first call and the calls after it {d12:.2e} (peak {float(y.abs().max()):.3f}); {full_engine.split_info()}")
+    assert d12 == 0.0
     old = E.ROWS_PER_PASS
     try:
         E.ROWS_PER_PASS = 14                                          # 19 passes instead of 9, different pass boundaries

@@ -316,6 +316,36 @@ def test_800_iterations_against_the_oracle(pack):
     assert lg <= 1e-3 and kept >= 0.3, (lg, lo, kept)
 
 
+@pytest.mark.parametrize("n", [2880000, 2880002])
+def test_c3_full_length_800_iterations_against_the_oracle(pack, n):
+    """BASELINE configs[2] at ITS OWN size and iteration count: one channel of 60 s at 48 kHz (N = 2 880 000: the 625 x 2304 plan on
+    the two-barrier kernels, whose twiddle runs are specific to that length) and 60 s + 2 samples (no packed plan: the paired chirp-z
+    loop), all 800 iterations on the device, in the float32 oracle and in the float64 run of the same loop (about 1 and 2 minutes
+    of host time per length).  Round-off compounds over the iterations as (1 + eps)^800 in ANY float32 implementation, so the gates
+    are those of test_800_iterations_against_the_oracle: the device's error against float64 within 2x (max) / 2.5x (rms) of the
+    float32 oracle's own, and the LSD against float64 over the bins a float32 transform resolves <= 1e-3 dB."""
+    from egregora_amd import fatllama_engine as fe
+    info = fe.plan_info(n, 1)
+    assert ((info["M1"], info["M2"]) == (625, 2304)) == (n == 2880000) and bool(info.get("chirpz_kind", 0)) == (n != 2880000), info
+    x = synth(1, n, seed=2880 + n % 7)
+    got = run_gpu(pack, x, 1, 800, 0.6)
+    want = ofl.enhance_channels(x, 1, 800, 0.6, normalize=False, autoscale=False)
+    exact = ofl.enhance_channels(x, 1, 800, 0.6, normalize=False, autoscale=False, exact=True)
+    scale = float(np.max(np.abs(want)))
+    rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
+    mg, mo = float(np.max(np.abs(got - exact))), float(np.max(np.abs(want - exact)))
+    seg = slice(0, 960000)                         # the reference's metric on the first 20 s (every frame sees the same loop)
+    lg, kept = om.lsd_masked(exact[:, seg], got[:, seg], f32_run=want[:, seg], margin_db=F32_MARGIN_DB)
+    lo, _ = om.lsd_masked(exact[:, seg], want[:, seg], f32_run=want[:, seg], margin_db=F32_MARGIN_DB)
+    print(f"\nC3 length N = {n}, 800 iterations: max err device {mg:.3e} oracle32 {mo:.3e} (peak {scale:.0f}); rms {rms(got - exact):.3e} / "
+          f"{rms(want - exact):.3e}; LSD vs float64 over the {kept:.1%} of bins >= {F32_MARGIN_DB:.0f} dB above the float32 floor: device {lg:.2e} dB, "
+          f"oracle32 {lo:.2e} dB; plain LSD(device, oracle32) {om.lsd_audio(want[:, seg], got[:, seg])[0]:.2e} dB")
+    assert np.isfinite(got).all()
+    assert mg <= 2.0 * mo and mg <= 1e-4 * scale, (mg, mo, scale)
+    assert rms(got - exact) <= 2.5 * rms(want - exact) + 1e-9 * scale
+    assert lg <= 1e-3 and kept >= 0.3, (lg, lo, kept)
+
+
 VARIANTS = [  # (variant list for the device, FatLlamaSpec overrides, threshold, data scale)
     ("", {}, 50.0, 100.0),
     ("soft", {"threshold_kind": "soft"}, 50.0, 100.0),

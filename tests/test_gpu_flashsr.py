@@ -573,13 +573,12 @@ def test_full_size_engine_vs_torch_reference_one_row(pack):
         gt = got_st[k].permute(0, 3, 1, 2)
         assert rel_l2(gt, want_st[k]) <= 5e-4, (k, rel_l2(gt, want_st[k]))
     assert rel_l2(y, want) <= 2e-3, rel_l2(y, want)
-    # The same gates on the PRODUCT call's steady state: egr_flashsr_infer, first call = the walk above (three bf16 terms, measures the
-    # operand maxima), second call = two fp16 terms per operand scaled from those maxima (csrc/egr_nn_gemm_s3.hip scheme 1).
+    # The same gates on the PRODUCT call: egr_flashsr_infer = two fp16 terms per operand, every batch row scaled from its own maximum
+    # on the device (csrc/egr_nn_gemm_s3.hip scheme 1); its first call is its steady state.
     ids = torch.zeros(1, dtype=torch.int64, device="cuda")
-    y_first = e.c_infer(x.cuda(), ids, 0)
-    assert torch.equal(y_first, y) and e.split_info()["calibrated"]
     y_h = e.c_infer(x.cuda(), ids, 0)
-    assert e.split_info()["reruns"] == 0 and not torch.equal(y_h, y)
+    assert e.split_info()["enabled"] and not torch.equal(y_h, y)
+    assert torch.equal(e.c_infer(x.cuda(), ids, 0), y_h)
     e.set_split("f16x2+forward")
     h_st = {}
     y_hf = e.c_forward(x.cuda(), nz, h_st)

@@ -7,7 +7,12 @@ L_ = native.lib(); p = lambda t: C.c_void_p(t.data_ptr())
 filt = torch.from_numpy(A.kaiser_sinc_filter(12)).cuda()
 for (B, L, Cc) in [(26, 61440, 64), (26, 122880, 32), (26, 245760, 16), (26, 15360, 128), (26, 3072, 256), (3, 1000, 48)]:
     x = torch.randn(B, L, Cc, device='cuda'); al = 0.1 * torch.randn(Cc, device='cuda'); be = 0.1 * torch.randn(Cc, device='cuda'); y = torch.empty_like(x)
-    run = lambda: native.check(L_.egr_snake_aa(p(x), p(al), p(be), p(filt), p(y), B, L, Cc, 12, native.stream_ptr()), "snake")
+    ra = torch.zeros(B * 32, device='cuda')
+    import os
+    if os.environ.get("SNAKE_RA", "1") == "1":
+        run = lambda: native.check(L_.egr_snake_aa_ra(p(x), p(al), p(be), p(filt), p(y), B, L, Cc, 12, p(ra), native.stream_ptr()), "snake")
+    else:
+        run = lambda: native.check(L_.egr_snake_aa(p(x), p(al), p(be), p(filt), p(y), B, L, Cc, 12, native.stream_ptr()), "snake")
     run(); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
     for _ in range(10): run()
