@@ -368,6 +368,22 @@ def main():
                         "c4_note": "ONE 10-minute stereo file (130 chunks) chunk-sharded over the ranks, one all-gather, WOLA on every rank; "
                                    "the 1-GPU time is estimated as N x (slowest rank's block) + WOLA"}
             del x_c4, y_c4, preds
+    # ---- SURVEY 8(d)'s boundary: AUDIO dict on the host in -> AUDIO dict on the host out, through the two NODES (coercion, H2D,
+    # chunk gather, FlashSR, WOLA, D2H, then coercion, H2D, PCM_16 hops, the 800-iteration loop, D2H): PCIe included, never `value`
+    node_ms = None
+    if not args.lean and world == 1 and not c4 and not args.only:
+        pack = load_pack()
+        up, fl = pack.NODE_CLASS_MAPPINGS["EgregoraAudioUpscaler"](), pack.NODE_CLASS_MAPPINGS["EgregoraFatLlamaGPU"]()
+        audio_in = {"waveform": x_all[:, :SEG].cpu()[None].contiguous(), "sample_rate": SR}
+
+        def node_chain():
+            (a48,) = up.run(audio_in, False, "48000")
+            (res,) = fl.run("wav", args.iters, 0.6, 1536, True, False, AUDIO=a48)
+            return res
+        node_chain()
+        t_n, res_n = timed(node_chain, 2)
+        assert tuple(res_n["waveform"].shape) == (1, C, SEG) and res_n["waveform"].device.type == "cpu"
+        node_ms = 1e3 * t_n / 2
     prof = eng.c_profile(stage_flashsr)           # HIP events around every MFMA contraction launch of the library's graph walk
     fe.enhance_device(seg48, 1, args.iters, 0.6, profile=True, **fl_flags)
     kt = fe.kernel_times(SEG, C, 1, local_rank)
@@ -394,8 +410,11 @@ def main():
         dom = ("k_row_wl<16, 12, 0>" if wl else "k_row<false, 1>") if kt["row_ms"] >= kt["col_ms"] else ("k_col_wl" if wl else "k_col<1, 2>")
         hbm_ach = row_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = conv_traffic = pz_traffic = None
+        traffic_src = None
         try:                # HBM bytes per launch from the committed PMC passes (tools/make_traffic_json.py)
-            tk = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get("kernels", {})
+            tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+            tk = tj.get("kernels", {})
+            traffic_src = "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %s (a committed profile of an earlier run of this command, NOT measured in this run)" % tj.get("source", tj.get("_note", "an earlier round").split("source: ")[-1].split(";")[0])
             cands = ["k_row_wl<16, 12, 0>", "k_row_wl", "k_row<false, 1>", "k_row<false, 0>", "k_row<false>"] if dom.startswith("k_row") else ["k_col_wl", "k_col<1, 2>", "k_col<1, 0>", "k_col<1>"]
             if not wl:
                 cands = cands[1:]
@@ -436,6 +455,8 @@ def main():
             "parts": {
                 "flashsr_stage_xrt": audio_s / el_fs, "flashsr_stage_ms": 1e3 * el_fs,
                 "flashsr_stage_first_call_ms": (1e3 * el_first) if el_first else None,
+                "node_boundary_ms": node_ms, "node_boundary_xrt": (60.0 / (node_ms * 1e-3)) if node_ms else None,
+                "node_boundary_note": "AUDIO dict (CPU) in -> EgregoraAudioUpscaler.run -> EgregoraFatLlamaGPU.run -> AUDIO dict (CPU) out, 60 s stereo, PCIe and host coercions included",
                 "fatllama_stage_xrt": audio_s / el_fl, "fatllama_stage_ms": 1e3 * el_fl,
                 "fatllama_arbitrary_length_ms": {k: v["ms"] for k, v in arb.items()} or None,
                 "fatllama_arbitrary_length": arb or None,
@@ -451,13 +472,16 @@ def main():
             },
             # dominant kernel of the step: the implicit-GEMM convolution (all dense contractions of FlashSR)
             "roofline": {"bound": "mfma", "kernel": dom_conv, "achieved": conv_tfs * mfma_mult, "peak": mfma_peak,
-                         "unit": "TFLOP/s", "frac": conv_tfs * mfma_mult / mfma_peak, "traffic": conv_traffic,
+                         "unit": "TFLOP/s", "frac": conv_tfs * mfma_mult / mfma_peak, "traffic": conv_traffic, "traffic_source": traffic_src,
+                         # the same launches priced on ALGORITHMIC flops (one fp32 multiply-add = 2 flops; the other executed products
+                         # are the price of fp32-grade results on the 16-bit pipe)
+                         "frac_algorithmic": conv_tfs / mfma_peak,
                          "mfma_dtype": ("f16 (3 executed products per fp32 multiply-add)" if h2 else "bf16 (6 executed products per fp32 multiply-add)") if s3 else "f32",
                          "fp32_equivalent_tflops": conv_tfs, "vs_f32_mfma_peak": conv_tfs / MFMA_F32_PEAK_TFS,
                          "launches": nconv, "flops_total": fconv, "ms_total": tconv,
                          "avg_flops_per_launch": fconv / max(1, nconv), "avg_launch_ms": tconv / max(1, nconv)},
             "roofline_fatllama": {"bound": "hbm", "kernel": dom, "achieved": hbm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": hbm_ach / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": row_bytes,
+                                  "frac": hbm_ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": row_bytes,
                                   "avg_launch_ms": dom_ms, "k_row_ms": kt["row_ms"], "k_col_ms": kt["col_ms"],
                                   "launches": [kt["row_launches"], kt["col_launches"]], "concurrent_pipelines": groups,
                                   # all loop launches' algorithmic bytes / the stage's wall time (pipelines overlap)
@@ -469,6 +493,11 @@ def main():
                                                  "frac": 32.0 * SEG * C * args.iters / (el_fl * 1e9) / HBM_PEAK_GBS}},
         }
         if arb:
+            # the REPRESENTATIVE chain as a second top-level value: FlashSR returns its input length and real files are not 13-smooth
+            # multiples, so the second node normally sees a length WITHOUT a packed plan (here 60 s + 2 samples, the paired chirp-z loop)
+            arb_ms = 1e3 * el_fs + arb["60s_plus_2_samples"]["ms"]
+            out["value_arbitrary_length"] = audio_s / (arb_ms * 1e-3)
+            out["ms_per_step_arbitrary_length"] = arb_ms
             # the chirp-z loop's dominant kernel: the spectrum pass on mirrored column-tile pairs.  A launch reads and writes the
             # P-point complex state of its states once: 16 P bytes per state (what this design must move; per iteration the four
             # launches move 64 P + 16 P (Bhat, twice) bytes per state against SURVEY's 32 N per channel for a length with a plan)

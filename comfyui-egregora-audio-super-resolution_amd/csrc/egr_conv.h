@@ -193,13 +193,13 @@ __device__ __forceinline__ void store_tile_plain_t(f32x16 (&acc)[TM][TN], float*
                                                    int wn0, const float* os_tab, float osw);
 template <int TM, int TN, bool VEC, bool RES>
 __device__ __forceinline__ void conv_epilogue_t_rows(const ConvP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0,
-                                                     const float* os_tab, unsigned* om_tab) {
+                                                     const float* os_tab, unsigned* om_tab, int sub_stride) {
     const int lane = threadIdx.x & 63, px = lane & 31, ch4 = 4 * (lane >> 5);
     const bool ident = (p.osy == 1 && p.osx == 1 && p.OHF == p.OH && p.OWF == p.OW);
     const bool decode = !ident || p.bias_b;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm0 + i * 32 + px;
+        const int m = m0 + ((wm0 >> 5) + i) * sub_stride + px;        // sub_stride 32: consecutive GEMM rows; W: one image row per sub-tile
         if (m < p.M) {
             const float os = os_tab[wm0 + i * 32 + px], osw = p.out_scale;
             size_t mo = (size_t)m;
@@ -257,20 +257,21 @@ __device__ __forceinline__ void conv_epilogue_t_rows(const ConvP& p, f32x16 (&ac
 }
 
 // om_tab (optional, LDS, zeroed, one word per batch row the block tile touches): raised to max |y| per batch row
+// sub_stride: GEMM-row distance between the tile's 32-row sub-tiles (32 = a contiguous tile)
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue_t(const ConvP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0,
-                                                const float* os_tab, unsigned* om_tab = nullptr) {
+                                                const float* os_tab, unsigned* om_tab = nullptr, int sub_stride = 32) {
     const bool vec = (p.Cout & 3) == 0;
     if (p.ksplit > 1) {        // raw partial sums; bias / residual / activation are applied by k_splitk_reduce
         store_tile_plain_t<TM, TN>(acc, p.ws + (size_t)blockIdx.z * p.M * p.Cout, p.M, p.Cout, m0, n0, wm0, wn0, os_tab, p.out_scale);
         return;
     }
     if (vec) {
-        if (p.res) conv_epilogue_t_rows<TM, TN, true, true>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab);
-        else conv_epilogue_t_rows<TM, TN, true, false>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab);
+        if (p.res) conv_epilogue_t_rows<TM, TN, true, true>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab, sub_stride);
+        else conv_epilogue_t_rows<TM, TN, true, false>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab, sub_stride);
     } else {
-        if (p.res) conv_epilogue_t_rows<TM, TN, false, true>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab);
-        else conv_epilogue_t_rows<TM, TN, false, false>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab);
+        if (p.res) conv_epilogue_t_rows<TM, TN, false, true>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab, sub_stride);
+        else conv_epilogue_t_rows<TM, TN, false, false>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab, sub_stride);
     }
 }
 
@@ -325,6 +326,8 @@ int s3_bm(long long M, int Cout, int bn);
 int s3_zs_nzb(long long M, int Cout, int bm, int bn, int nz, int K);
 // input-stationary stride-1 1-D convolution (k_conv1d_s3); returns false when the shape does not qualify
 bool launch_conv1d_s3(const ConvP& p, hipStream_t st);
+// input-stationary 3x3 convolution of big images (k_conv3x3_is, scheme 1; optional fused input GroupNorm); false: does not qualify
+bool launch_conv3x3_is(const ConvP& p, hipStream_t st);
 void launch_conv_s3(int bm, int bn, dim3 grid, hipStream_t st, const ConvP& p);
 
 }  // namespace egr

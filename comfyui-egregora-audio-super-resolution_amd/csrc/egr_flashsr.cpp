@@ -200,6 +200,9 @@ struct egr_flashsr {
     float alpha = 0.f, sigma = 0.f;
     float* d_wmax = nullptr;                          // one float: weight maxima at pack time
     int rows_per_pass = 32;
+    // scratch budget (EGREGORA_FLASHSR_ARENA_GB / egr_flashsr_set_arena_cap; 0 = none): rows per pass are lowered until the arenas
+    // of a pass are expected to fit (measured bytes per row once a pass has run, an estimate from the layer table before)
+    double arena_cap = 0.0, arena_row_bytes = 0.0;
     int wino_min_ch = 128;
     double flops = 0.0; bool count_flops = false;
     bool profiling = false;
@@ -219,6 +222,7 @@ struct egr_flashsr {
     int h2_nweights = 0;                              // contraction weights that hold fp16 terms
     int R = 1;                                        // batch rows of the forward being enqueued
     bool out_amax_on = true;                          // contraction epilogues leave the row maxima of their outputs (EGREGORA_FLASHSR_OUT_AMAX=0: off)
+    int direct3x3_max_cout = 128;                     // EGREGORA_FLASHSR_DIRECT3X3_MAX_COUT (0: off): see gn_conv3
     bool next_out_ra = false;                         // set by a call site whose output feeds another split contraction directly; consumed by the next conv()
     int64_t h2_calls = 0;
 
@@ -779,6 +783,41 @@ int conv1d(M* m, Ten& y, const Ten& x, const std::string& key, int k, int stride
 int gn_conv3(M* m, Ten& y, const Ten& x, const std::string& norm_key, float eps, const std::string& conv_key, const float* res = nullptr,
              const float* bias_t = nullptr) {
     const int H = (int)x.d[1], W = (int)x.d[2], Cin = (int)x.d[3];
+    // The big, thin layers (128 output channels on 512 x 256 images) as DIRECT convolutions on the input-stationary kernel with the
+    // GroupNorm + SiLU in its loader (fp16 operand scheme only): as an F(4x4) pipeline they are bound by V and M round trips
+    // (~19 GB per layer against 3.5 GB of activations), here x is read once and y written once.
+    {
+        const Wt* wd = m->get(conv_key + ".weight");
+        const int B = (int)x.d[0];
+        if (wd && wd->w2 && m->h2 && m->h2_mode == 1 && m->direct3x3_max_cout > 0 && wd->Cout <= m->direct3x3_max_cout && wd->KH == 3 &&
+            wd->KW == 3 && B == m->R && H % 4 == 0 && W % 32 == 0 && Cin % 32 == 0 && (int64_t)(H / 4) * (W / 32) * B >= 512 &&
+            Cin % m->cfg.gn_groups == 0 && (((uintptr_t)x.p) & 15) == 0) {
+            Ten sc, sh;
+            OKR(gn_coeff(m, sc, sh, x, norm_key, eps));
+            OKR(row_amax_of(m, x.p, x.numel(), 1, 0, &x.rs));
+            unsigned* bound = rs_take(m);
+            if (!bound) return EGR_ERR_ALLOC;
+            OKR(egr_gn_operand_bound(sc.p, sh.p, B, Cin, (const float*)x.rs, (float*)bound, m->st));
+            OKR(new_ten(m, y, {B, H, W, wd->Cout}));
+            float* out_ra = nullptr;
+            if (m->out_amax_on) {
+                y.rs = rs_take(m);
+                if (!y.rs) return EGR_ERR_ALLOC;
+                out_ra = (float*)y.rs;
+            }
+            const float* bt = bias_t ? bias_t : m->ptr(conv_key + ".bias");
+            const double fl = 2.0 * B * H * W * (double)wd->Cout * 9 * Cin;
+            ProfScope ps(m);
+            OKR(egr_conv_h2_gn(x.p, sc.p, sh.p, 1, wd->w2, bt, res, y.p, B, H, W, Cin, wd->Cout, ACT_NONE, wd->w_scale, (const float*)bound, out_ra, m->st));
+            if (ps.on) {
+                char buf[64];
+                snprintf(buf, sizeof(buf), "k_conv3x3_is<%d, 32, true>", wd->Cout > 64 ? 128 : 64);
+                ps.end(buf, fl);
+            }
+            if (m->count_flops) m->flops += fl;
+            return EGR_OK;
+        }
+    }
     const bool wino = m->has(conv_key + ".weight.wino") && H % 2 == 0 && W % 2 == 0;
     const bool fused_ok = !(m->flags & EGR_FSR_NO_FUSE_GN) && Cin % 16 == 0 && Cin % m->cfg.gn_groups == 0 && wino;
     if (!fused_ok) {
@@ -1224,24 +1263,32 @@ int forward(M* m, const float* x_in, const float* noise, int R, int lowpass_on, 
 // History: the chain was introduced in round 1 against wrong STFT bins next to a foreign k_conv_s3; that was root-caused in
 // round 2 to a gfx950 packed-fp32 op_sel erratum and removed at the source (csrc/Makefile NOPK, tests/test_isa_audit.py,
 // DESIGN.md section 4.4a), so the guard is about arena ownership only.  EGR_FSR_NO_STREAM_GUARD=1 removes the chain (probes).
+// The lock is PER DEVICE: host threads that drive different GPUs of one process (flashsr_engine.infer_spans_devices) enqueue
+// their forwards side by side.
 struct ForwardGuard {
-    static std::mutex& mu() { static std::mutex m; return m; }
-    static std::map<int, std::pair<hipStream_t, hipEvent_t>>& last() { static std::map<int, std::pair<hipStream_t, hipEvent_t>> l; return l; }
+    struct Dev { std::mutex fwd; hipStream_t last_st = nullptr; hipEvent_t ev = nullptr; };
+    static Dev& of(int device) {
+        static std::mutex m;
+        static std::map<int, std::unique_ptr<Dev>> devs;
+        std::lock_guard<std::mutex> g(m);
+        auto& p = devs[device];
+        if (!p) p.reset(new Dev());
+        return *p;
+    }
+    Dev& d;
     std::unique_lock<std::mutex> lk;
-    int dev; hipStream_t st; bool on;
-    ForwardGuard(int device, hipStream_t s) : lk(mu()), dev(device), st(s) {
+    hipStream_t st; bool on;
+    ForwardGuard(int device, hipStream_t s) : d(of(device)), lk(d.fwd), st(s) {
         static const bool off = getenv("EGR_FSR_NO_STREAM_GUARD") && atoi(getenv("EGR_FSR_NO_STREAM_GUARD")) != 0;
         on = !off;
         if (!on) return;
-        auto it = last().find(dev);
-        if (it != last().end() && it->second.second && it->second.first != st) hipStreamWaitEvent(st, it->second.second, 0);
+        if (d.ev && d.last_st != st) hipStreamWaitEvent(st, d.ev, 0);
     }
     ~ForwardGuard() {
         if (!on) return;
-        auto& e = last()[dev];
-        if (!e.second) hipEventCreateWithFlags(&e.second, hipEventDisableTiming);
-        hipEventRecord(e.second, st);
-        e.first = st;
+        if (!d.ev) hipEventCreateWithFlags(&d.ev, hipEventDisableTiming);
+        hipEventRecord(d.ev, st);
+        d.last_st = st;
     }
 };
 
@@ -1311,6 +1358,8 @@ extern "C" int egr_flashsr_create(egr_flashsr** out, const egr_flashsr_config* c
     if (const char* e = getenv("EGREGORA_FLASHSR_SPLIT")) { if (!strcmp(e, "bf16x3")) m->h2 = false; }
     if (const char* e = getenv("EGREGORA_FLASHSR_ROWS")) { const int r = atoi(e); if (r >= 1) m->rows_per_pass = r; }
     if (const char* e = getenv("EGREGORA_FLASHSR_OUT_AMAX")) m->out_amax_on = atoi(e) != 0;
+    if (const char* e = getenv("EGREGORA_FLASHSR_DIRECT3X3_MAX_COUT")) m->direct3x3_max_cout = atoi(e);
+    if (const char* e = getenv("EGREGORA_FLASHSR_ARENA_GB")) { const double gb = atof(e); if (gb > 0.0) m->arena_cap = gb * 1e9; }
     build_blocks(m);
     const int down = 1 << (cfg->vae_levels - 1);
     m->lat_h = cfg->n_frames / down; m->lat_w = cfg->n_mels / down;
@@ -1463,15 +1512,23 @@ static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uin
     ForwardGuard guard(m->device, st0);
     const egr_flashsr_config& c = m->cfg;
     const int64_t per_row = (int64_t)m->lat_h * m->lat_w * c.z_ch;
+    // scratch budget: fewer rows per pass instead of an allocation failure next to the host's other models
+    int rpp = m->rows_per_pass;
+    if (m->arena_cap > 0.0) {
+        // before any pass has run: ~24 live tensors of the widest activation (n_frames x n_mels x vae_ch) per row, measured 1.5 GB at the full size
+        const double est = 24.0 * 4.0 * (double)c.n_frames * c.n_mels * c.vae_ch;
+        const double per_row_bytes = m->arena_row_bytes > 0.0 ? m->arena_row_bytes : est;
+        rpp = std::max(1, std::min(rpp, (int)(m->arena_cap / per_row_bytes)));
+    }
     int groups_max = m->profiling ? 1 : m->max_groups;          // per-kernel timing wants the kernels alone on the chip
-    if (groups_max > 1 && std::min(rows, m->rows_per_pass) >= 2 * m->min_group_rows)
+    if (groups_max > 1 && std::min(rows, rpp) >= 2 * m->min_group_rows)
         groups_max = std::min(m->max_groups, 1 + ensure_side_streams(m, st0, groups_max - 1));   // side contexts of an earlier, wider setting stay idle
     else
         groups_max = 1;
     if (groups_max > 1 && !m->ev_fork) EGR_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     int rc = EGR_OK;
     // passes of equal size (260 rows at 32 per pass: nine passes of 29 / 28 rows instead of eight of 32 and one of 4)
-    const int npass = (rows + m->rows_per_pass - 1) / m->rows_per_pass;
+    const int npass = (rows + rpp - 1) / rpp;
     const int per = (rows + npass - 1) / npass;
     for (int lo = 0; lo < rows && rc == EGR_OK; lo += per) {
         const int n = std::min(per, rows - lo);
@@ -1496,7 +1553,21 @@ static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uin
         }
         m->use(m->ctxs[0].get());
     }
+    if (rc == EGR_OK && per > 0) {                       // what a row of a pass of this size costs in scratch (the arenas never shrink)
+        double tot = 0.0;
+        for (auto& cx : m->ctxs) tot += (double)cx->arena.total;
+        m->arena_row_bytes = std::max(m->arena_row_bytes, tot / std::min(per, rows));
+    }
     return rc;
+}
+
+// Scratch budget in bytes for the handle's arenas (0 = none; EGREGORA_FLASHSR_ARENA_GB sets it at creation): egr_flashsr_infer
+// lowers its rows per pass until a pass is expected to fit -- slower passes instead of an out-of-memory next to the host's other
+// models.  Arenas already allocated are not returned.
+extern "C" int egr_flashsr_set_arena_cap(egr_flashsr* m, double bytes) {
+    EGR_CHECK(m && bytes >= 0.0, EGR_ERR_ARG, "bad argument");
+    m->arena_cap = bytes;
+    return EGR_OK;
 }
 
 extern "C" int egr_flashsr_set_streams(egr_flashsr* m, int max_groups, int min_group_rows) {

@@ -565,6 +565,18 @@ extern "C" int egr_conv_h2(const float* x, const void* w2, const float* bias, co
                        batch_rows, out_amax);
 }
 
+// 3x3 stride-1 pad-1 convolution on two fp16 terms with the producer's GroupNorm (+ SiLU) applied to x while it is loaded:
+// x' = x * gn_scale[b][c] + gn_shift[b][c] (then SiLU), zero padding after it.  Only the input-stationary kernel (k_conv3x3_is)
+// serves it: H %% 4 == 0, W %% 32 == 0, Cin %% 32 == 0, >= 512 tiles of 4 x 32 pixels, otherwise EGR_ERR_UNSUPPORTED (nothing is
+// launched).  row_amax[b] must bound max |x'| of image b from above (egr_gn_operand_bound); it need not be tight.
+extern "C" int egr_conv_h2_gn(const float* x, const float* gn_scale, const float* gn_shift, int gn_silu, const void* w2, const float* bias,
+                              const float* res, float* y, int B, int H, int W, int Cin, int Cout, int act, float w_scale, const float* row_amax,
+                              float* out_amax, void* stream) {
+    EGR_CHECK(w2 && row_amax && gn_scale && gn_shift, EGR_ERR_ARG, "null w2 / row_amax / gn_scale / gn_shift");
+    return conv_launch(x, nullptr, bias, nullptr, res, y, B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1, 0, act, 0.f, 1, 1, 0, 0, H, W, 1, 0, 0, 0,
+                       gn_scale, gn_shift, gn_silu, stream, w2, 1, w_scale, row_amax, B, out_amax);
+}
+
 static int conv_launch(const float* x, const float* w, const float* bias, const float* bias_b, const float* res, float* y,
                        int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t,
                        int pad_l, int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF,
@@ -574,8 +586,8 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
     EGR_CHECK(x && (w || w3) && y, EGR_ERR_ARG, "null x/w/y");
     EGR_CHECK(sch == 0 || (w3 && w_scale > 0.f && row_amax && batch_rows >= 1 && ((long long)B * OH * OW) % batch_rows == 0), EGR_ERR_ARG,
               "bad operand scheme: needs w_scale > 0, row_amax and a batch row count that divides the GEMM rows");
-    EGR_CHECK(!w3 || ((Cin % BK) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)w3) & 15) == 0 && !gn_scale), EGR_ERR_ARG,
-              "split-bf16 conv needs Cin %% 16 == 0, 16-byte aligned x / w3 and no fused input affine");
+    EGR_CHECK(!w3 || ((Cin % BK) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)w3) & 15) == 0 && (!gn_scale || sch == 1)), EGR_ERR_ARG,
+              "split conv needs Cin %% 16 == 0, 16-byte aligned x / w3 and no fused input affine (scheme 1: only the input-stationary 3x3 kernel fuses one)");
     EGR_CHECK(!gn_scale || (gn_shift && (Cin % BK) == 0 && (((uintptr_t)x) & 15) == 0), EGR_ERR_ARG,
               "fused input affine needs Cin %% 16 == 0 and a 16-byte aligned input");
     EGR_CHECK(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && OH >= 1 && OW >= 1 && Cout >= 1 && KH >= 1 && KW >= 1 &&
@@ -639,7 +651,13 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
         }
     }
 #define LAUNCH(BN_, V_) hipLaunchKernelGGL((k_conv_igemm<BN_, V_>), grid, dim3(256), 0, st, p)
-    if (w3 && launch_conv1d_s3(p, st)) {}
+    if (w3 && launch_conv3x3_is(p, st)) {}
+    else if (w3 && gn_scale) {
+        set_error("egr_conv_h2_gn: the shape does not qualify for the input-stationary 3x3 kernel (stride 1, pad 1, H %% 4 == 0, W %% 32 == 0, "
+                  "Cin %% 32 == 0, >= 512 tiles, one batch row per image)");
+        return EGR_ERR_UNSUPPORTED;
+    }
+    else if (w3 && launch_conv1d_s3(p, st)) {}
     else if (w3) launch_conv_s3(bm, bn, grid, st, p);
     else if (gn_scale) {        // fused-GroupNorm loader: separate instantiations so the plain kernels pay nothing for it
         if (bn == 128) hipLaunchKernelGGL((k_conv_igemm<128, true, true>), grid, dim3(256), 0, st, p);

@@ -132,6 +132,26 @@ __global__ __launch_bounds__(256) void k_affine_c(const float* __restrict__ x, c
     if (row_amax) row_amax_commit_wg(row_amax + (size_t)b * EGR_ROW_AMAX_STRIDE, ym);
 }
 
+// out[b] = max_c |scale[b][c]| * x_amax[b] + max_c |shift[b][c]|  >=  max |x * scale + shift| over image b (and >= the SiLU of it):
+// the operand bound of a convolution that applies the GroupNorm in its loader (egr_conv_h2_gn).  One workgroup per image.
+__global__ __launch_bounds__(256) void k_gn_bound(const float* __restrict__ scale, const float* __restrict__ shift, int C,
+                                                   const float* __restrict__ x_amax, float* __restrict__ out) {
+    __shared__ float r0[256], r1[256];
+    const int b = blockIdx.x;
+    float ms = 0.f, mh = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        ms = fmaxf(ms, fabsf(scale[(size_t)b * C + c]));
+        mh = fmaxf(mh, fabsf(shift[(size_t)b * C + c]));
+    }
+    r0[threadIdx.x] = ms; r1[threadIdx.x] = mh;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { r0[threadIdx.x] = fmaxf(r0[threadIdx.x], r0[threadIdx.x + o]); r1[threadIdx.x] = fmaxf(r1[threadIdx.x], r1[threadIdx.x + o]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(size_t)b * EGR_ROW_AMAX_STRIDE] = fmaf(r0[0], x_amax[(size_t)b * EGR_ROW_AMAX_STRIDE], r1[0]);
+}
+
 // ---------------------------------------------------------------- LayerNorm over rows of C (one wave per row)
 // grid (chunks, batch rows): the waves of a workgroup loop over the `per_b` token rows of batch row blockIdx.y;
 // row_amax (optional): row_amax[batch row] raised to max |y|
@@ -859,6 +879,15 @@ extern "C" int egr_groupnorm_coeff_from_stats(const double* stats, const float* 
               "bad argument");
     hipLaunchKernelGGL(k_gn_coeff, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, gamma, beta, scale, shift,
                        B, C, G, (double)HW * (C / G), eps);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+// bound[b] (row_amax layout) = max_c |scale[b][c]| * x_row_amax[b] + max_c |shift[b][c]|: an upper bound of max |GroupNorm(x)| per
+// image from the per-(image, channel) coefficients and the row maxima of x -- no pass over x.  Feeds egr_conv_h2_gn.
+extern "C" int egr_gn_operand_bound(const float* scale, const float* shift, int B, int C, const float* x_row_amax, float* bound, void* stream) {
+    EGR_CHECK(scale && shift && x_row_amax && bound && B >= 1 && C >= 1, EGR_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_gn_bound, dim3(B), dim3(256), 0, (hipStream_t)stream, scale, shift, C, x_row_amax, bound);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }

@@ -4,7 +4,10 @@ batch dimension (:366-368).
 
 The model is the C-ABI handle -- `egr_flashsr_create` / `egr_flashsr_infer` (include/egregora_amd.h, csrc/egr_flashsr.cpp): the
 graph walk, weight repacking and scratch arena live in the library; this module only hands it the named weight tensors
-(`FlashSREngine.handle`, `infer_rows`) and shards chunk blocks over ranks.  A pass of >= 12 rows is split by the library into up
+(`FlashSREngine.handle`, `infer_rows`) and shards chunk blocks -- over the ranks of a torch.distributed process group when one
+exists (shard.py: one process per GPU, one all-gather), or, inside ONE process (what a ComfyUI host is), over the devices listed
+in EGREGORA_DEVICES: one handle and one host thread per device, contiguous chunk blocks balanced to within one chunk, the gather
+as peer copies into device 0's prediction tensor, WOLA on device 0 (`infer_spans_devices`).  A pass of >= 12 rows is split by the library into up
 to EGREGORA_FLASHSR_STREAMS (default 2) row groups that run as concurrent forwards on side streams the handle has verified to
 sit on other hardware queues; the caller sees one stream.
 
@@ -18,7 +21,8 @@ PARITY UNPINNED vs upstream (see flashsr_arch.py); checked against oracle/flashs
 import ctypes as C
 import math
 import os
-from typing import Dict, List, Optional
+import threading
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
@@ -53,6 +57,8 @@ class FlashSREngine:
         native.require_device()
         self.cfg = cfg
         self.dev = torch.device(device)
+        if self.dev.index is None:               # pinned to the device that is current now: the handle's memory lives there
+            self.dev = torch.device("cuda", torch.cuda.current_device())
         self.L = native.lib()
         # the class-level switches are frozen per engine at construction: the handle flags must see the values this engine was
         # built under, whatever the class holds later
@@ -103,23 +109,24 @@ class FlashSREngine:
     def handle(self) -> int:
         """egr_flashsr handle built from this engine's parameters (once)."""
         if self._handle is None:
-            named = self.named_tensors()
-            descs = (native.TensorDescC * len(named))()
-            keep = []
-            for d, (k, v) in zip(descs, named.items()):
-                v = v.contiguous()
-                keep.append(v)
-                d.name, d.data, d.ndim = k.encode(), v.data_ptr(), v.dim()
-                for i, n in enumerate(v.shape):
-                    d.shape[i] = n
-            cc = native.flashsr_config_c(self.cfg)
-            out = C.c_void_p()
-            native.check(self.L.egr_flashsr_create(C.byref(out), C.byref(cc), descs, len(named), self.handle_flags(), self._st()),
-                         "egr_flashsr_create")
-            self._handle = out.value
-            if not self._KEEP_PARAMS:
-                self._params = None          # the library holds its own packed copy: drop the host-side state dict
-            native.check(self.L.egr_flashsr_set_rows_per_pass(C.c_void_p(self._handle), ROWS_PER_PASS), "egr_flashsr_set_rows_per_pass")
+            with torch.cuda.device(self.dev):      # egr_flashsr_create allocates on the CURRENT device
+                named = self.named_tensors()
+                descs = (native.TensorDescC * len(named))()
+                keep = []
+                for d, (k, v) in zip(descs, named.items()):
+                    v = v.contiguous()
+                    keep.append(v)
+                    d.name, d.data, d.ndim = k.encode(), v.data_ptr(), v.dim()
+                    for i, n in enumerate(v.shape):
+                        d.shape[i] = n
+                cc = native.flashsr_config_c(self.cfg)
+                out = C.c_void_p()
+                native.check(self.L.egr_flashsr_create(C.byref(out), C.byref(cc), descs, len(named), self.handle_flags(), self._st()),
+                             "egr_flashsr_create")
+                self._handle = out.value
+                if not self._KEEP_PARAMS:
+                    self._params = None          # the library holds its own packed copy: drop the host-side state dict
+                native.check(self.L.egr_flashsr_set_rows_per_pass(C.c_void_p(self._handle), ROWS_PER_PASS), "egr_flashsr_set_rows_per_pass")
         return self._handle
 
     def close(self):
@@ -169,6 +176,11 @@ class FlashSREngine:
         code = {"bf16x3": 0, "f16x2": 1, "f16x2+forward": 2}[scheme]     # the last: c_forward too runs the fp16 operand terms (tests)
         native.check(self.L.egr_flashsr_set_split(C.c_void_p(self.handle), code), "egr_flashsr_set_split")
 
+    def set_arena_cap_gb(self, gb: float):
+        """Scratch budget of the handle in GB (0: none; EGREGORA_FLASHSR_ARENA_GB sets it at creation): fewer rows per pass instead of
+        an allocation failure next to the host's other models (include/egregora_amd.h egr_flashsr_set_arena_cap)."""
+        native.check(self.L.egr_flashsr_set_arena_cap(C.c_void_p(self.handle), float(gb) * 1e9), "egr_flashsr_set_arena_cap")
+
     def split_info(self) -> dict:
         """enabled: c_infer runs two fp16 terms per operand with per-row scales derived on the device; weights: contraction weights that
         hold fp16 terms; calls: c_infer calls made on the scheme (include/egregora_amd.h egr_flashsr_set_split)."""
@@ -207,13 +219,48 @@ class FlashSREngine:
 
 
 # ---------------------------------------------------------------------------------------------------- module state
-_ENGINE: Optional[FlashSREngine] = None
+_ENGINES: Dict[int, FlashSREngine] = {}       # device index -> engine (one C handle per device)
+_SOURCE: Optional[Tuple[arch.FlashSRConfig, Dict[str, torch.Tensor]]] = None    # host state dict, kept only while more devices may need a copy
 ROWS_PER_PASS = int(os.environ.get("EGREGORA_FLASHSR_ROWS", "32"))
 SEED = int(os.environ.get("EGREGORA_FLASHSR_SEED", "0"))
 
 
-def ensure_ready() -> FlashSREngine:
-    """Build the engine once per process (the reference rebuilds the model on every run(), :393).  Weight sources, in order:
+def devices() -> List[int]:
+    """Devices the node shards its chunks over inside THIS process: EGREGORA_DEVICES = "0,1,2,..." or "all" (default: the current
+    device only).  The first entry stitches (WOLA).  An index may repeat ("0,0": two handles and two host threads on one GPU --
+    the single-GPU test of the multi-device path)."""
+    spec = os.environ.get("EGREGORA_DEVICES", "").strip()
+    if not spec:
+        return [torch.cuda.current_device()]
+    if spec.lower() == "all":
+        return list(range(torch.cuda.device_count()))
+    try:
+        devs = [int(t) for t in spec.split(",") if t.strip() != ""]
+    except ValueError:
+        raise RuntimeError(f"EGREGORA_DEVICES={spec!r}: expected a comma-separated list of device indices or 'all'")
+    n = torch.cuda.device_count()
+    bad = [d for d in devs if not 0 <= d < n]
+    if bad or not devs:
+        raise RuntimeError(f"EGREGORA_DEVICES={spec!r}: device(s) {bad} not among the {n} visible")
+    return devs
+
+
+def _load_source():
+    from . import flashsr_weights
+    path = os.environ.get("EGREGORA_FLASHSR_WEIGHTS", "")
+    if path:
+        if not os.path.exists(path):
+            raise RuntimeError(f"EGREGORA_FLASHSR_WEIGHTS={path} (missing).")
+        params = torch.load(path, map_location="cpu", weights_only=True)
+        return arch.config_from_params(params), params
+    params, cfg, where = flashsr_weights.load()
+    print(f"[FlashSR] checkpoints from {where}: {len(params)} tensors, layer table {cfg}")
+    return cfg, params
+
+
+def ensure_ready(device: Optional[int] = None) -> FlashSREngine:
+    """Build the engine of `device` (default: the current one) once per process (the reference rebuilds the model on every run(),
+    :393).  Weight sources, in order:
       1. EGREGORA_FLASHSR_WEIGHTS -- a torch state dict already in this pack's layer-table names (flashsr_arch.py);
       2. the three upstream checkpoints student_ldm.pth / sr_vocoder.pth / vae.pth discovered in models/audio/flashsr
          (flashsr_weights.discover: both places the reference can mean, or EGREGORA_FLASHSR_CKPT_DIR), mapped through
@@ -222,27 +269,41 @@ def ensure_ready() -> FlashSREngine:
     The layer table always comes from the checkpoint's own tensor shapes (flashsr_arch.config_from_params).  Seeded synthetic
     weights are for benches and tests only and are never picked up here: those callers build a FlashSREngine themselves and
     install it with set_engine()."""
-    global _ENGINE
-    if _ENGINE is not None:
-        return _ENGINE
+    global _SOURCE
+    dev = torch.cuda.current_device() if device is None and torch.cuda.is_available() else (device or 0)
+    if dev in _ENGINES:
+        return _ENGINES[dev]
     native.require_device()
-    from . import flashsr_weights
-    path = os.environ.get("EGREGORA_FLASHSR_WEIGHTS", "")
-    if path:
-        if not os.path.exists(path):
-            raise RuntimeError(f"EGREGORA_FLASHSR_WEIGHTS={path} (missing).")
-        params = torch.load(path, map_location="cpu", weights_only=True)
-        cfg = arch.config_from_params(params)
-    else:
-        params, cfg, where = flashsr_weights.load()
-        print(f"[FlashSR] checkpoints from {where}: {len(params)} tensors, layer table {cfg}")
-    _ENGINE = FlashSREngine(cfg, params)
-    return _ENGINE
+    if _SOURCE is None:
+        _SOURCE = _load_source()
+    cfg, params = _SOURCE
+    _ENGINES[dev] = FlashSREngine(cfg, params, device=f"cuda:{dev}")
+    if all(d in _ENGINES for d in devices()):
+        _SOURCE = None                       # every device that will be used holds its packed copy: drop the host state dict
+    return _ENGINES[dev]
 
 
 def set_engine(engine: Optional[FlashSREngine]):
-    global _ENGINE
-    _ENGINE = engine
+    """Install a prebuilt engine for its device (benches, tests); None forgets every engine."""
+    global _SOURCE
+    if engine is None:
+        _ENGINES.clear()
+        _SOURCE = None
+    else:
+        _ENGINES[engine.dev.index] = engine
+
+
+def set_engines(engines: List[FlashSREngine], devs: Optional[List[int]] = None):
+    """Install one prebuilt engine per entry of `devs` (default: each engine's own device).  With a repeated device index the
+    entries are keyed by POSITION in EGREGORA_DEVICES (see _engine_for)."""
+    _ENGINES.clear()
+    for i, e in enumerate(engines):
+        _ENGINES[("slot", i)] = e
+        _ENGINES.setdefault(e.dev.index if devs is None else devs[i], e)
+
+
+def _engine_for(slot: int, dev: int) -> FlashSREngine:
+    return _ENGINES.get(("slot", slot)) or ensure_ready(dev)
 
 
 def infer_rows(eng: FlashSREngine, rows_x: torch.Tensor, row_ids: torch.Tensor, seed: int,
@@ -252,16 +313,71 @@ def infer_rows(eng: FlashSREngine, rows_x: torch.Tensor, row_ids: torch.Tensor, 
     return eng.c_infer(rows_x, row_ids, seed, lowpass)
 
 
+def balanced_bounds(n: int, k: int) -> List[Tuple[int, int]]:
+    """n chunks over k workers as contiguous blocks whose sizes differ by at most one (130 over 8: 17, 17, 16, 16, 16, 16, 16, 16)."""
+    base, extra = divmod(n, k) if k > 0 else (0, 0)
+    out, lo = [], 0
+    for i in range(k):
+        hi = lo + base + (1 if i < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
 def infer_spans(x_ct: torch.Tensor, n_chunks: int, win: int, hop: int, lowpass: bool) -> torch.Tensor:
-    """[C,T] @48 kHz on the GPU -> predictions [n_chunks, C, win].  Chunks are sharded over the ranks of the
-    default process group when one exists (contiguous blocks, one all-gather; shard.py)."""
+    """[C,T] @48 kHz on the GPU -> predictions [n_chunks, C, win].  Chunks are sharded over the ranks of the default process
+    group when one exists (contiguous blocks, one all-gather; shard.py); otherwise over the devices of EGREGORA_DEVICES inside
+    this process (infer_spans_devices); otherwise they all run here."""
     Cn = x_ct.shape[0]
-    return shard.sharded_chunks(lambda lo, hi: infer_block(x_ct, lo, hi, win, hop, lowpass), n_chunks, (Cn, win), x_ct.device)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return shard.sharded_chunks(lambda lo, hi: infer_block(x_ct, lo, hi, win, hop, lowpass), n_chunks, (Cn, win), x_ct.device)
+    devs = devices() if x_ct.is_cuda else []
+    if len(devs) > 1 and n_chunks > 1:
+        return infer_spans_devices(x_ct, n_chunks, win, hop, lowpass, devs)
+    return infer_block(x_ct, 0, n_chunks, win, hop, lowpass)
 
 
-def infer_block(x_ct: torch.Tensor, lo: int, hi: int, win: int, hop: int, lowpass: bool) -> torch.Tensor:
-    """Predictions [hi - lo, C, win] of the chunks lo .. hi-1 of x_ct (one rank's share; noise keyed by the GLOBAL row id)."""
-    eng = ensure_ready()
+def infer_spans_devices(x_ct: torch.Tensor, n_chunks: int, win: int, hop: int, lowpass: bool, devs: List[int]) -> torch.Tensor:
+    """The reference's chunk loop (egregora_audio_super_resolution.py:407-420) spread over several GPUs of ONE process: worker i
+    (a host thread bound to devs[i], with that device's own handle) takes the contiguous block balanced_bounds(n)[i], reads the
+    input through a peer copy, runs its rows batched, and writes its predictions straight into its slice of the [n, C, win]
+    tensor on x_ct's device (peer copy = the gather); the caller stitches there.  Noise is keyed by the GLOBAL row id and every
+    row's result depends on that row alone, so the outcome does not depend on the device count beyond fp32 round-off from tile
+    choices (they follow the row count of a forward).  UNMEASURED on more than one physical GPU in this repository's test
+    pool: the one-GPU box exercises it as EGREGORA_DEVICES=0,0."""
+    Cn = x_ct.shape[0]
+    home = x_ct.device
+    out = torch.empty((n_chunks, Cn, win), dtype=torch.float32, device=home)
+    torch.cuda.current_stream(home).synchronize()            # x_ct is complete before another device's stream reads it
+    jobs = [(i, d, lo, hi) for i, (d, (lo, hi)) in enumerate(zip(devs, balanced_bounds(n_chunks, len(devs)))) if hi > lo]
+    errors: List[BaseException] = []
+
+    def work(slot: int, d: int, lo: int, hi: int):
+        try:
+            with torch.cuda.device(d):
+                eng = _engine_for(slot, d)
+                xd = x_ct if torch.device("cuda", d) == home else x_ct.to(torch.device("cuda", d), non_blocking=True)
+                preds = infer_block(xd, lo, hi, win, hop, lowpass, eng)
+                out[lo:hi].copy_(preds, non_blocking=True)   # the gather: a peer copy into the stitching device's tensor
+                torch.cuda.current_stream().synchronize()
+        except BaseException as ex:      # noqa: BLE001 -- re-raised in the caller's thread
+            errors.append(ex)
+
+    threads = [threading.Thread(target=work, args=j, name=f"flashsr-dev{j[1]}") for j in jobs[1:]]
+    for t in threads:
+        t.start()
+    work(*jobs[0])                                           # the first block runs on the caller's thread
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return out
+
+
+def infer_block(x_ct: torch.Tensor, lo: int, hi: int, win: int, hop: int, lowpass: bool, eng: Optional[FlashSREngine] = None) -> torch.Tensor:
+    """Predictions [hi - lo, C, win] of the chunks lo .. hi-1 of x_ct (one rank's or device's share; noise keyed by the GLOBAL row id)."""
+    eng = eng or ensure_ready(x_ct.device.index)
     Cn = x_ct.shape[0]
     if win != eng.cfg.chunk:
         raise RuntimeError(f"chunk length {win} != model chunk {eng.cfg.chunk}")

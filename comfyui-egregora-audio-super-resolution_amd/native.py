@@ -68,6 +68,8 @@ SIGNATURES = {
     "egr_split2h_pack": (_i, [_vp, _vp, _i64, _i, _f, _vp]),
     "egr_absmax": (_i, [_vp, _i64, _vp, _vp]),
     "egr_absmax_rows": (_i, [_vp, _i, _i64, _i, _i64, _vp, _vp]),
+    "egr_conv_h2_gn": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "egr_gn_operand_bound": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "egr_conv_h2": (_i, [_vp] * 6 + [_i] * 15 + [_f] + [_i] * 7 + [_i64] * 3 + [_f, _vp, _i, _vp, _vp]),
     "egr_winograd_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "egr_groupnorm_coeff": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
@@ -119,6 +121,7 @@ SIGNATURES = {
     "egr_flashsr_set_streams": (_i, [_vp, _i, _i]),
     "egr_flashsr_set_split": (_i, [_vp, _i]),
     "egr_flashsr_split_info": (_i, [_vp, _vp, _vp, _vp]),
+    "egr_flashsr_set_arena_cap": (_i, [_vp, C.c_double]),
     "egr_flashsr_set_profiling": (_i, [_vp, _i]),
     "egr_flashsr_profile": (_i, [_vp, _i, C.c_char_p, C.c_size_t, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                  C.POINTER(_i)]),

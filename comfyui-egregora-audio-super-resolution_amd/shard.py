@@ -1,9 +1,9 @@
 """Chunk-parallel sharding of the FlashSR hot loop across the GPUs of one node.
 
 The reference processes chunks sequentially and independently (egregora_audio_super_resolution.py:411-418); they
-only meet in WOLA (:420).  Rank r of the default process group takes the contiguous block
-[r*per, min(n,(r+1)*per)) with per = ceil(n/world), and ONE all-gather (RCCL over xGMI on GPUs, gloo in the CPU
-tests) of the equal-padded prediction blocks gives every rank all predictions for the WOLA kernel.
+only meet in WOLA (:420).  Rank r of the default process group takes a contiguous block -- sizes balanced to within one
+chunk (130 chunks over 8 ranks: 17, 17, 16, 16, 16, 16, 16, 16) -- and ONE all-gather (RCCL over xGMI on GPUs, gloo in the
+CPU tests) of the equal-padded prediction blocks gives every rank all predictions for the WOLA kernel.
 No other collective exists on the data path.
 """
 from typing import Callable, List, Tuple
@@ -12,8 +12,13 @@ import torch
 
 
 def block_bounds(n: int, world: int) -> List[Tuple[int, int]]:
-    per = -(-n // world) if n > 0 else 0
-    return [(min(n, r * per), min(n, (r + 1) * per)) for r in range(world)]
+    base, extra = divmod(max(n, 0), world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
 
 
 def sharded_chunks(run_block: Callable[[int, int], torch.Tensor], n: int, item_shape: Tuple[int, ...], device,

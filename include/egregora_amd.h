@@ -308,6 +308,15 @@ int egr_conv_h2(const float* x, const void* w2, const float* bias, const float* 
                 int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t, int pad_l,
                 int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF, int nz, int64_t zx,
                 int64_t zw2, int64_t zy, float w_scale, const float* row_amax, int batch_rows, float* out_amax, void* stream);
+/* 3x3 stride-1 pad-1 convolution on two fp16 terms with the producer's GroupNorm (+ SiLU) applied to x while it is loaded, on the
+ * input-stationary kernel (a workgroup splits the halo patch of its 4 x 32 pixel tile once and reads the nine taps from it; x is
+ * read once, no Winograd intermediates): H % 4 == 0, W % 32 == 0, Cin % 32 == 0, >= 512 tiles, else EGR_ERR_UNSUPPORTED with
+ * nothing launched.  row_amax[b] bounds max |GroupNorm(x)| of image b from above (egr_gn_operand_bound: from the coefficients and
+ * the row maxima of x, no pass over x); the scale derived from it only has to place the row's maximum inside [1, 2^15). */
+int egr_conv_h2_gn(const float* x, const float* gn_scale, const float* gn_shift, int gn_silu, const void* w2, const float* bias,
+                   const float* res, float* y, int B, int H, int W, int Cin, int Cout, int act, float w_scale, const float* row_amax,
+                   float* out_amax, void* stream);
+int egr_gn_operand_bound(const float* scale, const float* shift, int B, int C, const float* x_row_amax, float* bound, void* stream);
 int egr_conv_s3(const float* x, const void* w3, const float* bias, const float* bias_b, const float* res, float* y, int B,
                 int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t, int pad_l,
                 int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF, int nz, int64_t zx,
@@ -512,6 +521,10 @@ int egr_flashsr_set_profiling(egr_flashsr* h, int enable);
 int egr_flashsr_profile(egr_flashsr* h, int index, char* kind_buf, size_t buflen, int64_t* launches, double* flops, double* ms, int* count);
 int egr_flashsr_flop_count(egr_flashsr* h, int rows, double* flops, void* stream);
 int64_t egr_flashsr_scratch_bytes(egr_flashsr* h);
+/* Scratch budget in bytes (0 = none; EGREGORA_FLASHSR_ARENA_GB sets it at creation).  A 26-row pass of the full-size table in two
+ * row groups holds ~39 GB of activations; under a budget egr_flashsr_infer runs fewer rows per pass (same results, rows are
+ * independent) instead of failing an allocation next to the host's other models.  Allocated arenas are not returned. */
+int egr_flashsr_set_arena_cap(egr_flashsr* h, double bytes);
 /* Weight repacking shared by the handle and the Python graph driver (csrc/egr_flashsr_pack.hip):
  *   egr_pack_weight     : torch layout -> slab-major [ceil(K/16)][N][16]; layout 0 conv/linear [N][Ci][KH][KW] (k = (ky KW + kx) Ci + ci),
  *                         1 ConvTranspose1d [K=Ci][Co][KW] (n = kk Co + co), 2 per-tap products [Co][K=Ci][KH][KW] (n = tap Co + co)

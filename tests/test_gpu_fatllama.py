@@ -316,34 +316,70 @@ def test_800_iterations_against_the_oracle(pack):
     assert lg <= 1e-3 and kept >= 0.3, (lg, lo, kept)
 
 
-@pytest.mark.parametrize("n", [2880000, 2880002])
-def test_c3_full_length_800_iterations_against_the_oracle(pack, n):
+def f64_loop_on_gpu(x, iters, thr):
+    """The oracle's loop (oracle/fatllama.py ist_loop, default spec, factor 1) in FLOAT64 through torch.fft on the GPU: the yardstick
+    for lengths at which the host transform is too slow (pocketfft needs ~0.5 s per iteration at N = 2.88 M in float64, 1.5 s for
+    N = 2 x a prime).  An independent transform (rocFFT, double precision); pinned to the oracle's own float64 run below."""
+    y = torch.from_numpy(np.asarray(x, np.float64)).cuda()
+    y[..., -1] = 0.0                               # linear up-rating by 1: the last input sample's slot stays zero (oracle.interpolate)
+    t = float(thr)
+    d = torch.where(y.abs() > t, y, torch.zeros_like(y))
+    n = y.shape[-1]
+    for _ in range(int(iters)):
+        X = torch.fft.rfft(d, dim=-1)
+        X = torch.where(X.abs() > t, X, torch.zeros_like(X))
+        d = torch.fft.irfft(X, n=n, dim=-1)
+    return (y + d).cpu().numpy()
+
+
+def test_c3_full_length_800_iterations_against_the_oracle(pack):
     """BASELINE configs[2] at ITS OWN size and iteration count: one channel of 60 s at 48 kHz (N = 2 880 000: the 625 x 2304 plan on
     the two-barrier kernels, whose twiddle runs are specific to that length) and 60 s + 2 samples (no packed plan: the paired chirp-z
-    loop), all 800 iterations on the device, in the float32 oracle and in the float64 run of the same loop (about 1 and 2 minutes
-    of host time per length).  Round-off compounds over the iterations as (1 + eps)^800 in ANY float32 implementation, so the gates
-    are those of test_800_iterations_against_the_oracle: the device's error against float64 within 2x (max) / 2.5x (rms) of the
-    float32 oracle's own, and the LSD against float64 over the bins a float32 transform resolves <= 1e-3 dB."""
+    loop), all 800 iterations.  Round-off compounds over the iterations as (1 + eps)^800 in ANY float32 implementation -- at this
+    length the float32 pocketfft oracle itself ends 1.6e-4 of the peak from float64 -- so the gates are relative to the oracle's own
+    error, as in test_800_iterations_against_the_oracle: the device's error against float64 within 2x (max) / 2.5x (rms) of the
+    float32 oracle's, and the LSD against float64 over the bins a float32 transform resolves (module docstring) <= 1e-3 dB; the
+    plain LSD (all bins, including those float32 cannot resolve: 0.8e-3 dB for the float32 ORACLE at this length) is printed and
+    held to 3x the oracle's, like the rms error.  The float32 oracle runs on the host for N = 2 880 000 (~3 minutes);
+    the float64 yardstick is the same loop through torch.fft in double precision on the GPU (checked here against the oracle's own
+    float64 run at a small size); for N + 2 -- where the host transform (N = 2 x a prime) would take half an hour -- the device is
+    held to the float32 oracle's error at the neighbouring length N (same data, same statistics)."""
     from egregora_amd import fatllama_engine as fe
-    info = fe.plan_info(n, 1)
-    assert ((info["M1"], info["M2"]) == (625, 2304)) == (n == 2880000) and bool(info.get("chirpz_kind", 0)) == (n != 2880000), info
-    x = synth(1, n, seed=2880 + n % 7)
-    got = run_gpu(pack, x, 1, 800, 0.6)
-    want = ofl.enhance_channels(x, 1, 800, 0.6, normalize=False, autoscale=False)
-    exact = ofl.enhance_channels(x, 1, 800, 0.6, normalize=False, autoscale=False, exact=True)
-    scale = float(np.max(np.abs(want)))
+    try:
+        small = synth(1, 48000, seed=5)
+        pin = f64_loop_on_gpu(small, 20, 0.6)
+    except Exception as ex:      # noqa: BLE001 -- no double-precision FFT in this torch build: nothing to measure against in bounded time
+        pytest.skip(f"torch.fft in float64 on the GPU is not available here ({ex})")
+    want_small = ofl.enhance_channels(small, 1, 20, 0.6, normalize=False, autoscale=False, exact=True)
+    assert float(np.max(np.abs(pin - want_small))) <= 1e-9 * float(np.max(np.abs(want_small))), "the GPU float64 loop IS the oracle's float64 loop"
     rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
-    mg, mo = float(np.max(np.abs(got - exact))), float(np.max(np.abs(want - exact)))
     seg = slice(0, 960000)                         # the reference's metric on the first 20 s (every frame sees the same loop)
-    lg, kept = om.lsd_masked(exact[:, seg], got[:, seg], f32_run=want[:, seg], margin_db=F32_MARGIN_DB)
-    lo, _ = om.lsd_masked(exact[:, seg], want[:, seg], f32_run=want[:, seg], margin_db=F32_MARGIN_DB)
-    print(f"\nC3 length N = {n}, 800 iterations: max err device {mg:.3e} oracle32 {mo:.3e} (peak {scale:.0f}); rms {rms(got - exact):.3e} / "
-          f"{rms(want - exact):.3e}; LSD vs float64 over the {kept:.1%} of bins >= {F32_MARGIN_DB:.0f} dB above the float32 floor: device {lg:.2e} dB, "
-          f"oracle32 {lo:.2e} dB; plain LSD(device, oracle32) {om.lsd_audio(want[:, seg], got[:, seg])[0]:.2e} dB")
-    assert np.isfinite(got).all()
-    assert mg <= 2.0 * mo and mg <= 1e-4 * scale, (mg, mo, scale)
-    assert rms(got - exact) <= 2.5 * rms(want - exact) + 1e-9 * scale
-    assert lg <= 1e-3 and kept >= 0.3, (lg, lo, kept)
+    ref_err = None
+    for n in (2880000, 2880002):
+        info = fe.plan_info(n, 1)
+        assert ((info["M1"], info["M2"]) == (625, 2304)) == (n == 2880000) and bool(info.get("chirpz_kind", 0)) == (n != 2880000), info
+        x = synth(1, 2880002, seed=2880)[:, :n].copy()
+        got = run_gpu(pack, x, 1, 800, 0.6)
+        exact = f64_loop_on_gpu(x, 800, 0.6)
+        scale = float(np.max(np.abs(exact)))
+        mg, rg = float(np.max(np.abs(got - exact))), rms(got - exact)
+        if n == 2880000:
+            want = ofl.enhance_channels(x, 1, 800, 0.6, normalize=False, autoscale=False)
+            ref_err = (float(np.max(np.abs(want - exact))), rms(want - exact))
+            lo_plain = om.lsd_audio(exact[:, seg], want[:, seg])[0]
+            lo, _ = om.lsd_masked(exact[:, seg], want[:, seg], f32_run=want[:, seg], margin_db=F32_MARGIN_DB)
+            print(f"\nfloat32 oracle at N = {n}, 800 iterations: max err {ref_err[0]:.3e} ({ref_err[0] / scale:.2e} of the peak {scale:.0f}), rms {ref_err[1]:.3e}, "
+                  f"LSD vs float64 plain {lo_plain:.2e} dB, over the resolvable bins {lo:.2e} dB")
+        f32_run = want[:, seg] if n == 2880000 else got[:, seg]      # (N + 2: the device's own deviation sets the floor; `kept` guards it)
+        lg, kept = om.lsd_masked(exact[:, seg], got[:, seg], f32_run=f32_run, margin_db=F32_MARGIN_DB)
+        lg_plain = om.lsd_audio(exact[:, seg], got[:, seg])[0]
+        print(f"device at N = {n} ({'625 x 2304 plan' if n == 2880000 else 'paired chirp-z'}), 800 iterations: max err {mg:.3e} ({mg / scale:.2e} of the peak), "
+              f"rms {rg:.3e}; ratios to the float32 oracle {mg / ref_err[0]:.2f} / {rg / ref_err[1]:.2f}; LSD vs float64 plain {lg_plain:.2e} dB, over the "
+              f"{kept:.1%} of bins >= {F32_MARGIN_DB:.0f} dB above the float32 floor {lg:.2e} dB")
+        assert np.isfinite(got).all()
+        assert mg <= 2.0 * ref_err[0] and mg <= 5e-4 * scale, (n, mg, ref_err, scale)
+        assert rg <= 2.5 * ref_err[1] + 1e-9 * scale, (n, rg, ref_err)
+        assert lg <= 1e-3 and kept >= 0.3 and lg_plain <= 3.0 * lo_plain, (n, lg, kept, lg_plain, lo_plain)
 
 
 VARIANTS = [  # (variant list for the device, FatLlamaSpec overrides, threshold, data scale)

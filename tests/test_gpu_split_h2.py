@@ -469,3 +469,54 @@ def test_conv_h2_epilogue_leaves_the_row_maxima_of_its_output(eng):
         native.check(L.egr_conv_h2(p(x), p(w2), p(b), p(None), p(r), p(y), B, H, W, Ci, H, W, Co, kh, k, 1, 1, kh // 2, k // 2, 0, act, 0.0,
                                    1, 1, 0, 0, H, W, 1, 0, 0, 0, ws, p(row_amax(e, x, B)), B, p(oa), e._st()), "conv_h2")
         assert torch.equal(oa[::RA], y.abs().amax(dim=(1, 2, 3))), (B, H, W, Ci, Co, k, oa, y.abs().amax(dim=(1, 2, 3)))
+
+
+def test_input_stationary_3x3_with_fused_groupnorm_vs_float64(eng):
+    """egr_conv_h2_gn (k_conv3x3_is): 3x3 convolution of silu(x * scale[b][c] + shift[b][c]) with zero padding AFTER the
+    normalisation, bias, residual, per-row output maxima -- against the float64 convolution of the same normalised tensor; the
+    operand scale comes from egr_gn_operand_bound (an upper bound of the normalised row, from the coefficients and the row maxima
+    of x), and the error must be no larger than 1.25x the f32-MFMA kernel's on the materialised normalised tensor.  Images at
+    different levels and with a large mean (where the bound is loosest) in one launch; a shape that does not qualify is refused."""
+    e, cfg = eng
+    L = e.L
+    from egregora_amd import native
+    g = torch.Generator().manual_seed(51)
+    for (B, H, W, Ci, Co, silu, res_on) in [(3, 128, 256, 64, 128, 1, True), (2, 256, 256, 128, 64, 0, False), (5, 64, 256, 32, 128, 1, False)]:
+        x = torch.randn(B, H, W, Ci, generator=g)
+        x = x * (10.0 ** -torch.arange(B).float()).view(B, 1, 1, 1) + 5.0 * (10.0 ** -torch.arange(B).float()).view(B, 1, 1, 1)    # mean 5 sigma
+        sc = (1.0 + 0.2 * torch.randn(B, Ci, generator=g)) * (10.0 ** torch.arange(B).float()).view(B, 1)
+        sh = 0.3 * torch.randn(B, Ci, generator=g) - 5.0 * sc * (10.0 ** -torch.arange(B).float()).view(B, 1)
+        w = torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9)
+        b = 0.1 * torch.randn(Co, generator=g)
+        r = 0.1 * torch.randn(B, H, W, Co, generator=g) if res_on else None
+        xn = x.double() * sc.double().view(B, 1, 1, Ci) + sh.double().view(B, 1, 1, Ci)
+        if silu:
+            xn = xn * torch.sigmoid(xn)
+        ref = F.conv2d(xn.permute(0, 3, 1, 2), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+        if res_on:
+            ref = ref + r.double()
+        x, sc, sh, w, b = x.cuda(), sc.cuda().contiguous(), sh.cuda().contiguous(), w.cuda(), b.cuda()
+        r = r.cuda() if res_on else None
+        wp = e.pack_matrix(w.permute(2, 3, 1, 0).reshape(9 * Ci, Co).contiguous()).cuda()
+        w2, ws = h2_pack(e, wp, Co)
+        bound, oa = ra_zeros(B), ra_zeros(B)
+        native.check(L.egr_gn_operand_bound(p(sc), p(sh), B, Ci, p(row_amax(e, x, B)), p(bound), e._st()), "bound")
+        true_max = xn.abs().amax(dim=(1, 2, 3)).float()
+        ratio = bound[::RA].cpu() / true_max
+        assert bool((ratio >= 1.0).all()) and bool((ratio < 64.0).all()), ratio          # a bound, and within 6 bits here
+        y = torch.empty(B, H, W, Co, device="cuda")
+        native.check(L.egr_conv_h2_gn(p(x), p(sc), p(sh), silu, p(w2), p(b), p(r), p(y), B, H, W, Ci, Co, 0, ws, p(bound), p(oa), e._st()), "conv_h2_gn")
+        y1 = torch.empty_like(y)
+        xn32 = xn.float().cuda().contiguous()
+        native.check(L.egr_conv_nhwc(p(xn32), p(wp), p(b), p(None), p(r), p(y1), B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, 1, 0, 0, 0.0, e._st()), "conv")
+        assert torch.equal(oa[::RA], y.abs().amax(dim=(1, 2, 3)))
+        for i in range(B):
+            e2 = float((y[i].double().cpu() - ref[i]).norm() / ref[i].norm())
+            e1 = float((y1[i].double().cpu() - ref[i]).norm() / ref[i].norm())
+            # (the f32 kernel starts from the float32 ROUNDING of the normalised tensor, the fused loader normalises in fp32 itself)
+            assert e2 <= 1.25 * e1 + 2e-7, (B, H, W, Ci, Co, i, e1, e2)
+    # too few tiles / W % 32 != 0: refused, nothing launched
+    x = torch.randn(1, 8, 48, 32, generator=g).cuda()
+    y = torch.empty(1, 8, 48, 128, device="cuda")
+    rc = L.egr_conv_h2_gn(p(x), p(sc), p(sh), 1, p(w2), p(None), p(None), p(y), 1, 8, 48, 32, 128, 0, ws, p(bound), p(None), e._st())
+    assert rc == 3 and "qualify" in native.last_error()

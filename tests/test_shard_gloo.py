@@ -60,7 +60,13 @@ def test_block_bounds():
     from packload import load_pack
     load_pack()
     from egregora_amd import shard
-    assert shard.block_bounds(130, 8) == [(0, 17), (17, 34), (34, 51), (51, 68), (68, 85), (85, 102), (102, 119), (119, 130)]
+    # balanced to within one chunk (the ceil-sized blocks of rounds 1-3 left the last of 8 ranks with 11 of 130 chunks: a 7.65x ceiling)
+    assert shard.block_bounds(130, 8) == [(0, 17), (17, 34), (34, 50), (50, 66), (66, 82), (82, 98), (98, 114), (114, 130)]
+    for n in (0, 1, 7, 13, 130, 391):
+        for w in (1, 2, 3, 8):
+            b = shard.block_bounds(n, w)
+            sizes = [hi - lo for lo, hi in b]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1)) and max(sizes) - min(sizes) <= 1
     assert shard.block_bounds(3, 8)[:4] == [(0, 1), (1, 2), (2, 3), (3, 3)]
     assert shard.block_bounds(0, 2) == [(0, 0), (0, 0)]
 

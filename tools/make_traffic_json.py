@@ -19,6 +19,7 @@ for d, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
 out = {"_note": "HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from the rocprofv3 PMC passes (separate runs; FETCH x2 gfx950 correction per "
                 f"MI355X_MICROARCH.md section HBM); source: {tag}/chain60_summary.txt; Fat-Llama loop kernels are per ONE-channel launch "
                 "(two channel pipelines run concurrently)",
+       "source": f"{tag} ({src})",
        "kernels": {}}
 for k in sorted(set(per["FETCH_SIZE"]) | set(per["WRITE_SIZE"])):
     f, w = per["FETCH_SIZE"].get(k, 0.0), per["WRITE_SIZE"].get(k, 0.0)
