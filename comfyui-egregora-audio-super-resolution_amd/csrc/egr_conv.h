@@ -54,6 +54,10 @@ struct ConvP {
     // scheme 1, optional: out_amax[m / rows_div] is raised to max |y| over the GEMM rows of each batch row (after bias / residual /
     // activation) -- the row maxima of y for the NEXT split contraction that reads it, without a pass over y.  Not with split-K.
     unsigned* out_amax;
+    // k_conv3x3_is, optional: GroupNorm partial statistics of y -- part[(unit) * (Cout / 4) + quad] = (sum, sum of squares) over the 32
+    // pixels of one sub-tile row and the 4 channels of a quad, unit = ((b * H + y) * (W / 32) + x / 32): the statistics of y are then
+    // a fixed-order reduction over 1/32 of y's bytes (egr_groupnorm_stats_from_partials with tiles_per_image = H * W / 32)
+    float2* gn_part;
 };
 
 // scheme 1: the power of two that brings a row whose largest magnitude has the bits `amax_bits` into [2^14, 2^15), and its
@@ -193,7 +197,7 @@ __device__ __forceinline__ void store_tile_plain_t(f32x16 (&acc)[TM][TN], float*
                                                    int wn0, const float* os_tab, float osw);
 template <int TM, int TN, bool VEC, bool RES>
 __device__ __forceinline__ void conv_epilogue_t_rows(const ConvP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0,
-                                                     const float* os_tab, unsigned* om_tab, int sub_stride) {
+                                                     const float* os_tab, unsigned* om_tab, int sub_stride, float2* part = nullptr) {
     const int lane = threadIdx.x & 63, px = lane & 31, ch4 = 4 * (lane >> 5);
     const bool ident = (p.osy == 1 && p.osx == 1 && p.OHF == p.OH && p.OWF == p.OW);
     const bool decode = !ident || p.bias_b;
@@ -235,6 +239,12 @@ __device__ __forceinline__ void conv_epilogue_t_rows(const ConvP& p, f32x16 (&ac
                             v.z = apply_act(v.z, p.act, p.act_param); v.w = apply_act(v.w, p.act, p.act_param);
                             *(float4*)(p.y + rowo + n) = v;
                             vm = fmaxf(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))), vm);
+                            if (part) {              // (sum, sum of squares) of this quad over the 32 pixels of the sub-tile: lanes px = 0 write
+                                float ps = (v.x + v.y) + (v.z + v.w), pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+                                for (int o = 16; o >= 1; o >>= 1) { ps += __shfl_xor(ps, o); pq += __shfl_xor(pq, o); }
+                                if (px == 0) part[((size_t)(m / 32)) * (p.Cout >> 2) + (n >> 2)] = make_float2(ps, pq);
+                            }
                         }
                     } else {
 #pragma unroll
@@ -260,15 +270,15 @@ __device__ __forceinline__ void conv_epilogue_t_rows(const ConvP& p, f32x16 (&ac
 // sub_stride: GEMM-row distance between the tile's 32-row sub-tiles (32 = a contiguous tile)
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue_t(const ConvP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0,
-                                                const float* os_tab, unsigned* om_tab = nullptr, int sub_stride = 32) {
+                                                const float* os_tab, unsigned* om_tab = nullptr, int sub_stride = 32, float2* part = nullptr) {
     const bool vec = (p.Cout & 3) == 0;
     if (p.ksplit > 1) {        // raw partial sums; bias / residual / activation are applied by k_splitk_reduce
         store_tile_plain_t<TM, TN>(acc, p.ws + (size_t)blockIdx.z * p.M * p.Cout, p.M, p.Cout, m0, n0, wm0, wn0, os_tab, p.out_scale);
         return;
     }
     if (vec) {
-        if (p.res) conv_epilogue_t_rows<TM, TN, true, true>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab, sub_stride);
-        else conv_epilogue_t_rows<TM, TN, true, false>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab, sub_stride);
+        if (p.res) conv_epilogue_t_rows<TM, TN, true, true>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab, sub_stride, part);
+        else conv_epilogue_t_rows<TM, TN, true, false>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab, sub_stride, part);
     } else {
         if (p.res) conv_epilogue_t_rows<TM, TN, false, true>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab, sub_stride);
         else conv_epilogue_t_rows<TM, TN, false, false>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab, sub_stride);

@@ -807,8 +807,18 @@ int gn_conv3(M* m, Ten& y, const Ten& x, const std::string& norm_key, float eps,
             }
             const float* bt = bias_t ? bias_t : m->ptr(conv_key + ".bias");
             const double fl = 2.0 * B * H * W * (double)wd->Cout * 9 * Cin;
+            // GroupNorm partial statistics of y from the epilogue (the next norm then reads 1/32 of y's bytes instead of y)
+            void* gpart = nullptr;
+            const int G = m->cfg.gn_groups;
+            if (!(m->flags & EGR_FSR_NO_GN_PARTIALS) && wd->Cout % G == 0 && (wd->Cout / G) % 4 == 0) {
+                auto part = std::make_shared<Ten>();
+                OKR(new_ten(m, *part, {(int64_t)B * H * W / 32, wd->Cout / 4, 2}));
+                gpart = part->p;
+                y.part = part;
+                y.part_tiles = H * W / 32;
+            }
             ProfScope ps(m);
-            OKR(egr_conv_h2_gn(x.p, sc.p, sh.p, 1, wd->w2, bt, res, y.p, B, H, W, Cin, wd->Cout, ACT_NONE, wd->w_scale, (const float*)bound, out_ra, m->st));
+            OKR(egr_conv_h2_gn(x.p, sc.p, sh.p, 1, wd->w2, bt, res, y.p, B, H, W, Cin, wd->Cout, ACT_NONE, wd->w_scale, (const float*)bound, out_ra, gpart, m->st));
             if (ps.on) {
                 char buf[64];
                 snprintf(buf, sizeof(buf), "k_conv3x3_is<%d, 32, true>", wd->Cout > 64 ? 128 : 64);

@@ -501,7 +501,7 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
                        int pad_l, int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF,
                        int nz, long long zx, long long zw, long long zy, const float* gn_scale, const float* gn_shift,
                        int gn_silu, void* stream, const void* w3 = nullptr, int sch = 0, float w_scale = 1.f,
-                       const float* row_amax = nullptr, int batch_rows = 0, float* out_amax = nullptr);
+                       const float* row_amax = nullptr, int batch_rows = 0, float* out_amax = nullptr, void* gn_part = nullptr);
 
 extern "C" int egr_conv_nhwc(const float* x, const float* w, const float* bias, const float* bias_b, const float* res,
                              float* y, int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
@@ -569,12 +569,15 @@ extern "C" int egr_conv_h2(const float* x, const void* w2, const float* bias, co
 // x' = x * gn_scale[b][c] + gn_shift[b][c] (then SiLU), zero padding after it.  Only the input-stationary kernel (k_conv3x3_is)
 // serves it: H %% 4 == 0, W %% 32 == 0, Cin %% 32 == 0, >= 512 tiles of 4 x 32 pixels, otherwise EGR_ERR_UNSUPPORTED (nothing is
 // launched).  row_amax[b] must bound max |x'| of image b from above (egr_gn_operand_bound); it need not be tight.
+// gn_part (optional, [B * H * W / 32][Cout / 4] float2): GroupNorm partial statistics of y, (sum, sum of squares) per 32-pixel row
+// segment and channel quad -- egr_groupnorm_stats_from_partials(part, B, H * W / 32, Cout, G) then gives the statistics of y
+// without a pass over it ((Cout / G) % 4 == 0).
 extern "C" int egr_conv_h2_gn(const float* x, const float* gn_scale, const float* gn_shift, int gn_silu, const void* w2, const float* bias,
                               const float* res, float* y, int B, int H, int W, int Cin, int Cout, int act, float w_scale, const float* row_amax,
-                              float* out_amax, void* stream) {
+                              float* out_amax, void* gn_part, void* stream) {
     EGR_CHECK(w2 && row_amax && gn_scale && gn_shift, EGR_ERR_ARG, "null w2 / row_amax / gn_scale / gn_shift");
     return conv_launch(x, nullptr, bias, nullptr, res, y, B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1, 0, act, 0.f, 1, 1, 0, 0, H, W, 1, 0, 0, 0,
-                       gn_scale, gn_shift, gn_silu, stream, w2, 1, w_scale, row_amax, B, out_amax);
+                       gn_scale, gn_shift, gn_silu, stream, w2, 1, w_scale, row_amax, B, out_amax, gn_part);
 }
 
 static int conv_launch(const float* x, const float* w, const float* bias, const float* bias_b, const float* res, float* y,
@@ -582,7 +585,7 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
                        int pad_l, int up2, int act, float act_param, int osy, int osx, int ooy, int oox, int OHF, int OWF,
                        int nz, long long zx, long long zw, long long zy, const float* gn_scale, const float* gn_shift,
                        int gn_silu, void* stream, const void* w3, int sch, float w_scale, const float* row_amax, int batch_rows,
-                       float* out_amax) {
+                       float* out_amax, void* gn_part) {
     EGR_CHECK(x && (w || w3) && y, EGR_ERR_ARG, "null x/w/y");
     EGR_CHECK(sch == 0 || (w3 && w_scale > 0.f && row_amax && batch_rows >= 1 && ((long long)B * OH * OW) % batch_rows == 0), EGR_ERR_ARG,
               "bad operand scheme: needs w_scale > 0, row_amax and a batch row count that divides the GEMM rows");
@@ -604,6 +607,7 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
     p.sch = sch; p.out_scale = sch ? 1.0f / w_scale : 1.0f; p.row_amax = sch ? (const unsigned*)row_amax : nullptr;
     p.rows_div = sch ? (int)(M / batch_rows) : 1;
     p.out_amax = (sch && nz == 1) ? (unsigned*)out_amax : nullptr;
+    p.gn_part = (float2*)gn_part;
     EGR_CHECK(osy >= 1 && osx >= 1 && ooy >= 0 && oox >= 0 && (OH - 1) * osy + ooy < OHF && (OW - 1) * osx + oox < OWF,
               EGR_ERR_ARG, "bad output placement");
     p.osy = osy; p.osx = osx; p.ooy = ooy; p.oox = oox; p.OHF = OHF; p.OWF = OWF;

@@ -387,29 +387,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
         if (c0 >= p.Cin) { c0 = 0; ++tap; set_tap(tap); }
     };
     auto load_tile = [&](Stage& r) {
-#ifdef S3_ABL_NOGLOBAL
-        if (c0 > 0 || tap > 0) { c0 += S3_BK; return; }
-#endif
         load_tile_issue(r);
         load_tile_advance();
     };
     auto store_tile = [&](const Stage& r, int buf) {
         uint4 q[3];
-#ifdef S3_ABL_NOSPLIT
-        q[0] = q[1] = q[2] = make_uint4(__float_as_uint(r.a0.x), __float_as_uint(r.a0.y), __float_as_uint(r.a1.x), __float_as_uint(r.a1.y));
-#else
         split_x8<SCH>(r.a0, r.a1, a_scale0, q);
-#endif
-#ifdef S3_ABL_NOSTORE
-        if (buf > 1)
-#endif
         {
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) As[buf][pl][a_slot] = q[pl];
             if (AP > 1) {
-#ifndef S3_ABL_NOSPLIT
                 split_x8<SCH>(r.a2, r.a3, a_scale1, q);
-#endif
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) As[buf][pl][a_slot + 256] = q[pl];
             }
@@ -498,9 +486,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
                         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
             }
         }
-#ifndef S3_ABL_NOBARRIER
         __syncthreads();
-#endif
     };
 
     if constexpr (SCH == 1 && TM <= 2 && BM == 128) {
@@ -516,9 +502,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
         SB sb;
         sb.b0 = sb.b1 = sb.b2 = sb.b3 = make_uint4(0, 0, 0, 0);
         auto a_issue = [&](SA& r) {
-#ifdef S3_ABL_NOGLOBAL
-            if (c0 > 0 || tap > 0) return;
-#endif
             const float* sp = aptr0 + astep0 * c0;
             r.a0 = *(const float4*)sp;
             r.a1 = *(const float4*)(sp + 4);
@@ -528,9 +511,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
             if (c0 >= p.Cin) { c0 = 0; ++tap; set_tap(tap); }
         };
         auto b_issue = [&](SB& r) {
-#ifdef S3_ABL_NOGLOBAL
-            if (c0 > S3_BK || tap > 0) return;
-#endif
             r.b0 = *bptr0;
             if (256 < NBQ) r.b1 = *bptr1;
             if (512 < NBQ) r.b2 = *bptr2;
@@ -544,23 +524,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
         };
         auto storeA = [&](const SA& ra, int buf) {
             uint4 q[3];
-#ifdef S3_ABL_NOSPLIT
-            q[0] = q[1] = make_uint4(__float_as_uint(ra.a0.x), __float_as_uint(ra.a0.y), __float_as_uint(ra.a1.x), __float_as_uint(ra.a1.y));
-#else
             split_x8<1>(ra.a0, ra.a1, a_scale0, q);
-#endif
-#ifdef S3_ABL_NOSTORE
-            if (buf > 1)
-#endif
             {
             As[buf][0][a_slot] = q[0];
             As[buf][1][a_slot] = q[1];
             }
         };
         auto storeB = [&](const SB& rb, int buf) {
-#ifdef S3_ABL_NOSTORE
-            if (buf > 1)
-#endif
             {
             if (NBQ >= 256 || tid < NBQ) Bs[buf][0][bslot0] = rb.b0;
             if (NBQ >= 512 || tid + 256 < NBQ) Bs[buf][0][bslot1] = rb.b1;
@@ -627,9 +597,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
                             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
                 }
             }
-#ifndef S3_ABL_NOBARRIER
             __syncthreads();
-#endif
         };
         typedef std::integral_constant<bool, true> FullT;
         typedef std::integral_constant<bool, false> TailT;
@@ -652,9 +620,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_s3(ConvP p) {
         if (t < n) { slab2(t, 1, sa0, TailT()); ++t; }
         if (t < n) { slab2(t, 0, sa1, TailT()); ++t; }
         if (t < n) { slab2(t, 1, sa0, TailT()); ++t; }
-#ifdef S3_ABL_NOEPI
-        if (acc[0][0][0] == 123.456f)
-#endif
         unsigned* const om = (!ZS && p.out_amax && p.ksplit <= 1) ? om_tab : nullptr;
         if (!ZS) conv_epilogue_t<TM, TN>(p, acc, m0, n0, wm0, wn0, os_tab, om);
         if (om) out_amax_commit(p, om_tab, m0, BM);
@@ -1188,7 +1153,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_is(ConvP p) {
     if (ws < wtotal) slab(ws, sA);
     // tile rows are image rows: GEMM row of (sub-tile t, pixel px) = (b H + y0 + t) W + x0 + px -> row stride W between sub-tiles
     unsigned* const om = p.out_amax ? om_tab : nullptr;
-    conv_epilogue_t<TM, TN>(p, acc, (b * p.H + y0) * p.W + x0, n0, wm0, wn0, os_tab, om, p.W);
+    // (sub-tile rows start at multiples of 32 in x: m / 32 is the partial-statistics unit (b H + y) (W / 32) + x / 32)
+    conv_epilogue_t<TM, TN>(p, acc, (b * p.H + y0) * p.W + x0, n0, wm0, wn0, os_tab, om, p.W, p.gn_part);
     if (om) out_amax_commit(p, om_tab, (b * p.H + y0) * p.W + x0, 1);
 }
 

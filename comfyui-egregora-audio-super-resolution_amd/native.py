@@ -68,7 +68,7 @@ SIGNATURES = {
     "egr_split2h_pack": (_i, [_vp, _vp, _i64, _i, _f, _vp]),
     "egr_absmax": (_i, [_vp, _i64, _vp, _vp]),
     "egr_absmax_rows": (_i, [_vp, _i, _i64, _i, _i64, _vp, _vp]),
-    "egr_conv_h2_gn": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "egr_conv_h2_gn": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "egr_gn_operand_bound": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "egr_conv_h2": (_i, [_vp] * 6 + [_i] * 15 + [_f] + [_i] * 7 + [_i64] * 3 + [_f, _vp, _i, _vp, _vp]),
     "egr_winograd_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

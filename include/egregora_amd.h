@@ -312,10 +312,12 @@ int egr_conv_h2(const float* x, const void* w2, const float* bias, const float* 
  * input-stationary kernel (a workgroup splits the halo patch of its 4 x 32 pixel tile once and reads the nine taps from it; x is
  * read once, no Winograd intermediates): H % 4 == 0, W % 32 == 0, Cin % 32 == 0, >= 512 tiles, else EGR_ERR_UNSUPPORTED with
  * nothing launched.  row_amax[b] bounds max |GroupNorm(x)| of image b from above (egr_gn_operand_bound: from the coefficients and
- * the row maxima of x, no pass over x); the scale derived from it only has to place the row's maximum inside [1, 2^15). */
+ * the row maxima of x, no pass over x); the scale derived from it only has to place the row's maximum inside [1, 2^15).
+ * gn_part (optional, [B * H * W / 32][Cout / 4] float2): (sum, sum of squares) of y per 32-pixel row segment and channel quad, for
+ * egr_groupnorm_stats_from_partials(part, B, H * W / 32, Cout, G). */
 int egr_conv_h2_gn(const float* x, const float* gn_scale, const float* gn_shift, int gn_silu, const void* w2, const float* bias,
                    const float* res, float* y, int B, int H, int W, int Cin, int Cout, int act, float w_scale, const float* row_amax,
-                   float* out_amax, void* stream);
+                   float* out_amax, void* gn_part, void* stream);
 int egr_gn_operand_bound(const float* scale, const float* shift, int B, int C, const float* x_row_amax, float* bound, void* stream);
 int egr_conv_s3(const float* x, const void* w3, const float* bias, const float* bias_b, const float* res, float* y, int B,
                 int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int dil, int pad_t, int pad_l,

@@ -14,6 +14,8 @@ Tolerances (floating point; stated per north_star "within 1e-3 LSD"):
     into a +-1 LSB flip wherever x*32767 lands within ~0.01 of a rounding boundary (~2% of samples for ANY
     two float32 pipelines): require |diff| <= 1 LSB everywhere and <= 5% of samples differing.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -342,8 +344,10 @@ def test_c3_full_length_800_iterations_against_the_oracle(pack):
     plain LSD (all bins, including those float32 cannot resolve: 0.8e-3 dB for the float32 ORACLE at this length) is printed and
     held to 3x the oracle's, like the rms error.  The float32 oracle runs on the host for N = 2 880 000 (~3 minutes);
     the float64 yardstick is the same loop through torch.fft in double precision on the GPU (checked here against the oracle's own
-    float64 run at a small size); for N + 2 -- where the host transform (N = 2 x a prime) would take half an hour -- the device is
-    held to the float32 oracle's error at the neighbouring length N (same data, same statistics)."""
+    float64 run at a small size).  For N + 2 the host transform is Bluestein's (N = 2 x a prime): 248 s for the float32 run, and
+    ELEVEN times noisier than at N (max 2.70 = 1.6e-4 of the peak, rms 0.543, plain LSD 1.2e-2 dB against 0.43 / 0.049 / 0.8e-3):
+    those numbers were measured once on the GPU box's host by tools/probe_c3_plus2_oracle.py (same data, same seed) and are the
+    reference errors the device's chirp-z path is held to at that length; EGR_TEST_SLOW_ORACLE=1 recomputes them here."""
     from egregora_amd import fatllama_engine as fe
     try:
         small = synth(1, 48000, seed=5)
@@ -354,6 +358,7 @@ def test_c3_full_length_800_iterations_against_the_oracle(pack):
     assert float(np.max(np.abs(pin - want_small))) <= 1e-9 * float(np.max(np.abs(want_small))), "the GPU float64 loop IS the oracle's float64 loop"
     rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
     seg = slice(0, 960000)                         # the reference's metric on the first 20 s (every frame sees the same loop)
+    ORACLE32_AT_N_PLUS_2 = (2.7021, 0.54261, 1.214e-2)       # max, rms, plain LSD (dB) vs float64: tools/probe_c3_plus2_oracle.py
     ref_err = None
     for n in (2880000, 2880002):
         info = fe.plan_info(n, 1)
@@ -363,14 +368,17 @@ def test_c3_full_length_800_iterations_against_the_oracle(pack):
         exact = f64_loop_on_gpu(x, 800, 0.6)
         scale = float(np.max(np.abs(exact)))
         mg, rg = float(np.max(np.abs(got - exact))), rms(got - exact)
-        if n == 2880000:
+        slow = bool(int(os.environ.get("EGR_TEST_SLOW_ORACLE", "0")))
+        if n != 2880000 and not slow:
+            ref_err, lo_plain, want = ORACLE32_AT_N_PLUS_2[:2], ORACLE32_AT_N_PLUS_2[2], None
+        else:
             want = ofl.enhance_channels(x, 1, 800, 0.6, normalize=False, autoscale=False)
             ref_err = (float(np.max(np.abs(want - exact))), rms(want - exact))
             lo_plain = om.lsd_audio(exact[:, seg], want[:, seg])[0]
             lo, _ = om.lsd_masked(exact[:, seg], want[:, seg], f32_run=want[:, seg], margin_db=F32_MARGIN_DB)
             print(f"\nfloat32 oracle at N = {n}, 800 iterations: max err {ref_err[0]:.3e} ({ref_err[0] / scale:.2e} of the peak {scale:.0f}), rms {ref_err[1]:.3e}, "
                   f"LSD vs float64 plain {lo_plain:.2e} dB, over the resolvable bins {lo:.2e} dB")
-        f32_run = want[:, seg] if n == 2880000 else got[:, seg]      # (N + 2: the device's own deviation sets the floor; `kept` guards it)
+        f32_run = want[:, seg] if want is not None else got[:, seg]  # (N + 2: the device's own deviation sets the floor; `kept` guards it)
         lg, kept = om.lsd_masked(exact[:, seg], got[:, seg], f32_run=f32_run, margin_db=F32_MARGIN_DB)
         lg_plain = om.lsd_audio(exact[:, seg], got[:, seg])[0]
         print(f"device at N = {n} ({'625 x 2304 plan' if n == 2880000 else 'paired chirp-z'}), 800 iterations: max err {mg:.3e} ({mg / scale:.2e} of the peak), "
@@ -379,7 +387,10 @@ def test_c3_full_length_800_iterations_against_the_oracle(pack):
         assert np.isfinite(got).all()
         assert mg <= 2.0 * ref_err[0] and mg <= 5e-4 * scale, (n, mg, ref_err, scale)
         assert rg <= 2.5 * ref_err[1] + 1e-9 * scale, (n, rg, ref_err)
-        assert lg <= 1e-3 and kept >= 0.3 and lg_plain <= 3.0 * lo_plain, (n, lg, kept, lg_plain, lo_plain)
+        # (at N + 2 the Bluestein round-off floor of ANY float32 run leaves only ~2 % of the bins 80 dB above it -- the float32 oracle's
+        # plain LSD is 1.2e-2 dB there; the device's chirp-z path must be no worse than the oracle and meet 1e-3 dB on what is resolvable)
+        assert lg <= 1e-3 and kept >= (0.3 if n == 2880000 else 0.01), (n, lg, kept)
+        assert lg_plain <= (3.0 if n == 2880000 else 1.0) * lo_plain, (n, lg_plain, lo_plain)
 
 
 VARIANTS = [  # (variant list for the device, FatLlamaSpec overrides, threshold, data scale)

@@ -261,3 +261,29 @@ def test_hook_variants_on_other_row_lengths(pack, rows, variant, thr):
     assert float(np.sum(np.square(a - b, dtype=np.float64))) <= 1e-6 * float(np.sum(np.square(b, dtype=np.float64)))
     y = x.copy(); y[:, -1] = 0
     assert rms(a - 2 * y) > 1e-4 * rms(y)
+
+
+def test_120s_plan_625x4608_on_the_generic_row_kernel_and_the_filters(pack):
+    """N = 5 760 000 (120 s at 48 kHz) plans as 625 x 4608 -- a row longer than the generic kernels' 4096-point limit, admitted by
+    the planner for k_row_wl<32, 12> (csrc/egr_plan.cpp).  The same plan also serves EGR_FL_WL=0 and the single-pass users of the
+    plan (egr_band_filter / egr_spectral_gain through k_row<false> with 147 KB of LDS): those paths must work at that row length
+    too.  Loop: two-barrier kernels vs stage-by-stage kernels vs the oracle; band filter: Parseval against numpy's rfft."""
+    from egregora_amd import device_ops as ops, fatllama_engine as fe
+    n = 5760000
+    info = fe.plan_info(n, 1)
+    assert (info["M1"], info["M2"]) == (625, 4608), info
+    x = synth(1, n, seed=120)
+    a = run(x, 2, wl=True)
+    b = run(x, 2, wl=False)
+    want = ofl.enhance_channels(x, 1, 2, 0.6, normalize=False, autoscale=False)
+    scale = float(np.max(np.abs(want)))
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    assert float(np.max(np.abs(a - want))) <= 2e-5 * scale and float(np.max(np.abs(b - want))) <= 2e-5 * scale
+    assert float(np.max(np.abs(a - b))) <= 4e-6 * scale
+    # the high-band energy ratio of the null-test node on the same plan (forward passes + gain hook + inverse passes)
+    xt = torch.from_numpy((x / 32768.0).astype(np.float32)).cuda()
+    got = ops.band_energy_hi_db(xt, 48000, 8000.0)
+    X = np.abs(np.fft.rfft(x[0].astype(np.float64) / 32768.0)) ** 2
+    f = np.fft.rfftfreq(n, 1.0 / 48000)
+    ref = 10.0 * np.log10(X[f >= 8000.0].sum() / (X.sum() + 1e-20) + 1e-20)
+    assert abs(got - ref) <= 1e-3, (got, ref)

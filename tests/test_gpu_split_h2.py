@@ -505,7 +505,12 @@ def test_input_stationary_3x3_with_fused_groupnorm_vs_float64(eng):
         ratio = bound[::RA].cpu() / true_max
         assert bool((ratio >= 1.0).all()) and bool((ratio < 64.0).all()), ratio          # a bound, and within 6 bits here
         y = torch.empty(B, H, W, Co, device="cuda")
-        native.check(L.egr_conv_h2_gn(p(x), p(sc), p(sh), silu, p(w2), p(b), p(r), p(y), B, H, W, Ci, Co, 0, ws, p(bound), p(oa), e._st()), "conv_h2_gn")
+        part = torch.zeros(B * H * W // 32, Co // 4, 2, device="cuda")
+        native.check(L.egr_conv_h2_gn(p(x), p(sc), p(sh), silu, p(w2), p(b), p(r), p(y), B, H, W, Ci, Co, 0, ws, p(bound), p(oa), p(part), e._st()), "conv_h2_gn")
+        # the GroupNorm partials: (sum, sum of squares) per 32-pixel row segment and channel quad
+        yq = y.double().view(B * H * W // 32, 32, Co // 4, 4)
+        assert float((part[..., 0].double() - yq.sum(dim=(1, 3))).abs().max()) <= 1e-4 * float(yq.abs().sum(dim=(1, 3)).max())
+        assert float((part[..., 1].double() - (yq * yq).sum(dim=(1, 3))).abs().max()) <= 1e-4 * float((yq * yq).sum(dim=(1, 3)).max())
         y1 = torch.empty_like(y)
         xn32 = xn.float().cuda().contiguous()
         native.check(L.egr_conv_nhwc(p(xn32), p(wp), p(b), p(None), p(r), p(y1), B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, 1, 0, 0, 0.0, e._st()), "conv")
@@ -518,5 +523,5 @@ def test_input_stationary_3x3_with_fused_groupnorm_vs_float64(eng):
     # too few tiles / W % 32 != 0: refused, nothing launched
     x = torch.randn(1, 8, 48, 32, generator=g).cuda()
     y = torch.empty(1, 8, 48, 128, device="cuda")
-    rc = L.egr_conv_h2_gn(p(x), p(sc), p(sh), 1, p(w2), p(None), p(None), p(y), 1, 8, 48, 32, 128, 0, ws, p(bound), p(None), e._st())
+    rc = L.egr_conv_h2_gn(p(x), p(sc), p(sh), 1, p(w2), p(None), p(None), p(y), 1, 8, 48, 32, 128, 0, ws, p(bound), p(None), p(None), e._st())
     assert rc == 3 and "qualify" in native.last_error()

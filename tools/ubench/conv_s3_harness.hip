@@ -1,7 +1,10 @@
-// Dev harness: times k_conv_s3 standalone (no torch), optionally with ablation macros (-DS3_ABL_NOGLOBAL etc.) to see what
-// bounds the kernel.  Build (from the repo root):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I comfyui-egregora-audio-super-resolution_amd/csrc [-DS3_ABL_...] \
+// Dev harness: times k_conv_s3 standalone (no torch).  Build (from the repo root):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I comfyui-egregora-audio-super-resolution_amd/csrc \
 //         tools/ubench/conv_s3_harness.hip -o tools/ubench/conv_s3_<tag>
+// The round-3 ablation study (global loads / operand split / LDS stores / barrier / epilogue switched off one at a time through
+// -DS3_ABL_* branches INSIDE the kernel; results in profiles/r03/conv_s3_ablation.log) lived in the product translation unit; the
+// branches were removed from it in round 4 (git show 4c5e402:comfyui-egregora-audio-super-resolution_amd/csrc/egr_nn_gemm_s3.hip
+// has them).  run_conv_s3_ablation.sh / run_conv_s3_quick.sh therefore time the shipped kernel only.
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -26,7 +29,15 @@ int main(int argc, char** argv) {
     p.x = x; p.w3 = (const uint4*)w3; p.y = y; p.B = B; p.H = H; p.W = W; p.Cin = Ci; p.OH = H; p.OW = W; p.Cout = Co; p.KH = k; p.KW = k;
     p.stride = 1; p.dil = 1; p.pad_t = k / 2; p.pad_l = k / 2; p.M = (int)M; p.K = (int)K; p.osy = p.osx = 1; p.OHF = H; p.OWF = W;
     p.ksplit = 1; p.kt_per = (int)ns; p.zeros = zeros;
-    p.sch = sch; p.a_scale = sch ? 4096.f : 1.f; p.out_scale = sch ? 1.f / (4096.f * 8192.f) : 1.f; p.amax = nullptr;
+    // scheme 1: per-batch-row operand maxima on the device (here: 4.0 for every row, one float per 128-byte line)
+    unsigned* ra = nullptr;
+    hipMalloc((void**)&ra, (size_t)B * EGR_ROW_AMAX_STRIDE * 4);
+    {
+        std::vector<float> h((size_t)B * EGR_ROW_AMAX_STRIDE, 4.0f);
+        hipMemcpy(ra, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    }
+    p.sch = sch; p.out_scale = sch ? 1.f / 8192.f : 1.f; p.row_amax = sch ? ra : nullptr; p.rows_div = sch ? H * W : 1;
+    p.out_amax = nullptr; p.gn_part = nullptr;
     if (getenv("S3_XCD")) p.xcd_remap = 1;
     const int bn = getenv("S3_BN") ? atoi(getenv("S3_BN")) : (Co > 64 ? 128 : (Co > 32 ? 64 : 32));
     const int bm = getenv("S3_BM") ? atoi(getenv("S3_BM")) : egr::s3_bm(M, Co, bn);
