@@ -266,12 +266,82 @@ __device__ __forceinline__ void conv_epilogue_t_rows(const ConvP& p, f32x16 (&ac
     }
 }
 
+// The common case without a single data-dependent branch: whole tile inside the problem, identity placement, no per-row bias, no
+// activation, Cout % 4 == 0 -- the Winograd GEMMs, the phase convolutions and most 1x1 layers.  (The general routine below tests
+// bounds, bias, residual and the activation kind per stored quad: ~10 instructions, a branch and a wait each, 128 times per thread;
+// measured 17 % of the K = 1024 GEMM.)  BIAS / RES are compile-time; the residual quads of a sub-tile row are requested together.
+template <int TM, int TN, bool BIAS, bool RES, bool PART>
+__device__ __forceinline__ void conv_epilogue_t_fast(const ConvP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0,
+                                                     const float* os_tab, unsigned* om_tab, int sub_stride, float2* part) {
+    const int lane = threadIdx.x & 63, px = lane & 31, ch4 = 4 * (lane >> 5);
+    const float osw = p.out_scale;
+    const int nb = n0 + wn0 + ch4;
+    float4 bv[TN][4];
+    if (BIAS) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bv[j][g] = *(const float4*)(p.bias + nb + j * 32 + 8 * g);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + ((wm0 >> 5) + i) * sub_stride + px;
+        const float os = os_tab[wm0 + i * 32 + px] * osw;         // (two exact powers of two: their product is exact unless it leaves fp32's range)
+        float* row = p.y + (size_t)m * p.Cout + nb;
+        float4 rv[TN][4];
+        if (RES) {
+            const float* rr = p.res + (size_t)m * p.Cout + nb;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rv[j][g] = *(const float4*)(rr + j * 32 + 8 * g);
+        }
+        float vm = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v = make_float4(acc[i][j][4 * g] * os, acc[i][j][4 * g + 1] * os, acc[i][j][4 * g + 2] * os, acc[i][j][4 * g + 3] * os);
+                if (BIAS) { v.x += bv[j][g].x; v.y += bv[j][g].y; v.z += bv[j][g].z; v.w += bv[j][g].w; }
+                if (RES) { v.x += rv[j][g].x; v.y += rv[j][g].y; v.z += rv[j][g].z; v.w += rv[j][g].w; }
+                *(float4*)(row + j * 32 + 8 * g) = v;
+                vm = fmaxf(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))), vm);
+                if (PART) {                      // GroupNorm partials: (sum, sum of squares) of the quad over the sub-tile's 32 pixels
+                    float ps = (v.x + v.y) + (v.z + v.w), pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+                    for (int o = 16; o >= 1; o >>= 1) { ps += __shfl_xor(ps, o); pq += __shfl_xor(pq, o); }
+                    if (px == 0) part[((size_t)(m / 32)) * (p.Cout >> 2) + ((nb + j * 32 + 8 * g) >> 2)] = make_float2(ps, pq);
+                }
+            }
+        if (om_tab) atomicMax(&om_tab[m / p.rows_div - m0 / p.rows_div], __float_as_uint(vm));
+    }
+}
+
 // om_tab (optional, LDS, zeroed, one word per batch row the block tile touches): raised to max |y| per batch row
 // sub_stride: GEMM-row distance between the tile's 32-row sub-tiles (32 = a contiguous tile)
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue_t(const ConvP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0,
                                                 const float* os_tab, unsigned* om_tab = nullptr, int sub_stride = 32, float2* part = nullptr) {
     const bool vec = (p.Cout & 3) == 0;
+    {
+        // (m0 + wm0 + ... : the last row this wave touches; sub-tiles of one wave are consecutive)
+        const int m_last = m0 + ((wm0 >> 5) + TM - 1) * sub_stride + 31;
+        const bool fast = vec && p.ksplit <= 1 && !p.bias_b && p.act == ACT_NONE && p.osy == 1 && p.osx == 1 && p.OHF == p.OH &&
+                          p.OWF == p.OW && m_last < p.M && n0 + wn0 + TN * 32 <= p.Cout;
+        if (fast && part) {                           // (the input-stationary 3x3 kernel: bias always, residual on the second conv of a block)
+            if (p.bias && p.res) { conv_epilogue_t_fast<TM, TN, true, true, true>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab, sub_stride, part); return; }
+            if (p.bias && !p.res) { conv_epilogue_t_fast<TM, TN, true, false, true>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab, sub_stride, part); return; }
+        } else if (fast) {                            // wave-uniform
+            if (p.bias) {
+                if (p.res) conv_epilogue_t_fast<TM, TN, true, true, false>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab, sub_stride, nullptr);
+                else conv_epilogue_t_fast<TM, TN, true, false, false>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab, sub_stride, nullptr);
+            } else {
+                if (p.res) conv_epilogue_t_fast<TM, TN, false, true, false>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab, sub_stride, nullptr);
+                else conv_epilogue_t_fast<TM, TN, false, false, false>(p, acc, m0, n0, wm0, wn0, os_tab, om_tab, sub_stride, nullptr);
+            }
+            return;
+        }
+    }
     if (p.ksplit > 1) {        // raw partial sums; bias / residual / activation are applied by k_splitk_reduce
         store_tile_plain_t<TM, TN>(acc, p.ws + (size_t)blockIdx.z * p.M * p.Cout, p.M, p.Cout, m0, n0, wm0, wn0, os_tab, p.out_scale);
         return;
