@@ -276,13 +276,6 @@ __device__ __forceinline__ void conv_epilogue_t_fast(const ConvP& p, f32x16 (&ac
     const int lane = threadIdx.x & 63, px = lane & 31, ch4 = 4 * (lane >> 5);
     const float osw = p.out_scale;
     const int nb = n0 + wn0 + ch4;
-    float4 bv[TN][4];
-    if (BIAS) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bv[j][g] = *(const float4*)(p.bias + nb + j * 32 + 8 * g);
-    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + ((wm0 >> 5) + i) * sub_stride + px;
@@ -302,7 +295,7 @@ __device__ __forceinline__ void conv_epilogue_t_fast(const ConvP& p, f32x16 (&ac
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 v = make_float4(acc[i][j][4 * g] * os, acc[i][j][4 * g + 1] * os, acc[i][j][4 * g + 2] * os, acc[i][j][4 * g + 3] * os);
-                if (BIAS) { v.x += bv[j][g].x; v.y += bv[j][g].y; v.z += bv[j][g].z; v.w += bv[j][g].w; }
+                if (BIAS) { const float4 t = *(const float4*)(p.bias + nb + j * 32 + 8 * g); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }   // (L1 hits; 64 registers if held)
                 if (RES) { v.x += rv[j][g].x; v.y += rv[j][g].y; v.z += rv[j][g].z; v.w += rv[j][g].w; }
                 *(float4*)(row + j * 32 + 8 * g) = v;
                 vm = fmaxf(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))), vm);

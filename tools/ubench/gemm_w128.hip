@@ -186,6 +186,167 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     }
 }
 
+// ---- the shipped design as a pure GEMM (k_conv_s3<128, 256, 1, false, 1>'s slab2 loop: 64 x 128 wave tiles, two workgroups per CU), for
+// quick experiments on its loop.  V2W: 0 = as shipped (two LDS buffers, A operands read after the barrier); 1 = ring of THREE LDS
+// buffers, the A operands and the first B operands of slab s + 1 are read during slab s (their buffer was published by the barrier
+// that ended slab s - 1), A requested one slab ahead instead of two to pay for the registers.
+#ifndef V2W
+#define V2W 0
+#endif
+__global__ __launch_bounds__(256, 2) void k_gemm_2wg(const float* __restrict__ A, const uint4* __restrict__ W2, float* __restrict__ C, int M, int N, int K,
+                                                      const unsigned* __restrict__ row_amax, int rows_div, float out_scale) {
+    constexpr int NB = V2W ? 3 : 2;
+    __shared__ uint4 As[NB][2][128 * 2];
+    __shared__ uint4 Bs[NB][2][256 * 2];
+    __shared__ float os_tab[128];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 128;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 256;
+    const int ar = tid >> 1, ah = tid & 1;
+    const float s0 = row_scale(row_amax[(size_t)((m0 + ar) / rows_div) * EGR_ROW_AMAX_STRIDE]);
+    if (tid < 128) os_tab[tid] = row_inv(row_amax[(size_t)((m0 + tid) / rows_div) * EGR_ROW_AMAX_STRIDE]);
+    const float* ap0 = A + (size_t)(m0 + ar) * K + ah * 8;
+    const int a_slot = ar * 2 + (ah ^ ((ar >> 3) & 1));
+    const uint4* bp0; const uint4* bp1; const uint4* bp2; const uint4* bp3;
+    int bs0, bs1, bs2, bs3;
+#define BSET(I, PTR, SLOT) { const int e = tid + 256 * (I), plane = e >> 9, rem = e & 511, nl = rem >> 1, half = rem & 1; \
+        PTR = W2 + ((size_t)plane * N + n0 + nl) * 2 + half; SLOT = plane * 512 + nl * 2 + (half ^ ((nl >> 3) & 1)); }
+    BSET(0, bp0, bs0) BSET(1, bp1, bs1) BSET(2, bp2, bs2) BSET(3, bp3, bs3)
+#undef BSET
+    const unsigned bstep = (unsigned)N * 4;
+    const int li = lane & 31, lk = lane >> 5;
+    const int o_slot = li * 2 + (lk ^ ((li >> 3) & 1));
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    struct SA { float4 a0, a1; };
+    struct SB { uint4 b0, b1, b2, b3; };
+    const int ns = K / 16;
+    // (running pointers, as the shipped kernel: the slab index `s` of a request is implied by the call order)
+    auto a_issue = [&](SA& r, int) { r.a0 = *(const float4*)ap0; r.a1 = *(const float4*)(ap0 + 4); ap0 += 16; };
+    auto b_issue = [&](SB& r, int) { r.b0 = *bp0; r.b1 = *bp1; r.b2 = *bp2; r.b3 = *bp3; bp0 += bstep; bp1 += bstep; bp2 += bstep; bp3 += bstep; };
+    auto storeA = [&](const SA& r, int buf) { uint4 q0, q1; split2h_x8(r.a0, r.a1, s0, q0, q1); As[buf][0][a_slot] = q0; As[buf][1][a_slot] = q1; };
+    auto storeB = [&](const SB& r, int buf) { Bs[buf][0][bs0] = r.b0; Bs[buf][0][bs1] = r.b1; Bs[buf][0][bs2] = r.b2; Bs[buf][0][bs3] = r.b3; };
+    typedef std::integral_constant<bool, true> FullT;
+    typedef std::integral_constant<bool, false> TailT;
+#if V2W == 0
+    SA sa0, sa1;
+    SB sb;
+    auto slab2 = [&](int t, int cur, SA& ra, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        uint4 a[2][2], b[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) a[i][q] = As[cur][q][(wm0 + i * 32) * 2 + o_slot];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) b[0][q] = Bs[cur][q][wn0 * 2 + o_slot];
+        if (FULL || t + 1 < ns) storeB(sb, cur ^ 1);
+        if (FULL || t + 2 < ns) b_issue(sb, t + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (FULL || t + 1 < ns) storeA(ra, cur ^ 1);
+        if (FULL || t + 3 < ns) a_issue(ra, t + 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j + 1 < 4) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) b[(j + 1) & 1][q] = Bs[cur][q][(wn0 + (j + 1) * 32) * 2 + o_slot];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(b[j & 1][0]), as_hf(a[i][1]), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(b[j & 1][1]), as_hf(a[i][0]), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(b[j & 1][0]), as_hf(a[i][0]), acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    };
+    a_issue(sa0, 0); b_issue(sb, 0);
+    storeA(sa0, 0); storeB(sb, 0);
+    __syncthreads();
+    sa1 = sa0;
+    if (1 < ns) { b_issue(sb, 1); __builtin_amdgcn_sched_barrier(0); a_issue(sa1, 1); }
+    __builtin_amdgcn_sched_barrier(0);
+    if (2 < ns) a_issue(sa0, 2);
+    int t = 0;
+    for (; t + 4 < ns; t += 2) { slab2(t, 0, sa1, FullT()); slab2(t + 1, 1, sa0, FullT()); }
+    for (; t < ns; t += 2) { slab2(t, 0, sa1, TailT()); if (t + 1 < ns) slab2(t + 1, 1, sa0, TailT()); }
+#else
+    SA sa;
+    SB sb;
+    uint4 a0[2][2], a1[2][2], bq[2][2];
+    a_issue(sa, 0); b_issue(sb, 0);
+    storeA(sa, 0); storeB(sb, 0);
+    if (1 < ns) { a_issue(sa, 1); b_issue(sb, 1); storeA(sa, 1); storeB(sb, 1); }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a0[i][q] = As[0][q][(wm0 + i * 32) * 2 + o_slot];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) bq[0][q] = Bs[0][q][wn0 * 2 + o_slot];
+    if (2 < ns) { b_issue(sb, 2); a_issue(sa, 2); }
+    auto step = [&](int s, int c0, int c1, int c2, uint4 (&ac)[2][2], uint4 (&an)[2][2], auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        if (FULL || s + 2 < ns) storeB(sb, c2);
+        if (FULL || s + 3 < ns) b_issue(sb, s + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (FULL || s + 2 < ns) storeA(sa, c2);
+        if (FULL || s + 3 < ns) a_issue(sa, s + 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j + 1 < 4) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) bq[(j + 1) & 1][q] = Bs[c0][q][(wn0 + (j + 1) * 32) * 2 + o_slot];
+            } else if (FULL || s + 1 < ns) {     // last column block: the A operands and the first B operands of slab s + 1
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) an[i][q] = As[c1][q][(wm0 + i * 32) * 2 + o_slot];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) bq[0][q] = Bs[c1][q][wn0 * 2 + o_slot];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(bq[j & 1][0]), as_hf(ac[i][1]), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(bq[j & 1][1]), as_hf(ac[i][0]), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(bq[j & 1][0]), as_hf(ac[i][0]), acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    };
+    int s = 0;
+    for (; s + 9 < ns; s += 6) {
+        step(s, 0, 1, 2, a0, a1, FullT());
+        step(s + 1, 1, 2, 0, a1, a0, FullT());
+        step(s + 2, 2, 0, 1, a0, a1, FullT());
+        step(s + 3, 0, 1, 2, a1, a0, FullT());
+        step(s + 4, 1, 2, 0, a0, a1, FullT());
+        step(s + 5, 2, 0, 1, a1, a0, FullT());
+    }
+    for (; s < ns; s += 2) {
+        step(s, s % 3, (s + 1) % 3, (s + 2) % 3, a0, a1, TailT());
+        if (s + 1 < ns) step(s + 1, (s + 1) % 3, (s + 2) % 3, s % 3, a1, a0, TailT());
+    }
+#endif
+    const int px = lane & 31, ch4 = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm0 + i * 32 + px;
+        const float os = os_tab[wm0 + i * 32 + px] * out_scale;
+        float* row = C + (size_t)m * N + n0 + wn0 + ch4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(float4*)(row + j * 32 + 8 * g) = make_float4(acc[i][j][4 * g] * os, acc[i][j][4 * g + 1] * os, acc[i][j][4 * g + 2] * os, acc[i][j][4 * g + 3] * os);
+    }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 int main(int argc, char** argv) {
@@ -213,13 +374,17 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto ref = [&]() { if (egr_conv_h2(dA, dW2, nullptr, nullptr, nullptr, dC1, M, 1, 1, K, 1, 1, N, 1, 1, 1, 1, 0, 0, 0, 0, 0.f, 1, 1, 0, 0, 1, 1, 1, 0, 0, 0, ws, dRA, rows, nullptr, nullptr)) { printf("conv_h2: %s\n", egr_last_error()); exit(1); } };
-    auto neu = [&]() { hipLaunchKernelGGL(k_gemm_w128, dim3(M / 256, N / 256), dim3(256), 0, 0, dA, (const uint4*)dW2, dC2, M, N, K, (const unsigned*)dRA, rows_div, 1.0f / ws); };
+    const bool two = getenv("KERN") && atoi(getenv("KERN")) == 2;
+    auto neu = [&]() {
+        if (two) hipLaunchKernelGGL(k_gemm_2wg, dim3(M / 128, N / 256), dim3(256), 0, 0, dA, (const uint4*)dW2, dC2, M, N, K, (const unsigned*)dRA, rows_div, 1.0f / ws);
+        else hipLaunchKernelGGL(k_gemm_w128, dim3(M / 256, N / 256), dim3(256), 0, 0, dA, (const uint4*)dW2, dC2, M, N, K, (const unsigned*)dRA, rows_div, 1.0f / ws);
+    };
     ref(); neu(); CK(hipDeviceSynchronize());
     float t1, t2;
     hipEventRecord(e0); for (int i = 0; i < reps; ++i) ref(); hipEventRecord(e1); CK(hipDeviceSynchronize()); hipEventElapsedTime(&t1, e0, e1);
     hipEventRecord(e0); for (int i = 0; i < reps; ++i) neu(); hipEventRecord(e1); CK(hipDeviceSynchronize()); hipEventElapsedTime(&t2, e0, e1);
     const double fl = 2.0 * M * N * K;
-    printf("shipped k_conv_s3: %.3f ms  %.1f TF/s-eq   |   k_gemm_w128: %.3f ms  %.1f TF/s-eq   (x%.2f)\n", t1 / reps, fl / (t1 / reps * 1e-3) / 1e12, t2 / reps,
+    printf("shipped k_conv_s3: %.3f ms  %.1f TF/s-eq   |   experiment: %.3f ms  %.1f TF/s-eq   (x%.2f)\n", t1 / reps, fl / (t1 / reps * 1e-3) / 1e12, t2 / reps,
            fl / (t2 / reps * 1e-3) / 1e12, t1 / t2);
     std::vector<float> c1((size_t)M * N), c2((size_t)M * N);
     CK(hipMemcpy(c1.data(), dC1, c1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(c2.data(), dC2, c2.size() * 4, hipMemcpyDeviceToHost));
