@@ -179,6 +179,8 @@ struct FsrCtx {
     // whole when a forward starts
     unsigned* rs_pool = nullptr;
     size_t rs_cap = 0, rs_used = 0;
+    unsigned* rs_ones = nullptr;                      // "maximum 1.0" for every row (operands known to lie in [0, 1]: soft-max outputs); rs_ones_rows entries
+    int rs_ones_rows = 0;
 };
 
 struct egr_flashsr {
@@ -870,7 +872,16 @@ int attention(M* m, Ten& o, const Ten& q, const Ten& k, const Ten& v, int B, int
     const float scale = 1.0f / sqrtf((float)d);
     const float sc = (float)pow((double)d, -0.5);
     (void)scale;
-    if (s3)
+    // fp16 operand scheme: both products on two fp16 terms, every operand scaled per batch row from its own maximum (q / k / v carry
+    // theirs from the epilogues of their projections; the soft-max output lies in [0, 1]: a constant)
+    const bool h2 = s3 && m->h2 && m->h2_mode == 1 && B == m->R;
+    if (h2) {
+        OKR(row_amax_of(m, q.p, q.numel(), 1, 0, &q.rs));
+        OKR(row_amax_of(m, k.p, k.numel(), 1, 0, &k.rs));
+        OKR(row_amax_of(m, v.p, v.numel(), 1, 0, &v.rs));
+        OKR(egr_bgemm_nt_h2(q.p, k.p, S.p, B, heads, T, T, d, Cc, Cc, T, (int64_t)T * Cc, d, (int64_t)T * Cc, d, (int64_t)heads * T * T,
+                            (int64_t)T * T, sc, (const float*)q.rs, (const float*)k.rs, nullptr, m->st));
+    } else if (s3)
         OKR(egr_bgemm_nt_s3(q.p, k.p, S.p, B, heads, T, T, d, Cc, Cc, T, (int64_t)T * Cc, d, (int64_t)T * Cc, d, (int64_t)heads * T * T,
                             (int64_t)T * T, sc, m->st));
     else
@@ -882,6 +893,12 @@ int attention(M* m, Ten& o, const Ten& q, const Ten& k, const Ten& v, int B, int
         Ten vt;
         OKR(new_ten(m, vt, {B, Cc, T}));
         OKR(egr_transpose_batched(v.p, vt.p, B, T, Cc, m->st));
+        if (h2) {
+            float* o_ra = nullptr;                 // o feeds the output projection: its row maxima ride along
+            OKR(rs_for_output(m, o, &o_ra));
+            OKR(egr_bgemm_nt_h2(S.p, vt.p, o.p, B, heads, T, d, T, T, T, Cc, (int64_t)heads * T * T, (int64_t)T * T, (int64_t)Cc * T, (int64_t)d * T,
+                                (int64_t)T * Cc, d, 1.0f, (const float*)m->cx->rs_ones, (const float*)v.rs, o_ra, m->st));
+        } else
         OKR(egr_bgemm_nt_s3(S.p, vt.p, o.p, B, heads, T, d, T, T, T, Cc, (int64_t)heads * T * T, (int64_t)T * T, (int64_t)Cc * T, (int64_t)d * T,
                             (int64_t)T * Cc, d, 1.0f, m->st));
     } else {
@@ -987,8 +1004,11 @@ int vae_attn(M* m, Ten& y, const Ten& x, const std::string& name) {
     const int B = (int)x.d[0], H = (int)x.d[1], W = (int)x.d[2], Cc = (int)x.d[3];
     Ten h, q, k, v, o;
     OKR(groupnorm(m, h, x, name + ".norm", 1e-6f, false));
+    m->next_out_ra = true;
     OKR(conv1x1(m, q, h, name + ".q"));
+    m->next_out_ra = true;
     OKR(conv1x1(m, k, h, name + ".k"));
+    m->next_out_ra = true;
     OKR(conv1x1(m, v, h, name + ".v"));
     OKR(attention(m, o, q, k, v, B, H * W, Cc, 1));
     o.view({B, H, W, Cc});
@@ -1068,8 +1088,11 @@ int unet_block(M* m, Ten& y, const Ten& x, const std::string& base, bool has_att
         const std::string an = base + ".st.attn" + std::to_string(a);
         Ten n_, q, k, v, o, t2;
         OKR(layernorm(m, n_, t, an + "_ln"));
+        m->next_out_ra = true;                         // q, k, v feed the attention products: their row maxima ride along
         OKR(linear(m, q, n_, an + ".to_q", nullptr, ACT_NONE, false));
+        m->next_out_ra = true;
         OKR(linear(m, k, n_, an + ".to_k", nullptr, ACT_NONE, false));
+        m->next_out_ra = true;
         OKR(linear(m, v, n_, an + ".to_v", nullptr, ACT_NONE, false));
         OKR(attention(m, o, q, k, v, B, T, Cc, heads));
         OKR(linear(m, t2, o, an + ".to_out", t.p));
@@ -1240,6 +1263,14 @@ int forward(M* m, const float* x_in, const float* noise, int R, int lowpass_on, 
         }
         EGR_HIP(hipMemsetAsync(cx->rs_pool, 0, cx->rs_cap * sizeof(unsigned), m->st));
         cx->rs_used = 0;
+        if (cx->rs_ones_rows < R) {
+            if (cx->rs_ones) { hipStreamSynchronize(m->st); hipFree(cx->rs_ones); cx->rs_ones = nullptr; }
+            const size_t n = (size_t)R * EGR_ROW_AMAX_STRIDE;
+            if (hipMalloc((void**)&cx->rs_ones, n * sizeof(unsigned)) != hipSuccess) { set_error("hipMalloc(row maxima constants) failed"); return EGR_ERR_ALLOC; }
+            std::vector<unsigned> ones(n, 0x3f800000u);
+            EGR_HIP(hipMemcpy(cx->rs_ones, ones.data(), n * sizeof(unsigned), hipMemcpyHostToDevice));
+            cx->rs_ones_rows = R;
+        }
     }
     Ten xl;
     if (lowpass_on) { OKR(lowpass(m, xl, x_in, R, c.chunk)); x = xl.p; }
@@ -1335,6 +1366,7 @@ extern "C" int egr_flashsr_destroy(egr_flashsr* m) {
         for (auto& kv : c->lp_plans) egr_fatllama_plan_destroy(kv.second);
         if (c->gn_ws) hipFree(c->gn_ws);
         if (c->rs_pool) hipFree(c->rs_pool);
+        if (c->rs_ones) hipFree(c->rs_ones);
         if (c->done) hipEventDestroy(c->done);
         if (i > 0 && c->st) hipStreamDestroy(c->st);
     }
@@ -1452,6 +1484,7 @@ static int ensure_side_streams(egr_flashsr* m, hipStream_t caller, int want) {
             for (auto& kv : m->ctxs[i]->lp_plans) egr_fatllama_plan_destroy(kv.second);
             if (m->ctxs[i]->gn_ws) hipFree(m->ctxs[i]->gn_ws);
             if (m->ctxs[i]->rs_pool) hipFree(m->ctxs[i]->rs_pool);
+            if (m->ctxs[i]->rs_ones) hipFree(m->ctxs[i]->rs_ones);
             if (m->ctxs[i]->done) hipEventDestroy(m->ctxs[i]->done);
             hipStreamDestroy(m->ctxs[i]->st);
             m->ctxs.erase(m->ctxs.begin() + i);

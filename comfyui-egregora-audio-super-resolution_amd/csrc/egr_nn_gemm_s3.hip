@@ -1192,14 +1192,18 @@ struct GemmS3P {
     long long sa1, sa2, sb1, sb2, sc1, sc2;
     float alpha;
     const float* zeros;
+    // scheme 1 (two fp16 terms): bits of max |A| and max |B| per OUTER batch index b1 (EGR_ROW_AMAX_STRIDE apart); out_amax optional
+    const unsigned* a_amax; const unsigned* b_amax; unsigned* out_amax;
 };
 
-template <int BN>
+// SCH 0: three bf16 terms per operand, six products; SCH 1: two fp16 terms of the operands scaled per outer batch index from their
+// own maxima (as k_conv_s3's scheme 1: both operands are activations here), three products
+template <int BN, int SCH = 0>
 __global__ __launch_bounds__(256, 2) void k_bgemm_s3(GemmS3P p) {
     typedef S3Cfg<128, BN> TC;
-    constexpr int TM = TC::TM, TN = TC::TN;
-    __shared__ uint4 As[2][3][128 * 2];
-    __shared__ uint4 Bs[2][3][BN * 2];
+    constexpr int TM = TC::TM, TN = TC::TN, NP = SCH ? 2 : 3;
+    __shared__ uint4 As[2][NP][128 * 2];
+    __shared__ uint4 Bs[2][NP][BN * 2];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm0 = (wave / TC::WN) * (128 / TC::WM), wn0 = (wave % TC::WN) * (BN / TC::WN);
     const int m0 = blockIdx.x * 128, n0 = blockIdx.y * BN;
@@ -1207,6 +1211,12 @@ __global__ __launch_bounds__(256, 2) void k_bgemm_s3(GemmS3P p) {
     const float* A = p.a + b1 * p.sa1 + b2 * p.sa2;
     const float* Bm = p.b + b1 * p.sb1 + b2 * p.sb2;
     float* Cm = p.c + b1 * p.sc1 + b2 * p.sc2;
+    float sa = 1.f, sb = 1.f, alpha = p.alpha;
+    if constexpr (SCH == 1) {
+        const unsigned ba = p.a_amax[(size_t)b1 * EGR_ROW_AMAX_STRIDE], bb = p.b_amax[(size_t)b1 * EGR_ROW_AMAX_STRIDE];
+        sa = h2_row_scale(ba); sb = h2_row_scale(bb);
+        alpha = p.alpha * h2_row_inv(ba) * h2_row_inv(bb);         // (both inverses are powers of two)
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -1234,12 +1244,14 @@ __global__ __launch_bounds__(256, 2) void k_bgemm_s3(GemmS3P p) {
         aptr += astep; bptr += bstep;
     };
     auto store = [&](int buf) {
-        uint4 q0, q1, q2;
-        split3_x8(ra0, ra1, q0, q1, q2);
-        As[buf][0][slot] = q0; As[buf][1][slot] = q1; As[buf][2][slot] = q2;
+        uint4 q[3];
+        split_x8<SCH>(ra0, ra1, sa, q);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) As[buf][pl][slot] = q[pl];
         if (tid < 2 * BN) {
-            split3_x8(rb0, rb1, q0, q1, q2);
-            Bs[buf][0][slot] = q0; Bs[buf][1][slot] = q1; Bs[buf][2][slot] = q2;
+            split_x8<SCH>(rb0, rb1, sb, q);
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) Bs[buf][pl][slot] = q[pl];
         }
     };
     load();
@@ -1252,26 +1264,37 @@ __global__ __launch_bounds__(256, 2) void k_bgemm_s3(GemmS3P p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) a[i][q] = As[cur][q][(wm0 + i * 32) * 2 + o_slot];
+            for (int q = 0; q < NP; ++q) a[i][q] = As[cur][q][(wm0 + i * 32) * 2 + o_slot];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) b[j][q] = Bs[cur][q][(wn0 + j * 32) * 2 + o_slot];
+            for (int q = 0; q < NP; ++q) b[j][q] = Bs[cur][q][(wn0 + j * 32) * 2 + o_slot];
         if (kt + 1 < ktiles) store(cur ^ 1);
         if (kt + 2 < ktiles) load();
+        if constexpr (SCH == 0) {
 #define G3_MMA(QA, QB)                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =            \
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[i][QA]), as_bf(b[j][QB]), acc[i][j], 0, 0, 0);
-        G3_MMA(2, 0)
-        G3_MMA(0, 2)
-        G3_MMA(1, 1)
-        G3_MMA(1, 0)
-        G3_MMA(0, 1)
-        G3_MMA(0, 0)
+            G3_MMA(2, 0)
+            G3_MMA(0, 2)
+            G3_MMA(1, 1)
+            G3_MMA(1, 0)
+            G3_MMA(0, 1)
+            G3_MMA(0, 0)
 #undef G3_MMA
+        } else {
+#define G3_MMA(QA, QB)                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =            \
+        __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(a[i][QA]), as_hf(b[j][QB]), acc[i][j], 0, 0, 0);
+            G3_MMA(1, 0)
+            G3_MMA(0, 1)
+            G3_MMA(0, 0)
+#undef G3_MMA
+        }
         __syncthreads();
     }
     const int col = lane & 31, rhalf = lane >> 5;
+    float vm = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1281,32 +1304,62 @@ __global__ __launch_bounds__(256, 2) void k_bgemm_s3(GemmS3P p) {
                 float* row = Cm + (size_t)m * p.ldc + n0 + wn0 + col;
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    if (n0 + wn0 + j * 32 + col < p.N) row[j * 32] = p.alpha * acc[i][j][r];
+                    if (n0 + wn0 + j * 32 + col < p.N) { const float v = alpha * acc[i][j][r]; row[j * 32] = v; vm = fmaxf(vm, fabsf(v)); }
             }
         }
+    if (SCH == 1 && p.out_amax) {                // max |C| per outer batch index: one checked atomic per wave
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) vm = fmaxf(vm, __shfl_xor(vm, o));
+        unsigned* slot_o = p.out_amax + (size_t)b1 * EGR_ROW_AMAX_STRIDE;
+        const unsigned bits = __float_as_uint(vm);
+        if (lane == 0 && bits > __hip_atomic_load(slot_o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot_o, bits);
+    }
 }
 
 }  // namespace egr
 
-extern "C" int egr_bgemm_nt_s3(const float* a, const float* b, float* c, int nb1, int nb2, int M, int N, int K, int lda, int ldb,
-                               int ldc, int64_t sa1, int64_t sa2, int64_t sb1, int64_t sb2, int64_t sc1, int64_t sc2, float alpha,
-                               void* stream) {
+static int bgemm_nt_launch(const float* a, const float* b, float* c, int nb1, int nb2, int M, int N, int K, int lda, int ldb, int ldc, int64_t sa1,
+                           int64_t sa2, int64_t sb1, int64_t sb2, int64_t sc1, int64_t sc2, float alpha, const float* a_amax, const float* b_amax,
+                           float* out_amax, void* stream) {
     EGR_CHECK(a && b && c && nb1 >= 1 && nb2 >= 1 && M >= 1 && N >= 1 && K >= 16, EGR_ERR_ARG, "bad gemm argument");
     EGR_CHECK((long long)nb1 * nb2 <= 65535, EGR_ERR_ARG, "too many batches");
     EGR_CHECK(K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0 && sa1 % 4 == 0 &&
                   sa2 % 4 == 0 && sb1 % 4 == 0 && sb2 % 4 == 0, EGR_ERR_UNSUPPORTED,
-              "split-bf16 batched GEMM needs K %% 16 == 0 and 16-byte aligned rows");
+              "split batched GEMM needs K %% 16 == 0 and 16-byte aligned rows");
     const float* zeros = nullptr;
     { const int zrc = zero_page(&zeros); if (zrc) return zrc; }
     GemmS3P p;
     p.a = a; p.b = b; p.c = c; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.nb2 = nb2;
     p.sa1 = sa1; p.sa2 = sa2; p.sb1 = sb1; p.sb2 = sb2; p.sc1 = sc1; p.sc2 = sc2; p.alpha = alpha; p.zeros = zeros;
+    p.a_amax = (const unsigned*)a_amax; p.b_amax = (const unsigned*)b_amax; p.out_amax = (unsigned*)out_amax;
     const int bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
     dim3 grid((M + 127) / 128, (N + bn - 1) / bn, nb1 * nb2);
     hipStream_t st = (hipStream_t)stream;
-    if (bn == 128) hipLaunchKernelGGL((k_bgemm_s3<128>), grid, dim3(256), 0, st, p);
-    else if (bn == 64) hipLaunchKernelGGL((k_bgemm_s3<64>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_bgemm_s3<32>), grid, dim3(256), 0, st, p);
+    if (a_amax) {
+        if (bn == 128) hipLaunchKernelGGL((k_bgemm_s3<128, 1>), grid, dim3(256), 0, st, p);
+        else if (bn == 64) hipLaunchKernelGGL((k_bgemm_s3<64, 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_bgemm_s3<32, 1>), grid, dim3(256), 0, st, p);
+    } else {
+        if (bn == 128) hipLaunchKernelGGL((k_bgemm_s3<128>), grid, dim3(256), 0, st, p);
+        else if (bn == 64) hipLaunchKernelGGL((k_bgemm_s3<64>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_bgemm_s3<32>), grid, dim3(256), 0, st, p);
+    }
     EGR_HIP(hipGetLastError());
     return EGR_OK;
+}
+
+// The same product on two fp16 terms per operand (both operands are activations: each is scaled per OUTER batch index b1 -- the batch
+// row -- by the power of two derived from its own maximum, a_amax[b1] / b_amax[b1] in the row_amax layout); out_amax (optional):
+// max |C| per b1.
+extern "C" int egr_bgemm_nt_h2(const float* a, const float* b, float* c, int nb1, int nb2, int M, int N, int K, int lda, int ldb, int ldc,
+                               int64_t sa1, int64_t sa2, int64_t sb1, int64_t sb2, int64_t sc1, int64_t sc2, float alpha, const float* a_amax,
+                               const float* b_amax, float* out_amax, void* stream) {
+    EGR_CHECK(a_amax && b_amax, EGR_ERR_ARG, "null operand maxima");
+    return bgemm_nt_launch(a, b, c, nb1, nb2, M, N, K, lda, ldb, ldc, sa1, sa2, sb1, sb2, sc1, sc2, alpha, a_amax, b_amax, out_amax, stream);
+}
+
+extern "C" int egr_bgemm_nt_s3(const float* a, const float* b, float* c, int nb1, int nb2, int M, int N, int K, int lda, int ldb,
+                               int ldc, int64_t sa1, int64_t sa2, int64_t sb1, int64_t sb2, int64_t sc1, int64_t sc2, float alpha,
+                               void* stream) {
+    return bgemm_nt_launch(a, b, c, nb1, nb2, M, N, K, lda, ldb, ldc, sa1, sa2, sb1, sb2, sc1, sc2, alpha, nullptr, nullptr, nullptr, stream);
 }

@@ -85,6 +85,7 @@ SIGNATURES = {
     "egr_groupnorm_stats_from_partials": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "egr_groupnorm_coeff_from_stats": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "egr_bgemm_nt_s3": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_i64] * 6 + [_f, _vp]),
+    "egr_bgemm_nt_h2": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_i64] * 6 + [_f, _vp, _vp, _vp, _vp]),
     "egr_bgemm": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_i64] * 6 + [_i, _f, _vp]),
     "egr_groupnorm_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "egr_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),

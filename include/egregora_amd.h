@@ -341,6 +341,12 @@ int egr_winograd_output(const float* M, const float* bias, const float* res, flo
  * otherwise EGR_ERR_UNSUPPORTED (callers fall back to egr_bgemm). */
 int egr_bgemm_nt_s3(const float* a, const float* b, float* c, int nb1, int nb2, int M, int N, int K, int lda, int ldb, int ldc,
                     int64_t sa1, int64_t sa2, int64_t sb1, int64_t sb2, int64_t sc1, int64_t sc2, float alpha, void* stream);
+/* The same product on TWO fp16 terms per operand (ABI 4; both operands are activations): the operands of outer batch index b1 -- the
+ * batch row -- are scaled by powers of two derived in the kernel from a_amax[b1] / b_amax[b1] (row_amax layout: egr_absmax_rows or a
+ * producer's out_amax); out_amax (optional, zeroed by the caller): max |C| per b1. */
+int egr_bgemm_nt_h2(const float* a, const float* b, float* c, int nb1, int nb2, int M, int N, int K, int lda, int ldb, int ldc,
+                    int64_t sa1, int64_t sa2, int64_t sb1, int64_t sb2, int64_t sc1, int64_t sc2, float alpha, const float* a_amax,
+                    const float* b_amax, float* out_amax, void* stream);
 
 /* Winograd F(4x4,3x3) (4x fewer multiplies; H and W multiples of 4): same three steps with 36 components,
  *   V [36][P][C], P = B*(H/4)*(W/4) tiles, V[6i+j] = (B^T d B)[i][j] of the 6x6 input tile at (4ty-1, 4tx-1);

@@ -525,3 +525,44 @@ def test_input_stationary_3x3_with_fused_groupnorm_vs_float64(eng):
     y = torch.empty(1, 8, 48, 128, device="cuda")
     rc = L.egr_conv_h2_gn(p(x), p(sc), p(sh), 1, p(w2), p(None), p(None), p(y), 1, 8, 48, 32, 128, 0, ws, p(bound), p(None), p(None), e._st())
     assert rc == 3 and "qualify" in native.last_error()
+
+
+def test_attention_products_on_two_fp16_terms(eng):
+    """egr_bgemm_nt_h2 (both operands activations, each scaled per batch row from its own maximum) against the three-term bf16 form
+    and float64, in the two shapes attention uses: S = alpha q k^T per head out of [B][T][C] tensors, and o = P v with P in [0, 1]
+    (constant maxima) and v transposed; batch rows at different levels; out_amax."""
+    e, cfg = eng
+    L = e.L
+    from egregora_amd import native
+    g = torch.Generator().manual_seed(71)
+    B, heads, T, d = 3, 4, 160, 32
+    Cc = heads * d
+    lv = (10.0 ** -torch.arange(B).float()).view(B, 1, 1)
+    q = (torch.randn(B, T, Cc, generator=g) * lv).cuda()
+    k = (torch.randn(B, T, Cc, generator=g) * lv * 3.0).cuda()
+    S3, S2 = torch.empty(B, heads, T, T, device="cuda"), torch.empty(B, heads, T, T, device="cuda")
+    alpha = d ** -0.5
+    args = (B, heads, T, T, d, Cc, Cc, T, T * Cc, d, T * Cc, d, heads * T * T, T * T, alpha)
+    native.check(L.egr_bgemm_nt_s3(p(q), p(k), p(S3), *args, e._st()), "bgemm_s3")
+    native.check(L.egr_bgemm_nt_h2(p(q), p(k), p(S2), *args, p(row_amax(e, q, B)), p(row_amax(e, k, B)), p(None), e._st()), "bgemm_h2")
+    ref = alpha * torch.einsum("bthd,bshd->bhts", q.double().view(B, T, heads, d), k.double().view(B, T, heads, d))
+    for b in range(B):
+        r3 = float((S3[b].double() - ref[b]).norm() / ref[b].norm())
+        r2 = float((S2[b].double() - ref[b]).norm() / ref[b].norm())
+        assert r2 <= 1.25 * r3 + 1e-8, (b, r3, r2)
+    # P v: P = softmax rows in [0, 1] (constant maxima of 1), v transposed per batch row [C][T]
+    P = torch.softmax(S2.view(B * heads * T, T), dim=1).view(B, heads, T, T).contiguous()
+    v = (torch.randn(B, T, Cc, generator=g) * lv).cuda()
+    vt = v.transpose(1, 2).contiguous()                             # [B][C][T]
+    ones = torch.ones(B * RA, device="cuda")
+    o3, o2 = torch.empty(B, T, Cc, device="cuda"), torch.empty(B, T, Cc, device="cuda")
+    oa = ra_zeros(B)
+    args = (B, heads, T, d, T, T, T, Cc, heads * T * T, T * T, Cc * T, d * T, T * Cc, d, 1.0)
+    native.check(L.egr_bgemm_nt_s3(p(P), p(vt), p(o3), *args, e._st()), "bgemm_s3")
+    native.check(L.egr_bgemm_nt_h2(p(P), p(vt), p(o2), *args, p(ones), p(row_amax(e, v, B)), p(oa), e._st()), "bgemm_h2")
+    ref = torch.einsum("bhts,bshd->bthd", P.double(), v.double().view(B, T, heads, d)).reshape(B, T, Cc)
+    for b in range(B):
+        r3 = float((o3[b].double() - ref[b]).norm() / ref[b].norm())
+        r2 = float((o2[b].double() - ref[b]).norm() / ref[b].norm())
+        assert r2 <= 1.25 * r3 + 1e-8, (b, r3, r2)
+    assert torch.equal(oa[::RA], o2.abs().amax(dim=(1, 2)))
