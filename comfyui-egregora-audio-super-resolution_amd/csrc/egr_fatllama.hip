@@ -944,8 +944,9 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
                     p->wl_row_entry = &e;
                     p->wl_row = 1;
                 }
-        if (!off && !p->bluestein && a.L == 625 && a.ncols % EGR_WL_COL_TC == 0) {
-            if ((rc = table(25, 25, 625, &p->wl_ct.t3))) return fail(rc);
+        if (!off && !p->bluestein && wl_col_radix(a.L)) {
+            const int r = wl_col_radix(a.L);
+            if ((rc = table(r, r, r * r, &p->wl_ct.t3))) return fail(rc);
             p->wl_col = 1;
         }
         p->wl_inner = 0; p->wl_it = nullptr;
@@ -1237,9 +1238,7 @@ extern "C" int egr_fatllama_trace_once(egr_fatllama_plan* p, void* stream) {
                 else hipLaunchKernelGGL(k_row<false>, grow, blk, EGR_LDS(p->sp.lds_row), st, R, M, p->d_work);
             } else {
                 if (p->wl_col) {
-                    ColP Awl = A;
-                    Awl.TC = EGR_WL_COL_TC; Awl.TClog2 = 3; Awl.ntiles = A.ncols / EGR_WL_COL_TC; Awl.tiles_per_xcd = ceil_div(Awl.ntiles, 8);
-                    hipLaunchKernelGGL(k_col_wl, dim3(8 * Awl.tiles_per_xcd, C), dim3(EGR_WL_COL_THREADS), EGR_LDS(EGR_WL_COL_LDS), st, Awl, p->wl_ct, M, p->d_work);
+                    wl_launch_col(A, p->wl_ct, M, p->d_work, C, st);
                 } else if (p->col_sched == 2) hipLaunchKernelGGL((k_col<1, 2>), gA, dim3(EGR_FL_COL_THREADS), EGR_LDS(p->sp.lds_col / 2), st, A, M, N, 0.6f, p->d_work, (float*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr);
                 else hipLaunchKernelGGL(k_col<1>, gA, blk, EGR_LDS(p->sp.lds_col), st, A, M, N, 0.6f, p->d_work, (float*)nullptr, (unsigned*)nullptr);
             }
@@ -1388,8 +1387,6 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         const WlRowEntry* wle = (const WlRowEntry*)p->wl_row_entry;
         const bool wl_variant = relative || R.soft != 0;          // k_row_wl<.., 1>: level from the iteration's maximum and / or soft shrink
         const bool wlr = p->wl_row != 0 && wle, wlc = p->wl_col != 0;
-        ColP Awl = A;
-        Awl.TC = EGR_WL_COL_TC; Awl.TClog2 = 3; Awl.ntiles = A.ncols / EGR_WL_COL_TC; Awl.tiles_per_xcd = ceil_div(Awl.ntiles, 8);
         // no ping-pong buffer; the row kernel's two rows are padded by one element per 2^EGR_FL_ROW_PAD
         const size_t lrs = EGR_LDS((size_t)2 * (R.L + (EGR_FL_ROW_PAD ? R.L >> EGR_FL_ROW_PAD : 0)) * sizeof(cplx));
         const size_t lcs = EGR_LDS(p->sp.lds_col / 2);
@@ -1440,7 +1437,7 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
                 }
                 if (it + 1 < max_iter) {
                     if (prof) fl_prof_begin(p, 1, sg, &slot);
-                    if (wlc) hipLaunchKernelGGL(k_col_wl, dim3(8 * Awl.tiles_per_xcd, cn), dim3(EGR_WL_COL_THREADS), EGR_LDS(EGR_WL_COL_LDS), sg, Awl, p->wl_ct, M, wk);
+                    if (wlc) wl_launch_col(A, p->wl_ct, M, wk, cn, sg);
                     else if (cs2) hipLaunchKernelGGL((k_col<1, 2>), gAg, blkc, lcs, sg, A, M, N, thr, wk, og, pk, (const unsigned*)nullptr);
                     else hipLaunchKernelGGL(k_col<1>, gAg, blk, lc, sg, A, M, N, thr, wk, og, pk);
                     if (prof) fl_prof_end(p, sg, &slot);

@@ -21,7 +21,7 @@
 //   Barriers: after the cross-forward LDS writes, before the cross-inverse LDS reads.  LDS passes per element: 8 (was 16).
 //   A self-paired row (o = 0; o = R/2 for even R) takes its pairs from LDS with the generic loop of k_row (two more barriers).
 //
-// k_col_wl -- a tile of 8 adjacent columns of L = 625 = 25 x 25 points, one thread per (b, column):
+// k_col_wl<R, TC> -- a tile of TC adjacent columns of L = R x R points (below: 625 = 25 x 25, TC = 8; also 441 = 21 x 21, TC = 12), one thread per (b, column):
 //   i = 25 a + b, n = c + 25 d:  thread (b, col) loads its 25 elements i = 25 a + b straight from global memory (64-byte row
 //   segments per 8 lanes, the same segments the staged tile load touched), x conj W_M^(col i) (a geometric run in double: two
 //   table products per thread, one double multiply per element), inverse radix-25 over a, LDS transpose (barrier), x conj
@@ -37,39 +37,56 @@ namespace egr {
 #ifndef EGR_WL_COL_WAVES
 #define EGR_WL_COL_WAVES 1
 #endif
-#define EGR_WL_COL_THREADS 256          // 25 x 8 = 200 active
-#define EGR_WL_COL_TC 8
-#define EGR_WL_COL_LDS (625 * EGR_WL_COL_TC * 8)
-
-// The pair hook of k_row (identical arithmetic): Za = Z[k], Zb = Z[M-k], Wkd = W_N^k in double.
-// HOOK 0: hard threshold against an absolute level (|X|^2 > thr2).  HOOK 1: the SPEC.md section 3 variants -- level tlev (absolute,
-// or thr x the spectrum maximum of this iteration), hard or soft shrink.  HOOK 2: no update; returns max(|X[k]|^2, |X[M-k]|^2).
+// Geometry of k_col_wl<R, TC>: columns of R x R points (625 = 25^2: lengths with the factor 5^4 -- every multiple of 5 s at 48 kHz;
+// 441 = 21^2: lengths with the factor 3^2 7^2 -- whole seconds at 44.1 kHz), TC adjacent columns per workgroup, R TC threads on
+// four waves.  For R = 25, TC = 8 (200 of 256 lanes) is what ships.  Measured against it on one box (C3 stage,
+// profiles/r04/fatllama_c3_experiments.log): TC = 12 (300 threads on FIVE waves: two waves of one workgroup share a SIMD) +1.1 ms;
+// TC = 10 (250 of 256 lanes, ragged last tile, 80-byte row segments) +0.6 ms -- the loop is bound by the latency chain of a
+// workgroup and by how the two channel pipelines interleave, not by lane fill.  R = 21: TC = 12 (252 threads).
+template <int R, int TC> struct WlCol {
+    static constexpr int THREADS = ((R * TC + 63) / 64) * 64;
+    static constexpr int LDS = R * R * TC * 8;
+};
+static inline int wl_col_radix(int L) { return L == 625 ? 25 : (L == 441 ? 21 : 0); }      // column lengths with a k_col_wl instantiation
+// The factors 1/2 of the real split are folded away: the hook works on 2 X (exact: a power of two commutes with every rounding),
+// compares against 4 thr^2 / 2 t, and the 1/4 this leaves joins 1/M.  The scaling by 1/M is a product with a two-term float value
+// (sc_hi + sc_lo = 1/(4M) to 2^-48: one rounding per result, as the product in double it replaces) -- a float 1/M alone carries a
+// relative error of up to 6e-8 that every iteration would apply again, in the same direction.
+struct WlScale { float hi, lo; };
+__device__ __forceinline__ WlScale wl_scale(const double scd) {
+    WlScale s;
+    const double q = 0.25 * scd;
+    s.hi = (float)q;
+    s.lo = (float)(q - (double)s.hi);
+    return s;
+}
+__device__ __forceinline__ float wl_scaled(const float v, const WlScale s) { return fmaf(v, s.hi, v * s.lo); }
 template <int HOOK>
-__device__ __forceinline__ float wl_pair_hook(const cplx Za, const cplx Zb, const dcplx Wkd, const float thr2, const float tlev, const int soft,
-                                              const double scd, cplx& na, cplx& nb) {
+__device__ __forceinline__ float wl_pair_hook(const cplx Za, const cplx Zb, const dcplx Wkd, const float thr2x4, const float tlevx2, const int soft,
+                                              const WlScale sc, cplx& na, cplx& nb) {
     const cplx Wk = make_float2((float)Wkd.x, (float)Wkd.y);
-    const cplx E = make_float2(0.5f * (Za.x + Zb.x), 0.5f * (Za.y - Zb.y));
-    const cplx O = make_float2(0.5f * (Za.y + Zb.y), -0.5f * (Za.x - Zb.x));
+    const cplx E = make_float2(Za.x + Zb.x, Za.y - Zb.y);                   // 2 E
+    const cplx O = make_float2(Za.y + Zb.y, Zb.x - Za.x);                   // 2 O
     const cplx WO = cmul(Wk, O);
-    cplx Xk = cadd(E, WO), Xm = csub(E, WO);
-    if (HOOK == 2) return fmaxf(Xk.x * Xk.x + Xk.y * Xk.y, Xm.x * Xm.x + Xm.y * Xm.y);
+    cplx Xk = cadd(E, WO), Xm = csub(E, WO);                                // 2 X[k], 2 X[M - k]
+    if (HOOK == 2) return 0.25f * fmaxf(Xk.x * Xk.x + Xk.y * Xk.y, Xm.x * Xm.x + Xm.y * Xm.y);
     if (HOOK == 1) {
         const float mk = sqrtf(Xk.x * Xk.x + Xk.y * Xk.y), mm = sqrtf(Xm.x * Xm.x + Xm.y * Xm.y);
-        float gk = mk > tlev ? 1.f : 0.f, gm = mm > tlev ? 1.f : 0.f;
+        float gk = mk > tlevx2 ? 1.f : 0.f, gm = mm > tlevx2 ? 1.f : 0.f;
         if (soft) {
-            if (mk > tlev) gk = 1.f - tlev / mk;
-            if (mm > tlev) gm = 1.f - tlev / mm;
+            if (mk > tlevx2) gk = 1.f - tlevx2 / mk;
+            if (mm > tlevx2) gm = 1.f - tlevx2 / mm;
         }
         Xk.x *= gk; Xk.y *= gk; Xm.x *= gm; Xm.y *= gm;
     } else {
-        if (!(Xk.x * Xk.x + Xk.y * Xk.y > thr2)) Xk = make_float2(0.f, 0.f);
-        if (!(Xm.x * Xm.x + Xm.y * Xm.y > thr2)) Xm = make_float2(0.f, 0.f);
+        if (!(Xk.x * Xk.x + Xk.y * Xk.y > thr2x4)) Xk = make_float2(0.f, 0.f);
+        if (!(Xm.x * Xm.x + Xm.y * Xm.y > thr2x4)) Xm = make_float2(0.f, 0.f);
     }
-    const cplx E2 = make_float2(0.5f * (Xk.x + Xm.x), 0.5f * (Xk.y + Xm.y));
-    const cplx H = make_float2(0.5f * (Xk.x - Xm.x), 0.5f * (Xk.y - Xm.y));
-    const cplx O2 = cmulc(H, Wk);
-    na = make_float2((float)(scd * (double)(E2.x - O2.y)), (float)(scd * (double)(E2.y + O2.x)));
-    nb = make_float2((float)(scd * (double)(E2.x + O2.y)), -(float)(scd * (double)(E2.y - O2.x)));
+    const cplx E2 = cadd(Xk, Xm);                                           // 4 E'
+    const cplx H = csub(Xk, Xm);
+    const cplx O2 = cmulc(H, Wk);                                           // 4 O'
+    na = make_float2(wl_scaled(E2.x - O2.y, sc), wl_scaled(E2.y + O2.x, sc));
+    nb = make_float2(wl_scaled(E2.x + O2.y, sc), wl_scaled(O2.x - E2.y, sc));
     return 0.f;
 }
 
@@ -175,8 +192,9 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
         tlev = p.thr * sqrtf(__uint_as_float(p.max2[ch]));
         thr2 = tlev * tlev;
     }
+    thr2 *= 4.f; tlev *= 2.f;                    // the hook judges 2 X (wl_pair_hook)
     const int soft = p.soft;
-    const double scd = p.inv_M_d;
+    const WlScale scd = wl_scale(p.inv_M_d);
     float mx2 = 0.f;
     if (!self) {
         if (lact) {
@@ -276,78 +294,86 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
 // row lengths with a k_row_wl instantiation: X(L, N1, Q)
 #define EGR_WL_ROW_LIST(X) \
     X(384, 6, 8) X(576, 4, 12) X(768, 12, 8) X(1152, 8, 12) X(1536, 24, 8) X(1728, 12, 12) X(1920, 30, 8) X(2304, 16, 12) \
-    X(2880, 20, 12) X(3072, 12, 16) X(3456, 24, 12) X(4032, 28, 12) X(4096, 16, 16) X(4608, 32, 12)
+    X(2880, 20, 12) X(3072, 12, 16) X(3456, 24, 12) X(4032, 28, 12) X(4096, 16, 16) X(4608, 32, 12) \
+    /* rows of 50 T points next to columns of 441: T seconds at 44.1 kHz, T = 2 N1 */ \
+    X(400, 4, 10) X(600, 6, 10) X(800, 8, 10) X(1000, 10, 10) X(1200, 12, 10) X(1400, 14, 10) X(1600, 16, 10) X(1800, 18, 10) \
+    X(2000, 20, 10) X(2400, 24, 10) X(2800, 28, 10) X(3000, 30, 10) X(3200, 32, 10)
 typedef void (*WlRowFn)(RowP, WlRowT, long long, cplx*);
 struct WlRowEntry { int L, n1, q, threads, lds; WlRowFn fn, fn_variant, fn_max; };      // hooks 0 / 1 / 2
 #define EGR_WL_ROW_ENTRY(LL, A, B) {LL, A, B, WlRow<A, B>::THREADS, WlRow<A, B>::LDS, k_row_wl<A, B, 0>, k_row_wl<A, B, 1>, k_row_wl<A, B, 2>},
 static const WlRowEntry kWlRows[] = {EGR_WL_ROW_LIST(EGR_WL_ROW_ENTRY)};
 
-// MODE 1 only (the middle pass of the loop): state -> twiddle^-1 -> IFFT_625 -> FFT_625 -> twiddle -> state, tiles of 8 columns.
-__global__ __launch_bounds__(EGR_WL_COL_THREADS, EGR_WL_COL_WAVES) void k_col_wl(ColP p, WlColT tb, long long M, cplx* __restrict__ work) {
+// MODE 1 only (the middle pass of the loop): state -> twiddle^-1 -> IFFT_(R^2) -> FFT_(R^2) -> twiddle -> state, tiles of TC columns.
+template <int R, int TC>
+__global__ __launch_bounds__((WlCol<R, TC>::THREADS), EGR_WL_COL_WAVES) void k_col_wl(ColP p, WlColT tb, long long M, cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     EGR_LDS_CANARY_ARM(smem);
-    __shared__ cplx t3s[625];
-    constexpr int TC = EGR_WL_COL_TC;
+    constexpr int RR = R * R, THREADS = WlCol<R, TC>::THREADS;
+    __shared__ cplx t3s[RR];
     const int tile = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
     if (tile >= p.ntiles) return;
     const int ch = blockIdx.y / p.nplanes, plane = blockIdx.y - ch * p.nplanes;
     const int nc = p.ncols;
     cplx* lds = (cplx*)EGR_LDS_BASE(smem);
     const int tid = threadIdx.x;
-    const int b = tid >> 3, cl = tid & 7, col = tile * TC + cl;
-    const bool act = tid < 25 * TC;
-    cplx* W = work + (size_t)ch * M + (size_t)plane * 625 * nc + col;
-    for (int e = tid; e < 625; e += EGR_WL_COL_THREADS) t3s[e] = tb.t3[e];
+    const int b = tid / TC, cl = tid - b * TC, col = tile * TC + cl;
+    const bool act = tid < R * TC && col < nc;
+    cplx* W = work + (size_t)ch * M + (size_t)plane * RR * nc + col;
+    for (int e = tid; e < RR; e += THREADS) t3s[e] = tb.t3[e];
     EGR_STAMP(p, 0);
-    cplx v[25];
-    // four-step twiddles W_M^(col (25 a + b)) of this thread's rows: first value and ratio from the hi/lo tables, in double
-    dcplx w0 = make_double2(1.0, 0.0), wst = w0;
+    cplx v[R], tw[R];
+    // four-step twiddles W_M^(col (R a + b)) of this thread's rows: first value and ratio from the hi/lo tables, in double
     if (act) {
 #pragma unroll
-        for (int a = 0; a < 25; ++a) v[a] = W[(size_t)(25 * a + b) * nc];
-        w0 = tw2d(p.big, (unsigned)col * (unsigned)b);
-        wst = tw2d(p.big, (unsigned)col * 25u);
+        for (int a = 0; a < R; ++a) v[a] = W[(size_t)(R * a + b) * nc];
+        const dcplx w0 = tw2d(p.big, (unsigned)col * (unsigned)b), wst = tw2d(p.big, (unsigned)col * (unsigned)R);
         dcplx cur = w0;
 #pragma unroll
-        for (int a = 0; a < 25; ++a) {
-            v[a] = cmulc(v[a], make_float2((float)cur.x, (float)cur.y));
+        for (int a = 0; a < R; ++a) {
+            tw[a] = make_float2((float)cur.x, (float)cur.y);             // kept for the way out: the run is formed once
+            v[a] = cmulc(v[a], tw[a]);
             cur = dcmul(cur, wst);
         }
-        wl_bfly_inv<25>(v);                              // v[c] = Z[c][b]
+        wl_bfly_inv<R>(v);                               // v[c] = Z[c][b]
 #pragma unroll
-        for (int c = 0; c < 25; ++c) lds[(c * 25 + b) * TC + cl] = v[c];
+        for (int c = 0; c < R; ++c) lds[(c * R + b) * TC + cl] = v[c];
     }
     __syncthreads();
     EGR_STAMP(p, 1);
     if (act) {
-        const cplx* tr = t3s + b * 25;                   // this thread is now c = b of the first step; row c of the (symmetric) table
+        const cplx* tr = t3s + b * R;                    // this thread is now c = b of the first step; row c of the (symmetric) table
 #pragma unroll
-        for (int j = 0; j < 25; ++j) {
-            const cplx z = lds[(b * 25 + j) * TC + cl];
+        for (int j = 0; j < R; ++j) {
+            const cplx z = lds[(b * R + j) * TC + cl];
             v[j] = j ? cmulc(z, tr[j]) : z;
         }
-        wl_bfly_inv<25>(v);                              // v[d] = t[c + 25 d]: the time-domain column (nothing happens to it in the loop)
+        wl_bfly_inv<R>(v);                               // v[d] = t[c + R d]: the time-domain column (nothing happens to it in the loop)
         EGR_STAMP(p, 2);
-        Bfly<25>::run(v);                                // forward over a' = d: v[c''] = Z2[c''][b' = c]
+        Bfly<R>::run(v);                                 // forward over a' = d: v[c''] = Z2[c''][b' = c]
 #pragma unroll
-        for (int j = 0; j < 25; ++j) lds[(b * 25 + j) * TC + cl] = j ? cmul(v[j], tr[j]) : v[j];      // transposed: into the row it has just read
+        for (int j = 0; j < R; ++j) lds[(b * R + j) * TC + cl] = j ? cmul(v[j], tr[j]) : v[j];      // transposed: into the row it has just read
     }
     __syncthreads();
     if (act) {
 #pragma unroll
-        for (int j = 0; j < 25; ++j) v[j] = lds[(j * 25 + b) * TC + cl];         // Z2[c'' = b][b' = j]
-        Bfly<25>::run(v);                                // v[d''] = X[c'' + 25 d'']
+        for (int j = 0; j < R; ++j) v[j] = lds[(j * R + b) * TC + cl];           // Z2[c'' = b][b' = j]
+        Bfly<R>::run(v);                                 // v[d''] = X[c'' + R d'']
         EGR_STAMP(p, 3);
-        dcplx cur = w0;
 #pragma unroll
-        for (int a = 0; a < 25; ++a) {
-            W[(size_t)(25 * a + b) * nc] = cmul(v[a], make_float2((float)cur.x, (float)cur.y));
-            cur = dcmul(cur, wst);
-        }
+        for (int a = 0; a < R; ++a) W[(size_t)(R * a + b) * nc] = cmul(v[a], tw[a]);
     }
     EGR_STAMP(p, 4);
 }
-
+// A: the plan's outer ColP (columns of 625 or 441 points); ny = grid.y (channels x planes)
+template <int R, int TC>
+static inline void wl_launch_col_t(ColP A, const WlColT& tb, long long M, cplx* work, int ny, hipStream_t st) {
+    A.TC = TC; A.TClog2 = 0; A.ntiles = (A.ncols + TC - 1) / TC; A.tiles_per_xcd = (A.ntiles + 7) / 8;      // (a ragged last tile is fine)
+    hipLaunchKernelGGL((k_col_wl<R, TC>), dim3(8 * A.tiles_per_xcd, ny), dim3(WlCol<R, TC>::THREADS), EGR_LDS((WlCol<R, TC>::LDS)), st, A, tb, M, work);
+}
+static inline void wl_launch_col(const ColP& A, const WlColT& tb, long long M, cplx* work, int ny, hipStream_t st) {
+    if (A.L == 441) wl_launch_col_t<21, 12>(A, tb, M, work, ny, st);
+    else wl_launch_col_t<25, 8>(A, tb, M, work, ny, st);
+}
 
 // k_colb_wl -- the INNER column pass of a three-level plan (length L = LA x LB <= 144 over n2 inside each k1 plane, stride M3), one
 // barrier: thread (b, col) loads n2 = LB a + b, radix-LA in registers, x W_L^(b c), transpose through LDS, thread (c, col) does the

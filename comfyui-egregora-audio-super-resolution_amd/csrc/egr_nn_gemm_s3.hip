@@ -1244,14 +1244,21 @@ __global__ __launch_bounds__(256, 2) void k_bgemm_s3(GemmS3P p) {
         aptr += astep; bptr += bstep;
     };
     auto store = [&](int buf) {
-        uint4 q[3];
-        split_x8<SCH>(ra0, ra1, sa, q);
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) As[buf][pl][slot] = q[pl];
-        if (tid < 2 * BN) {
-            split_x8<SCH>(rb0, rb1, sb, q);
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl) Bs[buf][pl][slot] = q[pl];
+        uint4 q0, q1, q2;
+        if constexpr (SCH == 0) {
+            split3_x8(ra0, ra1, q0, q1, q2);
+            As[buf][0][slot] = q0; As[buf][1][slot] = q1; As[buf][2][slot] = q2;
+            if (tid < 2 * BN) {
+                split3_x8(rb0, rb1, q0, q1, q2);
+                Bs[buf][0][slot] = q0; Bs[buf][1][slot] = q1; Bs[buf][2][slot] = q2;
+            }
+        } else {
+            split2h_x8(ra0, ra1, sa, q0, q1);
+            As[buf][0][slot] = q0; As[buf][1][slot] = q1;
+            if (tid < 2 * BN) {
+                split2h_x8(rb0, rb1, sb, q0, q1);
+                Bs[buf][0][slot] = q0; Bs[buf][1][slot] = q1;
+            }
         }
     };
     load();

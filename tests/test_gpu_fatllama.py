@@ -393,6 +393,44 @@ def test_c3_full_length_800_iterations_against_the_oracle(pack):
         assert lg_plain <= (3.0 if n == 2880000 else 1.0) * lo_plain, (n, lg_plain, lo_plain)
 
 
+def test_60_s_at_44k1_full_length_800_iterations_against_float64(pack):
+    """60 s at 44.1 kHz (N = 2 646 000 = 2 x 441 x 3000) at the headline iteration count: columns on k_col_wl<21, 12>, rows on
+    k_row_wl<30, 10> -- both new twiddle runs, so the compounding over 800 iterations is checked at this length too.  Yardstick:
+    the float64 loop on the GPU (pinned to the oracle's float64 run in test_c3_full_length_800_iterations_against_the_oracle);
+    reference error: the stage-by-stage kernels on the same plan (EGR_FL_WL=0), which the other tests hold to the float32 oracle."""
+    from egregora_amd import fatllama_engine as fe
+    n = 2646000
+    info = fe.plan_info(n, 1)
+    assert (info["M1"], info["M2"]) == (441, 3000), info
+    x = synth(1, n, seed=441)
+    try:
+        exact = f64_loop_on_gpu(x, 800, 0.6)
+    except Exception as ex:      # noqa: BLE001
+        pytest.skip(f"torch.fft in float64 on the GPU is not available here ({ex})")
+    rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
+    got = run_gpu(pack, x, 1, 800, 0.6)
+    old = os.environ.get("EGR_FL_WL")
+    os.environ["EGR_FL_WL"] = "0"
+    try:
+        fe.release_plans()
+        stage = run_gpu(pack, x, 1, 800, 0.6)
+        fe.release_plans()
+    finally:
+        if old is None:
+            os.environ.pop("EGR_FL_WL", None)
+        else:
+            os.environ["EGR_FL_WL"] = old
+    scale = float(np.max(np.abs(exact)))
+    mg, rg, ms, rs = float(np.max(np.abs(got - exact))), rms(got - exact), float(np.max(np.abs(stage - exact))), rms(stage - exact)
+    seg = slice(0, 882000)
+    lg, kept = om.lsd_masked(exact[:, seg], got[:, seg], f32_run=stage[:, seg], margin_db=F32_MARGIN_DB)
+    print(f"\n441 x 3000, 800 iterations: two-barrier kernels max err {mg:.3e} ({mg / scale:.2e} of the peak), rms {rg:.3e}; stage-by-stage "
+          f"kernels {ms:.3e} / {rs:.3e}; LSD vs float64 over the {kept:.1%} resolvable bins {lg:.2e} dB")
+    assert np.isfinite(got).all()
+    assert mg <= 2.0 * ms and mg <= 5e-4 * scale and rg <= 1.5 * rs + 1e-9 * scale, (mg, ms, rg, rs, scale)
+    assert lg <= 1e-3 and kept >= 0.3, (lg, kept)
+
+
 VARIANTS = [  # (variant list for the device, FatLlamaSpec overrides, threshold, data scale)
     ("", {}, 50.0, 100.0),
     ("soft", {"threshold_kind": "soft"}, 50.0, 100.0),

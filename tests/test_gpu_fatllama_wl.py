@@ -237,6 +237,47 @@ def test_two_barrier_row_kernel_for_every_instantiated_row_length(pack, rows):
         assert rms(a - exact) <= 2.5 * rms(want - exact) + 1e-9 * scale
 
 
+ROW_LENGTHS_441 = [400, 600, 800, 1000, 1200, 1400, 1600, 1800, 2000, 2400, 2800, 3000, 3200]
+
+
+@pytest.mark.parametrize("rows", ROW_LENGTHS_441)
+def test_44k1_family_columns_of_441_and_rows_of_50_t(pack, rows):
+    """T seconds at 44.1 kHz: N / 2 = 22 050 T = 441 x 50 T.  The planner takes columns of 441 = 21 x 21 points (k_col_wl<21, 12>)
+    and rows of 50 T = (T / 2) x 10^2 points (k_row_wl<T / 2, 10>, T = 8 ... 64 s) -- against the stage-by-stage kernels the same
+    plan runs with EGR_FL_WL=0 and, for the shorter ones, the oracle and float64."""
+    from egregora_amd import fatllama_engine as fe
+    n = 2 * 441 * rows
+    assert n == 44100 * (rows // 50)
+    info = fe.plan_info(n, 1)
+    assert (info["M1"], info["M2"], info["levels"]) == (441, rows, 2), info
+    x = synth(2, n, seed=rows)
+    a = run(x, 3, wl=True)
+    b = run(x, 3, wl=False)
+    scale = float(np.max(np.abs(b)))
+    err = float(np.max(np.abs(a - b)))
+    print(f"\n441 x {rows}: max diff {err / scale:.2e} of the peak, rms {rms(a - b) / scale:.2e}")
+    assert np.isfinite(a).all() and err <= 4e-6 * scale and rms(a - b) <= 4e-7 * scale
+    if n <= 1500000:
+        want = ofl.enhance_channels(x, 1, 3, 0.6, normalize=False, autoscale=False)
+        exact = ofl.enhance_channels(x, 1, 3, 0.6, normalize=False, autoscale=False, exact=True)
+        assert float(np.max(np.abs(a - want))) <= 2e-5 * scale
+        assert rms(a - exact) <= 2.5 * rms(want - exact) + 1e-9 * scale
+
+
+@pytest.mark.parametrize("rows,channels", [(1100, 2), (2200, 1), (50, 3)])
+def test_columns_of_441_next_to_the_stage_by_stage_row_kernel(pack, rows, channels):
+    """k_col_wl<21, 12> with row lengths that have no k_row_wl instantiation (1100 and 2200 are not (even) x 100 with a listed
+    radix; 50 leaves a RAGGED last tile: 50 = 4 x 12 + 2 columns), explicit split."""
+    n = 2 * 441 * rows
+    x = synth(channels, n, seed=rows + 1)
+    a = run(x, 3, wl=True, split=(441, rows, 1))
+    b = run(x, 3, wl=False, split=(441, rows, 1))
+    want = ofl.enhance_channels(x, 1, 3, 0.6, normalize=False, autoscale=False)
+    scale = float(np.max(np.abs(want)))
+    assert float(np.max(np.abs(a - b))) <= 4e-6 * scale and rms(a - b) <= 4e-7 * scale
+    assert float(np.max(np.abs(a - want))) <= 2e-5 * scale
+
+
 def test_two_barrier_row_kernel_with_an_even_row_count(pack):
     """M = 320 x 768: an even number of rows has TWO self-paired rows (o = 0 and o = R / 2), both on the LDS hook path of k_row_wl;
     the columns run the run-time-schedule kernel."""
