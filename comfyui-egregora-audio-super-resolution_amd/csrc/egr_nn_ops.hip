@@ -202,6 +202,43 @@ __global__ __launch_bounds__(256) void k_softmax(float* __restrict__ x, int cols
     for (int c = threadIdx.x; c < cols; c += 256) r[c] *= inv;
 }
 
+// The same with the row held in registers (cols <= 256 NI): one read and one write of the row instead of three and two.  Same
+// element-to-thread map and the same order of the per-thread sums as k_softmax, so the results are the same bits.
+template <int NI>
+__global__ __launch_bounds__(256) void k_softmax_reg(float* __restrict__ x, int cols) {
+    __shared__ float red[4];
+    float* r = x + (size_t)blockIdx.x * cols;
+    float v[NI];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        v[i] = c < cols ? r[c] : -INFINITY;
+        m = fmaxf(m, v[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+        if (threadIdx.x + 256 * i < cols) { v[i] = __expf(v[i] - m); s += v[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    s = red[0] + red[1] + red[2] + red[3];
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < cols) r[c] = v[i] * inv;
+    }
+}
+
 // ---------------------------------------------------------------- element-wise
 enum { EW_ADD = 0, EW_AXPBY = 1, EW_SILU = 2, EW_SCALE = 3, EW_COPY = 4, EW_ADD_SCALE = 5 };
 // grid (chunks, rows): a workgroup loops over the `n` elements of row blockIdx.y; row_amax (optional): max |y| per row
@@ -920,7 +957,11 @@ extern "C" int egr_layernorm_rows(const float* x, const float* gamma, const floa
 
 extern "C" int egr_softmax_rows(float* x, int64_t rows, int cols, void* stream) {
     EGR_CHECK(x && rows >= 1 && cols >= 1, EGR_ERR_ARG, "bad argument");
-    hipLaunchKernelGGL(k_softmax, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, cols);
+    const dim3 grid((unsigned)rows), blk(256);
+    if (cols <= 1024) hipLaunchKernelGGL(k_softmax_reg<4>, grid, blk, 0, (hipStream_t)stream, x, cols);
+    else if (cols <= 2048) hipLaunchKernelGGL(k_softmax_reg<8>, grid, blk, 0, (hipStream_t)stream, x, cols);
+    else if (cols <= 4096) hipLaunchKernelGGL(k_softmax_reg<16>, grid, blk, 0, (hipStream_t)stream, x, cols);
+    else hipLaunchKernelGGL(k_softmax, grid, blk, 0, (hipStream_t)stream, x, cols);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }

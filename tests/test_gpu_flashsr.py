@@ -364,6 +364,12 @@ def test_groupnorm_layernorm_softmax_geglu(eng):
     from egregora_amd import native
     native.check(e.L.egr_softmax_rows(C.c_void_p(sc.data_ptr()), 37, 300, native.stream_ptr()), "softmax")
     close(sc, torch.softmax(s, -1), 2e-5)
+    for cols in (1024, 1500, 2048, 4096, 5000):      # the row in registers up to 4096 columns (k_softmax_reg), the three-pass form beyond
+        s = torch.randn(5, cols, generator=g) * 6
+        sc = s.clone().cuda()
+        native.check(e.L.egr_softmax_rows(C.c_void_p(sc.data_ptr()), 5, cols, native.stream_ptr()), "softmax")
+        close(sc, torch.softmax(s.double(), -1).float(), 2e-5)
+        assert float(sc.sum(-1).sub(1).abs().max()) < 1e-5
     u = torch.randn(20, 64, generator=g)
     out = torch.empty(20, 32, device="cuda")
     native.check(e.L.egr_geglu(C.c_void_p(u.cuda().data_ptr()), C.c_void_p(out.data_ptr()), 20, 32, native.stream_ptr()), "geglu")
