@@ -224,13 +224,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if args.dry_run else "nccl", rank=rank, world_size=world)
+        # EGREGORA_BENCH_ONE_GPU=1 (tests only): every rank on device 0, collectives over gloo -- RCCL refuses two ranks on one device,
+        # and a 1-GPU box is all the test suite has; everything else (sharding, gather, timing, JSON) is the real multi-rank path
+        one_gpu = os.environ.get("EGREGORA_BENCH_ONE_GPU", "0") == "1"
+        dist.init_process_group("gloo" if (args.dry_run or one_gpu) else "nccl", rank=rank, world_size=world)
     if args.dry_run:
         rc = dry_run(args, rank, world, dist)
         if dist:
             dist.destroy_process_group()
         sys.exit(rc)
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(0 if os.environ.get("EGREGORA_BENCH_ONE_GPU", "0") == "1" else local_rank)
 
     from packload import load_pack
     load_pack()

@@ -1,0 +1,29 @@
+"""`python bench.py --gpus 2` end to end on ONE GPU: the driver's multi-GPU command line (bench.py re-executes itself under
+torch.distributed.run, one rank per GPU) with EGREGORA_BENCH_ONE_GPU=1, which puts every rank on device 0 and the collectives on
+gloo (RCCL refuses two ranks on one device).  Everything else is the real multi-rank path of SURVEY section 8(e): contiguous chunk
+blocks per rank (shard.block_bounds), egr_flashsr_infer per rank, ONE all-gather, WOLA on every rank, Fat-Llama on the rank's own
+60 s, barrier + max-over-ranks timing, one JSON line from rank 0.  Reference loop: /root/reference/egregora_audio_super_resolution.py:407-420."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_two_ranks_share_one_gpu_and_report_one_line():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["EGREGORA_BENCH_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--iters", "40",
+                        "--no-cpu-baseline", "--lean"], capture_output=True, text=True, timeout=1200, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    print(f"\n2 ranks on one GPU: {out['value']:.1f} xRT, {out['ms_per_step']:.1f} ms per step (two 60 s files, 40 Fat-Llama iterations)")
+    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["unit"] == "audio-sec/sec"
