@@ -90,7 +90,7 @@ __device__ __forceinline__ float wl_pair_hook(const cplx Za, const cplx Zb, cons
     return 0.f;
 }
 
-// Geometry of k_row_wl<N1, Q>: rows of L = N1 Q^2 points (N1 even: cross radix, Q x Q blocks on Q lanes of one wave).
+// Geometry of k_row_wl<N1, Q>: rows of L = N1 Q^2 points (N1: cross radix, even or odd; Q x Q blocks on Q lanes of one wave).
 template <int N1, int Q> struct WlRow {
     static constexpr int QQ = Q * Q, L = N1 * QQ;
     static constexpr int TS = Q + 2;                                   // row stride of the Q x Q transpose (even: 16-byte accesses)
@@ -100,8 +100,24 @@ template <int N1, int Q> struct WlRow {
     static constexpr int UPW = (N1 + LWAVES - 1) / LWAVES;             // units (block pairs) per wave, balanced
     static constexpr int THREADS = 64 * (LWAVES < 2 ? 2 : LWAVES);
     static constexpr int XIT = (2 * QQ + THREADS - 1) / THREADS;       // rounds of the 2 Q^2 cross butterflies
-    static constexpr int LDS = 2 * RS * 8;
+    static constexpr int LDS = (2 * RS + (N1 % 2 ? S : 0)) * 8;         // odd N1: a spare block (the middle unit of a self-paired row)
 };
+// the N1 twiddles W_L^(n2 k1) of one cross butterfly (row n2 of the [Q^2][N1] table): 16-byte loads where the row is aligned
+template <int N1>
+__device__ __forceinline__ void wl_load_tw(const cplx* __restrict__ row, cplx (&w)[N1]) {
+    if constexpr (N1 % 2 == 0) {
+        const float4* tp = (const float4*)row;
+#pragma unroll
+        for (int q = 0; q < N1 / 2; ++q) {
+            const float4 t = tp[q];
+            w[2 * q] = make_float2(t.x, t.y);
+            w[2 * q + 1] = make_float2(t.z, t.w);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < N1; ++k) w[k] = row[k];
+    }
+}
 
 template <int N1, int Q, int HOOK>
 __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRowT tb, long long M, cplx* __restrict__ work) {
@@ -109,7 +125,7 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
     EGR_LDS_CANARY_ARM(smem);
     using G = WlRow<N1, Q>;
     constexpr int L = G::L, QQ = G::QQ, S = G::S, TS = G::TS, RS = G::RS, THREADS = G::THREADS, XIT = G::XIT, UPW = G::UPW;
-    static_assert(N1 % 2 == 0 && S >= QQ && S % 2 == 0, "k_row_wl geometry");
+    static_assert(S >= QQ && S % 2 == 0, "k_row_wl geometry");
     const int R = p.R;
     const int oa = blockIdx.x;
     const int ob = (R - oa) % R;
@@ -126,9 +142,11 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
     const int xlim = self ? QQ : 2 * QQ;
     const int wv = tid >> 6, lane = tid & 63, un = lane / Q, l = lane - Q * un;
     const int k1 = UPW * wv + un;                                          // local step: block k1 of row a, block N1 - 1 - k1 of row b
-    const bool lact = un < UPW && k1 < N1 && !(self && k1 >= N1 / 2);      // a self-paired row: blocks k1 and N1 - 1 - k1 of the SAME row
+    const bool lact = un < UPW && k1 < N1 && !(self && k1 >= (N1 + 1) / 2);      // a self-paired row: blocks k1 and N1 - 1 - k1 of the SAME row
     cplx* ba = lds + (k1 < N1 ? k1 : 0) * S;
     cplx* bb = lds + (self ? 0 : RS) + (k1 < N1 ? N1 - 1 - k1 : 0) * S;
+    // odd N1, self-paired row: the middle block is its own partner -- the unit transforms it once (as A); its B half works on a spare block
+    if ((N1 & 1) && self && 2 * k1 == N1 - 1) bb = lds + 2 * RS;
     // the pair twiddles W_N^(o + R k), k = k1 + N1 l + N1 Q d: a geometric run in double over d (ratio W_(2L)^(N1 Q) = W_(2Q))
     dcplx wrun = make_double2(1.0, 0.0);
     if (lact) wrun = dcmul(tw2d(p.wo, (unsigned)oa), p.wk[k1 + N1 * l]);
@@ -144,18 +162,13 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
         cplx v[N1];
 #pragma unroll
         for (int n1 = 0; n1 < N1; ++n1) v[n1] = g[n1 * QQ + xn2];
-        const float4* tp = (const float4*)(tb.t1 + xn2 * N1);
-        float4 w[N1 / 2];
-#pragma unroll
-        for (int q = 0; q < N1 / 2; ++q) w[q] = tp[q];
+        cplx w[N1];
+        wl_load_tw<N1>(tb.t1 + xn2 * N1, w);
         Bfly<N1>::run(v);
         cplx* d = lds + xr * RS + xn2;
         d[0] = v[0];
 #pragma unroll
-        for (int q = 0; q < N1 / 2; ++q) {
-            if (q > 0) d[(2 * q) * S] = cmul(v[2 * q], make_float2(w[q].x, w[q].y));
-            d[(2 * q + 1) * S] = cmul(v[2 * q + 1], make_float2(w[q].z, w[q].w));
-        }
+        for (int k = 1; k < N1; ++k) d[k * S] = cmul(v[k], w[k]);
     }
     __syncthreads();
     EGR_STAMP(p, 1);
@@ -274,16 +287,12 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
         if (xt >= xlim) break;
         const int xr = xt >= QQ ? 1 : 0, xn2 = xt - QQ * xr;
         cplx* g = xr ? gb : ga;
-        const float4* tp = (const float4*)(tb.t1 + xn2 * N1);
         const cplx* s = lds + xr * RS + xn2;
-        cplx v[N1];
+        cplx v[N1], w[N1];
+        wl_load_tw<N1>(tb.t1 + xn2 * N1, w);
         v[0] = s[0];
 #pragma unroll
-        for (int q = 0; q < N1 / 2; ++q) {
-            const float4 w = tp[q];
-            if (q > 0) v[2 * q] = cmulc(s[(2 * q) * S], make_float2(w.x, w.y));
-            v[2 * q + 1] = cmulc(s[(2 * q + 1) * S], make_float2(w.z, w.w));
-        }
+        for (int k = 1; k < N1; ++k) v[k] = cmulc(s[k * S], w[k]);
         wl_bfly_inv<N1>(v);
 #pragma unroll
         for (int n1 = 0; n1 < N1; ++n1) g[n1 * QQ + xn2] = v[n1];
@@ -297,7 +306,9 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
     X(2880, 20, 12) X(3072, 12, 16) X(3456, 24, 12) X(4032, 28, 12) X(4096, 16, 16) X(4608, 32, 12) \
     /* rows of 50 T points next to columns of 441: T seconds at 44.1 kHz, T = 2 N1 */ \
     X(400, 4, 10) X(600, 6, 10) X(800, 8, 10) X(1000, 10, 10) X(1200, 12, 10) X(1400, 14, 10) X(1600, 16, 10) X(1800, 18, 10) \
-    X(2000, 20, 10) X(2400, 24, 10) X(2800, 28, 10) X(3000, 30, 10) X(3200, 32, 10)
+    X(2000, 20, 10) X(2400, 24, 10) X(2800, 28, 10) X(3000, 30, 10) X(3200, 32, 10) \
+    /* odd cross radices: 10 / 14 / 18 / 30 / 42 / 50 s at 44.1 kHz, 25 / 35 / 100 s at 48 kHz */ \
+    X(500, 5, 10) X(700, 7, 10) X(900, 9, 10) X(1500, 15, 10) X(2100, 21, 10) X(2500, 25, 10) X(960, 15, 8) X(1344, 21, 8) X(3840, 15, 16)
 typedef void (*WlRowFn)(RowP, WlRowT, long long, cplx*);
 struct WlRowEntry { int L, n1, q, threads, lds; WlRowFn fn, fn_variant, fn_max; };      // hooks 0 / 1 / 2
 #define EGR_WL_ROW_ENTRY(LL, A, B) {LL, A, B, WlRow<A, B>::THREADS, WlRow<A, B>::LDS, k_row_wl<A, B, 0>, k_row_wl<A, B, 1>, k_row_wl<A, B, 2>},

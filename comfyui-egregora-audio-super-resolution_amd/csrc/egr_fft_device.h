@@ -134,6 +134,7 @@ template <> struct Bfly<28> { static __device__ __forceinline__ void run(cplx (&
 template <> struct Bfly<30> { static __device__ __forceinline__ void run(cplx (&v)[30]) { BflyComp<5, 6>::run(v); } };
 template <> struct Bfly<32> { static __device__ __forceinline__ void run(cplx (&v)[32]) { BflyComp<4, 8>::run(v); } };
 // 44.1 kHz-family plans (csrc/egr_fatllama_wl.h): columns of 441 = 21 x 21 points, cross radices 14 and 18
+template <> struct Bfly<15> { static __device__ __forceinline__ void run(cplx (&v)[15]) { BflyComp<3, 5>::run(v); } };
 template <> struct Bfly<14> { static __device__ __forceinline__ void run(cplx (&v)[14]) { BflyComp<7, 2>::run(v); } };
 template <> struct Bfly<18> { static __device__ __forceinline__ void run(cplx (&v)[18]) { BflyComp<9, 2>::run(v); } };
 template <> struct Bfly<21> { static __device__ __forceinline__ void run(cplx (&v)[21]) { BflyComp<3, 7>::run(v); } };

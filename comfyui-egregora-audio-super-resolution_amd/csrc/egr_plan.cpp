@@ -163,8 +163,8 @@ FlSplit plan_split(int64_t N, int m1_hint, int tc_hint, int max_col) {
         // 38.8 -> 27, 50.9 -> 46, 72.6 -> 62, 85.9 -> 77 ms
         if (m1 == 625 && m2 % 8 == 0) score -= 2500.0;
         // columns of 441 = 21 x 21 points likewise (k_col_wl<21, 12>): the 44.1 kHz family, N / 2 = 441 x 50 T for T seconds; the
-        // rows of 50 T points run on k_row_wl<T / 2, 10> where instantiated (T = 8 ... 64 s in steps of 4), else stage by stage
-        if (m1 == 441 && m2 % 4 == 0 && M % 625 != 0) score -= 2500.0;
+        // rows of 50 T points run on k_row_wl<T / 2, 10> where instantiated (19 lengths, T = 8 ... 64 s), else stage by stage
+        if (m1 == 441 && m2 % 4 == 0) score -= 2500.0;
         if (score < best_score) {
             best_score = score;
             best.ok = true; best.levels = 2;

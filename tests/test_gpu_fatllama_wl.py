@@ -212,7 +212,7 @@ def test_two_barrier_column_kernel_next_to_the_stage_by_stage_row_kernel(pack, n
         assert rms(a - exact) <= 2.5 * rms(want - exact) + 1e-9 * scale
 
 
-ROW_LENGTHS = [384, 576, 768, 1152, 1536, 1728, 1920, 2880, 3072, 3456, 4032, 4096, 4608]
+ROW_LENGTHS = [384, 576, 768, 1152, 1536, 1728, 1920, 2880, 3072, 3456, 4032, 4096, 4608, 960, 1344, 3840]       # the last three: odd cross radix
 
 
 @pytest.mark.parametrize("rows", ROW_LENGTHS)
@@ -237,7 +237,7 @@ def test_two_barrier_row_kernel_for_every_instantiated_row_length(pack, rows):
         assert rms(a - exact) <= 2.5 * rms(want - exact) + 1e-9 * scale
 
 
-ROW_LENGTHS_441 = [400, 600, 800, 1000, 1200, 1400, 1600, 1800, 2000, 2400, 2800, 3000, 3200]
+ROW_LENGTHS_441 = [400, 600, 800, 1000, 1200, 1400, 1600, 1800, 2000, 2400, 2800, 3000, 3200, 500, 700, 900, 1500, 2100, 2500]      # the last six: odd cross radix
 
 
 @pytest.mark.parametrize("rows", ROW_LENGTHS_441)
@@ -275,6 +275,21 @@ def test_columns_of_441_next_to_the_stage_by_stage_row_kernel(pack, rows, channe
     want = ofl.enhance_channels(x, 1, 3, 0.6, normalize=False, autoscale=False)
     scale = float(np.max(np.abs(want)))
     assert float(np.max(np.abs(a - b))) <= 4e-6 * scale and rms(a - b) <= 4e-7 * scale
+    assert float(np.max(np.abs(a - want))) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("rows", [960, 1500])
+def test_odd_cross_radix_with_an_even_row_count(pack, rows):
+    """k_row_wl<15, 8> / <15, 10> with 320 rows: two self-paired rows (o = 0 and o = 160), whose middle block (7 of 15) is its own
+    partner -- the unit transforms it once and parks its second half on the spare LDS block."""
+    n = 2 * 320 * rows
+    x = synth(2, n, seed=rows + 7)
+    a = run(x, 3, wl=True, split=(320, rows, 1))
+    b = run(x, 3, wl=False, split=(320, rows, 1))
+    want = ofl.enhance_channels(x, 1, 3, 0.6, normalize=False, autoscale=False)
+    scale = float(np.max(np.abs(want)))
+    assert np.isfinite(a).all()
+    assert float(np.max(np.abs(a - b))) <= 4e-6 * scale
     assert float(np.max(np.abs(a - want))) <= 2e-5 * scale
 
 

@@ -48,7 +48,7 @@ def test_ist_three_level_matches_fft_loop(M1, M2, M3, iters):
     np.testing.assert_allclose(got, d, atol=1e-9 * N)
 
 
-@pytest.mark.parametrize("n1,q", [(16, 12), (6, 8), (4, 12), (12, 8), (30, 8), (20, 12), (12, 16), (28, 12), (16, 16), (30, 10), (4, 10), (14, 10)])
+@pytest.mark.parametrize("n1,q", [(16, 12), (6, 8), (4, 12), (12, 8), (30, 8), (20, 12), (12, 16), (28, 12), (16, 16), (30, 10), (4, 10), (14, 10), (15, 8), (5, 10), (21, 10), (15, 16)])
 def test_two_barrier_row_kernel_lane_map(n1, q):
     """csrc/egr_fatllama_wl.h k_row_wl<N1, Q>: the (block, lane, register) a thread holds is X[k1 + N1 (c + Q d)], the partner L-1-k
     of the real split sits at (N1-1 - k1, Q-1 - c, Q-1 - d) -- the reversed-lane unit of row b -- and the backward steps invert the
