@@ -300,16 +300,8 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
     EGR_STAMP(p, 5);
 }
 
-// row lengths with a k_row_wl instantiation: X(L, N1, Q)
-#define EGR_WL_ROW_LIST(X) \
-    X(384, 6, 8) X(576, 4, 12) X(768, 12, 8) X(1152, 8, 12) X(1536, 24, 8) X(1728, 12, 12) X(1920, 30, 8) X(2304, 16, 12) \
-    X(2880, 20, 12) X(3072, 12, 16) X(3456, 24, 12) X(4032, 28, 12) X(4096, 16, 16) X(4608, 32, 12) \
-    /* rows of 50 T points next to columns of 441: T seconds at 44.1 kHz, T = 2 N1 */ \
-    X(400, 4, 10) X(600, 6, 10) X(800, 8, 10) X(1000, 10, 10) X(1200, 12, 10) X(1400, 14, 10) X(1600, 16, 10) X(1800, 18, 10) \
-    X(2000, 20, 10) X(2400, 24, 10) X(2800, 28, 10) X(3000, 30, 10) X(3200, 32, 10) \
-    /* odd cross radices: 6 / 10 / 14 / 18 / 22 / 26 / 30 / 42 / 50 s at 44.1 kHz, 25 / 35 / 100 s at 48 kHz */ \
-    X(300, 3, 10) X(500, 5, 10) X(700, 7, 10) X(900, 9, 10) X(1100, 11, 10) X(1300, 13, 10) X(1500, 15, 10) X(2100, 21, 10) X(2500, 25, 10) \
-    X(960, 15, 8) X(1344, 21, 8) X(3840, 15, 16)
+// row lengths with a k_row_wl instantiation: EGR_WL_ROW_LIST(X), X(L, N1, Q)
+#include "egr_wl_rows.h"
 typedef void (*WlRowFn)(RowP, WlRowT, long long, cplx*);
 struct WlRowEntry { int L, n1, q, threads, lds; WlRowFn fn, fn_variant, fn_max; };      // hooks 0 / 1 / 2
 #define EGR_WL_ROW_ENTRY(LL, A, B) {LL, A, B, WlRow<A, B>::THREADS, WlRow<A, B>::LDS, k_row_wl<A, B, 0>, k_row_wl<A, B, 1>, k_row_wl<A, B, 2>},

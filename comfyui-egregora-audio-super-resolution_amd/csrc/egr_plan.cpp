@@ -11,6 +11,7 @@
 #include <string>
 
 #include "egr_common.h"
+#include "egr_wl_rows.h"
 
 namespace egr {
 
@@ -182,6 +183,30 @@ FlSplit plan_split(int64_t N, int m1_hint, int tc_hint, int max_col) {
         FftDesc fk;
         if (k >= 3 && k <= MAX_COL_INNER && make_schedule((int)k, &fk)) {
             FlSplit sp = plan_split_explicit(N, 625, (int)k, 2304, 0);
+            if (sp.ok) return sp;
+        }
+    }
+    // ---- the same shape for every row length with a two-barrier kernel: M = C x k x L, C = 625 or 441 columns on k_col_wl, rows of L
+    // points on k_row_wl<N1, Q> (egr_wl_rows.h), the inner pass of length k stage by stage or on k_colb_wl -- taken when no two-level
+    // plan with such columns exists (files beyond ~100 s: 150 s at 48 kHz = 625 x 2 x 2880, 120 s at 44.1 kHz = 441 x 2 x 3000).  The
+    // longest such row wins (the inner pass is the cheapest of the four; measured in profiles/r04/fatllama_lengths_end_of_round.log).
+    if (m1_hint <= 0 && tc_hint <= 0 && !(best.ok && (best.M1 == 625 || best.M1 == 441))) {
+        static const int wl_rows[] = {
+#define X(LL, A, B) LL,
+            EGR_WL_ROW_LIST(X)
+#undef X
+        };
+        int64_t bl = 0, bc = 0, bk = 0;
+        for (int64_t cols : {625LL, 441LL})
+            for (int L : wl_rows) {
+                if (M % (cols * L)) continue;
+                const int64_t k = M / (cols * L);
+                FftDesc fk;
+                if (k < 2 || k > MAX_COL_INNER || !make_schedule((int)k, &fk)) continue;
+                if (L > bl) { bl = L; bc = cols; bk = k; }
+            }
+        if (bl) {
+            FlSplit sp = plan_split_explicit(N, (int)bc, (int)bk, (int)bl, 0);
             if (sp.ok) return sp;
         }
     }

@@ -49,7 +49,9 @@ def test_abi_version_and_host_only_planning(pack):
     big = fe.plan_info(172800000, 1)            # BASELINE C5: 30 min at 96 kHz per channel
     assert big["supported"] and big["levels"] == 3 and big["M1"] * big["M2"] * big["M3"] == 86400000
     assert big["M1"] <= 2048 and big["M2"] <= 1024 and big["M3"] <= 4096
-    assert fe.plan_info(9600000, 1)["levels"] == 2          # two levels reach 2 * 2048 * 4096 samples (outer columns up to 2048)
+    assert fe.plan_info(16777216, 1)["levels"] == 2         # two levels reach 2 * 2048 * 4096 samples (outer columns up to 2048)
+    long48 = fe.plan_info(9600000, 1)           # 200 s at 48 kHz: three levels around the two-barrier kernels (625 columns, rows of 3840)
+    assert (long48["M1"], long48["M2"], long48["M3"]) == (625, 2, 3840)
     assert fe.plan_info(28800000, 1)["levels"] == 3
 
 

@@ -141,18 +141,20 @@ def test_three_level_plan_matches_oracle(pack, n, split):
     assert float(np.max(np.abs(got - want))) <= 2e-5 * scale
 
 
-@pytest.mark.parametrize("n,levels", [(9600000, 2), (19200000, 3)])
-def test_long_inputs_wide_columns_and_three_levels(pack, n, levels):
-    """200 s mono at 48 kHz plans as two levels with 1875-point outer columns on 4-column tiles (above the 1024 points of an 8-column
-    tile); 400 s (9.6 M complex points > 2048 x 4096) takes three levels.  2 iterations, vs the oracle."""
+@pytest.mark.parametrize("n,split,levels", [(9600000, (1875, 2560, 1), 2), (9600000, None, 3), (19200000, None, 3)])
+def test_long_inputs_wide_columns_and_three_levels(pack, n, split, levels):
+    """200 s mono at 48 kHz as two levels with 1875-point outer columns on 4-column tiles (above the 1024 points of an 8-column
+    tile; the planner's choice until round 4, now an explicit split) and as the planner plans it today -- three levels around the
+    two-barrier kernels, 625 x 2 x 3840; 400 s (9.6 M complex points > 2048 x 4096) takes three levels either way.  2 iterations,
+    vs the oracle."""
     from egregora_amd import fatllama_engine as fe
     info = fe.plan_info(n, 1)
-    assert info["supported"] and info["levels"] == levels and info["M1"] * info["M2"] * info["M3"] == n // 2
-    if levels == 2:
-        assert info["M1"] > 1024 and info["TC"] == 4
+    assert info["supported"] and info["M1"] * info["M2"] * info["M3"] == n // 2
+    if split is None:
+        assert info["levels"] == levels and info["M1"] == 625, info
     x = synth(1, n, seed=77)
     want = ofl.enhance_channels(x, 1, 2, 0.6, normalize=False, autoscale=False)
-    got = run_gpu(pack, x, 1, 2, 0.6)
+    got = run_gpu(pack, x, 1, 2, 0.6, **({"split": split} if split else {}))
     scale = float(np.max(np.abs(want)))
     assert float(np.max(np.abs(got - want))) <= 2e-5 * scale
     assert om.lsd_audio(want[:, :960000], got[:, :960000])[0] <= 1e-3

@@ -103,6 +103,25 @@ def test_two_barrier_kernels_inside_a_three_level_plan(pack):
     assert float(np.max(np.abs(a - want))) <= 2e-5 * scale
 
 
+@pytest.mark.parametrize("cols,k,rows", [(625, 2, 2880), (441, 3, 3000), (625, 13, 384), (441, 4, 2500)])
+def test_planner_takes_three_levels_around_any_two_barrier_row_length(pack, cols, k, rows):
+    """Files beyond ~100 s: N / 2 = C x k x L with C = 625 or 441 columns on k_col_wl and rows of L points on k_row_wl (150 s at 48 kHz
+    = 625 x 2 x 2880, 180 s at 44.1 kHz = 441 x 3 x 3000, ...) -- the planner's own choice when no two-level plan has such columns;
+    against the stage-by-stage kernels on the same split and, where the host transform is quick, the oracle."""
+    from egregora_amd import fatllama_engine as fe
+    n = 2 * cols * k * rows
+    info = fe.plan_info(n, 1)
+    assert (info["M1"], info["M2"], info["M3"], info["levels"]) == (cols, k, rows, 3), info
+    x = synth(1, n, seed=cols + k + rows)
+    a = run(x, 2, wl=True)
+    c = run(x, 2, wl=False, split=(cols, k, rows))
+    scale = float(np.max(np.abs(c)))
+    assert np.isfinite(a).all() and float(np.max(np.abs(a - c))) <= 4e-6 * scale and rms(a - c) <= 4e-7 * scale
+    if n <= 1500000:
+        want = ofl.enhance_channels(x, 1, 2, 0.6, normalize=False, autoscale=False)
+        assert float(np.max(np.abs(a - want))) <= 2e-5 * scale
+
+
 INNER = [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 21, 22, 24, 25, 26, 27, 28, 30, 32, 33, 35, 36, 39, 40, 42, 44, 45, 48, 49, 50,
          52, 54, 55, 56, 60, 63, 64, 72, 80, 90, 96, 100, 120, 144]
 
