@@ -361,3 +361,20 @@ def test_120s_plan_625x4608_on_the_generic_row_kernel_and_the_filters(pack):
     f = np.fft.rfftfreq(n, 1.0 / 48000)
     ref = 10.0 * np.log10(X[f >= 8000.0].sum() / (X.sum() + 1e-20) + 1e-20)
     assert abs(got - ref) <= 1e-3, (got, ref)
+
+
+@pytest.mark.parametrize("n,plan", [(7200000, (625, 2, 2880)), (5292000, (441, 2, 3000))])
+def test_single_pass_users_of_the_new_three_level_plans(pack, n, plan):
+    """The plans the round-4 planner takes for files beyond ~100 s (150 s at 48 kHz, 120 s at 44.1 kHz) also serve the single-pass
+    users of a plan (egr_band_filter / egr_spectral_gain: forward passes + gain hook + inverse passes on the stage-by-stage
+    kernels): the high-band energy ratio of the null-test node against numpy's rfft, on the planner's own plan."""
+    from egregora_amd import device_ops as ops, fatllama_engine as fe
+    info = fe.plan_info(n, 1)
+    assert (info["M1"], info["M2"], info["M3"]) == plan, info
+    x = synth(1, n, seed=n % 977)
+    xt = torch.from_numpy((x / 32768.0).astype(np.float32)).cuda()
+    got = ops.band_energy_hi_db(xt, 48000, 8000.0)
+    X = np.abs(np.fft.rfft(x[0].astype(np.float64) / 32768.0)) ** 2
+    f = np.fft.rfftfreq(n, 1.0 / 48000)
+    ref = 10.0 * np.log10(X[f >= 8000.0].sum() / (X.sum() + 1e-20) + 1e-20)
+    assert abs(got - ref) <= 1e-3, (got, ref)
