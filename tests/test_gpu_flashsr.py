@@ -668,6 +668,40 @@ def test_full_size_rows_of_different_level_in_one_pass_vs_float64(pack):
     e.close()
 
 
+def test_bench_shape_26_rows_in_two_row_groups_vs_float64(pack):
+    """The FlashSR stage of the headline bench at ITS OWN shape: 26 full-size rows (60 s stereo = 13 chunks x 2 channels) through
+    egr_flashsr_infer, which runs them as two concurrent 13-row groups on the handle's side streams (own scratch arena each) -- every
+    row against the float64 run of the same graph (f64_forward_on_gpu), LSD <= 1e-3 dB mean and p95 per row.  Rows at levels from
+    0 to -60 dB, different material per row."""
+    from egregora_amd import flashsr_arch as A, flashsr_engine as E
+    from oracle import metrics as om
+    cfg = A.FlashSRConfig()
+    P = A.init_params(cfg, 0)
+    e = E.FlashSREngine(cfg, P)
+    R_ = 26
+    g = torch.Generator().manual_seed(26)
+    t = torch.arange(cfg.chunk) / cfg.sr
+    rows_ = []
+    for r in range(R_):
+        f0 = 80.0 * (1.0 + 0.37 * r)
+        tone = sum(torch.sin(2 * math.pi * f0 * (k + 1) * t + r + k) / (k + 1) for k in range(5))
+        rows_.append((10.0 ** (-(r % 7) / 2.0)) * (0.5 * tone / tone.abs().max() + 0.03 * torch.randn(cfg.chunk, generator=g)))
+    x = torch.stack(rows_).float()
+    ids = torch.arange(R_, dtype=torch.int64, device="cuda")
+    y = e.c_infer(x.cuda(), ids, 3).cpu()
+    assert bool(torch.isfinite(y).all())
+    nz = e.noise(R_, ids, 3)
+    worst = (0.0, 0.0)
+    for lo in range(0, R_, 13):                 # the float64 graph in two halves (its im2col buffers are 8-byte)
+        exact = f64_forward_on_gpu(x[lo:lo + 13], nchw(nz[lo:lo + 13].cpu()), P, cfg)
+        for r in range(exact.shape[0]):
+            l = om.lsd_audio(exact[r:r + 1].numpy(), y[lo + r:lo + r + 1].numpy())
+            worst = (max(worst[0], l[0]), max(worst[1], l[1]))
+            assert l[0] <= 1e-3 and l[1] <= 1e-3, (lo + r, l)
+    print(f"\n26 rows, two 13-row groups: worst row LSD vs float64 mean / p95 = {worst[0]:.3e} / {worst[1]:.3e} dB")
+    e.close()
+
+
 def test_full_size_engine_shapes_and_determinism(pack):
     """Declared full-size architecture with synthetic weights: one row, shapes + finite output + same-seed repeatability."""
     from egregora_amd import flashsr_arch as A, flashsr_engine as E
