@@ -395,6 +395,34 @@ def test_c3_full_length_800_iterations_against_the_oracle(pack):
         assert lg_plain <= (3.0 if n == 2880000 else 1.0) * lo_plain, (n, lg_plain, lo_plain)
 
 
+def test_60_s_plus_1_sample_stereo_800_iterations_against_float64(pack):
+    """The other half of real files: an ODD length (N = 2 880 001: both channels in ONE chirp-z state as a channel pair, rows of 8192
+    points) at the headline iteration count, against the float64 loop on the GPU.  The host transform at this length is Bluestein's
+    (as at N + 2 in test_c3_full_length_800_iterations_against_the_oracle, whose recorded float32-oracle errors -- max 2.70, rms
+    0.543, plain LSD 1.2e-2 dB at the same data scale -- are the reference here too: same class of transform, same round-off floor)."""
+    from egregora_amd import fatllama_engine as fe
+    n = 2880001
+    info = fe.plan_info(n, 1)
+    assert info.get("chirpz_kind", 0) == 2, info
+    x = synth(2, n, seed=2881)
+    try:
+        exact = f64_loop_on_gpu(x, 800, 0.6)
+    except Exception as ex:      # noqa: BLE001
+        pytest.skip(f"torch.fft in float64 on the GPU is not available here ({ex})")
+    rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
+    got = run_gpu(pack, x, 1, 800, 0.6)
+    scale = float(np.max(np.abs(exact)))
+    mg, rg = float(np.max(np.abs(got - exact))), rms(got - exact)
+    seg = slice(0, 960000)
+    lg, kept = om.lsd_masked(exact[:, seg], got[:, seg], f32_run=got[:, seg], margin_db=F32_MARGIN_DB)
+    lg_plain = om.lsd_audio(exact[:, seg], got[:, seg])[0]
+    print(f"\nN = {n} stereo (channel pair), 800 iterations: max err {mg:.3e} ({mg / scale:.2e} of the peak {scale:.0f}), rms {rg:.3e}; "
+          f"LSD vs float64 plain {lg_plain:.2e} dB, over the {kept:.1%} resolvable bins {lg:.2e} dB")
+    assert np.isfinite(got).all()
+    assert mg <= 2.0 * 2.7021 and mg <= 5e-4 * scale and rg <= 2.5 * 0.54261, (mg, rg, scale)
+    assert lg <= 1e-3 and kept >= 0.01 and lg_plain <= 1.214e-2, (lg, kept, lg_plain)
+
+
 def test_60_s_at_44k1_full_length_800_iterations_against_float64(pack):
     """60 s at 44.1 kHz (N = 2 646 000 = 2 x 441 x 3000) at the headline iteration count: columns on k_col_wl<21, 12>, rows on
     k_row_wl<30, 10> -- both new twiddle runs, so the compounding over 800 iterations is checked at this length too.  Yardstick:
