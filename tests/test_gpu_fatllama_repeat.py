@@ -21,6 +21,10 @@ CONFIGS = [
     ("packed-two-barrier-rows-768", 2, 960000, 1, 3, 0.6, {}),                 # 625 x 768: k_row_wl<12, 8> + k_col_wl
     ("packed-two-barrier-rows-1920", 2, 2400000, 1, 3, 0.6, {}),               # 625 x 1920: k_row_wl<30, 8>
     ("packed-two-barrier-rows-4608", 1, 5760000, 1, 2, 0.6, {}),               # 625 x 4608: k_row_wl<32, 12>, 88 KB of LDS
+    ("packed-441-columns-rows-3000", 2, 2646000, 1, 3, 0.6, {}),               # 441 x 3000: k_col_wl<21, 12> + k_row_wl<30, 10> (60 s at 44.1 kHz)
+    ("packed-441-columns-odd-cross-radix", 2, 1323000, 1, 3, 0.6, {}),         # 441 x 1500: k_row_wl<15, 10>, the spare LDS block of the self-paired row
+    ("packed-odd-cross-radix-even-row-count", 2, 2 * 320 * 960, 1, 3, 0.6, {"split": (320, 960, 1)}),   # k_row_wl<15, 8>, two self-paired rows
+    ("packed-three-level-441", 1, 2 * 441 * 2 * 500, 1, 2, 0.6, {"split": (441, 2, 500)}),             # k_col_wl<21, 12>, inner 2, k_row_wl<5, 10>
     ("packed-relative-soft", 2, 9600, 1, 5, 0.02, {"variant": "relative,soft"}),
     ("chirpz-pairs-odd-centre", 2, 2 * 7919, 1, 4, 0.6, {}),
     ("chirpz-pairs-integer-centre", 2, 4 * 1013, 1, 4, 0.6, {}),
