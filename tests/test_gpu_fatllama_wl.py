@@ -337,6 +337,23 @@ def test_hook_variants_on_other_row_lengths(pack, rows, variant, thr):
     assert rms(a - 2 * y) > 1e-4 * rms(y)
 
 
+@pytest.mark.parametrize("rows,variant,thr", [(3000, "relative,soft", 0.02), (1500, "soft", 50.0), (500, "relative", 0.02)])
+def test_hook_variants_next_to_columns_of_441(pack, rows, variant, thr):
+    """The SPEC.md section 3 variants on the 44.1 kHz plans: k_row_wl<N1, 10, 1> / <N1, 10, 2> (N1 = 30 even, 15 and 5 odd -- the
+    self-paired row of an odd cross radix goes through the LDS hook path with its spare block) against the stage-by-stage kernels."""
+    from egregora_amd import fatllama_engine as fe
+    n = 2 * 441 * rows
+    info = fe.plan_info(n, 1)
+    assert (info["M1"], info["M2"]) == (441, rows), info
+    x = synth(2, n, seed=rows + 3, scale=100.0 if variant == "soft" else 8000.0)
+    a = run(x, 3, thr=thr, wl=True, variant=variant)
+    b = run(x, 3, thr=thr, wl=False, variant=variant)
+    assert np.isfinite(a).all()
+    assert float(np.sum(np.square(a - b, dtype=np.float64))) <= 1e-6 * float(np.sum(np.square(b, dtype=np.float64)))
+    y = x.copy(); y[:, -1] = 0
+    assert rms(a - 2 * y) > 1e-4 * rms(y)
+
+
 def test_120s_plan_625x4608_on_the_generic_row_kernel_and_the_filters(pack):
     """N = 5 760 000 (120 s at 48 kHz) plans as 625 x 4608 -- a row longer than the generic kernels' 4096-point limit, admitted by
     the planner for k_row_wl<32, 12> (csrc/egr_plan.cpp).  The same plan also serves EGR_FL_WL=0 and the single-pass users of the
