@@ -312,6 +312,7 @@ def main():
     assert lsd_iters[0] < 0.05, lsd_iters
     el_c2 = None
     arb = {}
+    other_len = {}
     c4_parts = {}
     c5_len = {}
     if not args.lean:
@@ -335,6 +336,19 @@ def main():
                         "P": info["M"], "split": [info["M1"], info["M2"], info["M3"]], "states": states,
                         "k_pz_rowconv_ms": k3["ms"][0], "k_pzpair_ms": k3["ms"][1], "k_pzcol_crop_ms": k3["ms"][2],
                         "states_per_launch": states // groups}
+        # ---- the Fat-Llama stage on other PACKED lengths: 60 s at 44.1 kHz (441 x 3000) and 150 s at 48 kHz (three levels, 625 x 2 x 2880) ----
+        other_len = {}
+        for tag, n in (("60s_at_44k1", 2646000), ("150s_at_48k", 7200000)):
+            try:
+                xo = (0.25 * torch.randn(C, n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(n % 997))).clamp_(-1.0, 1.0)
+                io = fe.plan_info(n, 1)
+                fe.enhance_device(xo, 1, 20, 0.6, **fl_flags)
+                e_o, yo = timed(lambda: fe.enhance_device(xo, 1, args.iters, 0.6, **fl_flags), 1)
+                assert bool(torch.isfinite(yo).all())
+                other_len[tag] = {"ms": 1e3 * e_o, "samples": n, "iterations": args.iters, "plan": [io["M1"], io["M2"], io["M3"]]}
+                del xo, yo
+            except Exception as ex:      # noqa: BLE001 -- an extra, never the headline
+                other_len[tag] = {"error": str(ex)[:200]}
         # ---- the Fat-Llama stage at BASELINE configs[4]'s length (30 min at 96 kHz: N = 172.8 M samples per channel, stereo, 200
         # iterations): the state (1.38 GB) leaves the memory-side cache, the passes stream from HBM (plan 625 x 60 x 2304) ----
         c5_len = {}
@@ -463,6 +477,7 @@ def main():
                 "fatllama_stage_xrt": audio_s / el_fl, "fatllama_stage_ms": 1e3 * el_fl,
                 "fatllama_arbitrary_length_ms": {k: v["ms"] for k, v in arb.items()} or None,
                 "fatllama_arbitrary_length": arb or None,
+                "fatllama_other_packed_lengths": other_len or None,
                 "chain60_with_arbitrary_length_fatllama_ms": (1e3 * el_fs + arb["60s_plus_2_samples"]["ms"]) if arb else None,
                 "fatllama_configs4_length": c5_len or None,
                 "configs1_flashsr_single_chunk_stereo_xrt": (3 * 5.12 / el_c2) if el_c2 else None,
