@@ -94,7 +94,10 @@ __device__ __forceinline__ float wl_pair_hook(const cplx Za, const cplx Zb, cons
 template <int N1, int Q> struct WlRow {
     static constexpr int QQ = Q * Q, L = N1 * QQ;
     static constexpr int TS = Q + 2;                                   // row stride of the Q x Q transpose (even: 16-byte accesses)
-    static constexpr int S = Q * TS + 4;                               // LDS block stride in elements (>= QQ and >= Q TS)
+    // LDS block stride in elements (>= QQ and >= Q TS).  Q = 10: six 80-byte lane groups per wave access -- a stride of 138 elements
+    // (1104 bytes = 80 mod 256) lays them end to end over the banks (two-way, the minimum) where 124 stacked three of them:
+    // 60 s at 44.1 kHz 29.9 -> 28.7 ms (profiles/r04/fatllama_c3_experiments.log)
+    static constexpr int S = Q == 10 ? 138 : Q * TS + 4;
     static constexpr int RS = N1 * S;
     static constexpr int LWAVES = (N1 + 64 / Q - 1) / (64 / Q);       // waves of the local step
     static constexpr int UPW = (N1 + LWAVES - 1) / LWAVES;             // units (block pairs) per wave, balanced
