@@ -541,6 +541,13 @@ def main():
                 "survey_32N": {"bytes_total": 32.0 * a["samples"] * C * args.iters,
                                "achieved": 32.0 * a["samples"] * C * args.iters / (a["ms"] * 1e6),
                                "frac": 32.0 * a["samples"] * C * args.iters / (a["ms"] * 1e6) / HBM_PEAK_GBS}}
+        if os.environ.get("EGREGORA_BENCH_ONE_GPU", "0") == "1":
+            # a test-only override (tests/test_gpu_bench_ranks.py): every rank shared device 0 and the collectives ran over gloo.  The line
+            # says so and carries no headline number, so a leaked environment variable cannot pass for a multi-GPU measurement.
+            out["one_gpu_override"] = True
+            out["value_one_gpu_override"] = out["value"]
+            out["value"] = None
+            out["note"] = "EGREGORA_BENCH_ONE_GPU=1: all %d ranks on ONE device, gloo collectives -- a path check, not a measurement" % world
         if not args.no_cpu_baseline and world == 1:
             def gpu_c1(c1, sr1, cpu_out):
                 from packload import load_pack as _lp

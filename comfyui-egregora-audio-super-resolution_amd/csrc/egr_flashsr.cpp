@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -45,6 +46,9 @@ enum { EW_ADD = 0, EW_AXPBY = 1, EW_SILU = 2, EW_SCALE = 3, EW_COPY = 4, EW_ADD_
 // block may be handed out again as soon as the host has enqueued its last consumer (stream order does the rest).  After the first
 // forward of a given row count no allocation reaches the runtime, and the footprint stays near the peak of simultaneously live
 // activations (exact-size free lists, the first version, held 47 GB for a 26-row pass; this holds the live peak + slab slack).
+static double g_arena_malloc_ms = 0.0;   // host time spent in the arenas' hipMalloc calls (EGR_FSR_TRACE=1 prints it per call)
+static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 struct Arena {
     struct Slab {
         char* base = nullptr;
@@ -72,6 +76,8 @@ struct Arena {
         if (!best) {
             Slab s;
             s.size = std::max(bytes, (size_t)1 << 31);                      // 2 GiB slabs, or one request if larger
+            const double t0 = now_ms();
+            struct T { double t0; ~T() { g_arena_malloc_ms += now_ms() - t0; } } timer{t0};
             if (hipMalloc((void**)&s.base, s.size) != hipSuccess) {
                 s.size = bytes;                                             // memory is tight: exactly what is needed
                 if (hipMalloc((void**)&s.base, s.size) != hipSuccess) {
@@ -179,6 +185,7 @@ struct FsrCtx {
     // whole when a forward starts
     unsigned* rs_pool = nullptr;
     size_t rs_cap = 0, rs_used = 0;
+    std::vector<unsigned*> rs_retired;                // pools outgrown in mid-forward: still read by enqueued kernels, freed when the next forward starts
     unsigned* rs_ones = nullptr;                      // "maximum 1.0" for every row (operands known to lie in [0, 1]: soft-max outputs); rs_ones_rows entries
     int rs_ones_rows = 0;
 };
@@ -490,7 +497,16 @@ const void* s3_of(const M* m, const Wt* w, int Cin, const float* x) {
 // R-entry slice of the context's pool of per-row maxima (zero at the start of the forward)
 unsigned* rs_take(M* m) {
     FsrCtx* c = m->cx;
-    if (c->rs_used + (size_t)m->R * EGR_ROW_AMAX_STRIDE > c->rs_cap) { set_error("FlashSR: pool of per-row operand maxima exhausted (%zu entries)", c->rs_cap); return nullptr; }
+    if (c->rs_used + (size_t)m->R * EGR_ROW_AMAX_STRIDE > c->rs_cap) {
+        // the start-of-forward size is a heuristic over the layer table; a graph that measures more tensors than it allowed for gets a
+        // second, larger pool here (zeroed on the forward's stream) instead of a failed call -- the next forward starts at that size
+        const size_t grown = std::max(2 * c->rs_cap, (size_t)64 * m->R * EGR_ROW_AMAX_STRIDE);
+        unsigned* np = nullptr;
+        if (hipMalloc((void**)&np, grown * sizeof(unsigned)) != hipSuccess) { set_error("FlashSR: hipMalloc(row maxima pool, %zu entries) failed", grown); return nullptr; }
+        if (hipMemsetAsync(np, 0, grown * sizeof(unsigned), m->st) != hipSuccess) { hipFree(np); set_error("FlashSR: hipMemsetAsync(row maxima pool) failed"); return nullptr; }
+        if (c->rs_pool) c->rs_retired.push_back(c->rs_pool);
+        c->rs_pool = np; c->rs_cap = grown; c->rs_used = 0;
+    }
     unsigned* p = c->rs_pool + c->rs_used;
     c->rs_used += (size_t)m->R * EGR_ROW_AMAX_STRIDE;
     return p;
@@ -682,7 +698,7 @@ int conv_winograd(M* m, Ten& y, const Ten& x, const std::string& key, int act, c
     const int silu = act == ACT_SILU ? 1 : 0;
     // fp16 operand scheme: the output transform leaves the per-row maxima of y (it may feed a 1x1 / strided / phase convolution)
     float* y_ra = nullptr;
-    if (f4 && m->h2 && m->h2_mode == 1 && B == m->R) {
+    if (f4 && m->h2 && m->h2_mode == 1 && m->out_amax_on && B == m->R) {
         y.rs = rs_take(m);
         if (!y.rs) return EGR_ERR_ALLOC;
         y_ra = (float*)y.rs;
@@ -1255,7 +1271,14 @@ int forward(M* m, const float* x_in, const float* noise, int R, int lowpass_on, 
     m->R = R;
     if (m->h2_mode == 1) {                         // per-row operand maxima of this forward: one zeroed pool per context
         FsrCtx* cx = m->cx;
-        const size_t need = (size_t)(2 * m->h2_nweights + 64) * (size_t)R * EGR_ROW_AMAX_STRIDE;
+        size_t slices = (size_t)(2 * m->h2_nweights + 64);
+        if (const char* e = getenv("EGR_FSR_RS_POOL_SLICES")) { const int v = atoi(e); if (v >= 1) slices = (size_t)v; }   // test knob: start small, exercise the growth in rs_take
+        const size_t need = slices * (size_t)R * EGR_ROW_AMAX_STRIDE;
+        if (!cx->rs_retired.empty()) {                 // pools a previous forward outgrew (rs_take): its kernels are done once the stream is
+            hipStreamSynchronize(m->st);
+            for (unsigned* q : cx->rs_retired) hipFree(q);
+            cx->rs_retired.clear();
+        }
         if (cx->rs_cap < need) {
             if (cx->rs_pool) { hipStreamSynchronize(m->st); hipFree(cx->rs_pool); cx->rs_pool = nullptr; cx->rs_cap = 0; }
             if (hipMalloc((void**)&cx->rs_pool, need * sizeof(unsigned)) != hipSuccess) { set_error("hipMalloc(row maxima pool) failed"); return EGR_ERR_ALLOC; }
@@ -1366,6 +1389,7 @@ extern "C" int egr_flashsr_destroy(egr_flashsr* m) {
         for (auto& kv : c->lp_plans) egr_fatllama_plan_destroy(kv.second);
         if (c->gn_ws) hipFree(c->gn_ws);
         if (c->rs_pool) hipFree(c->rs_pool);
+        for (unsigned* q : c->rs_retired) hipFree(q);
         if (c->rs_ones) hipFree(c->rs_ones);
         if (c->done) hipEventDestroy(c->done);
         if (i > 0 && c->st) hipStreamDestroy(c->st);
@@ -1450,9 +1474,9 @@ extern "C" int egr_flashsr_set_rows_per_pass(egr_flashsr* m, int rows) {
 extern "C" int egr_flashsr_forward(egr_flashsr* m, const float* x, const float* noise, int rows, int lowpass, float* y, float* const* stages,
                                    void* stream) {
     EGR_CHECK(m && x && noise && y && rows >= 1, EGR_ERR_ARG, "egr_flashsr_forward: null / empty argument");
+    ForwardGuard guard(m->device, (hipStream_t)stream);
     m->ctxs[0]->st = (hipStream_t)stream;
     m->use(m->ctxs[0].get());
-    ForwardGuard guard(m->device, m->st);
     // the introspection walk stays on the three-term kernels (bit-equal to the operator API) unless egr_flashsr_set_split(h, 2) asked
     // for the fp16 operand terms here too (stage taps for the tests)
     m->h2_mode = (m->h2 && m->h2_fwd && m->h2_nweights > 0) ? 1 : -1;
@@ -1484,6 +1508,7 @@ static int ensure_side_streams(egr_flashsr* m, hipStream_t caller, int want) {
             for (auto& kv : m->ctxs[i]->lp_plans) egr_fatllama_plan_destroy(kv.second);
             if (m->ctxs[i]->gn_ws) hipFree(m->ctxs[i]->gn_ws);
             if (m->ctxs[i]->rs_pool) hipFree(m->ctxs[i]->rs_pool);
+            for (unsigned* q : m->ctxs[i]->rs_retired) hipFree(q);
             if (m->ctxs[i]->rs_ones) hipFree(m->ctxs[i]->rs_ones);
             if (m->ctxs[i]->done) hipEventDestroy(m->ctxs[i]->done);
             hipStreamDestroy(m->ctxs[i]->st);
@@ -1511,18 +1536,16 @@ static int ensure_side_streams(egr_flashsr* m, hipStream_t caller, int want) {
 // handle's verified side streams, each with its own scratch arena (fork / join by events around the pass): one group's
 // matrix-bound kernels overlap another's HBM-bound ones and fill each other's tails (26 rows: 260 ms in one forward).
 static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uint64_t seed, const int64_t* row_ids, int64_t id_base, float* y,
-                      void* stream);
+                      void* stream, int h2_mode);
 
 extern "C" int egr_flashsr_infer(egr_flashsr* m, const float* x, int rows, int lowpass, uint64_t seed, const int64_t* row_ids, float* y,
                                  void* stream) {
     EGR_CHECK(m && x && y && rows >= 1, EGR_ERR_ARG, "egr_flashsr_infer: null / empty argument");
     // operand scheme of this call's forwards: two fp16 terms with per-row device-side scales (see the h2 fields of the handle), or
     // three bf16 terms.  Either way the call only enqueues work: no read-back, no host synchronisation.
-    m->h2_mode = (m->h2 && m->h2_nweights > 0 && !m->count_flops) ? 1 : -1;
-    if (m->h2_mode == 1) ++m->h2_calls;
-    const int rc = infer_once(m, x, rows, lowpass, seed, row_ids, 0, y, stream);
-    m->h2_mode = -1;
-    return rc;
+    // (the scheme is handed to infer_once, which publishes it in the handle only while it holds the device's forward lock)
+    const int h2_mode = (m->h2 && m->h2_nweights > 0 && !m->count_flops) ? 1 : -1;
+    return infer_once(m, x, rows, lowpass, seed, row_ids, 0, y, stream, h2_mode);
 }
 
 // enabled: egr_flashsr_infer runs the fp16 operand terms on this handle; weights: contraction weights that hold fp16 terms;
@@ -1548,11 +1571,16 @@ extern "C" int egr_flashsr_set_split(egr_flashsr* m, int scheme) {
 
 // rows of one call; row_ids NULL: implicit ids id_base .. id_base + rows - 1
 static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uint64_t seed, const int64_t* row_ids, int64_t id_base, float* y,
-                      void* stream) {
+                      void* stream, int h2_mode) {
     hipStream_t st0 = (hipStream_t)stream;
+    ForwardGuard guard(m->device, st0);                  // everything below touches per-handle state: inside the device's forward lock
+    struct ModeScope {                                   // the operand scheme of THIS call, visible to the operators while the lock is held
+        egr_flashsr* m;
+        ModeScope(egr_flashsr* mm, int mode) : m(mm) { m->h2_mode = mode; if (mode == 1) ++m->h2_calls; }
+        ~ModeScope() { m->h2_mode = -1; }
+    } mode_scope(m, h2_mode);
     m->ctxs[0]->st = st0;
     m->use(m->ctxs[0].get());
-    ForwardGuard guard(m->device, st0);
     const egr_flashsr_config& c = m->cfg;
     const int64_t per_row = (int64_t)m->lat_h * m->lat_w * c.z_ch;
     // scratch budget: fewer rows per pass instead of an allocation failure next to the host's other models
@@ -1563,11 +1591,17 @@ static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uin
         const double per_row_bytes = m->arena_row_bytes > 0.0 ? m->arena_row_bytes : est;
         rpp = std::max(1, std::min(rpp, (int)(m->arena_cap / per_row_bytes)));
     }
+    static const bool trace = getenv("EGR_FSR_TRACE") && atoi(getenv("EGR_FSR_TRACE")) != 0;
+    const double t_enter = now_ms(), malloc0 = g_arena_malloc_ms;
+    double t_side = 0.0;
     int groups_max = m->profiling ? 1 : m->max_groups;          // per-kernel timing wants the kernels alone on the chip
-    if (groups_max > 1 && std::min(rows, rpp) >= 2 * m->min_group_rows)
+    if (groups_max > 1 && std::min(rows, rpp) >= 2 * m->min_group_rows) {
+        const double t0 = now_ms();
         groups_max = std::min(m->max_groups, 1 + ensure_side_streams(m, st0, groups_max - 1));   // side contexts of an earlier, wider setting stay idle
-    else
+        t_side = now_ms() - t0;
+    } else {
         groups_max = 1;
+    }
     if (groups_max > 1 && !m->ev_fork) EGR_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     int rc = EGR_OK;
     // passes of equal size (260 rows at 32 per pass: nine passes of 29 / 28 rows instead of eight of 32 and one of 4)
@@ -1601,6 +1635,8 @@ static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uin
         for (auto& cx : m->ctxs) tot += (double)cx->arena.total;
         m->arena_row_bytes = std::max(m->arena_row_bytes, tot / std::min(per, rows));
     }
+    if (trace) fprintf(stderr, "[egr_flashsr_infer] rows %d: host %.1f ms (side-stream check %.1f, arena hipMalloc %.1f), arenas %.2f GB\n", rows,
+                       now_ms() - t_enter, t_side, g_arena_malloc_ms - malloc0, (double)egr_flashsr_scratch_bytes(m) / 1e9);
     return rc;
 }
 

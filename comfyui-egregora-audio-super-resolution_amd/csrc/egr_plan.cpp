@@ -7,7 +7,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
+#include <vector>
 #include <string>
 
 #include "egr_common.h"
@@ -196,19 +198,25 @@ FlSplit plan_split(int64_t N, int m1_hint, int tc_hint, int max_col) {
             EGR_WL_ROW_LIST(X)
 #undef X
         };
-        int64_t bl = 0, bc = 0, bk = 0;
+        // A third level costs two more passes over the state per iteration, so it only replaces a two-level plan the planner itself
+        // prices as slow (columns beyond 640 points: 4-column tiles; rows beyond 2560) -- 150 s at 48 kHz, 1800 x 4000 -> 625 x 2 x 2880.
+        const bool two_level_is_fine = best.ok && best.M1 <= 640 && best.M2 <= 2560;
+        struct Cand { int64_t L, cols, k; };
+        std::vector<Cand> cands;
         for (int64_t cols : {625LL, 441LL})
             for (int L : wl_rows) {
                 if (M % (cols * L)) continue;
                 const int64_t k = M / (cols * L);
                 FftDesc fk;
                 if (k < 2 || k > MAX_COL_INNER || !make_schedule((int)k, &fk)) continue;
-                if (L > bl) { bl = L; bc = cols; bk = k; }
+                cands.push_back({(int64_t)L, cols, k});
             }
-        if (bl) {
-            FlSplit sp = plan_split_explicit(N, (int)bc, (int)bk, (int)bl, 0);
-            if (sp.ok) return sp;
-        }
+        std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.L != b.L ? a.L > b.L : a.cols > b.cols; });
+        if (!two_level_is_fine)
+            for (const Cand& c : cands) {                  // longest row first; a length the explicit plan refuses falls through to the next
+                FlSplit sp = plan_split_explicit(N, (int)c.cols, (int)c.k, (int)c.L, 0, 4608);
+                if (sp.ok) return sp;
+            }
     }
     // ---- three levels: M = M1 * M2 * M3 (only when two do not fit) ----
     if (!best.ok) {

@@ -219,8 +219,13 @@ class FlashSREngine:
 
 
 # ---------------------------------------------------------------------------------------------------- module state
-_ENGINES: Dict[int, FlashSREngine] = {}       # device index -> engine (one C handle per device)
+# _ENGINES: device index -> engine (one C handle per device), plus ("slot", i) -> engine for position i of EGREGORA_DEVICES when a
+# device index repeats there ("0,0": two handles on one GPU -- a handle serves one host thread at a time).  Every read-modify-write
+# of the two globals happens under _LOCK; worker threads never build engines (infer_spans_devices resolves them on the caller's
+# thread before it starts the workers), so the checkpoints are read ONCE per process whatever the device count.
+_ENGINES: Dict[object, FlashSREngine] = {}
 _SOURCE: Optional[Tuple[arch.FlashSRConfig, Dict[str, torch.Tensor]]] = None    # host state dict, kept only while more devices may need a copy
+_LOCK = threading.RLock()
 ROWS_PER_PASS = int(os.environ.get("EGREGORA_FLASHSR_ROWS", "32"))
 SEED = int(os.environ.get("EGREGORA_FLASHSR_SEED", "0"))
 
@@ -258,6 +263,41 @@ def _load_source():
     return cfg, params
 
 
+def _build_engine(cfg, params, dev: int) -> "FlashSREngine":
+    """One engine on `dev` from the host state dict (a separate function so that the tests can count / slow down builds)."""
+    eng = FlashSREngine(cfg, params, device=f"cuda:{dev}")
+    eng.handle                                               # egr_flashsr_create now, on this thread: nothing is left for a worker to build
+    return eng
+
+
+def _slot_keys(devs: List[int]) -> List[object]:
+    """Registry key of every position of a device list: the device index the first time it appears, ("slot", i) for a repeat --
+    "0,0" is two handles (a handle serves one host thread at a time), "0,1,2" is one per device."""
+    seen, keys = set(), []
+    for i, d in enumerate(devs):
+        keys.append(d if d not in seen else ("slot", i))
+        seen.add(d)
+    return keys
+
+
+def _ensure(keys_devs: List[Tuple[object, int]]) -> List["FlashSREngine"]:
+    """Engines for (registry key, device) pairs, built serially under the module lock from ONE load of the checkpoints."""
+    global _SOURCE
+    with _LOCK:
+        missing = [(k, d) for k, d in keys_devs if k not in _ENGINES]
+        if missing:
+            native.require_device()
+            if _SOURCE is None:
+                _SOURCE = _load_source()
+            cfg, params = _SOURCE
+            for k, d in missing:
+                if k not in _ENGINES:                        # a key may repeat in the request
+                    _ENGINES[k] = _build_engine(cfg, params, d)
+            if all(k in _ENGINES for k in _slot_keys(devices())):
+                _SOURCE = None                               # every handle that will be used holds its packed copy: drop the host state dict
+        return [_ENGINES[k] for k, _ in keys_devs]
+
+
 def ensure_ready(device: Optional[int] = None) -> FlashSREngine:
     """Build the engine of `device` (default: the current one) once per process (the reference rebuilds the model on every run(),
     :393).  Weight sources, in order:
@@ -268,42 +308,35 @@ def ensure_ready(device: Optional[int] = None) -> FlashSREngine:
       3. otherwise the reference's "weights missing" error (:314-317).
     The layer table always comes from the checkpoint's own tensor shapes (flashsr_arch.config_from_params).  Seeded synthetic
     weights are for benches and tests only and are never picked up here: those callers build a FlashSREngine themselves and
-    install it with set_engine()."""
-    global _SOURCE
+    install it with set_engine().  Thread-safe: concurrent callers serialise on the module lock and the checkpoints are read once."""
     dev = torch.cuda.current_device() if device is None and torch.cuda.is_available() else (device or 0)
-    if dev in _ENGINES:
-        return _ENGINES[dev]
-    native.require_device()
-    if _SOURCE is None:
-        _SOURCE = _load_source()
-    cfg, params = _SOURCE
-    _ENGINES[dev] = FlashSREngine(cfg, params, device=f"cuda:{dev}")
-    if all(d in _ENGINES for d in devices()):
-        _SOURCE = None                       # every device that will be used holds its packed copy: drop the host state dict
-    return _ENGINES[dev]
+    eng = _ENGINES.get(dev)                                  # (a plain dict read: safe next to a locked writer under the GIL)
+    return eng if eng is not None else _ensure([(dev, dev)])[0]
+
+
+def engines_for(devs: List[int]) -> List[FlashSREngine]:
+    """One engine per POSITION of `devs` (a repeated device index gets its own handle), resolved or built on the calling thread."""
+    return _ensure(list(zip(_slot_keys(devs), devs)))
 
 
 def set_engine(engine: Optional[FlashSREngine]):
     """Install a prebuilt engine for its device (benches, tests); None forgets every engine."""
     global _SOURCE
-    if engine is None:
-        _ENGINES.clear()
-        _SOURCE = None
-    else:
-        _ENGINES[engine.dev.index] = engine
+    with _LOCK:
+        if engine is None:
+            _ENGINES.clear()
+            _SOURCE = None
+        else:
+            _ENGINES[engine.dev.index] = engine
 
 
 def set_engines(engines: List[FlashSREngine], devs: Optional[List[int]] = None):
-    """Install one prebuilt engine per entry of `devs` (default: each engine's own device).  With a repeated device index the
-    entries are keyed by POSITION in EGREGORA_DEVICES (see _engine_for)."""
-    _ENGINES.clear()
-    for i, e in enumerate(engines):
-        _ENGINES[("slot", i)] = e
-        _ENGINES.setdefault(e.dev.index if devs is None else devs[i], e)
-
-
-def _engine_for(slot: int, dev: int) -> FlashSREngine:
-    return _ENGINES.get(("slot", slot)) or ensure_ready(dev)
+    """Install one prebuilt engine per entry of `devs` (default: each engine's own device), keyed as engines_for() looks them up."""
+    devs = [e.dev.index for e in engines] if devs is None else list(devs)
+    with _LOCK:
+        _ENGINES.clear()
+        for k, e in zip(_slot_keys(devs), engines):
+            _ENGINES[k] = e
 
 
 def infer_rows(eng: FlashSREngine, rows_x: torch.Tensor, row_ids: torch.Tensor, seed: int,
@@ -350,13 +383,13 @@ def infer_spans_devices(x_ct: torch.Tensor, n_chunks: int, win: int, hop: int, l
     home = x_ct.device
     out = torch.empty((n_chunks, Cn, win), dtype=torch.float32, device=home)
     torch.cuda.current_stream(home).synchronize()            # x_ct is complete before another device's stream reads it
-    jobs = [(i, d, lo, hi) for i, (d, (lo, hi)) in enumerate(zip(devs, balanced_bounds(n_chunks, len(devs)))) if hi > lo]
+    engs = engines_for(devs)                                 # built here, serially, from one load of the checkpoints: the workers only run
+    jobs = [(engs[i], d, lo, hi) for i, (d, (lo, hi)) in enumerate(zip(devs, balanced_bounds(n_chunks, len(devs)))) if hi > lo]
     errors: List[BaseException] = []
 
-    def work(slot: int, d: int, lo: int, hi: int):
+    def work(eng: FlashSREngine, d: int, lo: int, hi: int):
         try:
             with torch.cuda.device(d):
-                eng = _engine_for(slot, d)
                 xd = x_ct if torch.device("cuda", d) == home else x_ct.to(torch.device("cuda", d), non_blocking=True)
                 preds = infer_block(xd, lo, hi, win, hop, lowpass, eng)
                 out[lo:hi].copy_(preds, non_blocking=True)   # the gather: a peer copy into the stitching device's tensor

@@ -53,6 +53,12 @@ def test_abi_version_and_host_only_planning(pack):
     long48 = fe.plan_info(9600000, 1)           # 200 s at 48 kHz: three levels around the two-barrier kernels (625 columns, rows of 3840)
     assert (long48["M1"], long48["M2"], long48["M3"]) == (625, 2, 3840)
     assert fe.plan_info(28800000, 1)["levels"] == 3
+    #  rows of 4608 are a candidate of the three-level family too (338.7 s at 48 kHz = 441 x 4 x 4608), and a third
+    # level -- two more passes per iteration -- never displaces a two-level plan the planner prices as fine (23.4 s: 500 x 1125)
+    l46 = fe.plan_info(16257024, 1)
+    assert (l46["M1"], l46["M2"], l46["M3"]) == (441, 4, 4608)
+    short = fe.plan_info(1125000, 1)
+    assert short["levels"] == 2 and short["M1"] <= 640 and short["M2"] <= 2560
 
 
 def test_planner_matches_python_model_schedule(pack):

@@ -24,6 +24,8 @@ def test_two_ranks_share_one_gpu_and_report_one_line():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    print(f"\n2 ranks on one GPU: {out['value']:.1f} xRT, {out['ms_per_step']:.1f} ms per step (two 60 s files, 40 Fat-Llama iterations)")
+    print(f"\n2 ranks on one GPU: {out['value_one_gpu_override']:.1f} xRT, {out['ms_per_step']:.1f} ms per step (two 60 s files, 40 Fat-Llama iterations)")
     assert out["n_gpus"] == 2 and out["steps"] == 1 and out["scaling"] == "weak"
-    assert out["value"] > 0 and out["unit"] == "audio-sec/sec"
+    # the override is written into the line and the headline field is withheld: a leaked variable cannot pass for a 2-GPU number
+    assert out["one_gpu_override"] is True and out["value"] is None and "ONE device" in out["note"]
+    assert out["value_one_gpu_override"] > 0 and out["unit"] == "audio-sec/sec"

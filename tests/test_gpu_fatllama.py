@@ -424,7 +424,8 @@ def test_60_s_plus_1_sample_stereo_800_iterations_against_float64(pack):
 
 
 @pytest.mark.parametrize("n,iters,plan", [(2646000, 800, (441, 3000, 1)), (1323000, 800, (441, 1500, 1)), (5760000, 400, (625, 4608, 1)),
-                                          (7200000, 200, (625, 2, 2880)), (5292000, 200, (441, 2, 3000))])
+                                          (7200000, 200, (625, 2, 2880)), (5292000, 200, (441, 2, 3000)),
+                                          (16257024, 50, (441, 4, 4608))])
 def test_round_4_plans_at_full_length_against_float64(pack, n, iters, plan):
     """The plans round 4 added, at full length and hundreds of iterations (their twiddle runs are new, so the compounding is
     checked per plan): 60 s at 44.1 kHz (columns on k_col_wl<21, 12>, rows on k_row_wl<30, 10>) and 30 s (odd cross radix 15) at

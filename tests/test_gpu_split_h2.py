@@ -298,6 +298,23 @@ def test_infer_is_a_pure_function_of_its_rows(pack):
         e_.close()
 
 
+def test_pool_of_row_maxima_grows_instead_of_failing_the_call(pack, monkeypatch):
+    """the per-forward pool of row-maximum slices is sized by a heuristic over the layer table; a graph that measures
+    more tensors than it allowed for used to fail egr_flashsr_infer with EGR_ERR_ALLOC.  With the pool started at TWO slices
+    (EGR_FSR_RS_POOL_SLICES, a test knob) the call grows it in mid-forward -- several times -- and returns the same bits."""
+    cfg, (ea, eb) = _engines(2)
+    x = (0.05 * torch.randn(3, cfg.chunk, generator=torch.Generator().manual_seed(12))).cuda()
+    want = ea.c_infer(x, None, 4)
+    monkeypatch.setenv("EGR_FSR_RS_POOL_SLICES", "2")
+    got = eb.c_infer(x, None, 4)
+    assert torch.equal(got, want)
+    assert torch.equal(eb.c_infer(x, None, 4), want)        # the next forward starts at the grown size (retired pools are freed there)
+    monkeypatch.delenv("EGR_FSR_RS_POOL_SLICES")
+    assert torch.equal(eb.c_infer(x, None, 4), want)
+    for e_ in (ea, eb):
+        e_.close()
+
+
 def test_rows_sharded_over_two_handles_are_bit_identical(pack):
     """A world-2 shard in one process: handle A takes rows 0..6, handle B rows 7..13 (each rank of shard.sharded_chunks owns its
     own handle); together they reproduce the 14-row call of ONE handle -- which runs the same two 7-row forwards as concurrent row

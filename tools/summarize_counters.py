@@ -4,7 +4,7 @@ import csv, glob, sys
 from collections import defaultdict
 
 out = sys.argv[1]
-for d, keep in (("pmc_mfma", ("k_conv_s3", "k_conv1d_s3", "k_bgemm_s3", "k_wino4", "k_conv_igemm")), ("pmc_wait", ("k_row", "k_col"))):
+for d, keep in (("pmc_mfma", ("k_conv_s3", "k_conv1d_s3", "k_conv3x3_is", "k_conv1d_rb", "k_bgemm_s3", "k_wino4", "k_conv_igemm", "k_snake")), ("pmc_wait", ("k_row", "k_col", "k_pz"))):
     ps = glob.glob(f"{out}/{d}/**/*counter_collection.csv", recursive=True)
     if not ps:
         print("no counter csv under", d)
