@@ -246,6 +246,11 @@ def main():
 
     cfg = A.FlashSRConfig()
     eng = E.FlashSREngine(cfg, A.init_params(cfg, seed=0))
+    t_build = time.perf_counter()
+    eng.handle
+    eng.warmup(E.WARMUP_ROWS)                               # what flashsr_engine.ensure_ready does for the node: one stereo chunk of silence
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
     E.set_engine(eng)
 
     c4 = args.workload == "c4"
@@ -292,7 +297,16 @@ def main():
     # what the FIRST call of a handle costs (scratch arena allocation, side-stream check; the arithmetic is the steady state's:
     # include/egregora_amd.h egr_flashsr_set_split) -- timed before the warm-up, outside the timed region
     el_first = None
+    el_torch_warm = None
     if args.only != "fatllama" and not args.lean:
+        # torch's own first kernels (arange / mul / add on int64 for the row ids, a copy) load torch's code objects: hundreds of ms that
+        # belong to the HOST runtime -- a ComfyUI process has run them long before this node's first call -- so they are warmed and
+        # reported separately; flashsr_stage_first_call_ms is then what the HANDLE's first call costs
+        t0 = time.perf_counter()
+        ids_w = (torch.arange(0, 4, device="cuda", dtype=torch.int64)[:, None] * 2 + torch.arange(2, device="cuda", dtype=torch.int64)[None, :]).reshape(-1)
+        _ = float(ids_w.sum().item()) + float(x_all[:, :64].contiguous().sum().item())
+        torch.cuda.synchronize()
+        el_torch_warm = time.perf_counter() - t0
         el_first, _ = timed(stage_flashsr, 1)
     for _ in range(args.warmup):
         step()
@@ -472,6 +486,8 @@ def main():
             "parts": {
                 "flashsr_stage_xrt": audio_s / el_fs, "flashsr_stage_ms": 1e3 * el_fs,
                 "flashsr_stage_first_call_ms": (1e3 * el_first) if el_first else None,
+                "torch_runtime_warmup_ms": (1e3 * el_torch_warm) if el_torch_warm else None,
+                "flashsr_handle_build_ms": 1e3 * t_build, "flashsr_warmup_rows": E.WARMUP_ROWS,
                 "node_boundary_ms": node_ms, "node_boundary_xrt": (60.0 / (node_ms * 1e-3)) if node_ms else None,
                 "node_boundary_note": "AUDIO dict (CPU) in -> EgregoraAudioUpscaler.run -> EgregoraFatLlamaGPU.run -> AUDIO dict (CPU) out, 60 s stereo, PCIe and host coercions included",
                 "fatllama_stage_xrt": audio_s / el_fl, "fatllama_stage_ms": 1e3 * el_fl,

@@ -1295,11 +1295,25 @@ int forward(M* m, const float* x_in, const float* noise, int R, int lowpass_on, 
             cx->rs_ones_rows = R;
         }
     }
+    // EGR_FSR_TRACE=2 (diagnosis of first-call costs): synchronise after every stage and print host / device-complete times
+    static const int trace_lv = getenv("EGR_FSR_TRACE") ? atoi(getenv("EGR_FSR_TRACE")) : 0;
+    const bool trace2 = trace_lv >= 2;
+    const double t_fwd = now_ms();
+    auto stage_mark = [&](const char* what) {
+        if (trace_lv == 1) fprintf(stderr, "[egr_flashsr forward R=%d] %-10s enqueued at %8.1f ms\n", R, what, now_ms() - t_fwd);
+        if (!trace2) return;
+        const double t_host = now_ms() - t_fwd;
+        hipStreamSynchronize(m->st);
+        fprintf(stderr, "[egr_flashsr forward R=%d] %-10s enqueued at %8.1f ms, complete at %8.1f ms (arena hipMalloc so far %.1f ms)\n", R, what, t_host,
+                now_ms() - t_fwd, g_arena_malloc_ms);
+    };
     Ten xl;
     if (lowpass_on) { OKR(lowpass(m, xl, x_in, R, c.chunk)); x = xl.p; }
     Ten mel, z_c, v, z0, mel_hat, y;
     OKR(log_mel(m, mel, x, R, c.chunk));
+    stage_mark("log_mel");
     OKR(vae_encode(m, z_c, mel));
+    stage_mark("vae_encode");
     {
         Ten nz, cat;                               // non-owning view of the caller's noise
         nz.view({R, m->lat_h, m->lat_w, c.z_ch});
@@ -1308,8 +1322,11 @@ int forward(M* m, const float* x_in, const float* noise, int R, int lowpass_on, 
         OKR(unet(m, v, std::move(cat)));
         OKR(eltwise(m, z0, nz, v.p, EW_AXPBY, m->alpha, -m->sigma));
     }
+    stage_mark("unet");
     OKR(vae_decode(m, mel_hat, z0));
+    stage_mark("vae_decode");
     OKR(vocoder(m, y, mel_hat, x, R));
+    stage_mark("vocoder");
     if (stages) {
         OKR(copy_out(m, stages[0], mel)); OKR(copy_out(m, stages[1], z_c)); OKR(copy_out(m, stages[2], v));
         OKR(copy_out(m, stages[3], z0)); OKR(copy_out(m, stages[4], mel_hat)); OKR(copy_out(m, stages[5], y));
@@ -1647,6 +1664,21 @@ extern "C" int egr_flashsr_set_arena_cap(egr_flashsr* m, double bytes) {
     EGR_CHECK(m && bytes >= 0.0, EGR_ERR_ARG, "bad argument");
     m->arena_cap = bytes;
     return EGR_OK;
+}
+
+extern "C" int egr_flashsr_warmup(egr_flashsr* m, int rows, void* stream) {
+    EGR_CHECK(m && rows >= 1, EGR_ERR_ARG, "bad argument");
+    const size_t n = (size_t)rows * m->cfg.chunk;
+    float* buf = nullptr;
+    if (hipMalloc((void**)&buf, 2 * n * sizeof(float)) != hipSuccess) { set_error("egr_flashsr_warmup: hipMalloc(%zu) failed", 2 * n * sizeof(float)); return EGR_ERR_ALLOC; }
+    int rc = EGR_OK;
+    if (hipMemsetAsync(buf, 0, n * sizeof(float), (hipStream_t)stream) != hipSuccess) rc = EGR_ERR_HIP;
+    const int64_t calls = m->h2_calls;
+    if (rc == EGR_OK) rc = egr_flashsr_infer(m, buf, rows, 0, 0, nullptr, buf + n, stream);
+    m->h2_calls = calls;                                 // (split_info counts the host's calls)
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess && rc == EGR_OK) { set_error("egr_flashsr_warmup: device work failed"); rc = EGR_ERR_HIP; }
+    hipFree(buf);
+    return rc;
 }
 
 extern "C" int egr_flashsr_set_streams(egr_flashsr* m, int max_groups, int min_group_rows) {

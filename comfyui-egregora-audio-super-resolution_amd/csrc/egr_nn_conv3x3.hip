@@ -1,0 +1,499 @@
+// Input-stationary 3x3 convolutions of the two-term fp16 operand scheme (scheme 1 of egr_nn_gemm_s3.hip) -- a translation unit of
+// their own so that the kernels can be rebuilt (and built in variants, tools/build_variant.sh) without the implicit-GEMM family.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "egr_conv.h"
+#include "egr_s3_split.h"
+
+// ------------------------------------------------------------------------------------------------------------------
+// Stride-1 pad-1 3x3 convolution, input-stationary in two dimensions (scheme 1 only): the 128-channel level of the VAE
+// (512 x 256 images) is HBM-bound as an F(4x4) pipeline -- V and M, 2.25x the tensor each, are written and read back: ~19 GB per
+// layer against 3.5 GB of activations -- and as an implicit GEMM every activation is loaded and split nine times.  Here a workgroup
+// owns 4 image rows x 32 pixels (the 128 GEMM rows of its tile = four 32-pixel MFMA sub-tiles, one image row each), splits the
+// (4 + 2) x (32 + 2) halo patch of a 32-channel chunk ONCE into LDS -- with the producer's GroupNorm (+ SiLU) applied on the way
+// (gn_scale / gn_shift per (image, channel); zero padding after it, as the reference pads the normalised tensor) -- and the nine
+// taps read their operands from it at row offsets (ky * 34 + kx).  x is read once (1.6x from L2), y written once; weights stream
+// through double-buffered LDS tiles exactly as in k_conv1d_s3.  With the GroupNorm fused the operand scale comes from a BOUND of
+// the normalised row (row_amax holds max |gn_scale| * max |x| + max |gn_shift|, csrc/egr_nn_ops.hip k_gn_bound): the scale only has
+// to put the row's maximum somewhere in [1, 2^15), and the bound is within a few bits of the true maximum.
+namespace egr {
+
+#ifdef C3_TIMING
+// dev (tools/build_variant.sh ... -DC3_TIMING): shader-clock sums over all waves of k_conv3x3_is -- barrier wait, operand-read wait, MFMA
+// phase, halo phase, loop, epilogue, wave count; read back through egr_debug_c3_timing
+__device__ unsigned long long c3_timing[8];
+#endif
+template <int BN, int CC, bool GN>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_is(ConvP p) {
+    typedef S3Cfg<128, BN> TC;
+    constexpr int TM = TC::TM, TN = TC::TN, NCH = CC / 8, NSL = CC / 16, PW = 34, PR = 6, RMAX = PR * PW;
+    constexpr int NP = 2;
+    static_assert(CC == 32, "one tap of a channel chunk = two 16-k weight slabs = one barrier");
+    __shared__ uint4 As[NP][RMAX * NCH];
+    __shared__ uint4 Bs[2][NSL][NP][BN * 2];     // the weight tiles of one TAP of the chunk (32 k): one barrier per 24 MFMAs per wave
+    __shared__ float os_tab[128];
+    __shared__ unsigned om_tab[1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm0 = (wave / TC::WN) * (128 / TC::WM), wn0 = (wave % TC::WN) * (BN / TC::WN);
+    const int tiles_x = p.W / 32;
+    const int b = blockIdx.z, ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, n0 = blockIdx.y * BN;
+    const int y0 = ty * 4, x0 = tx * 32;
+    const float* xb = p.x + (size_t)b * p.H * p.W * p.Cin;
+    const unsigned abits = p.row_amax[(size_t)b * EGR_ROW_AMAX_STRIDE];
+    const float a_scale = h2_row_scale(abits);
+    if (tid < 128) os_tab[tid] = h2_row_inv(abits);
+    if (tid == 0) om_tab[0] = 0u;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    constexpr int NBQ = 2 * NP * BN;             // chunks of ONE 16-k slab
+    const size_t b_slab = (size_t)p.Cout * 2 * NP;
+    const int cpt = p.Cin / 16;                  // slabs per tap in the weight pack
+#define C3_BSETUP(I, OFF, SLOT, OK)                                                                               \
+    size_t OFF;                                                                                                      \
+    int SLOT;                                                                                                        \
+    bool OK;                                                                                                         \
+    {                                                                                                                \
+        const int e = tid + 256 * (I);                                                                               \
+        const int plane = e / (2 * BN), rem = e - plane * 2 * BN, nl = rem >> 1, half = rem & 1;                     \
+        OK = e < NBQ && n0 + nl < p.Cout;                                                                            \
+        SLOT = plane * (BN * 2) + nl * 2 + (half ^ ((nl >> 3) & 1));                                                 \
+        OFF = ((size_t)plane * p.Cout + n0 + nl) * 2 + half;                                                         \
+    }
+    C3_BSETUP(0, boff0, bslot0, bok0)
+    C3_BSETUP(1, boff1, bslot1, bok1)
+#undef C3_BSETUP
+    static_assert(NBQ <= 512, "two weight chunks per thread and slab");
+    const uint4* zq = (const uint4*)p.zeros;
+    struct StageB { uint4 b0, b1, b2, b3; };     // (b0, b1): slab 0 of the tap, (b2, b3): slab 1
+    StageB sA, sB;
+    sA.b0 = sA.b1 = sA.b2 = sA.b3 = sB.b0 = sB.b1 = sB.b2 = sB.b3 = make_uint4(0, 0, 0, 0);
+    const int nchunks = p.Cin / CC, wtotal = nchunks * 9;       // wide slabs: (chunk, tap)
+    auto load_b = [&](int ws, StageB& r) {
+        const int cc = ws / 9, tap = ws - cc * 9;
+        const uint4* base = p.w3 + (size_t)(tap * cpt + cc * NSL) * b_slab;
+        r.b0 = bok0 ? base[boff0] : zq[0];
+        r.b2 = bok0 ? base[b_slab + boff0] : zq[0];
+        if (256 < NBQ) {
+            r.b1 = bok1 ? base[boff1] : zq[0];
+            r.b3 = bok1 ? base[b_slab + boff1] : zq[0];
+        }
+    };
+    auto store_b = [&](int buf, const StageB& r) {
+        if (tid < NBQ) { Bs[buf][0][0][bslot0] = r.b0; Bs[buf][1][0][bslot0] = r.b2; }
+        if (tid + 256 < NBQ) { Bs[buf][0][0][bslot1] = r.b1; Bs[buf][1][0][bslot1] = r.b3; }
+    };
+    const int li = lane & 31, lk = lane >> 5;
+    const int ob_slot = li * 2 + (lk ^ ((li >> 3) & 1));
+
+    // one tap of one channel chunk; `nx` holds the weight tiles of wide slab ws + 1 and is refilled with those of ws + 3
+#ifdef C3_TIMING
+    unsigned long long tm_bar = 0, tm_rd = 0, tm_mm = 0, tm_halo = 0, tm_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long tm_start = tm_last;
+#endif
+    auto slab = [&](int ws, StageB& nx) {
+        const int cur = ws & 1;
+        const int cc = ws / 9, tap = ws - cc * 9;
+#ifdef C3_TIMING
+        { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm_mm += t - tm_last; tm_last = t; }
+#endif
+#ifdef C3_ABL_NOHALO
+        if (ws == 0) {
+#else
+        if (tap == 0) {                          // new channel chunk: its halo patch -> LDS
+#endif
+            const int c0 = cc * CC;
+            constexpr int NIT = (RMAX * NCH + 255) / 256;
+            float4 hu[NIT], hv[NIT];
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int e = tid + 256 * i;
+                const int r = e / NCH, ch = e - r * NCH, pr = r / PW, pc = r - pr * PW;
+                const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
+                const bool ok = e < RMAX * NCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const float* src = ok ? xb + ((size_t)iy * p.W + ix) * p.Cin + c0 + ch * 8 : p.zeros;
+                hu[i] = *(const float4*)src;
+                hv[i] = *(const float4*)(src + 4);
+            }
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int e = tid + 256 * i;
+                if (e < RMAX * NCH) {
+                    const int r = e / NCH, ch = e - r * NCH;
+                    if (GN) {
+                        const int pr = r / PW, pc = r - pr * PW;
+                        const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
+                        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                        const float* gs = p.gn_scale + (size_t)b * p.Cin + c0 + ch * 8;
+                        const float* gh = p.gn_shift + (size_t)b * p.Cin + c0 + ch * 8;
+                        const float4 sa = *(const float4*)gs, sb = *(const float4*)(gs + 4), ha = *(const float4*)gh, hb = *(const float4*)(gh + 4);
+                        float v[8] = {fmaf(hu[i].x, sa.x, ha.x), fmaf(hu[i].y, sa.y, ha.y), fmaf(hu[i].z, sa.z, ha.z), fmaf(hu[i].w, sa.w, ha.w),
+                                      fmaf(hv[i].x, sb.x, hb.x), fmaf(hv[i].y, sb.y, hb.y), fmaf(hv[i].z, sb.z, hb.z), fmaf(hv[i].w, sb.w, hb.w)};
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            if (p.gn_silu) v[q] = v[q] / (1.f + __expf(-v[q]));
+                            if (!ok) v[q] = 0.f;                 // zero padding applies AFTER the normalisation
+                        }
+                        hu[i] = make_float4(v[0], v[1], v[2], v[3]);
+                        hv[i] = make_float4(v[4], v[5], v[6], v[7]);
+                    }
+                    uint4 q[3];
+                    split_x8<1>(hu[i], hv[i], a_scale, q);
+                    const int slot = r * NCH + (ch ^ ((r / (16 / NCH)) & (NCH - 1)));
+                    As[0][slot] = q[0];
+                    As[1][slot] = q[1];
+                }
+            }
+        }
+#ifdef C3_TIMING
+        { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm_halo += t - tm_last; tm_last = t; }
+#endif
+        __syncthreads();                         // weight tiles `cur` (stored one iteration ago) and the halo patch are visible
+#ifdef C3_TIMING
+        { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm_bar += t - tm_last; tm_last = t; }
+#endif
+        const int ky = tap / 3, kx = tap - ky * 3;
+        uint4 bq[NSL][TN][2], aq[NSL][TM][2];
+#pragma unroll
+        for (int cs = 0; cs < NSL; ++cs) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) bq[cs][j][q] = Bs[cur][cs][q][(wn0 + j * 32) * 2 + ob_slot];
+            const int ch = cs * 2 + lk;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = ((wm0 >> 5) + i + ky) * PW + li + kx;       // sub-tile (wm0 / 32 + i) = image row y0 + that
+                const int slot = r * NCH + (ch ^ ((r / (16 / NCH)) & (NCH - 1)));
+#pragma unroll
+                for (int q = 0; q < NP; ++q) aq[cs][i][q] = As[q][slot];
+            }
+        }
+#ifdef C3_TIMING
+        { __builtin_amdgcn_s_waitcnt(0xc07f); const unsigned long long t = __builtin_amdgcn_s_memtime(); tm_rd += t - tm_last; tm_last = t; }   // lgkmcnt(0): operands landed
+#endif
+#ifndef C3_ABL_NOB
+        if (ws + 1 < wtotal) store_b(cur ^ 1, nx);
+        if (ws + 3 < wtotal) load_b(ws + 3, nx);
+#endif
+        // weights as the first operand: transposed accumulators, 16-byte stores (conv_epilogue_t)
+#define C3_MMA(CS, QA, QB)                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =            \
+        __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(bq[CS][j][QB]), as_hf(aq[CS][i][QA]), acc[i][j], 0, 0, 0);
+#ifndef C3_ABL_NOMMA
+        C3_MMA(0, 1, 0)
+        C3_MMA(0, 0, 1)
+        C3_MMA(0, 0, 0)
+        C3_MMA(1, 1, 0)
+        C3_MMA(1, 0, 1)
+        C3_MMA(1, 0, 0)
+#else
+        _Pragma("unroll") for (int cs = 0; cs < NSL; ++cs) _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) { acc[i][j][q] += __uint_as_float(bq[cs][j][q].x ^ aq[cs][i][q].y); acc[i][j][q + 2] += __uint_as_float(bq[cs][j][q].z ^ aq[cs][i][q].w); }
+#endif
+#undef C3_MMA
+        if (tap == 8) __syncthreads();           // last tap of the chunk: everyone is done with the halo patch
+    };
+
+    load_b(0, sA);
+    store_b(0, sA);
+    if (1 < wtotal) load_b(1, sA);
+    if (2 < wtotal) load_b(2, sB);
+    int ws = 0;
+    for (; ws + 1 < wtotal; ws += 2) {
+        slab(ws, sA);
+        slab(ws + 1, sB);
+    }
+    if (ws < wtotal) slab(ws, sA);
+    // tile rows are image rows: GEMM row of (sub-tile t, pixel px) = (b H + y0 + t) W + x0 + px -> row stride W between sub-tiles
+#ifdef C3_TIMING
+    const unsigned long long tm_loop_end = __builtin_amdgcn_s_memtime();
+#endif
+    unsigned* const om = p.out_amax ? om_tab : nullptr;
+    // (sub-tile rows start at multiples of 32 in x: m / 32 is the partial-statistics unit (b H + y) (W / 32) + x / 32)
+#ifdef C3_ABL_NOEPI
+    {   // one value per thread keeps the accumulators alive
+        float sacc = 0.f;
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 1.2345e-30f) p.y[tid] = sacc;
+    }
+#else
+    conv_epilogue_t<TM, TN>(p, acc, (b * p.H + y0) * p.W + x0, n0, wm0, wn0, os_tab, om, p.W, p.gn_part);
+    if (om) out_amax_commit(p, om_tab, (b * p.H + y0) * p.W + x0, 1);
+#endif
+#ifdef C3_TIMING
+    if (lane == 0) {
+        const unsigned long long tm_end = __builtin_amdgcn_s_memtime();
+        const unsigned long long v[8] = {tm_bar, tm_rd, tm_mm, tm_halo, tm_loop_end - tm_start, tm_end - tm_loop_end, tm_start, tm_end};
+        for (int q = 0; q < 6; ++q) atomicAdd(&c3_timing[q], v[q]);
+        atomicAdd(&c3_timing[6], 1ull);
+    }
+#endif
+}
+
+// ---- k_conv3x3_isp: the same convolution with the halo patch of channel chunk c + 1 prepared WHILE chunk c multiplies ----
+// k_conv3x3_is stops its matrix pipe at every chunk boundary: the global loads of the 6 x 34 patch (an HBM / MALL round trip), the
+// fused GroupNorm + SiLU (an IEEE division per element), the operand split and the LDS stores all sit between two barriers -- about
+// a third of a workgroup's time, with nothing to cover it but the second workgroup of the CU.  Here the patch is DOUBLE-buffered in
+// LDS (2 x 26 KB; the weight tiles shrink to one 16-k slab per buffer, 16 KB: 68.5 KB per workgroup, still two per CU) and every
+// step of the phase is a compile-time position in the slab sequence of the PREVIOUS chunk.  A chunk is 18 slabs (9 taps x two
+// 16-k halves: an even number, so the weight buffer and the register stage of every slab are compile-time constants and each slab
+// is ONE basic block):
+//   slab 0              the patch of chunk c + 1 is requested (8 float4 per thread);
+//   slabs 4, 6, 8, 10   one of the thread's four patch items per slab is normalised, activated (x * rcp(1 + exp(-x)): v_rcp_f32,
+//                       1 ulp -- the operand keeps 22 bits), split into its two fp16 terms and stored into the OTHER patch buffer:
+//                       ~70 VALU instructions and two ds_write_b128 next to the slab's 12 MFMAs, in the matrix pipe's shadow;
+//   the barrier that opens chunk c + 1 publishes the patch -- nothing of the phase is left between barriers.
+// Weight tiles are fetched and stored unconditionally (the last slabs re-fetch the last tile): no run-time branch inside a slab.
+#define C3P_MAX_CIN 512                                      // channels whose GroupNorm coefficients the kernel stages in LDS
+template <int BN, int CC, bool GN, bool SILU>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_isp(ConvP p) {
+    typedef S3Cfg<128, BN> TC;
+    constexpr int TM = TC::TM, TN = TC::TN, NCH = CC / 8, NSL = CC / 16, PW = 34, PR = 6, RMAX = PR * PW;
+    constexpr int NP = 2, NIT = (RMAX * NCH + 255) / 256, SPC = 9 * NSL;      // SPC: slabs per chunk
+    static_assert(CC == 32 && NIT == 4 && 256 % NCH == 0 && SPC % 2 == 0, "four patch items per thread, all of one 8-channel group");
+    __shared__ uint4 As[2][NP][RMAX * NCH + 8];           // (+ 8 dump slots: threads without a fourth patch item store there, branch-free)
+    __shared__ uint4 Bs[2][NP][BN * 2];
+    __shared__ float os_tab[128];
+    __shared__ unsigned om_tab[1];
+    // GroupNorm scale / shift of this image's channels, staged once: the conversion slabs read them with ds_read (lgkmcnt) -- a global
+    // load there would make the slab wait vmcnt(0), i.e. for the weight tiles it has just requested (one L2 round trip per slab)
+    __shared__ float4 gn_tab[GN ? 2 * (C3P_MAX_CIN / 4) : 1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm0 = (wave / TC::WN) * (128 / TC::WM), wn0 = (wave % TC::WN) * (BN / TC::WN);
+    const int tiles_x = p.W / 32;
+    const int b = blockIdx.z, ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, n0 = blockIdx.y * BN;
+    const int y0 = ty * 4, x0 = tx * 32;
+    const float* xb = p.x + (size_t)b * p.H * p.W * p.Cin;
+    const unsigned abits = p.row_amax[(size_t)b * EGR_ROW_AMAX_STRIDE];
+    const float a_scale = h2_row_scale(abits);
+    if (tid < 128) os_tab[tid] = h2_row_inv(abits);
+    if (tid == 0) om_tab[0] = 0u;
+    if (GN) {
+        for (int i = tid; i < p.Cin / 4; i += 256) {
+            gn_tab[i] = ((const float4*)(p.gn_scale + (size_t)b * p.Cin))[i];
+            gn_tab[C3P_MAX_CIN / 4 + i] = ((const float4*)(p.gn_shift + (size_t)b * p.Cin))[i];
+        }
+        __syncthreads();
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- weight tiles: one 16-k slab = NP planes x BN channels x 2 halves 16-byte chunks, up to two per thread ----
+    constexpr int NBQ = 2 * NP * BN;
+    static_assert(NBQ <= 512, "two weight chunks per thread and slab");
+    const size_t b_slab = (size_t)p.Cout * 2 * NP;
+    const int cpt = p.Cin / 16;                  // slabs per tap in the weight pack
+#define C3_BSETUP(I, OFF, SLOT, OK)                                                                               \
+    size_t OFF;                                                                                                      \
+    int SLOT;                                                                                                        \
+    bool OK;                                                                                                         \
+    {                                                                                                                \
+        const int e = tid + 256 * (I);                                                                               \
+        const int plane = e / (2 * BN), rem = e - plane * 2 * BN, nl = rem >> 1, half = rem & 1;                     \
+        OK = e < NBQ && n0 + nl < p.Cout;                                                                            \
+        SLOT = plane * (BN * 2) + nl * 2 + (half ^ ((nl >> 3) & 1));                                                 \
+        OFF = ((size_t)plane * p.Cout + n0 + nl) * 2 + half;                                                         \
+    }
+    C3_BSETUP(0, boff0, bslot0, bok0)
+    C3_BSETUP(1, boff1, bslot1, bok1)
+#undef C3_BSETUP
+    const uint4* zq = (const uint4*)p.zeros;
+    struct StageB { uint4 b0, b1; };
+    StageB sA, sB;
+    sA.b0 = sA.b1 = sB.b0 = sB.b1 = make_uint4(0, 0, 0, 0);
+    const int nchunks = p.Cin / CC;
+    // the tile of slab s of chunk cc (s may run past the chunk: the next chunk's first slabs; past the end: the last tile again)
+    auto load_b = [&](int cc, int s, StageB& r) {
+        if (s >= SPC) { s -= SPC; ++cc; }
+        if (cc >= nchunks) { cc = nchunks - 1; s = SPC - 1; }
+        const int tap = s / NSL, cs = s - tap * NSL;
+        const uint4* base = p.w3 + (size_t)(tap * cpt + cc * NSL + cs) * b_slab;
+        r.b0 = bok0 ? base[boff0] : zq[0];
+        if (256 < NBQ) r.b1 = bok1 ? base[boff1] : zq[0];
+    };
+    auto store_b = [&](int buf, const StageB& r) {
+        if (NBQ >= 256 || tid < NBQ) Bs[buf][0][bslot0] = r.b0;            // (compile-time true for the wide tile: no exec-mask branch)
+        if (NBQ >= 512 || tid + 256 < NBQ) Bs[buf][0][bslot1] = r.b1;
+    };
+    const int li = lane & 31, lk = lane >> 5;
+    const int ob_slot = li * 2 + (lk ^ ((li >> 3) & 1));
+
+    // ---- the thread's four patch items: the same pixels for every channel chunk ----
+    const int hch = tid & (NCH - 1);
+    int hoff0, hoff1, hoff2, hoff3, hslot0, hslot1, hslot2, hslot3;
+    bool hok0, hok1, hok2, hok3;
+#define C3_HSETUP(I, OFF, SLOT, OK)                                                                                  \
+    {                                                                                                                \
+        const int e = tid + 256 * (I);                                                                               \
+        const int r = e / NCH, pr = r / PW, pc = r - pr * PW;                                                        \
+        const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;                                                                \
+        OK = e < RMAX * NCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;                        \
+        OFF = OK ? (iy * p.W + ix) * p.Cin + hch * 8 : hch * 8;                                                      \
+        SLOT = e < RMAX * NCH ? r * NCH + (hch ^ ((r / (16 / NCH)) & (NCH - 1))) : RMAX * NCH + (tid & 7);                \
+    }
+    C3_HSETUP(0, hoff0, hslot0, hok0)
+    C3_HSETUP(1, hoff1, hslot1, hok1)
+    C3_HSETUP(2, hoff2, hslot2, hok2)
+    C3_HSETUP(3, hoff3, hslot3, hok3)
+#undef C3_HSETUP
+    float4 hu0, hv0, hu1, hv1, hu2, hv2, hu3, hv3;          // the floats of the patch items between request and conversion
+    auto halo_issue = [&](int cc_in) {
+        const int c0 = min(cc_in, nchunks - 1) * CC;
+        const float* s0 = xb + hoff0 + c0; const float* s1 = xb + hoff1 + c0; const float* s2 = xb + hoff2 + c0; const float* s3 = xb + hoff3 + c0;
+        hu0 = *(const float4*)s0; hv0 = *(const float4*)(s0 + 4);
+        hu1 = *(const float4*)s1; hv1 = *(const float4*)(s1 + 4);
+        hu2 = *(const float4*)s2; hv2 = *(const float4*)(s2 + 4);
+        hu3 = *(const float4*)s3; hv3 = *(const float4*)(s3 + 4);
+    };
+    // GroupNorm + SiLU + zero padding + split of one item, straight into patch buffer `abuf` (a thread without the item writes a dump slot)
+    auto halo_finish = [&](const float4& u, const float4& v, bool ok, int slot, int cc_in, int abuf) {
+        float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+        if (GN) {
+            const int q0 = (min(cc_in, nchunks - 1) * CC + hch * 8) >> 2;
+            const float4 gsa = gn_tab[q0], gsb = gn_tab[q0 + 1], gha = gn_tab[C3P_MAX_CIN / 4 + q0], ghb = gn_tab[C3P_MAX_CIN / 4 + q0 + 1];
+            const float sc[8] = {gsa.x, gsa.y, gsa.z, gsa.w, gsb.x, gsb.y, gsb.z, gsb.w};
+            const float sh[8] = {gha.x, gha.y, gha.z, gha.w, ghb.x, ghb.y, ghb.z, ghb.w};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                x[q] = fmaf(x[q], sc[q], sh[q]);
+                if (SILU) x[q] = x[q] * __builtin_amdgcn_rcpf(1.f + __expf(-x[q]));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = ok ? x[q] : 0.f;  // zero padding applies AFTER the normalisation
+        uint4 q[3];
+        split_x8<1>(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), a_scale, q);
+        As[abuf][0][slot] = q[0];
+        As[abuf][1][slot] = q[1];
+    };
+
+    // slab S (compile-time) of chunk cc: tap S / 2, 16-k half S % 2; reads weight buffer S & 1 and patch buffer cc & 1; the register
+    // stage of its parity holds the tile of slab S + 1 and is refilled with that of S + 3
+    auto slab = [&](auto s_c, int cc) {
+        constexpr int S = decltype(s_c)::value, cur = S & 1, TAP = S / NSL, CS = S % NSL;
+        constexpr int ky = TAP / 3, kx = TAP - ky * 3;
+        StageB& nx = cur ? sB : sA;
+        const int ab = cc & 1;
+        __syncthreads();                         // weight tile `cur` (stored one slab ago) and, at slab 0, the patch of this chunk are visible
+        uint4 bq[TN][2], aq[TM][2];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) bq[j][q] = Bs[cur][q][(wn0 + j * 32) * 2 + ob_slot];
+        const int ch = CS * 2 + lk;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r = ((wm0 >> 5) + i + ky) * PW + li + kx;       // sub-tile (wm0 / 32 + i) = image row y0 + that
+            const int slot = r * NCH + (ch ^ ((r / (16 / NCH)) & (NCH - 1)));
+#pragma unroll
+            for (int q = 0; q < NP; ++q) aq[i][q] = As[ab][q][slot];
+        }
+        store_b(cur ^ 1, nx);
+        load_b(cc, S + 3, nx);
+        if (S == 0) halo_issue(cc + 1);
+        if (S == 4) halo_finish(hu0, hv0, hok0, hslot0, cc + 1, ab ^ 1);
+        if (S == 6) halo_finish(hu1, hv1, hok1, hslot1, cc + 1, ab ^ 1);
+        if (S == 8) halo_finish(hu2, hv2, hok2, hslot2, cc + 1, ab ^ 1);
+        if (S == 10) halo_finish(hu3, hv3, hok3, hslot3, cc + 1, ab ^ 1);
+        // weights as the first operand: transposed accumulators, 16-byte stores (conv_epilogue_t)
+#define C3_MMA(QA, QB)                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =            \
+        __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(bq[j][QB]), as_hf(aq[i][QA]), acc[i][j], 0, 0, 0);
+        C3_MMA(1, 0)
+        C3_MMA(0, 1)
+        C3_MMA(0, 0)
+#undef C3_MMA
+        if (S == 4 || S == 6 || S == 8 || S == 10) {
+            // the item's ~70 VALU / transcendental instructions go BETWEEN the slab's MFMAs, six per MFMA (the machine scheduler
+            // otherwise issues them as one block in front: ~350 cycles in which this wave feeds nothing to the matrix pipe)
+#pragma unroll
+            for (int k = 0; k < TM * TN * 3; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);
+            }
+        }
+    };
+    auto chunk = [&](int cc) {
+#define C3_S(N) slab(std::integral_constant<int, N>(), cc);
+        C3_S(0) C3_S(1) C3_S(2) C3_S(3) C3_S(4) C3_S(5) C3_S(6) C3_S(7) C3_S(8)
+        C3_S(9) C3_S(10) C3_S(11) C3_S(12) C3_S(13) C3_S(14) C3_S(15) C3_S(16) C3_S(17)
+#undef C3_S
+    };
+    static_assert(SPC == 18, "chunk() lists the 18 slabs of a chunk");
+
+    // prologue: the patch of chunk 0 and the first weight tiles
+    halo_issue(0);
+    load_b(0, 0, sA);
+    store_b(0, sA);
+    load_b(0, 1, sA);
+    load_b(0, 2, sB);
+    halo_finish(hu0, hv0, hok0, hslot0, 0, 0);
+    halo_finish(hu1, hv1, hok1, hslot1, 0, 0);
+    halo_finish(hu2, hv2, hok2, hslot2, 0, 0);
+    halo_finish(hu3, hv3, hok3, hslot3, 0, 0);
+    for (int cc = 0; cc < nchunks; ++cc) chunk(cc);
+    unsigned* const om = p.out_amax ? om_tab : nullptr;
+    conv_epilogue_t<TM, TN>(p, acc, (b * p.H + y0) * p.W + x0, n0, wm0, wn0, os_tab, om, p.W, p.gn_part);
+    if (om) out_amax_commit(p, om_tab, (b * p.H + y0) * p.W + x0, 1);
+}
+
+// true when the input-stationary 3x3 kernel applies (scheme 1, big images); launches it
+bool launch_conv3x3_is(const ConvP& p, hipStream_t st) {
+    static const bool off = getenv("EGR_S3_CONV3X3") && atoi(getenv("EGR_S3_CONV3X3")) == 0;
+    if (off || !p.sch || !p.w3 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.dil != 1 || p.pad_t != 1 || p.pad_l != 1 || p.up2 ||
+        p.OH != p.H || p.OW != p.W || (p.W % 32) != 0 || (p.H % 4) != 0 || (p.Cin % 32) != 0 || (p.Cout % 4) != 0 || p.ksplit > 1 ||
+        p.zs_nzb > 0 || p.nz > 1 || p.osy != 1 || p.osx != 1 || p.OHF != p.OH || p.OWF != p.OW || p.bias_b || p.B > 65535 ||
+        p.rows_div != p.H * p.W || (long long)(p.H / 4) * (p.W / 32) * p.B < 512)
+        return false;
+    const int bn = p.Cout > 64 ? 128 : 64;
+    const dim3 grid((p.H / 4) * (p.W / 32), (p.Cout + bn - 1) / bn, p.B);
+    // EGR_S3_CONV3X3 = 1: the round-4 kernel (halo phase between two barriers); default: the pipelined one (k_conv3x3_isp)
+    static const bool piped = !(getenv("EGR_S3_CONV3X3") && atoi(getenv("EGR_S3_CONV3X3")) == 1);
+    if (piped && (size_t)p.H * p.W * p.Cin < ((size_t)1 << 31) && p.Cin <= C3P_MAX_CIN) {
+        if (p.gn_scale && p.gn_silu) {
+            if (bn == 128) hipLaunchKernelGGL((k_conv3x3_isp<128, 32, true, true>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((k_conv3x3_isp<64, 32, true, true>), grid, dim3(256), 0, st, p);
+        } else if (p.gn_scale) {
+            if (bn == 128) hipLaunchKernelGGL((k_conv3x3_isp<128, 32, true, false>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((k_conv3x3_isp<64, 32, true, false>), grid, dim3(256), 0, st, p);
+        } else {
+            if (bn == 128) hipLaunchKernelGGL((k_conv3x3_isp<128, 32, false, false>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((k_conv3x3_isp<64, 32, false, false>), grid, dim3(256), 0, st, p);
+        }
+        return true;
+    }
+    if (p.gn_scale) {
+        if (bn == 128) hipLaunchKernelGGL((k_conv3x3_is<128, 32, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_conv3x3_is<64, 32, true>), grid, dim3(256), 0, st, p);
+    } else {
+        if (bn == 128) hipLaunchKernelGGL((k_conv3x3_is<128, 32, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_conv3x3_is<64, 32, false>), grid, dim3(256), 0, st, p);
+    }
+    return true;
+}
+
+}  // namespace egr
+
+
+#ifdef C3_TIMING
+extern "C" int egr_debug_c3_timing(unsigned long long* out8, int reset) {
+    if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(egr::c3_timing), 8 * sizeof(unsigned long long));
+    if (reset) { const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(egr::c3_timing), z, sizeof(z)); }
+    return 0;
+}
+#endif

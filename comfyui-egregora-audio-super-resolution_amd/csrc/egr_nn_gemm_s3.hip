@@ -20,97 +20,9 @@
 #include <type_traits>
 
 #include "egr_conv.h"
+#include "egr_s3_split.h"
 
 namespace egr {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-#define S3_BM 128
-#define S3_BK 16
-
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {        // RNE; a -> bits 0..15, b -> bits 16..31
-    f32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-
-// (a, b) -> packed bf16 pairs of the three split terms
-__device__ __forceinline__ void split3_pair(float a, float b, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
-    p0 = pk_bf16(a, b);
-    const float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);
-    p1 = pk_bf16(ra, rb);
-    const float sa = ra - __uint_as_float(p1 << 16), sb = rb - __uint_as_float(p1 & 0xffff0000u);
-    p2 = pk_bf16(sa, sb);
-}
-
-__device__ __forceinline__ void split3_x8(const float4& u, const float4& v, uint4& q0, uint4& q1, uint4& q2) {
-    split3_pair(u.x, u.y, q0.x, q1.x, q2.x);
-    split3_pair(u.z, u.w, q0.y, q1.y, q2.y);
-    split3_pair(v.x, v.y, q0.z, q1.z, q2.z);
-    split3_pair(v.z, v.w, q0.w, q1.w, q2.w);
-}
-
-// ---- scheme 1: two fp16 terms of the pre-scaled operand (x s = h0 + h1, h0 = f16(x s), h1 = f16(x s - h0); s a power of two that
-// brings the tensor's largest magnitude near 2^12, so every element down to 2^-15 of it keeps 22 significand bits and smaller ones
-// an absolute error of 2^-37 of the maximum).  f16 x f16 products are exact in fp32, so  a0 b0 + a0 b1 + a1 b0  carries the fp32
-// product up to a1 b1 and the two term roundings (each < 2^-22 |a b|) with HALF the matrix instructions of the bf16 scheme and
-// one third fewer LDS operand bytes; fewer accumulator roundings per 16 k (3 instead of 6) make the measured error against
-// float64 no larger (tests/test_gpu_split_h2.py).  s is per BATCH ROW and comes from the device: row_amax[b] holds the bits of
-// max |x| of row b (left there by the tensor's producer, or by k_absmax_rows), and h2_row_scale turns its exponent into the power
-// of two that puts the row's maximum in [2^14, 2^15) -- no host round trip, no history, and a quiet row next to a loud one keeps
-// its own 22 bits (csrc/egr_conv.h, csrc/egr_flashsr.cpp).
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ void split2h_pair(float a, float b, float s, uint32_t& p0, uint32_t& p1) {
-    const float as = a * s, bs = b * s;
-    const f32x2 v = {as, bs};
-    const f16x2 hi = __builtin_convertvector(v, f16x2);                // RNE (v_cvt_pk_f16_f32)
-    p0 = __builtin_bit_cast(uint32_t, hi);
-    const f32x2 r = {as - (float)hi[0], bs - (float)hi[1]};            // exact
-    p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
-}
-
-__device__ __forceinline__ void split2h_x8(const float4& u, const float4& v, float s, uint4& q0, uint4& q1) {
-    split2h_pair(u.x, u.y, s, q0.x, q1.x);
-    split2h_pair(u.z, u.w, s, q0.y, q1.y);
-    split2h_pair(v.x, v.y, s, q0.z, q1.z);
-    split2h_pair(v.z, v.w, s, q0.w, q1.w);
-}
-
-// raises *slot (the bits of a non-negative float, which order like unsigned integers) to the wave's maximum
-__device__ __forceinline__ void amax_commit(unsigned* slot, float m) {
-    if (!slot) return;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    const unsigned bits = __float_as_uint(m);
-    if ((threadIdx.x & 63) == 0 && bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
-}
-
-// the operand split of scheme SCH into its NP planes q[0..NP)
-template <int SCH>
-__device__ __forceinline__ void split_x8(const float4& u, const float4& v, float s, uint4 (&q)[3]) {
-    if constexpr (SCH == 0) split3_x8(u, v, q[0], q[1], q[2]);
-    else split2h_x8(u, v, s, q[0], q[1]);
-}
-
-// the partial products of one 32x32x16 block, smallest terms first
-template <int SCH>
-__device__ __forceinline__ void mma_split(const uint4 (&a)[3], const uint4 (&b)[3], f32x16& acc) {
-    if constexpr (SCH == 0) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[2]), __builtin_bit_cast(bf16x8, b[0]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[2]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, b[1]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, b[0]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[1]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]), acc, 0, 0, 0);
-    } else {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[1]), __builtin_bit_cast(f16x8, b[0]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[1]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[0]), acc, 0, 0, 0);
-    }
-}
 
 // packed fp32 weights -> [slab][2][Cout][16] f16 terms of w * scale
 __global__ __launch_bounds__(256) void k_split2h_pack(const float* __restrict__ w, uint4* __restrict__ w2, long long nslabs, int Cout,
@@ -192,18 +104,6 @@ __global__ __launch_bounds__(256) void k_split3_pack(const float* __restrict__ w
         dst[(size_t)Cout * 4] = q2;
     }
 }
-
-// <BM, BN> block tile, 4 waves.  256x128: waves 2x2, each 128x64 (TM 4, TN 2; the large-M workhorse: half the split work and
-// 0.7x the L2 traffic per MFMA of the 128x128 tile).  128xBN: small-M / thin-Cout layers and split-K.
-template <int BM, int BN> struct S3Cfg;
-template <> struct S3Cfg<256, 128> { static constexpr int WM = 2, WN = 2, TM = 4, TN = 2; };
-template <> struct S3Cfg<128, 256> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 4; };   // Cout >= 256: half the A work per MFMA
-template <> struct S3Cfg<128, 128> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 2; };
-template <> struct S3Cfg<128, 64> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 1; };
-template <> struct S3Cfg<128, 32> { static constexpr int WM = 4, WN = 1, TM = 1, TN = 1; };
-
-__device__ __forceinline__ bf16x8 as_bf(const uint4& v) { return __builtin_bit_cast(bf16x8, v); }
-__device__ __forceinline__ f16x8 as_hf(const uint4& v) { return __builtin_bit_cast(f16x8, v); }
 
 // plain tile store (z-streamed GEMMs have no bias / residual / activation / placement)
 template <int TM, int TN, bool OST = false>
@@ -972,209 +872,6 @@ bool launch_conv1d_s3(const ConvP& p, hipStream_t st) {
     }
     if (p.sch) { C1_LAUNCH(1) } else { C1_LAUNCH(0) }
 #undef C1_LAUNCH
-    return true;
-}
-
-}  // namespace egr
-
-// ------------------------------------------------------------------------------------------------------------------
-// Stride-1 pad-1 3x3 convolution, input-stationary in two dimensions (scheme 1 only): the 128-channel level of the VAE
-// (512 x 256 images) is HBM-bound as an F(4x4) pipeline -- V and M, 2.25x the tensor each, are written and read back: ~19 GB per
-// layer against 3.5 GB of activations -- and as an implicit GEMM every activation is loaded and split nine times.  Here a workgroup
-// owns 4 image rows x 32 pixels (the 128 GEMM rows of its tile = four 32-pixel MFMA sub-tiles, one image row each), splits the
-// (4 + 2) x (32 + 2) halo patch of a 32-channel chunk ONCE into LDS -- with the producer's GroupNorm (+ SiLU) applied on the way
-// (gn_scale / gn_shift per (image, channel); zero padding after it, as the reference pads the normalised tensor) -- and the nine
-// taps read their operands from it at row offsets (ky * 34 + kx).  x is read once (1.6x from L2), y written once; weights stream
-// through double-buffered LDS tiles exactly as in k_conv1d_s3.  With the GroupNorm fused the operand scale comes from a BOUND of
-// the normalised row (row_amax holds max |gn_scale| * max |x| + max |gn_shift|, csrc/egr_nn_ops.hip k_gn_bound): the scale only has
-// to put the row's maximum somewhere in [1, 2^15), and the bound is within a few bits of the true maximum.
-namespace egr {
-
-template <int BN, int CC, bool GN>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_is(ConvP p) {
-    typedef S3Cfg<128, BN> TC;
-    constexpr int TM = TC::TM, TN = TC::TN, NCH = CC / 8, NSL = CC / 16, PW = 34, PR = 6, RMAX = PR * PW;
-    constexpr int NP = 2;
-    static_assert(CC == 32, "one tap of a channel chunk = two 16-k weight slabs = one barrier");
-    __shared__ uint4 As[NP][RMAX * NCH];
-    __shared__ uint4 Bs[2][NSL][NP][BN * 2];     // the weight tiles of one TAP of the chunk (32 k): one barrier per 24 MFMAs per wave
-    __shared__ float os_tab[128];
-    __shared__ unsigned om_tab[1];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wm0 = (wave / TC::WN) * (128 / TC::WM), wn0 = (wave % TC::WN) * (BN / TC::WN);
-    const int tiles_x = p.W / 32;
-    const int b = blockIdx.z, ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, n0 = blockIdx.y * BN;
-    const int y0 = ty * 4, x0 = tx * 32;
-    const float* xb = p.x + (size_t)b * p.H * p.W * p.Cin;
-    const unsigned abits = p.row_amax[(size_t)b * EGR_ROW_AMAX_STRIDE];
-    const float a_scale = h2_row_scale(abits);
-    if (tid < 128) os_tab[tid] = h2_row_inv(abits);
-    if (tid == 0) om_tab[0] = 0u;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    constexpr int NBQ = 2 * NP * BN;             // chunks of ONE 16-k slab
-    const size_t b_slab = (size_t)p.Cout * 2 * NP;
-    const int cpt = p.Cin / 16;                  // slabs per tap in the weight pack
-#define C3_BSETUP(I, OFF, SLOT, OK)                                                                               \
-    size_t OFF;                                                                                                      \
-    int SLOT;                                                                                                        \
-    bool OK;                                                                                                         \
-    {                                                                                                                \
-        const int e = tid + 256 * (I);                                                                               \
-        const int plane = e / (2 * BN), rem = e - plane * 2 * BN, nl = rem >> 1, half = rem & 1;                     \
-        OK = e < NBQ && n0 + nl < p.Cout;                                                                            \
-        SLOT = plane * (BN * 2) + nl * 2 + (half ^ ((nl >> 3) & 1));                                                 \
-        OFF = ((size_t)plane * p.Cout + n0 + nl) * 2 + half;                                                         \
-    }
-    C3_BSETUP(0, boff0, bslot0, bok0)
-    C3_BSETUP(1, boff1, bslot1, bok1)
-#undef C3_BSETUP
-    static_assert(NBQ <= 512, "two weight chunks per thread and slab");
-    const uint4* zq = (const uint4*)p.zeros;
-    struct StageB { uint4 b0, b1, b2, b3; };     // (b0, b1): slab 0 of the tap, (b2, b3): slab 1
-    StageB sA, sB;
-    sA.b0 = sA.b1 = sA.b2 = sA.b3 = sB.b0 = sB.b1 = sB.b2 = sB.b3 = make_uint4(0, 0, 0, 0);
-    const int nchunks = p.Cin / CC, wtotal = nchunks * 9;       // wide slabs: (chunk, tap)
-    auto load_b = [&](int ws, StageB& r) {
-        const int cc = ws / 9, tap = ws - cc * 9;
-        const uint4* base = p.w3 + (size_t)(tap * cpt + cc * NSL) * b_slab;
-        r.b0 = bok0 ? base[boff0] : zq[0];
-        r.b2 = bok0 ? base[b_slab + boff0] : zq[0];
-        if (256 < NBQ) {
-            r.b1 = bok1 ? base[boff1] : zq[0];
-            r.b3 = bok1 ? base[b_slab + boff1] : zq[0];
-        }
-    };
-    auto store_b = [&](int buf, const StageB& r) {
-        if (tid < NBQ) { Bs[buf][0][0][bslot0] = r.b0; Bs[buf][1][0][bslot0] = r.b2; }
-        if (tid + 256 < NBQ) { Bs[buf][0][0][bslot1] = r.b1; Bs[buf][1][0][bslot1] = r.b3; }
-    };
-    const int li = lane & 31, lk = lane >> 5;
-    const int ob_slot = li * 2 + (lk ^ ((li >> 3) & 1));
-
-    // one tap of one channel chunk; `nx` holds the weight tiles of wide slab ws + 1 and is refilled with those of ws + 3
-    auto slab = [&](int ws, StageB& nx) {
-        const int cur = ws & 1;
-        const int cc = ws / 9, tap = ws - cc * 9;
-        if (tap == 0) {                          // new channel chunk: its halo patch -> LDS
-            const int c0 = cc * CC;
-            constexpr int NIT = (RMAX * NCH + 255) / 256;
-            float4 hu[NIT], hv[NIT];
-#pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const int e = tid + 256 * i;
-                const int r = e / NCH, ch = e - r * NCH, pr = r / PW, pc = r - pr * PW;
-                const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
-                const bool ok = e < RMAX * NCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const float* src = ok ? xb + ((size_t)iy * p.W + ix) * p.Cin + c0 + ch * 8 : p.zeros;
-                hu[i] = *(const float4*)src;
-                hv[i] = *(const float4*)(src + 4);
-            }
-#pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const int e = tid + 256 * i;
-                if (e < RMAX * NCH) {
-                    const int r = e / NCH, ch = e - r * NCH;
-                    if (GN) {
-                        const int pr = r / PW, pc = r - pr * PW;
-                        const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
-                        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                        const float* gs = p.gn_scale + (size_t)b * p.Cin + c0 + ch * 8;
-                        const float* gh = p.gn_shift + (size_t)b * p.Cin + c0 + ch * 8;
-                        const float4 sa = *(const float4*)gs, sb = *(const float4*)(gs + 4), ha = *(const float4*)gh, hb = *(const float4*)(gh + 4);
-                        float v[8] = {fmaf(hu[i].x, sa.x, ha.x), fmaf(hu[i].y, sa.y, ha.y), fmaf(hu[i].z, sa.z, ha.z), fmaf(hu[i].w, sa.w, ha.w),
-                                      fmaf(hv[i].x, sb.x, hb.x), fmaf(hv[i].y, sb.y, hb.y), fmaf(hv[i].z, sb.z, hb.z), fmaf(hv[i].w, sb.w, hb.w)};
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            if (p.gn_silu) v[q] = v[q] / (1.f + __expf(-v[q]));
-                            if (!ok) v[q] = 0.f;                 // zero padding applies AFTER the normalisation
-                        }
-                        hu[i] = make_float4(v[0], v[1], v[2], v[3]);
-                        hv[i] = make_float4(v[4], v[5], v[6], v[7]);
-                    }
-                    uint4 q[3];
-                    split_x8<1>(hu[i], hv[i], a_scale, q);
-                    const int slot = r * NCH + (ch ^ ((r / (16 / NCH)) & (NCH - 1)));
-                    As[0][slot] = q[0];
-                    As[1][slot] = q[1];
-                }
-            }
-        }
-        __syncthreads();                         // weight tiles `cur` (stored one iteration ago) and the halo patch are visible
-        const int ky = tap / 3, kx = tap - ky * 3;
-        uint4 bq[NSL][TN][2], aq[NSL][TM][2];
-#pragma unroll
-        for (int cs = 0; cs < NSL; ++cs) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int q = 0; q < NP; ++q) bq[cs][j][q] = Bs[cur][cs][q][(wn0 + j * 32) * 2 + ob_slot];
-            const int ch = cs * 2 + lk;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int r = ((wm0 >> 5) + i + ky) * PW + li + kx;       // sub-tile (wm0 / 32 + i) = image row y0 + that
-                const int slot = r * NCH + (ch ^ ((r / (16 / NCH)) & (NCH - 1)));
-#pragma unroll
-                for (int q = 0; q < NP; ++q) aq[cs][i][q] = As[q][slot];
-            }
-        }
-        if (ws + 1 < wtotal) store_b(cur ^ 1, nx);
-        if (ws + 3 < wtotal) load_b(ws + 3, nx);
-        // weights as the first operand: transposed accumulators, 16-byte stores (conv_epilogue_t)
-#define C3_MMA(CS, QA, QB)                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =            \
-        __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(bq[CS][j][QB]), as_hf(aq[CS][i][QA]), acc[i][j], 0, 0, 0);
-        C3_MMA(0, 1, 0)
-        C3_MMA(0, 0, 1)
-        C3_MMA(0, 0, 0)
-        C3_MMA(1, 1, 0)
-        C3_MMA(1, 0, 1)
-        C3_MMA(1, 0, 0)
-#undef C3_MMA
-        if (tap == 8) __syncthreads();           // last tap of the chunk: everyone is done with the halo patch
-    };
-
-    load_b(0, sA);
-    store_b(0, sA);
-    if (1 < wtotal) load_b(1, sA);
-    if (2 < wtotal) load_b(2, sB);
-    int ws = 0;
-    for (; ws + 1 < wtotal; ws += 2) {
-        slab(ws, sA);
-        slab(ws + 1, sB);
-    }
-    if (ws < wtotal) slab(ws, sA);
-    // tile rows are image rows: GEMM row of (sub-tile t, pixel px) = (b H + y0 + t) W + x0 + px -> row stride W between sub-tiles
-    unsigned* const om = p.out_amax ? om_tab : nullptr;
-    // (sub-tile rows start at multiples of 32 in x: m / 32 is the partial-statistics unit (b H + y) (W / 32) + x / 32)
-    conv_epilogue_t<TM, TN>(p, acc, (b * p.H + y0) * p.W + x0, n0, wm0, wn0, os_tab, om, p.W, p.gn_part);
-    if (om) out_amax_commit(p, om_tab, (b * p.H + y0) * p.W + x0, 1);
-}
-
-// true when the input-stationary 3x3 kernel applies (scheme 1, big images); launches it
-bool launch_conv3x3_is(const ConvP& p, hipStream_t st) {
-    static const bool off = getenv("EGR_S3_CONV3X3") && atoi(getenv("EGR_S3_CONV3X3")) == 0;
-    if (off || !p.sch || !p.w3 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.dil != 1 || p.pad_t != 1 || p.pad_l != 1 || p.up2 ||
-        p.OH != p.H || p.OW != p.W || (p.W % 32) != 0 || (p.H % 4) != 0 || (p.Cin % 32) != 0 || (p.Cout % 4) != 0 || p.ksplit > 1 ||
-        p.zs_nzb > 0 || p.nz > 1 || p.osy != 1 || p.osx != 1 || p.OHF != p.OH || p.OWF != p.OW || p.bias_b || p.B > 65535 ||
-        p.rows_div != p.H * p.W || (long long)(p.H / 4) * (p.W / 32) * p.B < 512)
-        return false;
-    const int bn = p.Cout > 64 ? 128 : 64;
-    const dim3 grid((p.H / 4) * (p.W / 32), (p.Cout + bn - 1) / bn, p.B);
-    if (p.gn_scale) {
-        if (bn == 128) hipLaunchKernelGGL((k_conv3x3_is<128, 32, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((k_conv3x3_is<64, 32, true>), grid, dim3(256), 0, st, p);
-    } else {
-        if (bn == 128) hipLaunchKernelGGL((k_conv3x3_is<128, 32, false>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((k_conv3x3_is<64, 32, false>), grid, dim3(256), 0, st, p);
-    }
     return true;
 }
 

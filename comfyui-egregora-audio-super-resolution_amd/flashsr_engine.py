@@ -171,6 +171,14 @@ class FlashSREngine:
                      "egr_flashsr_infer")
         return y
 
+    def warmup(self, rows: int = 2):
+        """egr_flashsr_warmup: one throw-away pass over `rows` rows of silence (default: one stereo chunk) -- the kernels' code objects
+        are loaded and the scratch for that row count exists before the host's first real call.  EGREGORA_FLASHSR_WARMUP=0 skips it."""
+        if os.environ.get("EGREGORA_FLASHSR_WARMUP", "1") == "0" or rows < 1:
+            return
+        with torch.cuda.device(self.dev):
+            native.check(self.L.egr_flashsr_warmup(C.c_void_p(self.handle), int(rows), self._st()), "egr_flashsr_warmup")
+
     def set_split(self, scheme: str):
         """"bf16x3" or "f16x2" for the following c_infer calls (the latter needs an engine built with SPLIT = "f16x2")."""
         code = {"bf16x3": 0, "f16x2": 1, "f16x2+forward": 2}[scheme]     # the last: c_forward too runs the fp16 operand terms (tests)
@@ -228,6 +236,9 @@ _SOURCE: Optional[Tuple[arch.FlashSRConfig, Dict[str, torch.Tensor]]] = None    
 _LOCK = threading.RLock()
 ROWS_PER_PASS = int(os.environ.get("EGREGORA_FLASHSR_ROWS", "32"))
 SEED = int(os.environ.get("EGREGORA_FLASHSR_SEED", "0"))
+# rows of the throw-away pass an engine runs when it is built (FlashSREngine.warmup): one stereo chunk loads every kernel the graph
+# launches at small row counts; EGREGORA_FLASHSR_WARMUP_ROWS=26 also sizes the arenas of a 60 s stereo file, 0 skips the pass
+WARMUP_ROWS = int(os.environ.get("EGREGORA_FLASHSR_WARMUP_ROWS", "2"))
 
 
 def devices() -> List[int]:
@@ -267,6 +278,7 @@ def _build_engine(cfg, params, dev: int) -> "FlashSREngine":
     """One engine on `dev` from the host state dict (a separate function so that the tests can count / slow down builds)."""
     eng = FlashSREngine(cfg, params, device=f"cuda:{dev}")
     eng.handle                                               # egr_flashsr_create now, on this thread: nothing is left for a worker to build
+    eng.warmup(WARMUP_ROWS)
     return eng
 
 

@@ -533,6 +533,12 @@ int64_t egr_flashsr_scratch_bytes(egr_flashsr* h);
  * row groups holds ~39 GB of activations; under a budget egr_flashsr_infer runs fewer rows per pass (same results, rows are
  * independent) instead of failing an allocation next to the host's other models.  Allocated arenas are not returned. */
 int egr_flashsr_set_arena_cap(egr_flashsr* h, double bytes);
+/* One throw-away egr_flashsr_infer over `rows` rows of silence, synchronised before it returns: the handle's kernels are loaded
+ * (HIP loads a kernel's code object at its first launch: ~200 ms of host time for the graph's ~150 instantiations), the scratch
+ * arenas and row-maxima pools for that row count exist and -- for rows >= 2 * min_group_rows -- the side streams are verified, so
+ * the host's first real call costs what every later call costs.  Replaces nothing in the reference (it rebuilds the model per call,
+ * egregora_audio_super_resolution.py:393); the engine calls it once when the handle is built (flashsr_engine.FlashSREngine.warmup). */
+int egr_flashsr_warmup(egr_flashsr* h, int rows, void* stream);
 /* Weight repacking shared by the handle and the Python graph driver (csrc/egr_flashsr_pack.hip):
  *   egr_pack_weight     : torch layout -> slab-major [ceil(K/16)][N][16]; layout 0 conv/linear [N][Ci][KH][KW] (k = (ky KW + kx) Ci + ci),
  *                         1 ConvTranspose1d [K=Ci][Co][KW] (n = kk Co + co), 2 per-tap products [Co][K=Ci][KH][KW] (n = tap Co + co)
