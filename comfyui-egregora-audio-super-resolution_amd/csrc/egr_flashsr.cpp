@@ -168,7 +168,7 @@ struct Wt {                        // one entry of the weight store
     int64_t numel = 0;
 };
 
-struct ProfRec { std::string kind; double flops; hipEvent_t a, b; };
+struct ProfRec { std::string kind; double flops; hipEvent_t a, b; std::string detail; };
 
 }  // namespace
 
@@ -477,10 +477,10 @@ struct ProfScope {
     explicit ProfScope(M* mm) : m(mm), on(mm->profiling) {
         if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, m->st); }
     }
-    void end(const std::string& kind, double flops) {
+    void end(const std::string& kind, double flops, const std::string& detail = std::string()) {
         if (!on) return;
         hipEventRecord(b, m->st);
-        m->prof.push_back(ProfRec{kind, flops, a, b});
+        m->prof.push_back(ProfRec{kind, flops, a, b, detail});
         on = false;
     }
     ~ProfScope() { if (on) { hipEventDestroy(a); hipEventDestroy(b); } }
@@ -594,7 +594,9 @@ int conv(M* m, Ten& y, const Ten& x, const std::string& wkey, int B, int H, int 
             snprintf(buf, sizeof(buf), "k_conv1d_s3<%d, %d>", Cout > 64 ? 128 : (Cout > 32 ? 64 : 32), Cin % 32 == 0 ? 32 : 16);
             kind = buf;
         }
-        ps.end(h2_kind(kind, h2), fl);
+        char det[160];
+        snprintf(det, sizeof(det), "%s B%d %dx%d Cin%d -> %dx%d Cout%d k%dx%d s%d d%d up%d", wkey.c_str(), B, H, W, Cin, OH, OW, Cout, KH, KW, stride, dil, up2);
+        ps.end(h2_kind(kind, h2), fl, det);
     }
     if (m->count_flops) m->flops += fl;
     return EGR_OK;
@@ -1703,9 +1705,13 @@ extern "C" int egr_flashsr_profile(egr_flashsr* m, int index, char* kind_buf, si
     EGR_CHECK(m != nullptr, EGR_ERR_ARG, "handle is null");
     EGR_HIP(hipDeviceSynchronize());
     std::map<std::string, std::tuple<int64_t, double, double>> agg;
+    static const bool dump = getenv("EGR_FSR_PROFILE_DUMP") && atoi(getenv("EGR_FSR_PROFILE_DUMP")) != 0;
     for (auto& r : m->prof) {
         float t = 0.f;
         hipEventElapsedTime(&t, r.a, r.b);
+        if (dump && count && !kind_buf)              // dev: every timed launch with its layer and shape (once per read-out)
+            fprintf(stderr, "[egr_flashsr profile] %-36s %9.3f ms %8.1f GFLOP %7.1f TF/s-eq  %s\n", r.kind.c_str(), t, r.flops / 1e9, t > 0 ? r.flops / t / 1e9 : 0.0,
+                    r.detail.c_str());
         auto& e = agg[r.kind];
         std::get<0>(e) += 1; std::get<1>(e) += r.flops; std::get<2>(e) += t;
     }

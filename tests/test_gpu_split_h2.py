@@ -315,6 +315,21 @@ def test_pool_of_row_maxima_grows_instead_of_failing_the_call(pack, monkeypatch)
         e_.close()
 
 
+def test_warmup_changes_nothing_but_the_first_call_cost(pack):
+    """egr_flashsr_warmup (one throw-away pass of silence when the engine is built): the next call's bits are those of a handle that was
+    never warmed, the host's call counter does not see it, and the scratch it sized is reported."""
+    from egregora_amd import native
+    cfg, (ea, eb) = _engines(2)
+    x = (0.05 * torch.randn(3, cfg.chunk, generator=torch.Generator().manual_seed(13))).cuda()
+    eb.warmup(2)
+    assert eb.split_info()["calls"] == 0
+    assert native.lib().egr_flashsr_scratch_bytes(eb.handle) > 0 and native.lib().egr_flashsr_scratch_bytes(ea.handle) == 0
+    assert torch.equal(eb.c_infer(x, None, 4), ea.c_infer(x, None, 4))
+    assert eb.split_info()["calls"] == 1
+    for e_ in (ea, eb):
+        e_.close()
+
+
 def test_rows_sharded_over_two_handles_are_bit_identical(pack):
     """A world-2 shard in one process: handle A takes rows 0..6, handle B rows 7..13 (each rank of shard.sharded_chunks owns its
     own handle); together they reproduce the 14-row call of ONE handle -- which runs the same two 7-row forwards as concurrent row

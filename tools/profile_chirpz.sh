@@ -44,3 +44,6 @@ for k, v in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[
           f"lds_conflict/lds_active={v.get('SQ_LDS_BANK_CONFLICT',0)/max(v.get('SQ_ACTIVE_INST_LDS',1),1):.2f} valu_insts={v.get('SQ_INSTS_VALU',0)/n:.3e}")
 PY
 cat $OUT/pz_stats.log | grep "^N =" ; cat $OUT/pz_summary.txt
+# (run BEFORE tools/profile_round.sh when both share a directory: make_traffic_json.py merges the pz_pmc_* passes) -- raw data is dropped
+# by profile_round.sh's clean-up or here when run alone
+if [ "${PZ_KEEP_RAW:-0}" != "1" ] && [ "${PZ_BEFORE_ROUND:-0}" != "1" ]; then rm -rf $OUT/pz_stats $OUT/pz_pmc_fetch $OUT/pz_pmc_write $OUT/pz_pmc_wait; fi

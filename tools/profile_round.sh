@@ -22,4 +22,8 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAV
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc_wait -o chain -- python bench.py --only fatllama --steps 1 --warmup 0 --iters 60 --no-cpu-baseline --lean > $OUT/bench_pmc_wait.log 2>&1
 python tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 python tools/summarize_counters.py $OUT > $OUT/counters.txt 2>&1
+python tools/make_traffic_json.py $OUT profiles/$TAG "${BUILD_COMMIT:-unknown}" > $OUT/traffic_kernels.txt 2>&1 && cp profiles/traffic.json $OUT/traffic.json
+# gpurun copies back at most 64 MiB: keep the per-kernel statistics, drop the raw traces and counter dumps
+for d in stats stats_g1; do f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/${d}_kernel_stats.csv; done
+rm -rf $OUT/stats $OUT/stats_g1 $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/pmc_wait $OUT/pz_stats $OUT/pz_pmc_fetch $OUT/pz_pmc_write $OUT/pz_pmc_wait
 cat $OUT/summary.txt $OUT/counters.txt
