@@ -232,6 +232,8 @@ struct egr_flashsr {
     int R = 1;                                        // batch rows of the forward being enqueued
     bool out_amax_on = true;                          // contraction epilogues leave the row maxima of their outputs (EGREGORA_FLASHSR_OUT_AMAX=0: off)
     int direct3x3_max_cout = 128;                     // EGREGORA_FLASHSR_DIRECT3X3_MAX_COUT (0: off): see gn_conv3
+    bool fused_amp = true;                            // EGREGORA_FLASHSR_FUSED_AMP=0: the thin AMP units as four launches each
+    int fused_amp_max_c = 16;                         // EGREGORA_FLASHSR_FUSED_AMP_MAX_C: widest stage that takes the fused unit (16 or 32)
     bool next_out_ra = false;                         // set by a call site whose output feeds another split contraction directly; consumed by the next conv()
     int64_t h2_calls = 0;
 
@@ -1187,6 +1189,27 @@ int amp(M* m, Ten& y, Ten&& h, int j) {
             const int d = c.voc_dils[di];
             const std::string b = "voc.amp." + std::to_string(j) + "." + std::to_string(ki) + "." + std::to_string(di);
             Ten xt, xc, xs, xn;
+            // the 16- and 32-channel stages (245 760 / 122 880 samples per row): the unit's four launches are pure streaming there -- one fused kernel
+            // keeps the L-tile on the CU (csrc/egr_nn_amp.hip); fp16 operand scheme only
+            {
+                const Wt* w1 = m->get(b + ".conv1.weight");
+                const Wt* w2 = m->get(b + ".conv2.weight");
+                const int Cc = (int)cur->d[2];
+                if (m->fused_amp && m->h2 && m->h2_mode == 1 && w1 && w2 && w1->w2 && w2->w2 && (Cc == 16 || Cc == 32) && Cc <= m->fused_amp_max_c && w1->Cout == Cc && w2->Cout == Cc && (k & 1) &&
+                    k <= 11 && d * (k - 1) / 2 <= 25 && c.aa_taps == 12 && cur->d[1] >= 16) {
+                    OKR(new_ten(m, xn, {cur->d[0], cur->d[1], cur->d[2]}));
+                    ProfScope ps(m);
+                    OKR(egr_amp_unit_h2(cur->p, xn.p, (int)cur->d[0], (int)cur->d[1], Cc, k, d, m->ptr(b + ".alpha1"), m->ptr(b + ".beta1"), w1->w2, w1->w_scale,
+                                        m->ptr(b + ".conv1.bias"), m->ptr(b + ".alpha2"), m->ptr(b + ".beta2"), w2->w2, w2->w_scale, m->ptr(b + ".conv2.bias"),
+                                        m->filt, c.aa_taps, m->st));
+                    const double fl = 2.0 * 2.0 * (double)cur->d[0] * cur->d[1] * Cc * Cc * k;
+                    if (ps.on) ps.end(Cc == 16 ? "k_amp_unit<16>" : "k_amp_unit<32>", fl, b);
+                    if (m->count_flops) m->flops += fl;
+                    x = std::move(xn);
+                    cur = &x;
+                    continue;
+                }
+            }
             OKR(snake(m, xt, *cur, b + ".alpha1", b + ".beta1"));
             OKR(conv1d(m, xc, xt, b + ".conv1", k, 1, d, d * (k - 1) / 2));
             xt.release();
@@ -1444,6 +1467,8 @@ extern "C" int egr_flashsr_create(egr_flashsr** out, const egr_flashsr_config* c
     if (const char* e = getenv("EGREGORA_FLASHSR_ROWS")) { const int r = atoi(e); if (r >= 1) m->rows_per_pass = r; }
     if (const char* e = getenv("EGREGORA_FLASHSR_OUT_AMAX")) m->out_amax_on = atoi(e) != 0;
     if (const char* e = getenv("EGREGORA_FLASHSR_DIRECT3X3_MAX_COUT")) m->direct3x3_max_cout = atoi(e);
+    if (const char* e = getenv("EGREGORA_FLASHSR_FUSED_AMP")) m->fused_amp = atoi(e) != 0;
+    if (const char* e = getenv("EGREGORA_FLASHSR_FUSED_AMP_MAX_C")) m->fused_amp_max_c = atoi(e);
     if (const char* e = getenv("EGREGORA_FLASHSR_ARENA_GB")) { const double gb = atof(e); if (gb > 0.0) m->arena_cap = gb * 1e9; }
     build_blocks(m);
     const int down = 1 << (cfg->vae_levels - 1);

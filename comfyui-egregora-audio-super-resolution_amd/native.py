@@ -129,6 +129,7 @@ SIGNATURES = {
     "egr_flashsr_flop_count": (_i, [_vp, _i, C.POINTER(C.c_double), _vp]),
     "egr_flashsr_scratch_bytes": (_i64, [_vp]),
     "egr_flashsr_warmup": (_i, [_vp, _i, _vp]),
+    "egr_amp_unit_h2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
     "egr_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "egr_phase_weights": (_i, [_vp, _vp, _i, _i, _vp]),
     "egr_winograd_pack_u": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -539,6 +539,15 @@ int egr_flashsr_set_arena_cap(egr_flashsr* h, double bytes);
  * the host's first real call costs what every later call costs.  Replaces nothing in the reference (it rebuilds the model per call,
  * egregora_audio_super_resolution.py:393); the engine calls it once when the handle is built (flashsr_engine.FlashSREngine.warmup). */
 int egr_flashsr_warmup(egr_flashsr* h, int rows, void* stream);
+/* One (kernel size k, dilation d) unit of a 16-channel AMP block of the vocoder as ONE kernel (csrc/egr_nn_amp.hip):
+ *   y = conv2(snake2(conv1(snake1(x)))) + x,  x, y [B][L][C = 16] channels-last fp32, y != x
+ * snake = the anti-aliased activation of egr_snake_aa (12-tap FIR), conv1 = k taps at dilation d, conv2 = k taps at dilation 1, both
+ * 'same'-padded with zeros; w?_h2 = egr_split2h_pack(slab-major pack of the conv weight, w?_scale).  Stands in for the four launches
+ * (snake, conv, snake, conv + residual) of the upstream vocoder's AMP unit as the reference reaches it through FlashSR.__call__
+ * (egregora_audio_super_resolution.py:361-369).  EGR_ERR_UNSUPPORTED (nothing launched) for shapes outside C = 16, odd k <= 11. */
+int egr_amp_unit_h2(const float* x, float* y, int B, int L, int C, int k, int d, const float* alpha1, const float* beta1, const void* w1_h2,
+                    float w1_scale, const float* bias1, const float* alpha2, const float* beta2, const void* w2_h2, float w2_scale,
+                    const float* bias2, const float* filt, int aa_taps, void* stream);
 /* Weight repacking shared by the handle and the Python graph driver (csrc/egr_flashsr_pack.hip):
  *   egr_pack_weight     : torch layout -> slab-major [ceil(K/16)][N][16]; layout 0 conv/linear [N][Ci][KH][KW] (k = (ky KW + kx) Ci + ci),
  *                         1 ConvTranspose1d [K=Ci][Co][KW] (n = kk Co + co), 2 per-tap products [Co][K=Ci][KH][KW] (n = tap Co + co)
