@@ -46,8 +46,10 @@ template <int C, int TL> struct AmpGeom {
 
 // the anti-aliased snake of k_snake_aa_reg on 16 consecutive rows l0 .. l0 + 15 of channel c, source rows in LDS: S[(clamp(l) - row0) * C + c]
 template <int C>
-__device__ __forceinline__ void amp_snake_run(const float* __restrict__ S, int row0, int nrows, int l0, int c, int L, const float (&f)[12], float a, float ib,
-                                              float (&out)[16]) {
+// (f2 = 2 f: the up-sampler's gain folded into its taps -- exact, a power of two commutes with every rounding; a_rev = a / 2 pi: v_sin_f32 takes
+// revolutions)
+__device__ __forceinline__ void amp_snake_run(const float* __restrict__ S, int row0, int nrows, int l0, int c, int L, const float (&f)[12], const float (&f2)[12],
+                                              float a_rev, float ib, float (&out)[16]) {
     constexpr int J = 16;
     float xw[J + 10];
 #pragma unroll
@@ -63,10 +65,9 @@ __device__ __forceinline__ void amp_snake_run(const float* __restrict__ S, int r
     for (int q = 0; q < 2 * J + 10; ++q) {
         float u = 0.f;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) u += xw[5 + (q >> 1) - j] * f[(q & 1) + 2 * j];
-        u *= 2.0f;
-        const float sn = __sinf(u * a);
-        sv[q] = u + ib * sn * sn;
+        for (int j = 0; j < 6; ++j) u += xw[5 + (q >> 1) - j] * f2[(q & 1) + 2 * j];
+        const float sn = __builtin_amdgcn_sinf(u * a_rev);
+        sv[q] = fmaf(ib * sn, sn, u);
     }
     const int i0 = 2 * l0 - 5, L2 = 2 * L;
     if (i0 < 0 || i0 + 2 * J + 9 > L2 - 1) {                    // runs at the sequence ends: up-rate indices clamp to [0, 2L - 1]
@@ -120,9 +121,9 @@ __global__ __launch_bounds__(256, 2) void k_amp_unit(AmpP p) {
     const int a1_row0 = c1_row0 - h1, R1 = R2 + 2 * h1;          // rows of a1 (conv1's operand)
     const int x_row0 = a1_row0 - AMP_SH, R0 = R1 + 2 * AMP_SH;   // rows of x
     const float* xb = p.x + (size_t)b * L * C;
-    float f[12];
+    float f[12], f2[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) f[i] = p.filt[i];
+    for (int i = 0; i < 12; ++i) { f[i] = p.filt[i]; f2[i] = 2.0f * f[i]; }
     // gains of the two FIRs (L1 norms): |snake_aa(v)| <= g_dn (g_up max |v| + 1 / b)
     float g_dn = 0.f, g_e = 0.f, g_o = 0.f;
 #pragma unroll
@@ -155,9 +156,9 @@ __global__ __launch_bounds__(256, 2) void k_amp_unit(AmpP p) {
         for (int it = tid; it < nruns * C; it += 256) {
             const int c = it % C, run = it / C;
             const int l0 = out_row0 + run * 16;
-            const float a = __expf(alpha[c]), ib = 1.0f / (__expf(beta[c]) + 1e-9f);
+            const float a_rev = __expf(alpha[c]) * 0.15915494309189535f, ib = 1.0f / (__expf(beta[c]) + 1e-9f);
             float o[16];
-            amp_snake_run<C>(S, src_row0, src_rows, l0, c, L, f, a, ib, o);
+            amp_snake_run<C>(S, src_row0, src_rows, l0, c, L, f, f2, a_rev, ib, o);
             _Float16* P0 = (_Float16*)AP;
             _Float16* P1 = (_Float16*)(AP + (size_t)G::RA * NCH);
 #pragma unroll
