@@ -561,6 +561,7 @@ int s3_launch(M* m, const Wt* w, const float* x, int64_t x_numel, unsigned** x_r
 }
 
 std::string h2_kind(std::string kind, bool h2) {      // "k_conv_s3<128, 256, 1, false>" -> "k_conv_s3<128, 256, 1, false, 1>"
+    if (h2 && kind.rfind("k_conv_s3<256, 128", 0) == 0) kind.replace(0, 18, "k_conv_s3<128, 128");      // the fp16-term path has no 256 x 128 tile
     if (h2 && !kind.empty() && kind.back() == '>' && kind.rfind("k_conv", 0) == 0) { kind.pop_back(); kind += ", 1>"; }
     return kind;
 }

@@ -618,7 +618,9 @@ static int conv_launch(const float* x, const float* w, const float* bias, const 
     static const bool narrow = !(getenv("EGR_S3_NARROW") && atoi(getenv("EGR_S3_NARROW")) == 0);
     if (w3 && narrow && nz <= 1 && (KH * KW * Cin + BK - 1) / BK < 32)
         while (bn > 64 && ((M + 127) / 128) * ((Cout + bn - 1) / bn) < 256) bn >>= 1;
-    int bm = w3 ? s3_bm(M, Cout, bn) : BM;
+    // (fp16 terms: the 256 x 128 tile loses to 128 x 128 on every layer that took it -- short-K streaming GEMMs with 128 outputs, 5 per
+    // forward: 5.1 -> 3.1 ms, profiles/r05/flashsr_kernel_experiments.log item 6 -- half the registers per workgroup, twice the workgroups in flight)
+    int bm = w3 ? (sch ? 128 : s3_bm(M, Cout, bn)) : BM;
     dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)((Cout + bn - 1) / bn));
     hipStream_t st = (hipStream_t)stream;
     // split-K when the output tiles alone cannot fill the chip and the K loop is long (deep UNet / latent layers)

@@ -591,7 +591,6 @@ void launch_conv_s3(int bm, int bn, dim3 grid, hipStream_t st, const ConvP& p_in
             if (bn == 256) hipLaunchKernelGGL((k_conv_s3<128, 256, 1, true, 1>), grid, dim3(256), 0, st, p);
             else hipLaunchKernelGGL((k_conv_s3<128, 128, 1, true, 1>), grid, dim3(256), 0, st, p);
         } else if (bn == 256) hipLaunchKernelGGL((k_conv_s3<128, 256, 1, false, 1>), grid, dim3(256), 0, st, p);
-        else if (bm == 256) hipLaunchKernelGGL((k_conv_s3<256, 128, 1, false, 1>), grid, dim3(256), 0, st, p);
         else if (bn == 128) hipLaunchKernelGGL((k_conv_s3<128, 128, 1, false, 1>), grid, dim3(256), 0, st, p);
         else if (bn == 64) hipLaunchKernelGGL((k_conv_s3<128, 64, 1, false, 1>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((k_conv_s3<128, 32, 1, false, 1>), grid, dim3(256), 0, st, p);

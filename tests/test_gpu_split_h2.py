@@ -323,7 +323,7 @@ def test_warmup_changes_nothing_but_the_first_call_cost(pack):
     x = (0.05 * torch.randn(3, cfg.chunk, generator=torch.Generator().manual_seed(13))).cuda()
     eb.warmup(2)
     assert eb.split_info()["calls"] == 0
-    assert native.lib().egr_flashsr_scratch_bytes(eb.handle) > 0 and native.lib().egr_flashsr_scratch_bytes(ea.handle) == 0
+    assert native.lib().egr_flashsr_scratch_bytes(eb.handle) >= native.lib().egr_flashsr_scratch_bytes(ea.handle) > 0      # (creation already uses the arena)
     assert torch.equal(eb.c_infer(x, None, 4), ea.c_infer(x, None, 4))
     assert eb.split_info()["calls"] == 1
     for e_ in (ea, eb):
