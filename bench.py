@@ -421,7 +421,7 @@ def main():
 
     if rank == 0:
         audio_s = total / SR
-        variants = {k: v for k, v in prof.items() if k.startswith("k_conv")}
+        variants = {k: v for k, v in prof.items() if k.startswith("k_conv") or k.startswith("k_amp")}
         fconv_all = sum(v[1] for v in variants.values())
         dom_conv = max(variants, key=lambda k: variants[k][2])          # the variant with the most GPU time
         nconv, fconv, tconv = variants[dom_conv]
@@ -451,7 +451,7 @@ def main():
                 cands = cands[1:]
             traffic = next((v["bytes"] for c in cands for k, v in tk.items() if k == c or k.startswith(c + "<")), None)
             conv_traffic = tk.get(dom_conv, {}).get("bytes")
-            pz_traffic = next((v["bytes"] for k, v in tk.items() if k.startswith("k_pzpair<false")), None)
+            pz_traffic = None
         except Exception:
             pass
         info = fe.plan_info(SEG, 1)
@@ -538,14 +538,16 @@ def main():
             a = arb["60s_plus_2_samples"]
             # the loop's three kernels: row convolution (reads and writes the state, reads Bhat: 24 P bytes per state), spectrum pass
             # and crop pass on column tiles (16 P bytes per state); the dominant one = the longest average launch
-            pzk = {"k_pz_rowconv_s": (a["k_pz_rowconv_ms"], 24.0), "k_pzpair_wl": (a["k_pzpair_ms"], 16.0), "k_pzcol_wl": (a["k_pzcol_crop_ms"], 16.0)}
+            pzk = {"k_pz_rowconv": (a["k_pz_rowconv_ms"], 24.0), "k_pzpair_wl": (a["k_pzpair_ms"], 16.0), "k_pzcol_wl": (a["k_pzcol_crop_ms"], 16.0)}
             pz_dom = max(pzk, key=lambda k: pzk[k][0])
             pz_ms, pz_bpp = pzk[pz_dom]
             byt = pz_bpp * a["P"] * a["states_per_launch"]
             ach = byt / (pz_ms * 1e-3) / 1e9 if pz_ms > 0 else 0.0
             try:
                 tk = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get("kernels", {})
-                pz_traffic = next((v["bytes"] for k, v in tk.items() if k.startswith(pz_dom) and ("4096" in k or "wl" in k)), pz_traffic)
+                # (the plan's kernels: rows of 4096 points -> k_pz_rowconv_f<.., 4096, ..>; column length 720 = 24 x 30 -> k_pzpair_wl / k_pzcol_wl<24, 30>)
+                hit = next(((k, v["bytes"]) for k, v in tk.items() if k.startswith(pz_dom) and (" %d," % a["split"][1] in k or "wl" in k)), None)
+                pz_traffic, pz_dom = (hit[1], hit[0]) if hit else (None, pz_dom)
             except Exception:
                 pass
             out["roofline_fatllama_chirpz"] = {

@@ -844,8 +844,9 @@ int gn_conv3(M* m, Ten& y, const Ten& x, const std::string& norm_key, float eps,
             OKR(egr_conv_h2_gn(x.p, sc.p, sh.p, 1, wd->w2, bt, res, y.p, B, H, W, Cin, wd->Cout, ACT_NONE, wd->w_scale, (const float*)bound, out_ra, gpart, m->st));
             if (ps.on) {
                 char buf[64];
-                snprintf(buf, sizeof(buf), "k_conv3x3_is<%d, 32, true>", wd->Cout > 64 ? 128 : 64);
-                ps.end(buf, fl);
+                static const bool old_kernel = getenv("EGR_S3_CONV3X3") && atoi(getenv("EGR_S3_CONV3X3")) == 1;      // (as launch_conv3x3_is chooses)
+                snprintf(buf, sizeof(buf), old_kernel ? "k_conv3x3_is<%d, 32, true>" : "k_conv3x3_isp<%d, 32, true, true>", wd->Cout > 64 ? 128 : 64);
+                ps.end(buf, fl, conv_key);
             }
             if (m->count_flops) m->flops += fl;
             return EGR_OK;

@@ -7,6 +7,8 @@
 set -u
 TAG=${1:-rXX}
 export TMPDIR=/tmp
+# no throw-away warm-up pass under the profiler: every FlashSR launch of the capture then has the bench's 26-row (or 13-row) shape
+export EGREGORA_FLASHSR_WARMUP=0
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o chain -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --lean > $OUT/bench_stats.log 2>&1
