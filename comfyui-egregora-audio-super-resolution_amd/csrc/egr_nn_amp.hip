@@ -295,24 +295,12 @@ extern "C" int egr_amp_unit_h2(const float* x, float* y, int B, int L, int C, in
     p.B = B; p.L = L; p.k = k; p.d = d;
     // tile lengths: 43 KB (C = 16, 256 rows) / 54 KB (C = 32, 128 rows) of LDS per workgroup -- two or three workgroups per CU
     if (C == 16) {
-        // tile length: the snake phases hand out (16-row run, channel) items to 256 threads, so TL + halo should fill whole rounds of
-        // 16 runs: 240 (one round for snake2, two for snake1, three workgroups per CU) or 496 (2 + 3 rounds for twice the rows, two per CU)
-        static const int tl = getenv("EGR_AMP_TL") ? atoi(getenv("EGR_AMP_TL")) : 240;
-        if (tl == 496) {
-            constexpr int TL = 496;
-            constexpr size_t lds = (size_t)AmpGeom<16, TL>::LDS;
-            static const hipError_t attr = hipFuncSetAttribute((const void*)k_amp_unit<16, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)attr;
-            hipLaunchKernelGGL((k_amp_unit<16, TL>), dim3((unsigned)((L + TL - 1) / TL), (unsigned)B), dim3(256), lds, (hipStream_t)stream, p);
-        } else if (tl == 256) {
-            constexpr int TL = 256;
-            constexpr size_t lds = (size_t)AmpGeom<16, TL>::LDS;
-            hipLaunchKernelGGL((k_amp_unit<16, TL>), dim3((unsigned)((L + TL - 1) / TL), (unsigned)B), dim3(256), lds, (hipStream_t)stream, p);
-        } else {
-            constexpr int TL = 240;
-            constexpr size_t lds = (size_t)AmpGeom<16, TL>::LDS;
-            hipLaunchKernelGGL((k_amp_unit<16, TL>), dim3((unsigned)((L + TL - 1) / TL), (unsigned)B), dim3(256), lds, (hipStream_t)stream, p);
-        }
+        // tile length 240: the snake phases hand out (16-row run, channel) items to 256 threads, and snake2's 240 + 2 h2 <= 250 rows are exactly
+        // one round (snake1: two); 256 rows waste half of a second round (+8 ... +17 % per unit), 496 rows halve the occupancy (+10 ... +20 %):
+        // profiles/r05/flashsr_kernel_experiments.log item 5
+        constexpr int TL = 240;
+        constexpr size_t lds = (size_t)AmpGeom<16, TL>::LDS;
+        hipLaunchKernelGGL((k_amp_unit<16, TL>), dim3((unsigned)((L + TL - 1) / TL), (unsigned)B), dim3(256), lds, (hipStream_t)stream, p);
     } else {
         constexpr int TL = 128;
         constexpr size_t lds = (size_t)AmpGeom<32, TL>::LDS;
