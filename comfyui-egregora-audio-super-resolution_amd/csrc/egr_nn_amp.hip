@@ -45,20 +45,28 @@ template <int C, int TL> struct AmpGeom {
 };
 
 // the anti-aliased snake of k_snake_aa_reg on 16 consecutive rows l0 .. l0 + 15 of channel c, source rows in LDS: S[(clamp(l) - row0) * C + c]
-template <int C>
 // (f2 = 2 f: the up-sampler's gain folded into its taps -- exact, a power of two commutes with every rounding; a_rev = a / 2 pi: v_sin_f32 takes
-// revolutions)
+// revolutions).  EDGE = false: a tile whose whole halo lies inside the sequence -- no clamping anywhere, the 26 window loads are one base
+// address + immediates
+template <int C, bool EDGE>
 __device__ __forceinline__ void amp_snake_run(const float* __restrict__ S, int row0, int nrows, int l0, int c, int L, const float (&f)[12], const float (&f2)[12],
                                               float a_rev, float ib, float (&out)[16]) {
     constexpr int J = 16;
     float xw[J + 10];
+    if constexpr (EDGE) {
 #pragma unroll
-    for (int i = 0; i < J + 10; ++i) {
-        int src = l0 - 5 + i;
-        src = src < 0 ? 0 : (src > L - 1 ? L - 1 : src);
-        int r = src - row0;
-        r = r < 0 ? 0 : (r > nrows - 1 ? nrows - 1 : r);       // (rows the tile does not hold belong to outputs that are discarded)
-        xw[i] = S[r * C + c];
+        for (int i = 0; i < J + 10; ++i) {
+            int src = l0 - 5 + i;
+            src = src < 0 ? 0 : (src > L - 1 ? L - 1 : src);
+            int r = src - row0;
+            r = r < 0 ? 0 : (r > nrows - 1 ? nrows - 1 : r);   // (rows the tile does not hold belong to outputs that are discarded)
+            xw[i] = S[r * C + c];
+        }
+    } else {
+        // (the last run of a phase may reach past the rows the tile holds: those outputs are discarded, the reads stay inside the LDS allocation)
+        const float* base = S + (l0 - 5 - row0) * C + c;
+#pragma unroll
+        for (int i = 0; i < J + 10; ++i) xw[i] = base[i * C];
     }
     float sv[2 * J + 10];
 #pragma unroll
@@ -70,7 +78,7 @@ __device__ __forceinline__ void amp_snake_run(const float* __restrict__ S, int r
         sv[q] = fmaf(ib * sn, sn, u);
     }
     const int i0 = 2 * l0 - 5, L2 = 2 * L;
-    if (i0 < 0 || i0 + 2 * J + 9 > L2 - 1) {                    // runs at the sequence ends: up-rate indices clamp to [0, 2L - 1]
+    if (EDGE && (i0 < 0 || i0 + 2 * J + 9 > L2 - 1)) {          // runs at the sequence ends: up-rate indices clamp to [0, 2L - 1]
         float s_first = 0.f, s_last = 0.f;
 #pragma unroll
         for (int q = 0; q < 2 * J + 10; ++q) {
@@ -103,8 +111,14 @@ __device__ __forceinline__ float amp_wg_max(float m, float* slot) {
     return r;
 }
 
+#ifndef AMP_LB16
+#define AMP_LB16 2
+#endif
+#ifndef AMP_TL16
+#define AMP_TL16 240
+#endif
 template <int C, int TL>
-__global__ __launch_bounds__(256, 2) void k_amp_unit(AmpP p) {
+__global__ __launch_bounds__(256, C == 16 ? AMP_LB16 : 2) void k_amp_unit(AmpP p) {
     static_assert(C == 16 || C == 32, "K = 32 of v_mfma_f32_16x16x32_f16 = two taps of 16 channels or one tap of 32");
     typedef AmpGeom<C, TL> G;
     constexpr int NCH = G::NCH;
@@ -121,6 +135,7 @@ __global__ __launch_bounds__(256, 2) void k_amp_unit(AmpP p) {
     const int a1_row0 = c1_row0 - h1, R1 = R2 + 2 * h1;          // rows of a1 (conv1's operand)
     const int x_row0 = a1_row0 - AMP_SH, R0 = R1 + 2 * AMP_SH;   // rows of x
     const float* xb = p.x + (size_t)b * L * C;
+    const bool interior = x_row0 >= 0 && x_row0 + R0 <= L;       // (uniform over the workgroup) every row any phase touches lies inside the sequence
     float f[12], f2[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) { f[i] = p.filt[i]; f2[i] = 2.0f * f[i]; }
@@ -158,13 +173,14 @@ __global__ __launch_bounds__(256, 2) void k_amp_unit(AmpP p) {
             const int l0 = out_row0 + run * 16;
             const float a_rev = __expf(alpha[c]) * 0.15915494309189535f, ib = 1.0f / (__expf(beta[c]) + 1e-9f);
             float o[16];
-            amp_snake_run<C>(S, src_row0, src_rows, l0, c, L, f, f2, a_rev, ib, o);
+            if (interior) amp_snake_run<C, false>(S, src_row0, src_rows, l0, c, L, f, f2, a_rev, ib, o);
+            else amp_snake_run<C, true>(S, src_row0, src_rows, l0, c, L, f, f2, a_rev, ib, o);
             _Float16* P0 = (_Float16*)AP;
             _Float16* P1 = (_Float16*)(AP + (size_t)G::RA * NCH);
 #pragma unroll
             for (int jj = 0; jj < 16; ++jj) {
                 const int l = l0 + jj, r = run * 16 + jj;
-                float v = ((unsigned)l < (unsigned)L) ? o[jj] * s : 0.f;          // outside the sequence: the convolution's zero padding
+                float v = (interior || (unsigned)l < (unsigned)L) ? o[jj] * s : 0.f;      // outside the sequence: the convolution's zero padding
                 const _Float16 hi = (_Float16)v;
                 const _Float16 lo = (_Float16)(v - (float)hi);
                 if (r < G::RA) { P0[r * C + c] = hi; P1[r * C + c] = lo; }
@@ -298,7 +314,7 @@ extern "C" int egr_amp_unit_h2(const float* x, float* y, int B, int L, int C, in
         // tile length 240: the snake phases hand out (16-row run, channel) items to 256 threads, and snake2's 240 + 2 h2 <= 250 rows are exactly
         // one round (snake1: two); 256 rows waste half of a second round (+8 ... +17 % per unit), 496 rows halve the occupancy (+10 ... +20 %):
         // profiles/r05/flashsr_kernel_experiments.log item 5
-        constexpr int TL = 240;
+        constexpr int TL = AMP_TL16;
         constexpr size_t lds = (size_t)AmpGeom<16, TL>::LDS;
         hipLaunchKernelGGL((k_amp_unit<16, TL>), dim3((unsigned)((L + TL - 1) / TL), (unsigned)B), dim3(256), lds, (hipStream_t)stream, p);
     } else {
