@@ -20,11 +20,8 @@
 // to put the row's maximum somewhere in [1, 2^15), and the bound is within a few bits of the true maximum.
 namespace egr {
 
-#ifdef C3_TIMING
-// dev (tools/build_variant.sh ... -DC3_TIMING): shader-clock sums over all waves of k_conv3x3_is -- barrier wait, operand-read wait, MFMA
-// phase, halo phase, loop, epilogue, wave count; read back through egr_debug_c3_timing
-__device__ unsigned long long c3_timing[8];
-#endif
+// (C3_ABL_NOEPI / _NOB / _NOHALO / _NOMMA: timing-only ablation builds of this kernel, tools/build_variant.sh + tools/r05_conv3x3_ablation.sh;
+// their results are wrong by construction.  profiles/r05/flashsr_kernel_experiments.log item 2)
 template <int BN, int CC, bool GN>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_is(ConvP p) {
     typedef S3Cfg<128, BN> TC;
@@ -95,16 +92,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_is(ConvP p) {
     const int ob_slot = li * 2 + (lk ^ ((li >> 3) & 1));
 
     // one tap of one channel chunk; `nx` holds the weight tiles of wide slab ws + 1 and is refilled with those of ws + 3
-#ifdef C3_TIMING
-    unsigned long long tm_bar = 0, tm_rd = 0, tm_mm = 0, tm_halo = 0, tm_last = __builtin_amdgcn_s_memtime();
-    const unsigned long long tm_start = tm_last;
-#endif
     auto slab = [&](int ws, StageB& nx) {
         const int cur = ws & 1;
         const int cc = ws / 9, tap = ws - cc * 9;
-#ifdef C3_TIMING
-        { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm_mm += t - tm_last; tm_last = t; }
-#endif
 #ifdef C3_ABL_NOHALO
         if (ws == 0) {
 #else
@@ -153,13 +143,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_is(ConvP p) {
                 }
             }
         }
-#ifdef C3_TIMING
-        { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm_halo += t - tm_last; tm_last = t; }
-#endif
         __syncthreads();                         // weight tiles `cur` (stored one iteration ago) and the halo patch are visible
-#ifdef C3_TIMING
-        { const unsigned long long t = __builtin_amdgcn_s_memtime(); tm_bar += t - tm_last; tm_last = t; }
-#endif
         const int ky = tap / 3, kx = tap - ky * 3;
         uint4 bq[NSL][TN][2], aq[NSL][TM][2];
 #pragma unroll
@@ -177,9 +161,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_is(ConvP p) {
                 for (int q = 0; q < NP; ++q) aq[cs][i][q] = As[q][slot];
             }
         }
-#ifdef C3_TIMING
-        { __builtin_amdgcn_s_waitcnt(0xc07f); const unsigned long long t = __builtin_amdgcn_s_memtime(); tm_rd += t - tm_last; tm_last = t; }   // lgkmcnt(0): operands landed
-#endif
 #ifndef C3_ABL_NOB
         if (ws + 1 < wtotal) store_b(cur ^ 1, nx);
         if (ws + 3 < wtotal) load_b(ws + 3, nx);
@@ -214,9 +195,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_is(ConvP p) {
     }
     if (ws < wtotal) slab(ws, sA);
     // tile rows are image rows: GEMM row of (sub-tile t, pixel px) = (b H + y0 + t) W + x0 + px -> row stride W between sub-tiles
-#ifdef C3_TIMING
-    const unsigned long long tm_loop_end = __builtin_amdgcn_s_memtime();
-#endif
     unsigned* const om = p.out_amax ? om_tab : nullptr;
     // (sub-tile rows start at multiples of 32 in x: m / 32 is the partial-statistics unit (b H + y) (W / 32) + x / 32)
 #ifdef C3_ABL_NOEPI
@@ -228,14 +206,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_is(ConvP p) {
 #else
     conv_epilogue_t<TM, TN>(p, acc, (b * p.H + y0) * p.W + x0, n0, wm0, wn0, os_tab, om, p.W, p.gn_part);
     if (om) out_amax_commit(p, om_tab, (b * p.H + y0) * p.W + x0, 1);
-#endif
-#ifdef C3_TIMING
-    if (lane == 0) {
-        const unsigned long long tm_end = __builtin_amdgcn_s_memtime();
-        const unsigned long long v[8] = {tm_bar, tm_rd, tm_mm, tm_halo, tm_loop_end - tm_start, tm_end - tm_loop_end, tm_start, tm_end};
-        for (int q = 0; q < 6; ++q) atomicAdd(&c3_timing[q], v[q]);
-        atomicAdd(&c3_timing[6], 1ull);
-    }
 #endif
 }
 
@@ -490,10 +460,3 @@ bool launch_conv3x3_is(const ConvP& p, hipStream_t st) {
 }  // namespace egr
 
 
-#ifdef C3_TIMING
-extern "C" int egr_debug_c3_timing(unsigned long long* out8, int reset) {
-    if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(egr::c3_timing), 8 * sizeof(unsigned long long));
-    if (reset) { const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(egr::c3_timing), z, sizeof(z)); }
-    return 0;
-}
-#endif

@@ -44,13 +44,3 @@ ms = e0.elapsed_time(e1) / reps
 fl = 2.0 * B * H * W * Co * K
 print(f"EGR_S3_CONV3X3={os.environ.get('EGR_S3_CONV3X3', '')!r}: {ms:.3f} ms per launch, {fl / ms / 1e9:.1f} TFLOP/s fp32-equivalent, "
       f"{3 * fl / ms / 1e9:.0f} executed f16; checksum {float(y.double().sum()):.6e} {float(y.double().abs().max()):.6e}")
-if hasattr(L, "egr_debug_c3_timing") or os.environ.get("EGREGORA_AMD_LIB", "").endswith("c3timing.so"):
-    # the -DC3_TIMING variant (tools/build_variant.sh c3timing egr_nn_conv3x3.hip "-DC3_TIMING"): where the waves of k_conv3x3_is spend their cycles
-    buf = (C.c_ulonglong * 8)()
-    L.egr_debug_c3_timing(None, 1)
-    run(); torch.cuda.synchronize()
-    L.egr_debug_c3_timing(buf, 0)
-    bar, rd, mm, halo, loop, epi, nw = [float(buf[i]) for i in range(7)]
-    print(f"  per wave (shader cycles, {int(nw)} waves): loop {loop / nw:.0f} = barrier wait {bar / nw:.0f} ({bar / loop:.1%}) + operand-read wait {rd / nw:.0f} ({rd / loop:.1%}) "
-          f"+ MFMA phase {mm / nw:.0f} ({mm / loop:.1%}) + halo phase {halo / nw:.0f} ({halo / loop:.1%}); epilogue {epi / nw:.0f} ({epi / (loop + epi):.1%} of the wave's life); "
-          f"MFMA-only floor 864 x 32 = 27648 cycles per wave alone on a SIMD")
