@@ -13,7 +13,7 @@ static float* g_zero_page = nullptr;
 namespace egr { int zero_page(const float** out) { *out = g_zero_page; return 0; }
 void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); } }
 int main(int argc, char** argv) {
-    int B = 26, H = 128, W = 64, Ci = 512, Co = 512, k = 3, reps = 5;
+    int B = 26, H = 128, W = 64, Ci = 512, Co = 512, k = 3, reps = getenv("S3_REPS") ? atoi(getenv("S3_REPS")) : 5;
     if (argc >= 7) { B = atoi(argv[1]); H = atoi(argv[2]); W = atoi(argv[3]); Ci = atoi(argv[4]); Co = atoi(argv[5]); k = atoi(argv[6]); }
     const long long M = (long long)B * H * W, K = (long long)k * k * Ci, ns = K / 16;
     float *x, *wp, *y, *zeros; void* w3;
