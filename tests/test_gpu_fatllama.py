@@ -516,6 +516,10 @@ def test_threshold_and_interpolation_variants_match_the_oracle(pack, variant, ov
     ("relative,soft", {"threshold_ref": "relative_to_max", "threshold_kind": "soft"}, 0.02, 8000.0, 2880000),
     ("", {}, 50.0, 100.0, 2880000),
     ("relative,soft", {"threshold_ref": "relative_to_max", "threshold_kind": "soft"}, 0.02, 8000.0, 2880002),
+    # two of the plans round 4 added, against the ORACLE (they were gated against the device's own stage-by-stage kernels and a
+    # float64 loop only): 60 s at 44.1 kHz (441 x 3000: k_col_wl<21, 12> + k_row_wl<30, 10>) and 150 s at 48 kHz (three levels, 625 x 2 x 2880)
+    ("relative,soft", {"threshold_ref": "relative_to_max", "threshold_kind": "soft"}, 0.02, 8000.0, 2646000),
+    ("", {}, 50.0, 100.0, 7200000),
 ])
 def test_real_gating_at_the_headline_length_against_the_oracle(pack, variant, over, thr, scale, n):
     """the default spec's 0.6 absolute threshold gates nothing on int16-scale data, so the full-length parity tests verify
@@ -528,7 +532,7 @@ def test_real_gating_at_the_headline_length_against_the_oracle(pack, variant, ov
     from egregora_amd import fatllama_engine as fe
     spec = dataclasses.replace(ofl.DEFAULT_SPEC, **over)
     info = fe.plan_info(n, 1)
-    assert bool(info.get("chirpz_kind", 0)) == (n != 2880000), info
+    assert bool(info.get("chirpz_kind", 0)) == (n == 2880002), info
     x = synth(1, n, seed=77 + len(variant), scale=scale)
     want = ofl.enhance_channels(x, 1, 50, thr, normalize=False, autoscale=False, spec=spec)
     got = run_gpu(pack, x, 1, 50, thr, variant=variant)
