@@ -254,9 +254,10 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
     const double scd = p.inv_M_d;
     float thr2 = p.thr2, tlev = p.thr;
     if (!MAXONLY && p.max2) {
-        tlev = p.thr * sqrtf(__uint_as_float(p.max2[ch]));
+        tlev = p.thr * sqrtf(fl_max2_read(p.max2, ch));
         thr2 = tlev * tlev;
     }
+    if (!MAXONLY && p.max2_zero && blockIdx.x == 0 && threadIdx.x < EGR_FL_MAX_SUB) fl_max2_clear(p.max2_zero, ch, threadIdx.x);
     const bool variant = !MAXONLY && (p.max2 != nullptr || p.soft);
     float mx2 = 0.f;
     if (fast2) {
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
                 if (mm > tlev) gm = 1.f - tlev / mm;
             }
             Xk.x *= gk; Xk.y *= gk; Xm.x *= gm; Xm.y *= gm;
+            mx2 = fmaxf(mx2, fmaxf(Xk.x * Xk.x + Xk.y * Xk.y, Xm.x * Xm.x + Xm.y * Xm.y));      // what the next iteration's spectrum will hold
         } else if (p.band) {
             const long long k = (long long)oa + (long long)R * k2;
             if (k < p.band_lo) Xk = make_float2(0.f, 0.f);
@@ -353,10 +355,19 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
     }
     if (MAXONLY) {
         mx2 = block_max(mx2, red);
-        if (threadIdx.x == 0) atomicMax(p.max2_out + ch, __float_as_uint(mx2));
+        if (threadIdx.x == 0) fl_max2_commit(p.max2_out, ch, mx2);
         return;
     }
+    if (p.max2_next) {                       // carried maximum: one commit per workgroup, behind the barrier that is there anyway
+        mx2 = wave_max(mx2);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx2;
+    }
     __syncthreads();
+    if (p.max2_next && threadIdx.x == 0) {
+        float r = red[0];
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fmaxf(r, red[i]);
+        fl_max2_commit(p.max2_next, ch, r);
+    }
     EGR_STAMP(p, 3);
     row_fft<SCHED>(cur, alt, p, nrows, L, true);
     EGR_STAMP(p, 4);
@@ -442,11 +453,11 @@ __global__ __launch_bounds__(1024) void k_colz(ColP p, ChirpP cp, long long P, f
             }
         }
         mx = block_max(mx, red);
-        if (threadIdx.x == 0) atomicMax(cp.max2_out + ch, __float_as_uint(mx));
+        if (threadIdx.x == 0) fl_max2_commit(cp.max2_out, ch, mx);
         return;
     }
     if (MODE == 1 && HOOK == 1 && cp.max2) {
-        thr *= sqrtf(__uint_as_float(cp.max2[ch]));
+        thr *= sqrtf(fl_max2_read(cp.max2, ch));
         thr2 = thr * thr;
     }
     if (MODE == 2) {
@@ -921,24 +932,28 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
     p->wl_row = p->wl_col = 0;
     {
         const bool off = getenv("EGR_FL_WL") && atoi(getenv("EGR_FL_WL")) == 0;
-        auto table = [&](int n, int m, int T, const cplx** d) {          // [n][m]: W_T^(i j)
-            std::vector<float2> t;
-            t.resize((size_t)n * m);
+        auto table = [&](int n, int m, int T, const cplx** d, const cplx** dlo) {          // [n][m]: W_T^(i j), and its low parts
+            std::vector<float2> t, tl;
+            t.resize((size_t)n * m); tl.resize((size_t)n * m);
             const long double two_pi = 6.283185307179586476925286766559L;
             for (int i = 0; i < n; ++i)
                 for (int j = 0; j < m; ++j) {
                     const long double ang = -two_pi * (long double)(((long long)i * j) % T) / (long double)T;
-                    t[(size_t)i * m + j] = make_float2((float)cosl(ang), (float)sinl(ang));
+                    const long double c = cosl(ang), sn = sinl(ang);
+                    const float2 h = make_float2((float)c, (float)sn);
+                    t[(size_t)i * m + j] = h;
+                    tl[(size_t)i * m + j] = make_float2((float)(c - (long double)h.x), (float)(sn - (long double)h.y));
                 }
-            return fl_upload(p, t, d);
+            const int rc2 = fl_upload(p, t, d);
+            return rc2 ? rc2 : fl_upload(p, tl, dlo);
         };
         p->wl_row_entry = nullptr;
         if (!off && !p->bluestein)
             for (const WlRowEntry& e : kWlRows)
                 if (e.L == r.L) {
                     const int qq = e.q * e.q;
-                    if ((rc = table(qq, e.n1, e.L, &p->wl_rt.t1))) return fail(rc);
-                    if ((rc = table(e.q, e.q, qq, &p->wl_rt.t2))) return fail(rc);
+                    if ((rc = table(qq, e.n1, e.L, &p->wl_rt.t1, &p->wl_rt.t1l))) return fail(rc);
+                    if ((rc = table(e.q, e.q, qq, &p->wl_rt.t2, &p->wl_rt.t2l))) return fail(rc);
                     const long double ang = -3.14159265358979323846264338327950288L / (long double)e.q;         // W_(2Q)
                     p->wl_rt.hook_step = make_double2((double)cosl(ang), (double)sinl(ang));
                     p->wl_row_entry = &e;
@@ -946,14 +961,15 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
                 }
         if (!off && !p->bluestein && wl_col_radix(a.L)) {
             const int r = wl_col_radix(a.L);
-            if ((rc = table(r, r, r * r, &p->wl_ct.t3))) return fail(rc);
+            if ((rc = table(r, r, r * r, &p->wl_ct.t3, &p->wl_ct.t3l))) return fail(rc);
             p->wl_col = 1;
         }
         p->wl_inner = 0; p->wl_it = nullptr;
         if (!off && !p->bluestein && sp.levels == 3 && wl_inner_supported(sp.M2)) {
             int la, lb, tcw;
             wl_inner_geometry(sp.M2, &la, &lb, &tcw);
-            if ((rc = table(lb, la, sp.M2, &p->wl_it))) return fail(rc);
+            const cplx* itl = nullptr;
+            if ((rc = table(lb, la, sp.M2, &p->wl_it, &itl))) return fail(rc);
             p->wl_colB = p->colB;
             p->wl_colB.TC = tcw; p->wl_colB.TClog2 = 0;
             p->wl_colB.ntiles = ceil_div(p->colB.ncols, tcw); p->wl_colB.tiles_per_xcd = ceil_div(p->wl_colB.ntiles, 8);
@@ -1317,15 +1333,23 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
     unsigned* peak_out = p->d_peaks + C;
     unsigned* peak_y = p->d_peaks + 2 * C;
     EGR_HIP(hipMemsetAsync(p->d_peaks, 0, 3 * C * sizeof(unsigned), st));
+    // EGR_FL_THR_RECOMPUTE: the maximum of every iteration's spectrum from a read-only pass of its own (rounds 1-5) instead of the
+    // one the previous iteration's hook carried forward; the two agree to the round-off of one float32 transform pair
+    const bool recompute = relative && (flags & EGR_FL_THR_RECOMPUTE) != 0;
     if (relative && max_iter > 0) {
-        const size_t need = (size_t)max_iter * C;
+        // a ring of EGR_FL_MAX_RING slots (fl_max2_*): iteration it reads slot it, leaves the next maximum in slot it + 1 and clears
+        // slot it + 2 (mod ring).  The legacy chirp-z loop keeps one slot per iteration.
+        const size_t nslots = (p->bluestein && !p->pz) ? (size_t)max_iter : (size_t)EGR_FL_MAX_RING;
+        const size_t need = nslots * C * EGR_FL_MAX_STRIDE;
         if (need > p->max2_cap) {
+            if (p->gexec) { EGR_HIP(hipDeviceSynchronize()); EGR_HIP(hipGraphExecDestroy(p->gexec)); p->gexec = nullptr; }      // it recorded the old ring
             if (p->d_max2) { EGR_HIP(hipFree(p->d_max2)); p->d_max2 = nullptr; p->max2_cap = 0; }
             EGR_HIP(hipMalloc((void**)&p->d_max2, need * sizeof(unsigned)));
             p->max2_cap = need;
         }
         EGR_HIP(hipMemsetAsync(p->d_max2, 0, need * sizeof(unsigned), st));
     }
+    auto max2_slot = [&](int it, int ch0) { return p->d_max2 + ((size_t)(it % EGR_FL_MAX_RING) * C + ch0) * EGR_FL_MAX_STRIDE; };
     // time-domain level of the opening pass: thr, thr * max|y| (relative) or none (every sample kept)
     const float thr0 = no_init ? -1.0f : thr;
     const unsigned* thr0_rel = (relative && !no_init) ? peak_y : nullptr;
@@ -1364,7 +1388,7 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         for (int it = 0; it < max_iter; ++it) {
             conv();
             if (relative) {                 // this iteration's spectrum maximum first (same pass, no write-back)
-                cp.max2_out = p->d_max2 + (size_t)it * C;
+                cp.max2_out = p->d_max2 + (size_t)it * C * EGR_FL_MAX_STRIDE;
                 hipLaunchKernelGGL((k_colz<3, 1>), gA, blk, lc, st, A, cp, P, thr, thr2, p->d_work, out, peak_out, (const unsigned*)nullptr);
                 cp.max2 = cp.max2_out;
             }
@@ -1414,14 +1438,23 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
                     else hipLaunchKernelGGL(k_col<4>, gBg, blk, lb, sg, B, M, N, thr, wk, og, pk);
                 }
             }
+            // the spectrum maximum by a pass of its own (forward row transforms + split, no write-back): only the FIRST iteration
+            // needs it -- d0 = T0(y) is not the image of a shrunk spectrum -- every later one finds the maximum its predecessor's hook left
+            auto max_pass = [&](int it) {
+                RowP Rm = R;
+                Rm.max2_out = max2_slot(it, c0);
+                if (wlr) hipLaunchKernelGGL(wle->fn_max, growg, dim3(wle->threads), EGR_LDS(wle->lds), sg, Rm, p->wl_rt, M, wk);
+                else if (rs1) hipLaunchKernelGGL((k_row<true, 1>), growg, blk, lrs, sg, Rm, M, wk);
+                else hipLaunchKernelGGL(k_row<true>, growg, blk, lr, sg, Rm, M, wk);
+            };
+            if (first && relative) max_pass(0);
             for (int it = it0; it < it1; ++it) {
                 RowP Rg = R;
-                if (relative) {        // this iteration's spectrum maximum first (forward row transforms + split, no write-back)
-                    Rg.max2_out = p->d_max2 + (size_t)it * C + c0;
-                    if (wlr) hipLaunchKernelGGL(wle->fn_max, growg, dim3(wle->threads), EGR_LDS(wle->lds), sg, Rg, p->wl_rt, M, wk);
-                    else if (rs1) hipLaunchKernelGGL((k_row<true, 1>), growg, blk, lrs, sg, Rg, M, wk);
-                    else hipLaunchKernelGGL(k_row<true>, growg, blk, lr, sg, Rg, M, wk);
-                    Rg.max2 = Rg.max2_out;
+                if (relative) {
+                    if (recompute && it > 0) max_pass(it);
+                    Rg.max2 = max2_slot(it, c0);
+                    Rg.max2_next = recompute ? nullptr : max2_slot(it + 1, c0);
+                    Rg.max2_zero = max2_slot(it + 2, c0);
                 }
                 if (prof) fl_prof_begin(p, 0, sg, &slot);
                 if (wlr && wl_variant) hipLaunchKernelGGL(wle->fn_variant, growg, dim3(wle->threads), EGR_LDS(wle->lds), sg, Rg, p->wl_rt, M, wk);
@@ -1473,7 +1506,9 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         // executable graph is kept while (out, threshold, geometry) stay the same.  Profiling runs use plain launches.
         constexpr int CH = 25;
         const bool profiling = p->profiling != 0;
-        const int n_graph = (!profiling && p->use_graph && !relative && max_iter > 2 * CH) ? (max_iter - 1) / CH : 0;
+        static_assert(CH == EGR_FL_MAX_RING, "the captured iterations address the ring of maxima by iteration mod CH");
+        const int n_graph = (!profiling && p->use_graph && !recompute && max_iter > 2 * CH) ? (max_iter - 1) / CH : 0;
+        const int g_kind = R.soft | (relative ? 2 : 0);
         int rc = fork(st);
         if (rc) return rc;
         for (int g = 0; g < ngroups; ++g) run_group(st, g, 0, 0, true, false, false);
@@ -1484,7 +1519,7 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
             // `out`), so the executable graph is keyed by (threshold, pipelines, hook kind) and survives calls with other buffers.
             // An executable graph is never destroyed while a launch of it may still be in flight (calls return asynchronously):
             // the device is drained first -- a re-capture is a rare, millisecond-scale event anyway.
-            if (!(p->gexec && p->g_thr == thr && p->g_groups == ngroups && p->g_iter_odd == R.soft)) {
+            if (!(p->gexec && p->g_thr == thr && p->g_groups == ngroups && p->g_iter_odd == g_kind)) {
                 if (p->gexec) { EGR_HIP(hipDeviceSynchronize()); EGR_HIP(hipGraphExecDestroy(p->gexec)); p->gexec = nullptr; }
                 hipGraph_t graph = nullptr;
                 // captured on a private stream (the caller's may be the legacy default stream, which cannot capture)
@@ -1505,7 +1540,7 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
                 hipError_t ie = hipGraphInstantiate(&p->gexec, graph, nullptr, nullptr, 0);
                 hipGraphDestroy(graph);
                 if (ie != hipSuccess) { p->gexec = nullptr; EGR_HIP(ie); }
-                p->g_out = out; p->g_thr = thr; p->g_groups = ngroups; p->g_iter_odd = R.soft;
+                p->g_out = out; p->g_thr = thr; p->g_groups = ngroups; p->g_iter_odd = g_kind;
             }
             for (int i = 0; i < n_graph; ++i) EGR_HIP(hipGraphLaunch(p->gexec, st));
             rc = fork(st);

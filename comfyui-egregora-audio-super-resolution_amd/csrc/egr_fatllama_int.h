@@ -115,6 +115,11 @@ struct RowP {
     // THIS iteration's spectrum (float bits, written by k_row<true>); soft: X max(0, 1 - t/|X|) instead of X [|X| > t].
     const unsigned* max2;
     unsigned* max2_out;    // k_row<true> only: where the maximum goes
+    // carried maximum (round 6): the spectrum the NEXT iteration will see is this iteration's post-shrink spectrum (S keeps the
+    // Hermitian symmetry, so fft(real(ifft(S(X)))) = S(X) up to round-off) -- the hook leaves max |S(X)|^2 in max2_next, and
+    // clears the ring slot two iterations ahead (max2_zero)
+    unsigned* max2_next;
+    unsigned* max2_zero;
     float thr;
     int soft;
 };
@@ -123,15 +128,45 @@ struct RowP {
 struct WlRowT {
     const cplx* t1;        // [Q^2][N1]: W_L^(n2 k1)
     const cplx* t2;        // [Q][Q]:    W_(Q^2)^(b c)
+    const cplx* t1l;       // the low parts of the same tables: t + tl = W to 2^-48 (cmul2)
+    const cplx* t2l;
     dcplx hook_step;       // W_(2Q): ratio of the pair twiddles between a lane's consecutive registers
 };
 struct WlColT {
     const cplx* t3;        // [25][25]: W_625^(b c)
+    const cplx* t3l;       // low parts
 };
 
 __device__ __forceinline__ void atomic_max_abs(unsigned* slot, float v) {
     // non-negative IEEE floats order like unsigned ints
     atomicMax(slot, __float_as_uint(v));
+}
+
+// Slots of the spectrum maxima of the relative threshold: per (ring slot, channel) EGR_FL_MAX_SUB words on lines of their own
+// (a line serves about one device-scope atomic per 25 ns, DESIGN.md 4.2b: a workgroup commits to sub-slot blockIdx.x mod 8 and
+// the reader takes the maximum of the eight).  All pointers below are the (slot, first channel of the launch) base.
+#define EGR_FL_MAX_SUB 8
+#define EGR_FL_MAX_LINE 32                                        // words per 128-byte line
+#define EGR_FL_MAX_STRIDE (EGR_FL_MAX_SUB * EGR_FL_MAX_LINE)      // words per (slot, channel)
+#define EGR_FL_MAX_RING 25                                        // ring slots = iterations of the captured loop graph
+__device__ __forceinline__ float fl_max2_read(const unsigned* base, int ch) {
+    const unsigned* b = base + (size_t)ch * EGR_FL_MAX_STRIDE;
+    unsigned m = b[0];
+#pragma unroll
+    for (int s = 1; s < EGR_FL_MAX_SUB; ++s) { const unsigned v = b[s * EGR_FL_MAX_LINE]; m = v > m ? v : m; }
+    return __uint_as_float(m);                                    // non-negative floats order like unsigned ints
+}
+__device__ __forceinline__ void fl_max2_commit(unsigned* base, int ch, float v) {
+    atomicMax(base + (size_t)ch * EGR_FL_MAX_STRIDE + (blockIdx.x & (EGR_FL_MAX_SUB - 1)) * EGR_FL_MAX_LINE, __float_as_uint(v));
+}
+// called by threads tid < EGR_FL_MAX_SUB of ONE workgroup per channel
+__device__ __forceinline__ void fl_max2_clear(unsigned* base, int ch, int tid) {
+    base[(size_t)ch * EGR_FL_MAX_STRIDE + tid * EGR_FL_MAX_LINE] = 0u;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
 }
 
 __device__ __forceinline__ float block_max(float v, float* red) {
@@ -155,7 +190,7 @@ struct ChirpP {
     int band;                // 1: the spectrum hook keeps bins min(n, N - n) >= band_lo instead of thresholding
     unsigned long long band_lo;
     int soft;                // 1: soft shrink X max(0, 1 - thr/|X|) instead of the hard threshold
-    const unsigned* max2;    // relative threshold: max_k |X[k]|^2 of this iteration per channel (float bits); level = thr sqrt(.)
+    const unsigned* max2;    // relative threshold: max_k |X[k]|^2 of this iteration per channel (fl_max2_read); level = thr sqrt(.)
     unsigned* max2_out;      // k_colz<3, 1> only: where that maximum goes
 };
 __device__ __forceinline__ cplx chirp(const ChirpP& c, unsigned long long n) {
@@ -194,7 +229,7 @@ struct egr_fatllama_plan {
     egr::cplx* d_bhat;         // FFT_P(b) / P in the passes' transposed layout
     egr::cplx* d_work;
     unsigned* d_peaks;   // [3*C]: peak_in[C], peak_out[C], peak_y[C]
-    unsigned* d_max2;    // [max2_cap]: per (iteration, channel) max |X|^2 of the relative-threshold variant
+    unsigned* d_max2;    // [max2_cap]: ring of per-(iteration, channel) max |X|^2 slots of the relative-threshold variant (fl_max2_*)
     size_t max2_cap;
     bool profiling;
     int threads;                  // workgroup size of the loop kernels (256 or 512)

@@ -57,8 +57,10 @@ struct PzHook {
     int soft;                   // soft shrink instead of the hard threshold
     int band;                   // keep bins >= band_lo instead of thresholding (egr_band_filter)
     unsigned long long band_lo;
-    const unsigned* max2;       // relative threshold: [C] max |X|^2 of this iteration per channel (float bits)
+    const unsigned* max2;       // relative threshold: max |X|^2 of this iteration per channel (slots of fl_max2_read)
     unsigned* max2_out;         // MAXONLY: where those maxima go
+    unsigned* max2_next;        // carried maximum: max |S(X)|^2 of this iteration = what the next iteration's spectrum holds (RowP)
+    unsigned* max2_zero;        // ring slot two iterations ahead, cleared by workgroup 0 of every state
 };
 
 __device__ __forceinline__ dcplx pz_chirp(const PzP& p, unsigned long long k) {       // w[k] = W_(2D)^(k^2 mod 2D)
@@ -360,6 +362,27 @@ struct PzColWlEntry { int L, la, lb, threads, lds; PzColWlFn fn; };
 #define PZ_COLWL_ENTRY(LEN, A, B) {LEN, A, B, PzColWl<A, B>::THREADS, PzColWl<A, B>::LDS, k_pzcol_wl<A, B>},
 static const PzColWlEntry kPzColWl[] = {PZ_COLWL_LIST(PZ_COLWL_ENTRY)};
 
+// Carried maximum of the relative threshold (PzHook::max2_next): per-wave maxima to LDS in front of a barrier the kernel has anyway,
+// ONE commit per workgroup and channel behind it; workgroup g = 0 of a state clears the ring slot two iterations ahead.
+__device__ __forceinline__ void pz_max_stage(const PzHook& h, float mxa, float mxb, float* red) {
+    if (!h.max2_next) return;
+    mxa = wave_max(mxa); mxb = wave_max(mxb);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = mxa; red[16 + (threadIdx.x >> 6)] = mxb; }
+}
+__device__ __forceinline__ void pz_max_commit(const PzP& p, const PzHook& h, int st, int g, const float* red) {
+    const int cha = p.kind == 1 ? st : 2 * st, chb = p.kind == 1 ? st : 2 * st + 1;
+    const bool hasb = p.kind == 2 && chb < p.C;
+    if (h.max2_zero && g == 0 && threadIdx.x < EGR_FL_MAX_SUB) {
+        fl_max2_clear(h.max2_zero, cha, threadIdx.x);
+        if (hasb) fl_max2_clear(h.max2_zero, chb, threadIdx.x);
+    }
+    if (!h.max2_next || threadIdx.x != 0) return;
+    float ra = red[0], rb = red[16];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) { ra = fmaxf(ra, red[i]); rb = fmaxf(rb, red[16 + i]); }
+    fl_max2_commit(h.max2_next, cha, ra);
+    if (hasb) fl_max2_commit(h.max2_next, chb, rb);
+}
+
 // The pair hook of the spectrum pass on natural-order positions p = i nc + c of a tile pair held in LDS; index k = p - s is valid
 // for 0 <= k < D.  at(i, slot): element i of right column t at slot t, of left column t at slot TC + t.  Shared by k_pzpair (stages
 // in place, interleaved tile) and k_pzpair_wl (rows of the thread-per-(row class, column) layout).
@@ -374,8 +397,8 @@ __device__ __forceinline__ void pz_pair_hook(const PzP& p, const PzHook& h, AT a
     const bool hasb = chb < p.C;
     double ta = (double)h.thr, tb = (double)h.thr;
     if (!MAXONLY && h.max2) {
-        ta = (double)(h.thr * sqrtf(__uint_as_float(h.max2[cha])));
-        tb = p.kind == 1 ? ta : (double)(h.thr * sqrtf(__uint_as_float(h.max2[hasb ? chb : cha])));
+        ta = (double)(h.thr * sqrtf(fl_max2_read(h.max2, cha)));
+        tb = p.kind == 1 ? ta : (double)(h.thr * sqrtf(fl_max2_read(h.max2, hasb ? chb : cha)));
     }
     const double ta2 = ta * ta, tb2 = tb * tb;
     const double sgn = p.odd ? -1.0 : 1.0;          // w[D - k] = (-1)^D w[k]
@@ -456,6 +479,11 @@ __device__ __forceinline__ void pz_pair_hook(const PzP& p, const PzHook& h, AT a
             if (!(ma2 > ta2)) Xk = make_double2(0.0, 0.0);
             if (!(mb2 > tb2)) Xm = make_double2(0.0, 0.0);
         }
+        if (h.max2_next) {                      // max |S(X)|^2: the spectrum of the next iteration
+            const float na2 = (float)(Xk.x * Xk.x + Xk.y * Xk.y), nb2 = (float)(Xm.x * Xm.x + Xm.y * Xm.y);
+            if (p.kind == 1) mxa = fmaxf(mxa, fmaxf(na2, nb2));
+            else { mxa = fmaxf(mxa, na2); mxb = fmaxf(mxb, nb2); }
+        }
         dcplx E2, O2;
         if (p.kind == 1) {
             E2 = make_double2(0.5 * (Xk.x + Xm.x), 0.5 * (Xk.y + Xm.y));
@@ -481,7 +509,7 @@ template <bool MAXONLY, class F>
 __global__ __launch_bounds__(F::MAXT, F::MINW2) void k_pzpair(PzP p, PzHook h, cplx* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     EGR_LDS_CANARY_ARM(smem);
-    __shared__ float red[16];
+    __shared__ float red[32];
     const int g = (blockIdx.x & 7) * p.g_per_xcd + (blockIdx.x >> 3);
     if (g >= p.G) return;
     const int st = blockIdx.y;
@@ -531,8 +559,8 @@ __global__ __launch_bounds__(F::MAXT, F::MINW2) void k_pzpair(PzP p, PzHook h, c
         mxa = block_max(mxa, red);
         if (p.kind == 2 && hasb) mxb = block_max(mxb, red);
         if (threadIdx.x == 0) {
-            atomicMax(h.max2_out + cha, __float_as_uint(mxa));
-            if (p.kind == 2 && hasb) atomicMax(h.max2_out + chb, __float_as_uint(mxb));
+            fl_max2_commit(h.max2_out, cha, mxa);
+            if (p.kind == 2 && hasb) fl_max2_commit(h.max2_out, chb, mxb);
         }
         return;
     }
@@ -545,7 +573,9 @@ __global__ __launch_bounds__(F::MAXT, F::MINW2) void k_pzpair(PzP p, PzHook h, c
         const long long k = (long long)i * nc + c - s;
         if (k < 0 || (unsigned long long)k >= D) cur[(size_t)i * TC2 + TC + t] = make_float2(0.f, 0.f);
     }
+    pz_max_stage(h, mxa, mxb, red);
     __syncthreads();
+    pz_max_commit(p, h, st, g, red);
     F::run(cur, p, TC2, lg + 1, false);
 #pragma unroll
     for (int k = 0; k < F::NE2; ++k) {
@@ -567,6 +597,7 @@ __global__ __launch_bounds__((PzColWl<LA, LB>::THREADS)) void k_pzpair_wl(PzP p,
     using G = PzColWl<LA, LB>;
     constexpr int TC = 4, TC2 = 8, LBP = G::LBP, L = LA * LB;
     __shared__ cplx ts[L];
+    __shared__ float red[32];
     const int g = (blockIdx.x & 7) * p.g_per_xcd + (blockIdx.x >> 3);
     if (g >= p.G) return;
     const int st = blockIdx.y;
@@ -629,7 +660,9 @@ __global__ __launch_bounds__((PzColWl<LA, LB>::THREADS)) void k_pzpair_wl(PzP p,
     __syncthreads();
     float mxa = 0.f, mxb = 0.f;
     pz_pair_hook<false>(p, h, [&](int i, int slot) { const int q = i / LA; return lds + ((i - q * LA) * LBP + q) * TC2 + slot; }, st, rs, rmask, selfmask, mxa, mxb);
+    pz_max_stage(h, mxa, mxb, red);
     __syncthreads();
+    pz_max_commit(p, h, st, g, red);
     if (b < LA) {
         const int c = b;
 #pragma unroll
@@ -1179,6 +1212,8 @@ int pz_loop(egr_fatllama_plan* plan, float* out, int max_iter, float thr, float 
     const PzP& q = z->p;
     const int C = plan->C;
     const bool relative = (flags & EGR_FL_THR_RELATIVE) != 0;
+    const bool recompute = relative && (flags & EGR_FL_THR_RECOMPUTE) != 0;
+    auto max2_slot = [&](int it, int ch0) { return plan->d_max2 + ((size_t)(it % EGR_FL_MAX_RING) * C + ch0) * EGR_FL_MAX_STRIDE; };
     PzHook h;
     memset(&h, 0, sizeof(h));
     h.thr = thr;
@@ -1229,9 +1264,14 @@ int pz_loop(egr_fatllama_plan* plan, float* out, int max_iter, float thr, float 
             run.conv(false, work, ns, sg, p_it, &slot);
             PzHook hg = h;
             if (relative) {
-                hg.max2_out = plan->d_max2 + (size_t)it * C + ch0;
-                run.pair(qg, hg, true, work, ns, sg, false, &slot);
-                hg.max2 = hg.max2_out;
+                // the spectrum maximum from a read-only pass only where no hook has left it: iteration 0 (or every one, on request)
+                if (it == 0 || recompute) {
+                    hg.max2_out = max2_slot(it, ch0);
+                    run.pair(qg, hg, true, work, ns, sg, false, &slot);
+                }
+                hg.max2 = max2_slot(it, ch0);
+                hg.max2_next = recompute ? nullptr : max2_slot(it + 1, ch0);
+                hg.max2_zero = max2_slot(it + 2, ch0);
             }
             run.pair(qg, hg, false, work, ns, sg, p_it, &slot);
             run.conv(true, work, ns, sg, false, &slot);
@@ -1250,24 +1290,28 @@ int pz_loop(egr_fatllama_plan* plan, float* out, int max_iter, float thr, float 
     };
     // The four launches of a middle iteration are the same every iteration and touch the plan's own state only: CH iterations of all
     // pipelines are captured once into a hipGraph and replayed (as the packed loop does, egr_fatllama.hip); keyed by (threshold,
-    // pipelines, hook kind), never destroyed while a launch of it may be in flight.  Profiling and the relative threshold (a new
-    // reduction slot per iteration) use plain launches.
+    // pipelines, hook kind), never destroyed while a launch of it may be in flight.  Profiling and EGR_FL_THR_RECOMPUTE use plain
+    // launches; the relative threshold's carried maxima live in a ring of CH slots addressed by iteration mod CH.
     constexpr int CH = 25;
     // (two pipelines: 113.9 -> 103.4 ms per 800 iterations of 60 s + 2 samples; a single pipeline measures the same either way)
-    const int n_graph = (!prof && plan->use_graph && !relative && ngroups == 2 && max_iter > 2 * CH) ? (max_iter - 1) / CH : 0;
+    static_assert(CH == EGR_FL_MAX_RING, "the captured iterations address the ring of maxima by iteration mod CH");
+    // relative threshold: iteration 0 (the one with a maximum pass of its own, behind its first convolution) stays outside the graph
+    const int pre = relative ? 1 : 0;
+    const int n_graph = (!prof && plan->use_graph && !recompute && ngroups == 2 && max_iter > 2 * CH) ? (max_iter - 1 - pre) / CH : 0;
+    const int g_kind = h.soft | (relative ? 2 : 0);
     int rc = fork(st);
     if (rc) return rc;
-    for (int g = 0; g < ngroups; ++g) run_group(st, g, 0, 0, true, false, false);
+    for (int g = 0; g < ngroups; ++g) run_group(st, g, 0, n_graph > 0 ? pre : 0, true, false, false);
     if (n_graph > 0) {
         rc = join(st);
         if (rc) return rc;
-        if (!(plan->gexec && plan->g_thr == thr && plan->g_groups == ngroups && plan->g_iter_odd == h.soft)) {
+        if (!(plan->gexec && plan->g_thr == thr && plan->g_groups == ngroups && plan->g_iter_odd == g_kind)) {
             if (plan->gexec) { EGR_HIP(hipDeviceSynchronize()); EGR_HIP(hipGraphExecDestroy(plan->gexec)); plan->gexec = nullptr; }
             hipGraph_t graph = nullptr;
             if (!plan->cap) EGR_HIP(hipStreamCreateWithFlags(&plan->cap, hipStreamNonBlocking));
             EGR_HIP(hipStreamBeginCapture(plan->cap, hipStreamCaptureModeThreadLocal));
             rc = fork(plan->cap);
-            if (!rc) for (int g = 0; g < ngroups; ++g) run_group(plan->cap, g, 0, CH, false, false, false);
+            if (!rc) for (int g = 0; g < ngroups; ++g) run_group(plan->cap, g, pre, pre + CH, false, false, false);
             if (!rc) rc = join(plan->cap);
             hipError_t ce = hipStreamEndCapture(plan->cap, &graph);
             if (rc || ce != hipSuccess) {
@@ -1280,13 +1324,13 @@ int pz_loop(egr_fatllama_plan* plan, float* out, int max_iter, float thr, float 
             hipError_t ie = hipGraphInstantiate(&plan->gexec, graph, nullptr, nullptr, 0);
             hipGraphDestroy(graph);
             if (ie != hipSuccess) { plan->gexec = nullptr; EGR_HIP(ie); }
-            plan->g_out = out; plan->g_thr = thr; plan->g_groups = ngroups; plan->g_iter_odd = h.soft;
+            plan->g_out = out; plan->g_thr = thr; plan->g_groups = ngroups; plan->g_iter_odd = g_kind;
         }
         for (int i = 0; i < n_graph; ++i) EGR_HIP(hipGraphLaunch(plan->gexec, st));
         rc = fork(st);
         if (rc) return rc;
     }
-    for (int g = 0; g < ngroups; ++g) run_group(st, g, n_graph * CH, max_iter, false, true, prof);
+    for (int g = 0; g < ngroups; ++g) run_group(st, g, n_graph > 0 ? pre + n_graph * CH : 0, max_iter, false, true, prof);
     return join(st);
 }
 

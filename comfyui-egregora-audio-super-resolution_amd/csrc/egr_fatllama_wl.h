@@ -37,6 +37,13 @@ namespace egr {
 #ifndef EGR_WL_COL_WAVES
 #define EGR_WL_COL_WAVES 1
 #endif
+// Precision switches of the two-barrier kernels (bit mask; round 6, profiles/r06/c3_error_attribution.txt):
+//   1  hook: a pair whose two bins both survive the threshold leaves as Z / M -- the real split followed by its inverse is the identity
+//   2  k_col_wl: the four-step twiddles W_M^(col i) as two floats      4  W_(R^2)^(b c) as two floats
+//   8  k_row_wl: W_L^(n2 k1) as two floats                             16 W_(Q^2)^(b c) as two floats      32 the pair twiddle W_N^k as two floats
+#ifndef EGR_WL_HILO
+#define EGR_WL_HILO 0
+#endif
 // Geometry of k_col_wl<R, TC>: columns of R x R points (625 = 25^2: lengths with the factor 5^4 -- every multiple of 5 s at 48 kHz;
 // 441 = 21^2: lengths with the factor 3^2 7^2 -- whole seconds at 44.1 kHz), TC adjacent columns per workgroup, R TC threads on
 // four waves.  For R = 25, TC = 8 (200 of 256 lanes) is what ships.  Measured against it on one box (C3 stage,
@@ -65,10 +72,12 @@ template <int HOOK>
 __device__ __forceinline__ float wl_pair_hook(const cplx Za, const cplx Zb, const dcplx Wkd, const float thr2x4, const float tlevx2, const int soft,
                                               const WlScale sc, cplx& na, cplx& nb) {
     const cplx Wk = make_float2((float)Wkd.x, (float)Wkd.y);
+    const cplx Wl = make_float2((float)(Wkd.x - (double)Wk.x), (float)(Wkd.y - (double)Wk.y));
     const cplx E = make_float2(Za.x + Zb.x, Za.y - Zb.y);                   // 2 E
     const cplx O = make_float2(Za.y + Zb.y, Zb.x - Za.x);                   // 2 O
-    const cplx WO = cmul(Wk, O);
+    const cplx WO = (EGR_WL_HILO & 32) ? cmul2(O, Wk, Wl) : cmul(Wk, O);
     cplx Xk = cadd(E, WO), Xm = csub(E, WO);                                // 2 X[k], 2 X[M - k]
+    float mxn = 0.f;
     if (HOOK == 2) return 0.25f * fmaxf(Xk.x * Xk.x + Xk.y * Xk.y, Xm.x * Xm.x + Xm.y * Xm.y);
     if (HOOK == 1) {
         const float mk = sqrtf(Xk.x * Xk.x + Xk.y * Xk.y), mm = sqrtf(Xm.x * Xm.x + Xm.y * Xm.y);
@@ -78,16 +87,26 @@ __device__ __forceinline__ float wl_pair_hook(const cplx Za, const cplx Zb, cons
             if (mm > tlevx2) gm = 1.f - tlevx2 / mm;
         }
         Xk.x *= gk; Xk.y *= gk; Xm.x *= gm; Xm.y *= gm;
+        mxn = 0.25f * fmaxf(Xk.x * Xk.x + Xk.y * Xk.y, Xm.x * Xm.x + Xm.y * Xm.y);      // max |S(X)|^2: the next iteration's spectrum
     } else {
         if (!(Xk.x * Xk.x + Xk.y * Xk.y > thr2x4)) Xk = make_float2(0.f, 0.f);
         if (!(Xm.x * Xm.x + Xm.y * Xm.y > thr2x4)) Xm = make_float2(0.f, 0.f);
     }
     const cplx E2 = cadd(Xk, Xm);                                           // 4 E'
     const cplx H = csub(Xk, Xm);
-    const cplx O2 = cmulc(H, Wk);                                           // 4 O'
+    const cplx O2 = (EGR_WL_HILO & 32) ? cmulc2(H, Wk, Wl) : cmulc(H, Wk);   // 4 O'
     na = make_float2(wl_scaled(E2.x - O2.y, sc), wl_scaled(E2.y + O2.x, sc));
     nb = make_float2(wl_scaled(E2.x + O2.y, sc), wl_scaled(O2.x - E2.y, sc));
-    return 0.f;
+    if ((EGR_WL_HILO & 1) && HOOK == 0) {
+        // both bins kept: split . un-split is the identity (E2 + i O2 = 4 Za exactly in exact arithmetic), so the pair leaves as Z / M
+        // with the scale's one rounding instead of the eight of the detour
+        const bool both = (Xk.x != 0.f || Xk.y != 0.f) && (Xm.x != 0.f || Xm.y != 0.f);
+        if (both) {
+            na = make_float2(wl_scaled(4.f * Za.x, sc), wl_scaled(4.f * Za.y, sc));
+            nb = make_float2(wl_scaled(4.f * Zb.x, sc), wl_scaled(4.f * Zb.y, sc));
+        }
+    }
+    return mxn;
 }
 
 // Geometry of k_row_wl<N1, Q>: rows of L = N1 Q^2 points (N1: cross radix, even or odd; Q x Q blocks on Q lanes of one wave).
@@ -170,6 +189,12 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
         Bfly<N1>::run(v);
         cplx* d = lds + xr * RS + xn2;
         d[0] = v[0];
+        if (EGR_WL_HILO & 8) {
+            cplx wl[N1];
+            wl_load_tw<N1>(tb.t1l + xn2 * N1, wl);
+#pragma unroll
+            for (int k = 1; k < N1; ++k) d[k * S] = cmul2(v[k], w[k], wl[k]);
+        } else
 #pragma unroll
         for (int k = 1; k < N1; ++k) d[k * S] = cmul(v[k], w[k]);
     }
@@ -180,6 +205,7 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
     if (lact) {
         // ---- local step, forward: Q^2 = Q x Q per block, wave-local transposes
         const cplx* t2 = tb.t2 + l * Q;
+        const cplx* t2l = tb.t2l + l * Q;
 #pragma unroll
         for (int a = 0; a < Q; ++a) { A[a] = ba[Q * a + l]; B[a] = bb[Q * a + l]; }
         wl_wave_sync();
@@ -188,6 +214,12 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
 #pragma unroll
         for (int c = 0; c < Q; ++c) {
             const cplx w = t2[c];
+            if (EGR_WL_HILO & 16) {
+                const cplx wl = t2l[c];
+                ba[c * TS + l] = c ? cmul2(A[c], w, wl) : A[c];
+                bb[(Q - 1 - c) * TS + l] = c ? cmul2(B[c], w, wl) : B[c];
+                continue;
+            }
             ba[c * TS + l] = c ? cmul(A[c], w) : A[c];
             bb[(Q - 1 - c) * TS + l] = c ? cmul(B[c], w) : B[c];          // row b: lane l will hold c' = Q - 1 - l
         }
@@ -204,10 +236,11 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
     }
     EGR_STAMP(p, 2);
     float thr2 = p.thr2, tlev = p.thr;
-    if (HOOK == 1 && p.max2) {                   // level relative to this iteration's spectrum maximum (written by k_row_wl<.., 2>)
-        tlev = p.thr * sqrtf(__uint_as_float(p.max2[ch]));
+    if (HOOK == 1 && p.max2) {                   // level relative to this iteration's spectrum maximum: carried from the previous
+        tlev = p.thr * sqrtf(fl_max2_read(p.max2, ch));      // iteration's hook, or written by k_row_wl<.., 2> (iteration 0)
         thr2 = tlev * tlev;
     }
+    if (HOOK == 1 && p.max2_zero && blockIdx.x == 0 && tid < EGR_FL_MAX_SUB) fl_max2_clear(p.max2_zero, ch, tid);
     thr2 *= 4.f; tlev *= 2.f;                    // the hook judges 2 X (wl_pair_hook)
     const int soft = p.soft;
     const WlScale scd = wl_scale(p.inv_M_d);
@@ -253,22 +286,32 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
         }
     }
     EGR_STAMP(p, 3);
+    __shared__ float red[16];
     if (HOOK == 2) {                             // the reduction a threshold RELATIVE to the spectrum's maximum needs: nothing is written back
-        __shared__ float red[16];
         mx2 = block_max(mx2, red);
-        if (tid == 0) atomicMax(p.max2_out + ch, __float_as_uint(mx2));
+        if (tid == 0) fl_max2_commit(p.max2_out, ch, mx2);
         return;
+    }
+    if (HOOK == 1 && p.max2_next) {              // carried maximum: per-wave value now, ONE commit behind the barrier below
+        mx2 = wave_max(mx2);
+        if (lane == 0) red[wv] = mx2;
     }
     if (lact) {
         // ---- local step, inverse
         const cplx* t2 = tb.t2 + l * Q;                  // row a: c = l; W_(Q^2)^(b c) is symmetric in (b, c)
         const cplx* t2b = tb.t2 + (Q - 1 - l) * Q;       // row b: c' = Q - 1 - l
+        const cplx* t2l = tb.t2l + l * Q;
+        const cplx* t2bl = tb.t2l + (Q - 1 - l) * Q;
         wl_bfly_inv<Q>(A);
         wl_bfly_inv<Q>(B);
 #pragma unroll
         for (int b2 = 0; b2 < Q; b2 += 2) {
-            const cplx a0 = b2 ? cmulc(A[b2], t2[b2]) : A[b2], a1 = cmulc(A[b2 + 1], t2[b2 + 1]);
-            const cplx c0 = b2 ? cmulc(B[b2], t2b[b2]) : B[b2], c1 = cmulc(B[b2 + 1], t2b[b2 + 1]);
+            cplx a0 = b2 ? cmulc(A[b2], t2[b2]) : A[b2], a1 = cmulc(A[b2 + 1], t2[b2 + 1]);
+            cplx c0 = b2 ? cmulc(B[b2], t2b[b2]) : B[b2], c1 = cmulc(B[b2 + 1], t2b[b2 + 1]);
+            if (EGR_WL_HILO & 16) {
+                a0 = b2 ? cmulc2(A[b2], t2[b2], t2l[b2]) : A[b2]; a1 = cmulc2(A[b2 + 1], t2[b2 + 1], t2l[b2 + 1]);
+                c0 = b2 ? cmulc2(B[b2], t2b[b2], t2bl[b2]) : B[b2]; c1 = cmulc2(B[b2 + 1], t2b[b2 + 1], t2bl[b2 + 1]);
+            }
             *(float4*)(ba + l * TS + b2) = make_float4(a0.x, a0.y, a1.x, a1.y);
             *(float4*)(bb + l * TS + b2) = make_float4(c0.x, c0.y, c1.x, c1.y);
         }
@@ -282,6 +325,12 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
         for (int a = 0; a < Q; ++a) { ba[Q * a + l] = A[a]; bb[Q * a + l] = B[a]; }
     }
     __syncthreads();
+    if (HOOK == 1 && p.max2_next && tid == 0) {
+        float r = red[0];
+#pragma unroll
+        for (int i = 1; i < THREADS / 64; ++i) r = fmaxf(r, red[i]);
+        fl_max2_commit(p.max2_next, ch, r);
+    }
     EGR_STAMP(p, 4);
     // ---- cross step, inverse: LDS blocks -> twiddle^-1 -> inverse radix N1 -> global
 #pragma unroll
@@ -294,6 +343,12 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
         cplx v[N1], w[N1];
         wl_load_tw<N1>(tb.t1 + xn2 * N1, w);
         v[0] = s[0];
+        if (EGR_WL_HILO & 8) {
+            cplx wl[N1];
+            wl_load_tw<N1>(tb.t1l + xn2 * N1, wl);
+#pragma unroll
+            for (int k = 1; k < N1; ++k) v[k] = cmulc2(s[k * S], w[k], wl[k]);
+        } else
 #pragma unroll
         for (int k = 1; k < N1; ++k) v[k] = cmulc(s[k * S], w[k]);
         wl_bfly_inv<N1>(v);
@@ -317,6 +372,7 @@ __global__ __launch_bounds__((WlCol<R, TC>::THREADS), EGR_WL_COL_WAVES) void k_c
     EGR_LDS_CANARY_ARM(smem);
     constexpr int RR = R * R, THREADS = WlCol<R, TC>::THREADS;
     __shared__ cplx t3s[RR];
+    __shared__ cplx t3ls[(EGR_WL_HILO & 4) ? RR : 1];
     const int tile = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
     if (tile >= p.ntiles) return;
     const int ch = blockIdx.y / p.nplanes, plane = blockIdx.y - ch * p.nplanes;
@@ -327,8 +383,10 @@ __global__ __launch_bounds__((WlCol<R, TC>::THREADS), EGR_WL_COL_WAVES) void k_c
     const bool act = tid < R * TC && col < nc;
     cplx* W = work + (size_t)ch * M + (size_t)plane * RR * nc + col;
     for (int e = tid; e < RR; e += THREADS) t3s[e] = tb.t3[e];
+    if (EGR_WL_HILO & 4) for (int e = tid; e < RR; e += THREADS) t3ls[e] = tb.t3l[e];
     EGR_STAMP(p, 0);
     cplx v[R], tw[R];
+    cplx twl[(EGR_WL_HILO & 2) ? R : 1];
     // four-step twiddles W_M^(col (R a + b)) of this thread's rows: first value and ratio from the hi/lo tables, in double
     if (act) {
 #pragma unroll
@@ -338,6 +396,10 @@ __global__ __launch_bounds__((WlCol<R, TC>::THREADS), EGR_WL_COL_WAVES) void k_c
 #pragma unroll
         for (int a = 0; a < R; ++a) {
             tw[a] = make_float2((float)cur.x, (float)cur.y);             // kept for the way out: the run is formed once
+            if (EGR_WL_HILO & 2) {
+                twl[a] = make_float2((float)(cur.x - (double)tw[a].x), (float)(cur.y - (double)tw[a].y));
+                v[a] = cmulc2(v[a], tw[a], twl[a]);
+            } else
             v[a] = cmulc(v[a], tw[a]);
             cur = dcmul(cur, wst);
         }
@@ -349,16 +411,21 @@ __global__ __launch_bounds__((WlCol<R, TC>::THREADS), EGR_WL_COL_WAVES) void k_c
     EGR_STAMP(p, 1);
     if (act) {
         const cplx* tr = t3s + b * R;                    // this thread is now c = b of the first step; row c of the (symmetric) table
+        const cplx* trl = t3ls + ((EGR_WL_HILO & 4) ? b * R : 0);
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const cplx z = lds[(b * R + j) * TC + cl];
+            if (EGR_WL_HILO & 4) { v[j] = j ? cmulc2(z, tr[j], trl[j]) : z; continue; }
             v[j] = j ? cmulc(z, tr[j]) : z;
         }
         wl_bfly_inv<R>(v);                               // v[d] = t[c + R d]: the time-domain column (nothing happens to it in the loop)
         EGR_STAMP(p, 2);
         Bfly<R>::run(v);                                 // forward over a' = d: v[c''] = Z2[c''][b' = c]
 #pragma unroll
-        for (int j = 0; j < R; ++j) lds[(b * R + j) * TC + cl] = j ? cmul(v[j], tr[j]) : v[j];      // transposed: into the row it has just read
+        for (int j = 0; j < R; ++j) {                     // transposed: into the row it has just read
+            if (EGR_WL_HILO & 4) { lds[(b * R + j) * TC + cl] = j ? cmul2(v[j], tr[j], trl[j]) : v[j]; continue; }
+            lds[(b * R + j) * TC + cl] = j ? cmul(v[j], tr[j]) : v[j];
+        }
     }
     __syncthreads();
     if (act) {
@@ -367,7 +434,7 @@ __global__ __launch_bounds__((WlCol<R, TC>::THREADS), EGR_WL_COL_WAVES) void k_c
         Bfly<R>::run(v);                                 // v[d''] = X[c'' + R d'']
         EGR_STAMP(p, 3);
 #pragma unroll
-        for (int a = 0; a < R; ++a) W[(size_t)(R * a + b) * nc] = cmul(v[a], tw[a]);
+        for (int a = 0; a < R; ++a) W[(size_t)(R * a + b) * nc] = (EGR_WL_HILO & 2) ? cmul2(v[a], tw[a], twl[(EGR_WL_HILO & 2) ? a : 0]) : cmul(v[a], tw[a]);
     }
     EGR_STAMP(p, 4);
 }

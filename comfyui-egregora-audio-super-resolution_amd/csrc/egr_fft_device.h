@@ -34,6 +34,18 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
 __device__ __forceinline__ cplx cmulc(cplx a, cplx b) {  // a * conj(b)
     return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
+// Products with a constant held as TWO floats (w = wh + wl to 2^-48): the low parts enter first, the result is rounded where a plain
+// product is, but the constant itself carries no rounding -- |wh + wl|^2 = 1 to 1e-15, where |float(w)|^2 - 1 ~ 6e-8 is a gain the
+// loop would apply to the same coefficient in the same direction in every iteration (W on the way in, conj W on the way out).
+__device__ __forceinline__ cplx cmul2(cplx a, cplx bh, cplx bl) {
+    return make_float2(fmaf(a.x, bh.x, fmaf(-a.y, bh.y, fmaf(a.x, bl.x, -a.y * bl.y))), fmaf(a.x, bh.y, fmaf(a.y, bh.x, fmaf(a.x, bl.y, a.y * bl.x))));
+}
+__device__ __forceinline__ cplx cmulc2(cplx a, cplx bh, cplx bl) {  // a * conj(b)
+    return make_float2(fmaf(a.x, bh.x, fmaf(a.y, bh.y, fmaf(a.x, bl.x, a.y * bl.y))), fmaf(a.y, bh.x, fmaf(-a.x, bh.y, fmaf(a.y, bl.x, -a.x * bl.y))));
+}
+#ifndef EGR_BFLY_HILO
+#define EGR_BFLY_HILO 0      // 1: the register butterflies' own constants (cos / sin of the odd radices, inner twiddles of the composites) as two floats
+#endif
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_float2(a.x - b.x, a.y - b.y); }
 
@@ -62,6 +74,12 @@ template <int R> struct Bfly {
             for (int n = 1; n <= H; ++n) {
                 const float cc = Trig<R>::c[(n * k) % R];
                 const float ss = Trig<R>::s[(n * k) % R];
+                if (EGR_BFLY_HILO) {
+                    const float cl = Trig<R>::cl[(n * k) % R], sl = Trig<R>::sl[(n * k) % R];
+                    c.x = fmaf(cc, a[n - 1].x, fmaf(cl, a[n - 1].x, c.x)); c.y = fmaf(cc, a[n - 1].y, fmaf(cl, a[n - 1].y, c.y));
+                    s.x = fmaf(ss, b[n - 1].x, fmaf(sl, b[n - 1].x, s.x)); s.y = fmaf(ss, b[n - 1].y, fmaf(sl, b[n - 1].y, s.y));
+                    continue;
+                }
                 c.x += cc * a[n - 1].x; c.y += cc * a[n - 1].y;
                 s.x += ss * b[n - 1].x; s.y += ss * b[n - 1].y;
             }
@@ -106,6 +124,10 @@ template <int R1, int R2> struct BflyComp {
 #pragma unroll
             for (int k1 = 0; k1 < R1; ++k1) {
                 const int m = (n2 * k1) % R;
+                if (EGR_BFLY_HILO && m != 0 && (4 * m) % R != 0) {          // (quarter turns are exact)
+                    y[k1 * R2 + n2] = cmul2(t[k1], make_float2(Trig<R>::c[m], -Trig<R>::s[m]), make_float2(Trig<R>::cl[m], -Trig<R>::sl[m]));
+                    continue;
+                }
                 y[k1 * R2 + n2] = (m == 0) ? t[k1] : cmul(t[k1], make_float2(Trig<R>::c[m], -Trig<R>::s[m]));
             }
         }

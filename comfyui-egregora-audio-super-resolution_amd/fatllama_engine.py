@@ -21,7 +21,9 @@ SAMPLE_WIDTH_BYTES = 2        # temp WAVs are PCM_16 (libsndfile default for flo
 # pre-threshold, linear up-rating by the rounded integer factor.  ratio_then_int (output length int(n * ratio), needs linspace)
 # is a host-side rule: it has no device flag of its own.
 VARIANT_FLAGS = {"relative": native.FL_THR_RELATIVE, "soft": native.FL_THR_SOFT, "no_init_thr": native.FL_NO_INIT_THR,
-                 "zero_stuff": native.FL_ZERO_STUFF, "linspace": native.FL_INTERP_LINSPACE, "ratio_then_int": native.FL_INTERP_LINSPACE}
+                 "zero_stuff": native.FL_ZERO_STUFF, "linspace": native.FL_INTERP_LINSPACE, "ratio_then_int": native.FL_INTERP_LINSPACE,
+                 # not a reading of upstream: how the device obtains the relative level (a pass per iteration instead of the carried maximum)
+                 "recompute": native.FL_THR_RECOMPUTE}
 
 
 def variant_names(names=None):

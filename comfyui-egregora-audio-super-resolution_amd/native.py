@@ -13,6 +13,7 @@ LIB_PATH = Path(__file__).resolve().parent / "libegregora_amd.so"
 EGR_OK = 0
 FL_NORMALIZE, FL_AUTOSCALE, FL_PCM_IN, FL_NODE_POST = 0x1, 0x2, 0x4, 0x8
 FL_THR_RELATIVE, FL_THR_SOFT, FL_NO_INIT_THR, FL_ZERO_STUFF, FL_INTERP_LINSPACE = 0x10, 0x20, 0x40, 0x80, 0x100      # SPEC.md section 3
+FL_THR_RECOMPUTE = 0x200     # with FL_THR_RELATIVE: a maximum pass in every iteration instead of the carried maximum (tests, A/B)
 FL_INFO_LEN = 48
 ABI_VERSION = 4          # include/egregora_amd.h EGR_ABI_VERSION
 

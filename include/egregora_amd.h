@@ -64,6 +64,8 @@ typedef struct egr_fatllama_plan egr_fatllama_plan;
 #define EGR_FL_NO_INIT_THR  0x40u /* d0 = y (no time-domain threshold before the first transform)                  */
 #define EGR_FL_ZERO_STUFF   0x80u /* up-rate by zero insertion (y[i*f] = x[i]) instead of linear interpolation      */
 #define EGR_FL_INTERP_LINSPACE 0x100u /* up-rate as numpy.interp(linspace(0, n-1, n_out), arange(n), x): endpoint-inclusive grid, no zero tail */
+#define EGR_FL_THR_RECOMPUTE 0x200u /* with THR_RELATIVE: max|X| of EVERY iteration from a read-only pass of its own (the form of rounds 1-5:
+                                     * twice the row passes) instead of the maximum the previous iteration's hook carried forward */
 
 /* Host-only planning query (no GPU needed): fills info[] =
  *   {supported (1 = packed real plan, 2 = chirp-z over M = P complex points per state), N, M, M1, M2, TC, nst1, nst2,
@@ -99,7 +101,10 @@ int egr_fatllama_plan_destroy(egr_fatllama_plan* plan);
  *       (autoscale) -> (normalise) -> (NODE_POST).
  * All max_iter iterations are executed (no fixed-point early exit).  The EGR_FL_THR_* / NO_INIT_THR / ZERO_STUFF flags select
  * the other readings of upstream's threshold and interpolation (SPEC.md section 3; oracle: FatLlamaSpec fields of the same
- * names); EGR_FL_THR_RELATIVE adds one reduction pass per iteration (packed-real and chirp-z plans alike). */
+ * names).  EGR_FL_THR_RELATIVE costs ONE extra read-only pass per call, not per iteration: the shrink keeps the spectrum's Hermitian
+ * symmetry, so the spectrum iteration i + 1 transforms to IS iteration i's shrunk spectrum (fft(real(ifft(S(X)))) = S(X) up to one
+ * float32 transform pair's round-off) and every hook leaves max |S(X)|^2 for its successor; only iteration 0, whose input is the
+ * time-domain d0, needs the maximum from a pass of its own (EGR_FL_THR_RECOMPUTE keeps the pass in every iteration). */
 int egr_fatllama_enhance(egr_fatllama_plan* plan, const float* x, float* out, int max_iter, float threshold,
                          unsigned flags, void* stream);
 
