@@ -294,6 +294,14 @@ def main():
             el = float(tt.item())
         return el, r
 
+    def timed_local(fn):
+        """this rank's own time for fn (no barrier, no max over ranks)"""
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, r
+
     # what the FIRST call of a handle costs (scratch arena allocation, side-stream check; the arithmetic is the steady state's:
     # include/egregora_amd.h egr_flashsr_set_split) -- timed before the warm-up, outside the timed region
     el_first = None
@@ -329,6 +337,28 @@ def main():
     other_len = {}
     c4_parts = {}
     c5_len = {}
+    rel = {}
+    per_rank = None
+    if not args.lean and not c4:
+        # ---- the OTHER reading of the threshold widget (SPEC.md section 3 threshold_ref = relative_to_max: threshold_value in [0, 1] is a
+        # fraction of the spectrum's maximum -- the only reading under which the reference's threshold / iterations widgets gate anything on
+        # int16-scale samples, egregora_fat_llama_gpu.py:240, README.md:50-51): the same chain with the Fat-Llama stage run that way, K steps
+        # timed like the headline; and the stage alone, hard and soft shrink ----
+        rel_flags = dict(fl_flags, variant="relative")
+
+        def step_rel():
+            y = stage_flashsr() if args.only != "fatllama" else x_all
+            seg = y[:, rank * SEG:(rank + 1) * SEG].contiguous()
+            return fe.enhance_device(seg, 1, args.iters, 0.6, **rel_flags)
+        step_rel()
+        el_rel, y_rel = timed(step_rel, args.steps)
+        assert bool(torch.isfinite(y_rel).all())
+        e_r, _ = timed(lambda: fe.enhance_device(seg48, 1, args.iters, 0.6, **rel_flags), 1)
+        fe.enhance_device(seg48, 1, 60, 0.02, **dict(fl_flags, variant="relative,soft"))
+        e_rs, y_rs = timed(lambda: fe.enhance_device(seg48, 1, args.iters, 0.02, **dict(fl_flags, variant="relative,soft")), 1)
+        assert bool(torch.isfinite(y_rs).all())
+        e_rc, _ = timed(lambda: fe.enhance_device(seg48, 1, args.iters, 0.6, **dict(fl_flags, variant="relative,recompute")), 1)
+        rel = {"chain_s": el_rel, "stage_ms": 1e3 * e_r, "stage_ms_soft": 1e3 * e_rs, "stage_ms_recompute": 1e3 * e_rc}
     if not args.lean:
         x_c2 = x_all[:, :cfg.chunk].contiguous()
         upscale_48k(x_c2, False)
@@ -342,11 +372,14 @@ def main():
             fe.enhance_device(xa, 1, 20, 0.6, **fl_flags)              # plan + first-touch
             e_a, ya = timed(lambda: fe.enhance_device(xa, 1, args.iters, 0.6, **fl_flags), 1)
             assert bool(torch.isfinite(ya).all())
+            fe.enhance_device(xa, 1, 60, 0.6, **dict(fl_flags, variant="relative"))
+            e_ar, yar = timed(lambda: fe.enhance_device(xa, 1, args.iters, 0.6, **dict(fl_flags, variant="relative")), 1)
+            assert bool(torch.isfinite(yar).all())
             fe.enhance_device(xa, 1, 12, 0.6, profile=True, **fl_flags)
             k3 = fe.kernel_times3(n, C, 1, local_rank)
             states = C if info["chirpz_kind"] == 1 else (C + 1) // 2
             groups = 2 if (states >= 2 and os.environ.get("EGR_FL_STREAMS", "2") != "1") else 1
-            arb[tag] = {"ms": 1e3 * e_a, "xrt": (n / SR) / e_a, "samples": n, "kind": info["chirpz_kind"], "D": info["D"],
+            arb[tag] = {"ms": 1e3 * e_a, "ms_relative_threshold": 1e3 * e_ar, "xrt": (n / SR) / e_a, "samples": n, "kind": info["chirpz_kind"], "D": info["D"],
                         "P": info["M"], "split": [info["M1"], info["M2"], info["M3"]], "states": states,
                         "k_pz_rowconv_ms": k3["ms"][0], "k_pzpair_ms": k3["ms"][1], "k_pzcol_crop_ms": k3["ms"][2],
                         "states_per_launch": states // groups}
@@ -383,6 +416,33 @@ def main():
             torch.cuda.empty_cache()
         except Exception as ex:      # noqa: BLE001 -- an extra, never the headline
             c5_len = {"error": str(ex)[:200]}
+        # ---- with N > 1: where a step's FlashSR time goes on EVERY rank (its chunk block, the one all-gather, WOLA), so that the first real
+        # scaling run explains itself; and ONE 60 s stereo file's Fat-Llama stage channel-split over two ranks ----
+        if world > 1:
+            nch_all = len(ag.spans(total))
+            lo_b, hi_b = shard.block_bounds(nch_all, world)[rank]
+            E.infer_block(x_all, lo_b, hi_b, ag.CHUNK_SAMPLES, ag.HOP_SAMPLES, False)
+            t_blk, blk = timed_local(lambda: E.infer_block(x_all, lo_b, hi_b, ag.CHUNK_SAMPLES, ag.HOP_SAMPLES, False))
+            per_c = -(-nch_all // world)
+            pad = torch.zeros((per_c, C, ag.CHUNK_SAMPLES), dtype=torch.float32, device="cuda")
+            pad[: hi_b - lo_b] = blk
+            gat = torch.empty((world * per_c, C, ag.CHUNK_SAMPLES), dtype=torch.float32, device="cuda")
+            try:
+                dist.all_gather_into_tensor(gat, pad)
+                t_ag, _ = timed_local(lambda: dist.all_gather_into_tensor(gat, pad))
+            except (RuntimeError, NotImplementedError):
+                t_ag = None
+            t_wo, _ = timed_local(lambda: device_ops.wola_stitch(gat[:nch_all], total, ag.CHUNK_SAMPLES, ag.HOP_SAMPLES))
+            t_fl, _ = timed_local(lambda: stage_fatllama(y48))
+            x60 = x_all[:, :SEG].contiguous()
+            fe.enhance_channel_parallel(x60, 1, 60, 0.6, True, False, True, True)
+            t_cp, _ = timed(lambda: fe.enhance_channel_parallel(x60, 1, args.iters, 0.6, True, False, True, True), 1)
+            mine = {"rank": rank, "chunks": hi_b - lo_b, "flashsr_block_ms": 1e3 * t_blk, "allgather_ms": (1e3 * t_ag) if t_ag is not None else None,
+                    "allgather_bytes_per_rank": per_c * C * ag.CHUNK_SAMPLES * 4, "wola_ms": 1e3 * t_wo, "fatllama_own_60s_ms": 1e3 * t_fl,
+                    "fatllama_channel_parallel_one_60s_file_ms": 1e3 * t_cp}
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+            del pad, gat, blk
         # ---- with N > 1: BASELINE configs[3] as north_star states it (ONE 10-minute stereo file over the N GPUs, strong scaling) ----
         if world > 1 and not c4:
             x_c4 = torch.from_numpy(synth(404, 600 * SR)).cuda()
@@ -412,9 +472,10 @@ def main():
             (res,) = fl.run("wav", args.iters, 0.6, 1536, True, False, AUDIO=a48)
             return res
         node_chain()
-        t_n, res_n = timed(node_chain, 2)
+        n_node = max(2, min(args.steps, 5))
+        t_n, res_n = timed(node_chain, n_node)
         assert tuple(res_n["waveform"].shape) == (1, C, SEG) and res_n["waveform"].device.type == "cpu"
-        node_ms = 1e3 * t_n / 2
+        node_ms = 1e3 * t_n / n_node
     prof = eng.c_profile(stage_flashsr)           # HIP events around every MFMA contraction launch of the library's graph walk
     fe.enhance_device(seg48, 1, args.iters, 0.6, profile=True, **fl_flags)
     kt = fe.kernel_times(SEG, C, 1, local_rank)
@@ -466,8 +527,9 @@ def main():
                                     "chain60: per GPU 60 s stereo 48 kHz; FlashSR (5.12 s chunks, hop 4.62 s, student_ldm "
                                     "1-step + VAE + sr_vocoder, declared architecture, synthetic weights, chunk-sharded with one "
                                     "all-gather, WOLA) then Fat-Llama max_iterations=%d thr=0.6 normalize on autoscale off, "
-                                    "threshold variant '%s' (SPEC.md section 3: absolute level, hard threshold, time-domain "
-                                    "pre-threshold, linear up-rating unless listed)" % (args.iters, os.environ.get("EGREGORA_FATLLAMA_SPEC", "") or "default"))
+                                    "threshold reading of the HEADLINE value: '%s' (SPEC.md section 3 default = absolute level on int16-scale "
+                                    "samples, hard threshold, time-domain pre-threshold, linear up-rating unless listed; the relative-to-maximum "
+                                    "reading is value_relative_threshold)" % (args.iters, os.environ.get("EGREGORA_FATLLAMA_SPEC", "") or "default"))
                                    + (f" [only={args.only}]" if args.only and not c4 else ""),
                        "flashsr_executor": "egr_flashsr_infer (C ABI, csrc/egr_flashsr.cpp)",
                        "lsd_800_vs_1_iteration_db": lsd_iters[0],
@@ -491,6 +553,10 @@ def main():
                 "node_boundary_ms": node_ms, "node_boundary_xrt": (60.0 / (node_ms * 1e-3)) if node_ms else None,
                 "node_boundary_note": "AUDIO dict (CPU) in -> EgregoraAudioUpscaler.run -> EgregoraFatLlamaGPU.run -> AUDIO dict (CPU) out, 60 s stereo, PCIe and host coercions included",
                 "fatllama_stage_xrt": audio_s / el_fl, "fatllama_stage_ms": 1e3 * el_fl,
+                "fatllama_stage_ms_relative": rel.get("stage_ms"), "fatllama_stage_ms_relative_soft": rel.get("stage_ms_soft"),
+                "fatllama_stage_ms_relative_with_a_maximum_pass_per_iteration": rel.get("stage_ms_recompute"),
+                "fatllama_arbitrary_length_ms_relative": {k: v["ms_relative_threshold"] for k, v in arb.items()} or None,
+                "per_rank": per_rank,
                 "fatllama_arbitrary_length_ms": {k: v["ms"] for k, v in arb.items()} or None,
                 "fatllama_arbitrary_length": arb or None,
                 "fatllama_other_packed_lengths": other_len or None,
@@ -526,12 +592,21 @@ def main():
                                                  "achieved": 32.0 * SEG * C * args.iters / (el_fl * 1e9),
                                                  "frac": 32.0 * SEG * C * args.iters / (el_fl * 1e9) / HBM_PEAK_GBS}},
         }
+        out["value_note"] = ("value = the chain with its input resident in HBM and its output left there (the bench contract); value_node_boundary = "
+                             "SURVEY.md 8(d)'s boundary: AUDIO dict on the host in -> the two NODES -> AUDIO dict on the host out, PCIe and host "
+                             "coercions included (1 GPU only); value_relative_threshold = the chain with the threshold read as a fraction of the "
+                             "spectrum's maximum (SPEC.md section 3), K steps timed like value")
+        out["value_node_boundary"] = (60.0 / (node_ms * 1e-3)) if node_ms else None
+        if rel:
+            out["value_relative_threshold"] = args.steps * audio_s / rel["chain_s"]
+            out["ms_per_step_relative_threshold"] = 1e3 * rel["chain_s"] / args.steps
         if arb:
             # the REPRESENTATIVE chain as a second top-level value: FlashSR returns its input length and real files are not 13-smooth
             # multiples, so the second node normally sees a length WITHOUT a packed plan (here 60 s + 2 samples, the paired chirp-z loop)
             arb_ms = 1e3 * el_fs + arb["60s_plus_2_samples"]["ms"]
             out["value_arbitrary_length"] = audio_s / (arb_ms * 1e-3)
             out["ms_per_step_arbitrary_length"] = arb_ms
+            out["value_arbitrary_length_relative_threshold"] = audio_s / ((1e3 * el_fs + arb["60s_plus_2_samples"]["ms_relative_threshold"]) * 1e-3)
             # the chirp-z loop's dominant kernel: the spectrum pass on mirrored column-tile pairs.  A launch reads and writes the
             # P-point complex state of its states once: 16 P bytes per state (what this design must move; per iteration the four
             # launches move 64 P + 16 P (Bhat, twice) bytes per state against SURVEY's 32 N per channel for a length with a plan)
@@ -565,6 +640,9 @@ def main():
             out["one_gpu_override"] = True
             out["value_one_gpu_override"] = out["value"]
             out["value"] = None
+            for k in ("value_relative_threshold", "value_arbitrary_length", "value_arbitrary_length_relative_threshold"):
+                if k in out:
+                    out[k + "_one_gpu_override"] = out.pop(k)
             out["note"] = "EGREGORA_BENCH_ONE_GPU=1: all %d ranks on ONE device, gloo collectives -- a path check, not a measurement" % world
         if not args.no_cpu_baseline and world == 1:
             def gpu_c1(c1, sr1, cpu_out):

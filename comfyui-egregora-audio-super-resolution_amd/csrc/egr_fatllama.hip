@@ -15,6 +15,11 @@
 // Long inputs add a third factor (state [M1][M2][M3], inner column pass k_col<3>/<4>); lengths without a packed
 // plan (odd, large primes) run the chirp-z path further down (k_colz, k_rowconv); egr_spectral_gain reuses the
 // passes as a zero-phase filter.  DESIGN.md section 2 has the derivations.
+// the register butterflies of this translation unit (packed-real loop kernels) carry their cos / sin constants as two floats: a rounded
+// constant is a gain the 800-iteration loop applies in the same direction every iteration (egr_fft_device.h, egr_fatllama_wl.h EGR_WL_HILO)
+#ifndef EGR_BFLY_HILO
+#define EGR_BFLY_HILO 15
+#endif
 #include "egr_fatllama_int.h"
 
 namespace egr {
@@ -688,9 +693,13 @@ __global__ __launch_bounds__(256) void k_noiter(float* __restrict__ y, long long
 }
 
 // autoscale / normalise / write patch / PCM_16 round trip, all driven by the 2*C peak scalars.
+// joint_ext (optional): the peak of channels this plan does NOT hold -- the other ranks' of a channel-parallel run
+// (egr_fatllama_joint_peak on every rank, one all-reduce(MAX) of that float, egr_fatllama_finalize): max is exact, so the result is
+// the single-plan result bit for bit.  joint_dst (optional, k_joint_peak): where this plan's own joint peak goes; nothing else is done.
 __global__ __launch_bounds__(256) void k_finalize(float* __restrict__ out, long long N, int C, unsigned flags,
                                                    const unsigned* __restrict__ peak_in,
-                                                   const unsigned* __restrict__ peak_out) {
+                                                   const unsigned* __restrict__ peak_out,
+                                                   const float* __restrict__ joint_ext, float* __restrict__ joint_dst) {
 #pragma clang fp contract(off)      // the roundings below are the PCM arithmetic of the reference, written out
     const int ch = blockIdx.y;
     float s_auto = 1.f;
@@ -705,6 +714,11 @@ __global__ __launch_bounds__(256) void k_finalize(float* __restrict__ out, long 
         if (c == ch) s_auto = s;
         joint = fmaxf(joint, m);
     }
+    if (joint_dst) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *joint_dst = joint;
+        return;
+    }
+    if (joint_ext) joint = fmaxf(joint, *joint_ext);
     const bool do_auto = (flags & EGR_FL_AUTOSCALE) != 0;
     const bool do_norm = (flags & EGR_FL_NORMALIZE) && joint > 0.f;
     float peak_final = do_norm ? 1.0f : joint;
@@ -954,6 +968,7 @@ static int build_plan(egr_fatllama_plan** out, int64_t n_in, int channels, int f
                     const int qq = e.q * e.q;
                     if ((rc = table(qq, e.n1, e.L, &p->wl_rt.t1, &p->wl_rt.t1l))) return fail(rc);
                     if ((rc = table(e.q, e.q, qq, &p->wl_rt.t2, &p->wl_rt.t2l))) return fail(rc);
+                    if ((rc = fl_upload_dtab(p, e.q, 1, qq, &p->wl_rt.t2d))) return fail(rc);
                     const long double ang = -3.14159265358979323846264338327950288L / (long double)e.q;         // W_(2Q)
                     p->wl_rt.hook_step = make_double2((double)cosl(ang), (double)sinl(ang));
                     p->wl_row_entry = &e;
@@ -1550,11 +1565,33 @@ extern "C" int egr_fatllama_enhance(egr_fatllama_plan* p, const float* x, float*
         rc = join(st);
         if (rc) return rc;
     }
-    if (flags & (EGR_FL_NORMALIZE | EGR_FL_AUTOSCALE | EGR_FL_NODE_POST)) {
+    if ((flags & (EGR_FL_NORMALIZE | EGR_FL_AUTOSCALE | EGR_FL_NODE_POST)) && !(flags & EGR_FL_DEFER_FINALIZE)) {
         const long long Nr = (long long)p->n_out;
         const int nb = (int)((Nr + 255) / 256 < 2048 ? (Nr + 255) / 256 : 2048);
-        hipLaunchKernelGGL(k_finalize, dim3(nb, C), blk256, 0, st, out, Nr, C, flags, peak_in, peak_out);
+        hipLaunchKernelGGL(k_finalize, dim3(nb, C), blk256, 0, st, out, Nr, C, flags, peak_in, peak_out, (const float*)nullptr, (float*)nullptr);
     }
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+// Channel-parallel runs (the Fat-Llama path shards over channels only; C = 2 => at most 2 GPUs, nothing is
+// exchanged until the joint normalise): every rank runs egr_fatllama_enhance on ITS channels with EGR_FL_DEFER_FINALIZE, asks for its
+// joint peak (a device float), the host all-reduces that one float with MAX, and egr_fatllama_finalize applies autoscale / normalise /
+// write patch / PCM_16 with the all-reduced value.  `flags` as given to enhance.
+extern "C" int egr_fatllama_joint_peak(egr_fatllama_plan* p, unsigned flags, float* joint_dev, void* stream) {
+    EGR_CHECK(p && joint_dev, EGR_ERR_ARG, "null plan / joint_dev");
+    hipLaunchKernelGGL(k_finalize, dim3(1, 1), dim3(64), 0, (hipStream_t)stream, (float*)nullptr, 0LL, p->C, flags, p->d_peaks, p->d_peaks + p->C,
+                       (const float*)nullptr, joint_dev);
+    EGR_HIP(hipGetLastError());
+    return EGR_OK;
+}
+
+extern "C" int egr_fatllama_finalize(egr_fatllama_plan* p, float* out, unsigned flags, const float* joint_dev, void* stream) {
+    EGR_CHECK(p && out, EGR_ERR_ARG, "null plan / out");
+    if (!(flags & (EGR_FL_NORMALIZE | EGR_FL_AUTOSCALE | EGR_FL_NODE_POST))) return EGR_OK;
+    const long long Nr = (long long)p->n_out;
+    const int nb = (int)((Nr + 255) / 256 < 2048 ? (Nr + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_finalize, dim3(nb, p->C), dim3(256), 0, (hipStream_t)stream, out, Nr, p->C, flags, p->d_peaks, p->d_peaks + p->C, joint_dev, (float*)nullptr);
     EGR_HIP(hipGetLastError());
     return EGR_OK;
 }

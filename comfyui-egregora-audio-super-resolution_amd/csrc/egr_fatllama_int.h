@@ -130,6 +130,7 @@ struct WlRowT {
     const cplx* t2;        // [Q][Q]:    W_(Q^2)^(b c)
     const cplx* t1l;       // the low parts of the same tables: t + tl = W to 2^-48 (cmul2)
     const cplx* t2l;
+    const dcplx* t2d;      // [Q]: W_(Q^2)^l in double (the ratio of a lane's run over c)
     dcplx hook_step;       // W_(2Q): ratio of the pair twiddles between a lane's consecutive registers
 };
 struct WlColT {

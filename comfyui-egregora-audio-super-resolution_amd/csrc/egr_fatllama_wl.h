@@ -41,8 +41,14 @@ namespace egr {
 //   1  hook: a pair whose two bins both survive the threshold leaves as Z / M -- the real split followed by its inverse is the identity
 //   2  k_col_wl: the four-step twiddles W_M^(col i) as two floats      4  W_(R^2)^(b c) as two floats
 //   8  k_row_wl: W_L^(n2 k1) as two floats                             16 W_(Q^2)^(b c) as two floats      32 the pair twiddle W_N^k as two floats
+//   64 k_row_wl: W_L^(n2 k1) as a geometric run in double from one table entry, products in double (instead of 8)
+//   128 k_row_wl: W_(Q^2)^(b c) likewise (instead of 16)               256 k_col_wl: the four-step twiddle products in double (instead of 2)
+// Shipped: 2 + 64 + 128 (and EGR_BFLY_HILO = 15 in this translation unit).  N = 2 880 000, 800 iterations, against the float64 loop, in units
+// of the float32 pocketfft oracle's own error (profiles/r06/c3_error_attribution_pass{1,2,3}.txt): none 2.27x rms / 1.51x max / plain LSD
+// 2.2e-3 dB at 28.1 ms per stereo stage; shipped 0.86x / 0.59x / 7.4e-4 dB at 29.8 ms.  Alone: bit 2 1.87x (+0.6 ms), 64 2.00x (+0.1; as two
+// floats from a table, bit 8, +5 ms), 128 2.06x (+0.9), butterfly constants 1.71x (+2), 4 / 32 / 1 within 3 % of none; everything 0.74x at 42 ms.
 #ifndef EGR_WL_HILO
-#define EGR_WL_HILO 0
+#define EGR_WL_HILO 194
 #endif
 // Geometry of k_col_wl<R, TC>: columns of R x R points (625 = 25^2: lengths with the factor 5^4 -- every multiple of 5 s at 48 kHz;
 // 441 = 21^2: lengths with the factor 3^2 7^2 -- whole seconds at 44.1 kHz), TC adjacent columns per workgroup, R TC threads on
@@ -80,11 +86,13 @@ __device__ __forceinline__ float wl_pair_hook(const cplx Za, const cplx Zb, cons
     float mxn = 0.f;
     if (HOOK == 2) return 0.25f * fmaxf(Xk.x * Xk.x + Xk.y * Xk.y, Xm.x * Xm.x + Xm.y * Xm.y);
     if (HOOK == 1) {
-        const float mk = sqrtf(Xk.x * Xk.x + Xk.y * Xk.y), mm = sqrtf(Xm.x * Xm.x + Xm.y * Xm.y);
-        float gk = mk > tlevx2 ? 1.f : 0.f, gm = mm > tlevx2 ? 1.f : 0.f;
+        // the comparison on squares as in the default hook; the soft gain 1 - t / |X| through v_rsq_f32 (1 ulp: 6e-8 of a gain <= 1) --
+        // round 5's two correctly rounded sqrtf and two divisions per pair were a tenth of the kernel
+        const float mk2 = Xk.x * Xk.x + Xk.y * Xk.y, mm2 = Xm.x * Xm.x + Xm.y * Xm.y;
+        float gk = mk2 > thr2x4 ? 1.f : 0.f, gm = mm2 > thr2x4 ? 1.f : 0.f;
         if (soft) {
-            if (mk > tlevx2) gk = 1.f - tlevx2 / mk;
-            if (mm > tlevx2) gm = 1.f - tlevx2 / mm;
+            if (mk2 > thr2x4) gk = 1.f - tlevx2 * __builtin_amdgcn_rsqf(mk2);
+            if (mm2 > thr2x4) gm = 1.f - tlevx2 * __builtin_amdgcn_rsqf(mm2);
         }
         Xk.x *= gk; Xk.y *= gk; Xm.x *= gm; Xm.y *= gm;
         mxn = 0.25f * fmaxf(Xk.x * Xk.x + Xk.y * Xk.y, Xm.x * Xm.x + Xm.y * Xm.y);      // max |S(X)|^2: the next iteration's spectrum
@@ -185,11 +193,20 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
 #pragma unroll
         for (int n1 = 0; n1 < N1; ++n1) v[n1] = g[n1 * QQ + xn2];
         cplx w[N1];
-        wl_load_tw<N1>(tb.t1 + xn2 * N1, w);
+        if (!(EGR_WL_HILO & 64)) wl_load_tw<N1>(tb.t1 + xn2 * N1, w);
         Bfly<N1>::run(v);
         cplx* d = lds + xr * RS + xn2;
         d[0] = v[0];
-        if (EGR_WL_HILO & 8) {
+        if (EGR_WL_HILO & 64) {                 // W_L^(n2 k1) as a geometric run in double from ONE table entry, the product in double
+            const dcplx st = p.twd[xn2];
+            dcplx cur = st;
+#pragma unroll
+            for (int k = 1; k < N1; ++k) {
+                const double vx = (double)v[k].x, vy = (double)v[k].y;
+                d[k * S] = make_float2((float)(vx * cur.x - vy * cur.y), (float)(vx * cur.y + vy * cur.x));
+                cur = dcmul(cur, st);
+            }
+        } else if (EGR_WL_HILO & 8) {
             cplx wl[N1];
             wl_load_tw<N1>(tb.t1l + xn2 * N1, wl);
 #pragma unroll
@@ -211,8 +228,19 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
         wl_wave_sync();
         Bfly<Q>::run(A);
         Bfly<Q>::run(B);
+        dcplx t2cur = make_double2(1.0, 0.0);
+        const dcplx t2st = (EGR_WL_HILO & 128) ? tb.t2d[l] : t2cur;        // W_(Q^2)^l: the run over c
 #pragma unroll
         for (int c = 0; c < Q; ++c) {
+            if (EGR_WL_HILO & 128) {
+                if (c) {
+                    const double ax = (double)A[c].x, ay = (double)A[c].y, bx = (double)B[c].x, by = (double)B[c].y;
+                    ba[c * TS + l] = make_float2((float)(ax * t2cur.x - ay * t2cur.y), (float)(ax * t2cur.y + ay * t2cur.x));
+                    bb[(Q - 1 - c) * TS + l] = make_float2((float)(bx * t2cur.x - by * t2cur.y), (float)(bx * t2cur.y + by * t2cur.x));
+                } else { ba[l] = A[0]; bb[(Q - 1) * TS + l] = B[0]; }
+                t2cur = dcmul(t2cur, t2st);
+                continue;
+            }
             const cplx w = t2[c];
             if (EGR_WL_HILO & 16) {
                 const cplx wl = t2l[c];
@@ -302,6 +330,8 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
         const cplx* t2b = tb.t2 + (Q - 1 - l) * Q;       // row b: c' = Q - 1 - l
         const cplx* t2l = tb.t2l + l * Q;
         const cplx* t2bl = tb.t2l + (Q - 1 - l) * Q;
+        dcplx ia_cur = make_double2(1.0, 0.0), ib_cur = ia_cur, ia_st = ia_cur, ib_st = ia_cur;
+        if (EGR_WL_HILO & 128) { ia_st = tb.t2d[l]; ib_st = tb.t2d[Q - 1 - l]; }
         wl_bfly_inv<Q>(A);
         wl_bfly_inv<Q>(B);
 #pragma unroll
@@ -311,6 +341,18 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
             if (EGR_WL_HILO & 16) {
                 a0 = b2 ? cmulc2(A[b2], t2[b2], t2l[b2]) : A[b2]; a1 = cmulc2(A[b2 + 1], t2[b2 + 1], t2l[b2 + 1]);
                 c0 = b2 ? cmulc2(B[b2], t2b[b2], t2bl[b2]) : B[b2]; c1 = cmulc2(B[b2 + 1], t2b[b2 + 1], t2bl[b2 + 1]);
+            }
+            if (EGR_WL_HILO & 128) {            // row a: W^(l b), row b: W^((Q - 1 - l) b) -- two runs in double
+                auto mulc = [](const cplx z, const dcplx w) {
+                    const double x = (double)z.x, y = (double)z.y;
+                    return make_float2((float)(x * w.x + y * w.y), (float)(y * w.x - x * w.y));
+                };
+                a0 = b2 ? mulc(A[b2], ia_cur) : A[b2];
+                c0 = b2 ? mulc(B[b2], ib_cur) : B[b2];
+                ia_cur = dcmul(ia_cur, ia_st); ib_cur = dcmul(ib_cur, ib_st);
+                a1 = mulc(A[b2 + 1], ia_cur);
+                c1 = mulc(B[b2 + 1], ib_cur);
+                ia_cur = dcmul(ia_cur, ia_st); ib_cur = dcmul(ib_cur, ib_st);
             }
             *(float4*)(ba + l * TS + b2) = make_float4(a0.x, a0.y, a1.x, a1.y);
             *(float4*)(bb + l * TS + b2) = make_float4(c0.x, c0.y, c1.x, c1.y);
@@ -341,9 +383,19 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
         cplx* g = xr ? gb : ga;
         const cplx* s = lds + xr * RS + xn2;
         cplx v[N1], w[N1];
-        wl_load_tw<N1>(tb.t1 + xn2 * N1, w);
+        if (!(EGR_WL_HILO & 64)) wl_load_tw<N1>(tb.t1 + xn2 * N1, w);
         v[0] = s[0];
-        if (EGR_WL_HILO & 8) {
+        if (EGR_WL_HILO & 64) {
+            const dcplx st = p.twd[xn2];
+            dcplx cur = st;
+#pragma unroll
+            for (int k = 1; k < N1; ++k) {
+                const cplx z = s[k * S];
+                const double vx = (double)z.x, vy = (double)z.y;
+                v[k] = make_float2((float)(vx * cur.x + vy * cur.y), (float)(vy * cur.x - vx * cur.y));
+                cur = dcmul(cur, st);
+            }
+        } else if (EGR_WL_HILO & 8) {
             cplx wl[N1];
             wl_load_tw<N1>(tb.t1l + xn2 * N1, wl);
 #pragma unroll
@@ -396,7 +448,10 @@ __global__ __launch_bounds__((WlCol<R, TC>::THREADS), EGR_WL_COL_WAVES) void k_c
 #pragma unroll
         for (int a = 0; a < R; ++a) {
             tw[a] = make_float2((float)cur.x, (float)cur.y);             // kept for the way out: the run is formed once
-            if (EGR_WL_HILO & 2) {
+            if (EGR_WL_HILO & 256) {                                     // the product itself in double; the run is formed again on the way out
+                const double vx = (double)v[a].x, vy = (double)v[a].y;
+                v[a] = make_float2((float)(vx * cur.x + vy * cur.y), (float)(vy * cur.x - vx * cur.y));
+            } else if (EGR_WL_HILO & 2) {
                 twl[a] = make_float2((float)(cur.x - (double)tw[a].x), (float)(cur.y - (double)tw[a].y));
                 v[a] = cmulc2(v[a], tw[a], twl[a]);
             } else
@@ -433,6 +488,16 @@ __global__ __launch_bounds__((WlCol<R, TC>::THREADS), EGR_WL_COL_WAVES) void k_c
         for (int j = 0; j < R; ++j) v[j] = lds[(j * R + b) * TC + cl];           // Z2[c'' = b][b' = j]
         Bfly<R>::run(v);                                 // v[d''] = X[c'' + R d'']
         EGR_STAMP(p, 3);
+        if (EGR_WL_HILO & 256) {
+            dcplx cur = tw2d(p.big, (unsigned)col * (unsigned)b);
+            const dcplx wst = tw2d(p.big, (unsigned)col * (unsigned)R);
+#pragma unroll
+            for (int a = 0; a < R; ++a) {
+                const double vx = (double)v[a].x, vy = (double)v[a].y;
+                W[(size_t)(R * a + b) * nc] = make_float2((float)(vx * cur.x - vy * cur.y), (float)(vx * cur.y + vy * cur.x));
+                cur = dcmul(cur, wst);
+            }
+        } else
 #pragma unroll
         for (int a = 0; a < R; ++a) W[(size_t)(R * a + b) * nc] = (EGR_WL_HILO & 2) ? cmul2(v[a], tw[a], twl[(EGR_WL_HILO & 2) ? a : 0]) : cmul(v[a], tw[a]);
     }

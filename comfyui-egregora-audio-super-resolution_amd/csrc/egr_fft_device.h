@@ -43,9 +43,17 @@ __device__ __forceinline__ cplx cmul2(cplx a, cplx bh, cplx bl) {
 __device__ __forceinline__ cplx cmulc2(cplx a, cplx bh, cplx bl) {  // a * conj(b)
     return make_float2(fmaf(a.x, bh.x, fmaf(a.y, bh.y, fmaf(a.x, bl.x, a.y * bl.y))), fmaf(a.y, bh.x, fmaf(-a.x, bh.y, fmaf(a.y, bl.x, -a.x * bl.y))));
 }
+// The register butterflies' own constants (cos / sin of the odd radices, inner twiddles of the composites) as two floats -- bit mask by
+// radix family: 1 radix 5 and 25 = 5 x 5; 2 radix 8 / 16 / 32 (W_16, W_32 inner twiddles); 4 radix 3 and 6 / 9 / 12; 8 every other radix
 #ifndef EGR_BFLY_HILO
-#define EGR_BFLY_HILO 0      // 1: the register butterflies' own constants (cos / sin of the odd radices, inner twiddles of the composites) as two floats
+#define EGR_BFLY_HILO 0
 #endif
+constexpr bool bfly_hilo(int R) {
+    return (R == 5 || R == 25) ? (EGR_BFLY_HILO & 1) != 0
+         : (R == 8 || R == 16 || R == 32) ? (EGR_BFLY_HILO & 2) != 0
+         : (R == 3 || R == 6 || R == 9 || R == 12) ? (EGR_BFLY_HILO & 4) != 0
+         : (EGR_BFLY_HILO & 8) != 0;
+}
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_float2(a.x - b.x, a.y - b.y); }
 
@@ -74,7 +82,7 @@ template <int R> struct Bfly {
             for (int n = 1; n <= H; ++n) {
                 const float cc = Trig<R>::c[(n * k) % R];
                 const float ss = Trig<R>::s[(n * k) % R];
-                if (EGR_BFLY_HILO) {
+                if (bfly_hilo(R)) {
                     const float cl = Trig<R>::cl[(n * k) % R], sl = Trig<R>::sl[(n * k) % R];
                     c.x = fmaf(cc, a[n - 1].x, fmaf(cl, a[n - 1].x, c.x)); c.y = fmaf(cc, a[n - 1].y, fmaf(cl, a[n - 1].y, c.y));
                     s.x = fmaf(ss, b[n - 1].x, fmaf(sl, b[n - 1].x, s.x)); s.y = fmaf(ss, b[n - 1].y, fmaf(sl, b[n - 1].y, s.y));
@@ -124,7 +132,7 @@ template <int R1, int R2> struct BflyComp {
 #pragma unroll
             for (int k1 = 0; k1 < R1; ++k1) {
                 const int m = (n2 * k1) % R;
-                if (EGR_BFLY_HILO && m != 0 && (4 * m) % R != 0) {          // (quarter turns are exact)
+                if (bfly_hilo(R) && m != 0 && (4 * m) % R != 0) {          // (quarter turns are exact)
                     y[k1 * R2 + n2] = cmul2(t[k1], make_float2(Trig<R>::c[m], -Trig<R>::s[m]), make_float2(Trig<R>::cl[m], -Trig<R>::sl[m]));
                     continue;
                 }

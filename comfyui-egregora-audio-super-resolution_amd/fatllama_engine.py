@@ -178,6 +178,53 @@ def enhance_device(x_ct: torch.Tensor, factor: int, max_iterations: int, thresho
     return out
 
 
+class _ChannelBlockBackend:
+    """shard.sharded_channels on the device: egr_fatllama_enhance with EGR_FL_DEFER_FINALIZE on this rank's channels, egr_fatllama_joint_peak,
+    egr_fatllama_finalize with the all-reduced peak (include/egregora_amd.h)."""
+
+    def __init__(self, x_ct, factor, max_iterations, threshold_value, flags, n_out=None):
+        self.x, self.factor, self.iters, self.thr, self.flags, self.n_out = x_ct, factor, int(max_iterations), float(threshold_value), flags, n_out
+        self.t_out = x_ct.shape[1] * factor if n_out is None else int(n_out)
+        self.L = native.lib()
+
+    def empty(self, rows):
+        return torch.empty((rows, self.t_out), dtype=torch.float32, device=self.x.device)
+
+    def zero_peak(self):
+        return torch.zeros(1, dtype=torch.float32, device=self.x.device)
+
+    def run_local(self, lo, hi):
+        xb = self.x[lo:hi].contiguous()
+        plan = _plan(xb.shape[1], hi - lo, self.factor, xb.device.index or 0, 0, 0, None, self.n_out)
+        out = self.empty(hi - lo)
+        native.check(self.L.egr_fatllama_enhance(C.c_void_p(plan), native.ptr(xb), native.ptr(out), self.iters, self.thr,
+                                                 self.flags | native.FL_DEFER_FINALIZE, native.stream_ptr()), "egr_fatllama_enhance")
+        return plan, out
+
+    def joint_peak(self, st):
+        j = self.zero_peak()
+        native.check(self.L.egr_fatllama_joint_peak(C.c_void_p(st[0]), self.flags, native.ptr(j), native.stream_ptr()), "egr_fatllama_joint_peak")
+        return j
+
+    def finalize(self, st, joint):
+        native.check(self.L.egr_fatllama_finalize(C.c_void_p(st[0]), native.ptr(st[1]), self.flags, native.ptr(joint), native.stream_ptr()),
+                     "egr_fatllama_finalize")
+        return st[1]
+
+
+def enhance_channel_parallel(x_ct: torch.Tensor, factor: int, max_iterations: int, threshold_value: float, normalize: bool, autoscale: bool,
+                             pcm_in: bool, node_post: bool, group=None, gather: bool = True, variant=None, n_out=None):
+    """enhance_device with the channels of x_ct [C, T] (replicated on every rank) spread over the ranks of `group` (SURVEY.md section
+    8(e): at most C ranks work; one 4-byte all-reduce(MAX) before the joint normalise).  Bit-identical to enhance_device on one rank."""
+    from . import shard
+    if not (x_ct.is_cuda and x_ct.dtype == torch.float32 and x_ct.dim() == 2):
+        raise RuntimeError("enhance_channel_parallel wants a [C,T] float32 tensor on the GPU")
+    flags = ((native.FL_NORMALIZE if normalize else 0) | (native.FL_AUTOSCALE if autoscale else 0) |
+             (native.FL_PCM_IN if pcm_in else 0) | (native.FL_NODE_POST if node_post else 0) | variant_flags(variant))
+    be = _ChannelBlockBackend(x_ct.contiguous(), factor, max_iterations, threshold_value, flags, n_out)
+    return shard.sharded_channels(be, x_ct.shape[0], group=group, gather=gather)
+
+
 def kernel_times(n_in: int, channels: int, factor: int, device: int = 0):
     L = native.lib()
     plan = _plan(n_in, channels, factor, device)

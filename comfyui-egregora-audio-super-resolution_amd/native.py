@@ -13,9 +13,10 @@ LIB_PATH = Path(__file__).resolve().parent / "libegregora_amd.so"
 EGR_OK = 0
 FL_NORMALIZE, FL_AUTOSCALE, FL_PCM_IN, FL_NODE_POST = 0x1, 0x2, 0x4, 0x8
 FL_THR_RELATIVE, FL_THR_SOFT, FL_NO_INIT_THR, FL_ZERO_STUFF, FL_INTERP_LINSPACE = 0x10, 0x20, 0x40, 0x80, 0x100      # SPEC.md section 3
+FL_DEFER_FINALIZE = 0x400    # enhance stops behind out = y + d; egr_fatllama_joint_peak / _finalize complete it (channel-parallel runs)
 FL_THR_RECOMPUTE = 0x200     # with FL_THR_RELATIVE: a maximum pass in every iteration instead of the carried maximum (tests, A/B)
 FL_INFO_LEN = 48
-ABI_VERSION = 4          # include/egregora_amd.h EGR_ABI_VERSION
+ABI_VERSION = 5          # include/egregora_amd.h EGR_ABI_VERSION
 
 # name -> (restype, argtypes); must list every symbol of include/egregora_amd.h
 _vp, _i, _i64, _f, _u = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint
@@ -32,6 +33,8 @@ SIGNATURES = {
     "egr_fatllama_plan_create_chirpz": (_i, [C.POINTER(_vp), _i64, _i, _i, _i]),
     "egr_fatllama_plan_destroy": (_i, [_vp]),
     "egr_fatllama_enhance": (_i, [_vp, _vp, _vp, _i, _f, _u, _vp]),
+    "egr_fatllama_joint_peak": (_i, [_vp, _u, _vp, _vp]),
+    "egr_fatllama_finalize": (_i, [_vp, _vp, _u, _vp, _vp]),
     "egr_spectral_gain": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "egr_fatllama_last_peaks": (_i, [_vp, C.POINTER(_f), C.POINTER(_f), _vp]),
     "egr_fatllama_set_profiling": (_i, [_vp, _i]),

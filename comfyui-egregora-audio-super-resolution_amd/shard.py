@@ -4,7 +4,12 @@ The reference processes chunks sequentially and independently (egregora_audio_su
 only meet in WOLA (:420).  Rank r of the default process group takes a contiguous block -- sizes balanced to within one
 chunk (130 chunks over 8 ranks: 17, 17, 16, 16, 16, 16, 16, 16) -- and ONE all-gather (RCCL over xGMI on GPUs, gloo in the
 CPU tests) of the equal-padded prediction blocks gives every rank all predictions for the WOLA kernel.
-No other collective exists on the data path.
+No other collective exists on the FlashSR data path.
+
+The Fat-Llama path shards over CHANNELS only (the reference hands upstream the whole file and every channel
+is one whole-signal transform per iteration, egregora_fat_llama_gpu.py:272-288; C = 2 => at most 2 GPUs): `sharded_channels` gives
+rank r a contiguous block of channels, and the channels meet in upstream's joint normalise alone -- ONE all-reduce(MAX) of a single
+float (4 bytes).  Ranks beyond the channel count idle ("replicas only" past C GPUs).
 """
 from typing import Callable, List, Tuple
 
@@ -44,3 +49,43 @@ def sharded_chunks(run_block: Callable[[int, int], torch.Tensor], n: int, item_s
     if world * per == n:
         return gathered
     return torch.cat([gathered[r * per: r * per + (b - a)] for r, (a, b) in enumerate(bounds) if b > a], 0)
+
+
+def sharded_channels(backend, channels: int, group=None, gather: bool = True):
+    """Channel-parallel Fat-Llama.  backend: .run_local(lo, hi) -> state (the loop on channels [lo, hi): out = y + d and per-channel
+    peaks, nothing joint yet), .joint_peak(state) -> float32 tensor [1] (max over ITS channels of the peak after autoscale; zeros for
+    an idle rank via .zero_peak()), .finalize(state, joint) -> [hi - lo, T] (autoscale / normalise by the JOINT peak / write patch /
+    PCM_16), .empty(rows) -> [rows, T] of the output's dtype and device.  Returns [channels, T] on every rank (gather=True: one
+    all-gather of the equal-padded blocks -- the output hand-over, not part of the arithmetic) or this rank's block."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        st = backend.run_local(0, channels)
+        return backend.finalize(st, backend.joint_peak(st))
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    bounds = block_bounds(channels, world)
+    lo, hi = bounds[rank]
+    st = backend.run_local(lo, hi) if hi > lo else None
+    joint = backend.joint_peak(st) if st is not None else backend.zero_peak()
+    host_hop = joint.is_cuda and dist.get_backend(group) == "gloo"          # (one-GPU test rigs: gloo collectives on host copies)
+    if host_hop:
+        jc = joint.cpu()
+        dist.all_reduce(jc, op=dist.ReduceOp.MAX, group=group)
+        joint.copy_(jc)
+    else:
+        dist.all_reduce(joint, op=dist.ReduceOp.MAX, group=group)          # the path's only exchange: 4 bytes
+    y = backend.finalize(st, joint) if st is not None else backend.empty(0)
+    if not gather:
+        return y
+    per = -(-channels // world)
+    local = backend.empty(per)
+    if hi > lo:
+        local[: hi - lo] = y
+    if host_hop:
+        lc = local.cpu()
+        parts = [torch.empty_like(lc) for _ in range(world)]
+        dist.all_gather(parts, lc, group=group)
+        parts = [t.to(local.device) for t in parts]
+    else:
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local, group=group)
+    return torch.cat([parts[r][: b - a] for r, (a, b) in enumerate(bounds) if b > a], 0)

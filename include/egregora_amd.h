@@ -27,8 +27,10 @@ extern "C" {
  * 3: two-term fp16 operand scheme (egr_split2h_pack, egr_absmax, egr_conv_h2, egr_flashsr_set_split / _split_info)
  * 4: the fp16 scheme's scales are per batch row and derived on the device: egr_conv_h2 takes (w_scale, row_amax, batch_rows)
  *    instead of (a_scale, w_scale, amax); egr_absmax_rows, egr_winograd4_input_ra / _output_ra, egr_snake_aa_ra, egr_randn_base added; egr_flashsr_split_info
- *    reports (enabled, weights, calls); egr_flashsr_infer no longer measures, verifies, re-runs or synchronises */
-#define EGR_ABI_VERSION 4
+ *    reports (enabled, weights, calls); egr_flashsr_infer no longer measures, verifies, re-runs or synchronises
+ * 5: egr_fatllama_joint_peak / egr_fatllama_finalize + EGR_FL_DEFER_FINALIZE (channel-parallel Fat-Llama: one 4-byte all-reduce(MAX));
+ *    EGR_FL_THR_RELATIVE carries the spectrum maximum from iteration to iteration (EGR_FL_THR_RECOMPUTE: the per-iteration pass) */
+#define EGR_ABI_VERSION 5
 
 #define EGR_OK 0
 #define EGR_ERR_ARG 1          /* bad argument */
@@ -64,6 +66,7 @@ typedef struct egr_fatllama_plan egr_fatllama_plan;
 #define EGR_FL_NO_INIT_THR  0x40u /* d0 = y (no time-domain threshold before the first transform)                  */
 #define EGR_FL_ZERO_STUFF   0x80u /* up-rate by zero insertion (y[i*f] = x[i]) instead of linear interpolation      */
 #define EGR_FL_INTERP_LINSPACE 0x100u /* up-rate as numpy.interp(linspace(0, n-1, n_out), arange(n), x): endpoint-inclusive grid, no zero tail */
+#define EGR_FL_DEFER_FINALIZE 0x400u /* stop behind out = y + d: autoscale / normalise / NODE_POST wait for egr_fatllama_finalize (channel-parallel runs) */
 #define EGR_FL_THR_RECOMPUTE 0x200u /* with THR_RELATIVE: max|X| of EVERY iteration from a read-only pass of its own (the form of rounds 1-5:
                                      * twice the row passes) instead of the maximum the previous iteration's hook carried forward */
 
@@ -107,6 +110,15 @@ int egr_fatllama_plan_destroy(egr_fatllama_plan* plan);
  * time-domain d0, needs the maximum from a pass of its own (EGR_FL_THR_RECOMPUTE keeps the pass in every iteration). */
 int egr_fatllama_enhance(egr_fatllama_plan* plan, const float* x, float* out, int max_iter, float threshold,
                          unsigned flags, void* stream);
+
+/* Channel-parallel runs (this path shards over CHANNELS only -- the reference transforms each channel of the
+ * file as one whole signal, egregora_fat_llama_gpu.py:272-288 -- and the channels meet in upstream's joint normalise alone): every rank
+ * holds a plan for ITS channels, calls egr_fatllama_enhance with EGR_FL_DEFER_FINALIZE (the loop, out = y + d, per-channel peaks; no
+ * autoscale / normalise / write patch / PCM_16 yet), egr_fatllama_joint_peak (this plan's max over channels of the peak after autoscale ->
+ * one device float), all-reduces that float with MAX (4 bytes: the only exchange), and egr_fatllama_finalize(flags, the all-reduced
+ * float).  max is exact: the ranks' outputs are the single-plan outputs bit for bit.  joint_dev == NULL: the plan's own channels only. */
+int egr_fatllama_joint_peak(egr_fatllama_plan* plan, unsigned flags, float* joint_dev, void* stream);
+int egr_fatllama_finalize(egr_fatllama_plan* plan, float* out, unsigned flags, const float* joint_dev, void* stream);
 
 /* y = irfft(rfft(x) * gain) per channel on a packed-real plan with factor 1: x, y [channels][N], gain
  * [channels][N/2+1] (real, one value per half-spectrum bin).  Used by the FlashSR input low-pass. */

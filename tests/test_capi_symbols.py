@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(pack):
 
 def test_abi_version_and_host_only_planning(pack):
     from egregora_amd import fatllama_engine as fe, native
-    assert native.lib().egr_abi_version() == native.ABI_VERSION == 4
+    assert native.lib().egr_abi_version() == native.ABI_VERSION == 5
     i = fe.plan_info(2880000, 1)
     assert i["supported"] and i["M1"] * i["M2"] == 1440000 and i["N"] == 2880000
     prod = 1

@@ -397,8 +397,14 @@ def test_c3_full_length_800_iterations_against_the_oracle(pack):
               f"rms {rg:.3e}; ratios to the float32 oracle {mg / ref_err[0]:.2f} / {rg / ref_err[1]:.2f}; LSD vs float64 plain {lg_plain:.2e} dB, over the "
               f"{kept:.1%} of bins >= {F32_MARGIN_DB:.0f} dB above the float32 floor {lg:.2e} dB")
         assert np.isfinite(got).all()
-        assert mg <= 2.0 * ref_err[0] and mg <= 5e-4 * scale, (n, mg, ref_err, scale)
-        assert rg <= 2.5 * ref_err[1] + 1e-9 * scale, (n, rg, ref_err)
+        # round 6: at the packed length the loop kernels carry their twiddles and butterfly constants as two floats /
+        # double runs (csrc/egr_fatllama_wl.h EGR_WL_HILO) and sit BELOW the float32 oracle's own error (measured 0.59x max, 0.86x rms,
+        # plain LSD 7.4e-4 dB; round 5: 1.51x / 2.27x / 2.2e-3 dB against gates of 2x / 2.5x / 3x the oracle's LSD)
+        kmax, krms = (1.5, 1.5) if n == 2880000 else (2.0, 2.5)
+        assert mg <= kmax * ref_err[0] and mg <= 5e-4 * scale, (n, mg, ref_err, scale)
+        assert rg <= krms * ref_err[1] + 1e-9 * scale, (n, rg, ref_err)
+        if n == 2880000:
+            assert lg_plain <= 1e-3, (n, lg_plain)          # north_star's bar on the PLAIN metric, every bin
         # (at N + 2 the Bluestein round-off floor of ANY float32 run leaves only ~2 % of the bins 80 dB above it -- the float32 oracle's
         # plain LSD is 1.2e-2 dB there; the device's chirp-z path must be no worse than the oracle and meet 1e-3 dB on what is resolvable)
         assert lg <= 1e-3 and kept >= (0.3 if n == 2880000 else 0.01), (n, lg, kept)

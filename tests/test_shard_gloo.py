@@ -125,3 +125,78 @@ def test_gather_then_wola_across_ranks_equals_the_single_rank_stitch(world):
     want = og.wola(single, total)
     for rank, y in res:
         np.testing.assert_array_equal(y, want)
+
+
+class _OracleChannelBackend:
+    """shard.sharded_channels with the oracle's arithmetic as the per-rank work (CPU; the device backend is fatllama_engine's
+    _ChannelBlockBackend, tests/test_gpu_bench_ranks.py): the loop per channel, the peak after autoscale, and the finalising
+    arithmetic of oracle.fatllama.enhance_channels with the JOINT peak handed in."""
+
+    def __init__(self, x, factor, iters, thr, autoscale):
+        self.x, self.f, self.iters, self.thr, self.autoscale = x, factor, iters, thr, autoscale
+        self.calls = []
+
+    def empty(self, rows):
+        return torch.zeros((rows, self.x.shape[1] * self.f), dtype=torch.float32)
+
+    def zero_peak(self):
+        return torch.zeros(1, dtype=torch.float32)
+
+    def run_local(self, lo, hi):
+        from oracle import fatllama as ofl
+        self.calls.append((lo, hi))
+        out = ofl.enhance_channels(self.x[lo:hi], self.f, self.iters, self.thr, normalize=False, autoscale=self.autoscale)
+        return out
+
+    def joint_peak(self, out):
+        return torch.tensor([float(np.max(np.abs(out)))], dtype=torch.float32)
+
+    def finalize(self, out, joint):
+        m = float(joint.item())
+        return torch.from_numpy((out / np.float32(m)).astype(np.float32) if m > 0 else out)
+
+
+def _channel_worker(rank, world, port, C, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from packload import load_pack
+    load_pack()
+    from egregora_amd import shard
+    rng = np.random.Generator(np.random.PCG64(9))
+    x = np.rint(rng.standard_normal((C, 4800)) * 3000.0 * (1.0 + np.arange(C))[:, None]).astype(np.float32)
+    be = _OracleChannelBackend(x, 1, 5, 40.0, autoscale=(C % 2 == 0))
+    out = shard.sharded_channels(be, C)
+    mine = shard.sharded_channels(be, C, gather=False)
+    q.put((rank, out.numpy(), mine.numpy(), be.calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,C", [(2, 2), (2, 1), (3, 2), (2, 5)])
+def test_channel_parallel_fatllama_equals_single_rank(world, C):
+    """one channel block per rank, ONE all-reduce(MAX) of a float before the joint normalise; ranks beyond
+    the channel count idle.  Every rank ends with the single-rank result bit for bit (max is exact)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400) + 100 + world * 11 + C
+    procs = [ctx.Process(target=_channel_worker, args=(r, world, port, C, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, str(ROOT))
+    from oracle import fatllama as ofl
+    rng = np.random.Generator(np.random.PCG64(9))
+    x = np.rint(rng.standard_normal((C, 4800)) * 3000.0 * (1.0 + np.arange(C))[:, None]).astype(np.float32)
+    want = ofl.enhance_channels(x, 1, 5, 40.0, normalize=True, autoscale=(C % 2 == 0))
+    rows = 0
+    for rank, out, mine, calls in sorted(res, key=lambda r: r[0]):
+        np.testing.assert_array_equal(out, want)
+        np.testing.assert_array_equal(mine, want[rows: rows + mine.shape[0]])
+        rows += mine.shape[0]
+        assert all(hi - lo >= 1 for lo, hi in calls)
+    assert rows == C
