@@ -29,4 +29,7 @@ void set_error(const char* fmt, ...);
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// egr_nn_conv3x3.hip: the k_conv3x3_isp instantiation launch_conv3x3_is picks (profile labels of egr_flashsr.cpp)
+const char* conv3x3_is_name(int cout, bool gn, bool silu);
+
 }  // namespace egr

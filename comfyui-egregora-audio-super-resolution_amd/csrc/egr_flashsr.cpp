@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <memory>
@@ -46,7 +47,9 @@ enum { EW_ADD = 0, EW_AXPBY = 1, EW_SILU = 2, EW_SCALE = 3, EW_COPY = 4, EW_ADD_
 // block may be handed out again as soon as the host has enqueued its last consumer (stream order does the rest).  After the first
 // forward of a given row count no allocation reaches the runtime, and the footprint stays near the peak of simultaneously live
 // activations (exact-size free lists, the first version, held 47 GB for a 26-row pass; this holds the live peak + slab slack).
-static double g_arena_malloc_ms = 0.0;   // host time spent in the arenas' hipMalloc calls (EGR_FSR_TRACE=1 prints it per call)
+// host time spent in the arenas' hipMalloc calls, in microseconds (EGR_FSR_TRACE=1 prints it per call); forwards on different devices run
+// under different per-device locks, so the counter is atomic
+static std::atomic<long long> g_arena_malloc_us{0};
 static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct Arena {
@@ -77,7 +80,7 @@ struct Arena {
             Slab s;
             s.size = std::max(bytes, (size_t)1 << 31);                      // 2 GiB slabs, or one request if larger
             const double t0 = now_ms();
-            struct T { double t0; ~T() { g_arena_malloc_ms += now_ms() - t0; } } timer{t0};
+            struct T { double t0; ~T() { g_arena_malloc_us += (long long)((now_ms() - t0) * 1e3); } } timer{t0};
             if (hipMalloc((void**)&s.base, s.size) != hipSuccess) {
                 s.size = bytes;                                             // memory is tight: exactly what is needed
                 if (hipMalloc((void**)&s.base, s.size) != hipSuccess) {
@@ -233,7 +236,6 @@ struct egr_flashsr {
     bool out_amax_on = true;                          // contraction epilogues leave the row maxima of their outputs (EGREGORA_FLASHSR_OUT_AMAX=0: off)
     int direct3x3_max_cout = 128;                     // EGREGORA_FLASHSR_DIRECT3X3_MAX_COUT (0: off): see gn_conv3
     bool fused_amp = true;                            // EGREGORA_FLASHSR_FUSED_AMP=0: the thin AMP units as four launches each
-    int fused_amp_max_c = 16;                         // EGREGORA_FLASHSR_FUSED_AMP_MAX_C: widest stage that takes the fused unit (16 or 32)
     bool next_out_ra = false;                         // set by a call site whose output feeds another split contraction directly; consumed by the next conv()
     int64_t h2_calls = 0;
 
@@ -843,10 +845,7 @@ int gn_conv3(M* m, Ten& y, const Ten& x, const std::string& norm_key, float eps,
             ProfScope ps(m);
             OKR(egr_conv_h2_gn(x.p, sc.p, sh.p, 1, wd->w2, bt, res, y.p, B, H, W, Cin, wd->Cout, ACT_NONE, wd->w_scale, (const float*)bound, out_ra, gpart, m->st));
             if (ps.on) {
-                char buf[64];
-                static const bool old_kernel = getenv("EGR_S3_CONV3X3") && atoi(getenv("EGR_S3_CONV3X3")) == 1;      // (as launch_conv3x3_is chooses)
-                snprintf(buf, sizeof(buf), old_kernel ? "k_conv3x3_is<%d, 32, true>" : "k_conv3x3_isp<%d, 32, true, true>", wd->Cout > 64 ? 128 : 64);
-                ps.end(buf, fl, conv_key);
+                ps.end(egr::conv3x3_is_name(wd->Cout, true, true), fl, conv_key);       // (the launcher's own choice: egr_nn_conv3x3.hip)
             }
             if (m->count_flops) m->flops += fl;
             return EGR_OK;
@@ -1197,7 +1196,7 @@ int amp(M* m, Ten& y, Ten&& h, int j) {
                 const Wt* w1 = m->get(b + ".conv1.weight");
                 const Wt* w2 = m->get(b + ".conv2.weight");
                 const int Cc = (int)cur->d[2];
-                if (m->fused_amp && m->h2 && m->h2_mode == 1 && w1 && w2 && w1->w2 && w2->w2 && (Cc == 16 || Cc == 32) && Cc <= m->fused_amp_max_c && w1->Cout == Cc && w2->Cout == Cc && (k & 1) &&
+                if (m->fused_amp && m->h2 && m->h2_mode == 1 && w1 && w2 && w1->w2 && w2->w2 && Cc == 16 && w1->Cout == Cc && w2->Cout == Cc && (k & 1) &&
                     k <= 11 && d * (k - 1) / 2 <= 25 && c.aa_taps == 12 && cur->d[1] >= 16) {
                     OKR(new_ten(m, xn, {cur->d[0], cur->d[1], cur->d[2]}));
                     ProfScope ps(m);
@@ -1332,7 +1331,7 @@ int forward(M* m, const float* x_in, const float* noise, int R, int lowpass_on, 
         const double t_host = now_ms() - t_fwd;
         hipStreamSynchronize(m->st);
         fprintf(stderr, "[egr_flashsr forward R=%d] %-10s enqueued at %8.1f ms, complete at %8.1f ms (arena hipMalloc so far %.1f ms)\n", R, what, t_host,
-                now_ms() - t_fwd, g_arena_malloc_ms);
+                now_ms() - t_fwd, 1e-3 * (double)g_arena_malloc_us.load());
     };
     Ten xl;
     if (lowpass_on) { OKR(lowpass(m, xl, x_in, R, c.chunk)); x = xl.p; }
@@ -1470,7 +1469,6 @@ extern "C" int egr_flashsr_create(egr_flashsr** out, const egr_flashsr_config* c
     if (const char* e = getenv("EGREGORA_FLASHSR_OUT_AMAX")) m->out_amax_on = atoi(e) != 0;
     if (const char* e = getenv("EGREGORA_FLASHSR_DIRECT3X3_MAX_COUT")) m->direct3x3_max_cout = atoi(e);
     if (const char* e = getenv("EGREGORA_FLASHSR_FUSED_AMP")) m->fused_amp = atoi(e) != 0;
-    if (const char* e = getenv("EGREGORA_FLASHSR_FUSED_AMP_MAX_C")) m->fused_amp_max_c = atoi(e);
     if (const char* e = getenv("EGREGORA_FLASHSR_ARENA_GB")) { const double gb = atof(e); if (gb > 0.0) m->arena_cap = gb * 1e9; }
     build_blocks(m);
     const int down = 1 << (cfg->vae_levels - 1);
@@ -1581,8 +1579,10 @@ static int ensure_side_streams(egr_flashsr* m, hipStream_t caller, int want) {
 // A pass of >= 2 * min_group_rows rows is split into up to max_groups contiguous ROW GROUPS that run as concurrent forwards on the
 // handle's verified side streams, each with its own scratch arena (fork / join by events around the pass): one group's
 // matrix-bound kernels overlap another's HBM-bound ones and fill each other's tails (26 rows: 260 ms in one forward).
+// h2_mode 0: the handle's scheme, decided under the device's forward lock; count_call: the call shows in egr_flashsr_split_info and in
+// the profile records (false for the warm-up pass)
 static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uint64_t seed, const int64_t* row_ids, int64_t id_base, float* y,
-                      void* stream, int h2_mode);
+                      void* stream, int h2_mode, bool count_call);
 
 extern "C" int egr_flashsr_infer(egr_flashsr* m, const float* x, int rows, int lowpass, uint64_t seed, const int64_t* row_ids, float* y,
                                  void* stream) {
@@ -1590,8 +1590,7 @@ extern "C" int egr_flashsr_infer(egr_flashsr* m, const float* x, int rows, int l
     // operand scheme of this call's forwards: two fp16 terms with per-row device-side scales (see the h2 fields of the handle), or
     // three bf16 terms.  Either way the call only enqueues work: no read-back, no host synchronisation.
     // (the scheme is handed to infer_once, which publishes it in the handle only while it holds the device's forward lock)
-    const int h2_mode = (m->h2 && m->h2_nweights > 0 && !m->count_flops) ? 1 : -1;
-    return infer_once(m, x, rows, lowpass, seed, row_ids, 0, y, stream, h2_mode);
+    return infer_once(m, x, rows, lowpass, seed, row_ids, 0, y, stream, 0, true);
 }
 
 // enabled: egr_flashsr_infer runs the fp16 operand terms on this handle; weights: contraction weights that hold fp16 terms;
@@ -1617,14 +1616,19 @@ extern "C" int egr_flashsr_set_split(egr_flashsr* m, int scheme) {
 
 // rows of one call; row_ids NULL: implicit ids id_base .. id_base + rows - 1
 static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uint64_t seed, const int64_t* row_ids, int64_t id_base, float* y,
-                      void* stream, int h2_mode) {
+                      void* stream, int h2_mode, bool count_call) {
     hipStream_t st0 = (hipStream_t)stream;
     ForwardGuard guard(m->device, st0);                  // everything below touches per-handle state: inside the device's forward lock
+    if (h2_mode == 0) h2_mode = (m->h2 && m->h2_nweights > 0 && !m->count_flops) ? 1 : -1;
     struct ModeScope {                                   // the operand scheme of THIS call, visible to the operators while the lock is held
-        egr_flashsr* m;
-        ModeScope(egr_flashsr* mm, int mode) : m(mm) { m->h2_mode = mode; if (mode == 1) ++m->h2_calls; }
-        ~ModeScope() { m->h2_mode = -1; }
-    } mode_scope(m, h2_mode);
+        egr_flashsr* m; bool prof;
+        ModeScope(egr_flashsr* mm, int mode, bool count) : m(mm), prof(mm->profiling) {
+            m->h2_mode = mode;
+            if (mode == 1 && count) ++m->h2_calls;
+            if (!count) m->profiling = false;            // a warm-up pass leaves no profile records behind
+        }
+        ~ModeScope() { m->h2_mode = -1; m->profiling = prof; }
+    } mode_scope(m, h2_mode, count_call);
     m->ctxs[0]->st = st0;
     m->use(m->ctxs[0].get());
     const egr_flashsr_config& c = m->cfg;
@@ -1638,7 +1642,7 @@ static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uin
         rpp = std::max(1, std::min(rpp, (int)(m->arena_cap / per_row_bytes)));
     }
     static const bool trace = getenv("EGR_FSR_TRACE") && atoi(getenv("EGR_FSR_TRACE")) != 0;
-    const double t_enter = now_ms(), malloc0 = g_arena_malloc_ms;
+    const double t_enter = now_ms(), malloc0 = 1e-3 * (double)g_arena_malloc_us.load();
     double t_side = 0.0;
     int groups_max = m->profiling ? 1 : m->max_groups;          // per-kernel timing wants the kernels alone on the chip
     if (groups_max > 1 && std::min(rows, rpp) >= 2 * m->min_group_rows) {
@@ -1682,7 +1686,7 @@ static int infer_once(egr_flashsr* m, const float* x, int rows, int lowpass, uin
         m->arena_row_bytes = std::max(m->arena_row_bytes, tot / std::min(per, rows));
     }
     if (trace) fprintf(stderr, "[egr_flashsr_infer] rows %d: host %.1f ms (side-stream check %.1f, arena hipMalloc %.1f), arenas %.2f GB\n", rows,
-                       now_ms() - t_enter, t_side, g_arena_malloc_ms - malloc0, (double)egr_flashsr_scratch_bytes(m) / 1e9);
+                       now_ms() - t_enter, t_side, 1e-3 * (double)g_arena_malloc_us.load() - malloc0, (double)egr_flashsr_scratch_bytes(m) / 1e9);
     return rc;
 }
 
@@ -1702,9 +1706,7 @@ extern "C" int egr_flashsr_warmup(egr_flashsr* m, int rows, void* stream) {
     if (hipMalloc((void**)&buf, 2 * n * sizeof(float)) != hipSuccess) { set_error("egr_flashsr_warmup: hipMalloc(%zu) failed", 2 * n * sizeof(float)); return EGR_ERR_ALLOC; }
     int rc = EGR_OK;
     if (hipMemsetAsync(buf, 0, n * sizeof(float), (hipStream_t)stream) != hipSuccess) rc = EGR_ERR_HIP;
-    const int64_t calls = m->h2_calls;
-    if (rc == EGR_OK) rc = egr_flashsr_infer(m, buf, rows, 0, 0, nullptr, buf + n, stream);
-    m->h2_calls = calls;                                 // (split_info counts the host's calls)
+    if (rc == EGR_OK) rc = infer_once(m, buf, rows, 0, 0, nullptr, 0, buf + n, stream, 0, false);      // (split_info counts the host's calls, not this one)
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess && rc == EGR_OK) { set_error("egr_flashsr_warmup: device work failed"); rc = EGR_ERR_HIP; }
     hipFree(buf);
     return rc;

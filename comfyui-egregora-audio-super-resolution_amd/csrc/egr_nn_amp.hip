@@ -1,5 +1,5 @@
 // One anti-aliased-multi-periodicity unit of the vocoder's thin stages as ONE kernel (fp16 operand scheme):
-//     y = conv2( snake2( conv1( snake1(x) ) ) ) + x        x, y [B][L][C] channels-last fp32, C = 16 or 32 (the 245 760- / 122 880-sample stages)
+//     y = conv2( snake2( conv1( snake1(x) ) ) ) + x        x, y [B][L][C] channels-last fp32, C = 16 (the 245 760-sample stage)
 // -- what flashsr_arch / oracle.flashsr_torch.vocoder run per (kernel size, dilation) of an AMP block, and what egr_flashsr.cpp used to
 // enqueue as snake -> k_conv1d_s3 -> snake -> k_conv1d_s3 (+ residual).  At 16 channels those four launches are pure streaming: each
 // reads and writes the whole [26][245 760][16] tensor (409 MB) for a few hundred flops per element -- 9 T bytes per unit, 3.3 TB/s
@@ -39,9 +39,14 @@ constexpr int AMP_MAXH1 = 25, AMP_MAXH2 = 5;
 
 template <int C, int TL> struct AmpGeom {
     static constexpr int R0 = TL + 2 * (AMP_SH + AMP_MAXH1 + AMP_SH + AMP_MAXH2);           // x rows (maximum)
+    // rows the x / c1 area holds: the clamp-free snake reads rows 16 run .. 16 run + 25 of its source per 16-row run; the source has n + 10
+    // rows for n output rows and the last run starts at 16 (ceil(n / 16) - 1) <= n - 1, so it reaches at most 15 rows past the source's last
+    // row (its outputs beyond n are discarded).  Those rows exist (16 spare ones) and are zeroed by P0 -- never another phase's planes, never
+    // stale LDS.
+    static constexpr int XR = R0 + 16;
     static constexpr int RA = ((TL + 2 * (AMP_SH + AMP_MAXH2) + 15) / 16) * 16 + 2 * AMP_MAXH1 + 2;   // operand rows an MFMA row block may touch
     static constexpr int NCH = C / 8;
-    static constexpr int LDS = R0 * C * 4 + 2 * RA * NCH * 16;
+    static constexpr int LDS = XR * C * 4 + 2 * RA * NCH * 16;
 };
 
 // the anti-aliased snake of k_snake_aa_reg on 16 consecutive rows l0 .. l0 + 15 of channel c, source rows in LDS: S[(clamp(l) - row0) * C + c]
@@ -63,7 +68,8 @@ __device__ __forceinline__ void amp_snake_run(const float* __restrict__ S, int r
             xw[i] = S[r * C + c];
         }
     } else {
-        // (the last run of a phase may reach past the rows the tile holds: those outputs are discarded, the reads stay inside the LDS allocation)
+        // (the last run of a phase reaches up to 10 rows past the rows its source holds: AmpGeom::XR keeps those rows inside the x / c1 area,
+        // zeroed by P0; the outputs that read them are discarded)
         const float* base = S + (l0 - 5 - row0) * C + c;
 #pragma unroll
         for (int i = 0; i < J + 10; ++i) xw[i] = base[i * C];
@@ -74,7 +80,7 @@ __device__ __forceinline__ void amp_snake_run(const float* __restrict__ S, int r
         float u = 0.f;
 #pragma unroll
         for (int j = 0; j < 6; ++j) u += xw[5 + (q >> 1) - j] * f2[(q & 1) + 2 * j];
-        const float sn = __builtin_amdgcn_sinf(u * a_rev);
+        const float sn = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(u * a_rev));      // v_sin_f32 is defined on |revolutions| <= 256: reduce first
         sv[q] = fmaf(ib * sn, sn, u);
     }
     const int i0 = 2 * l0 - 5, L2 = 2 * L;
@@ -119,12 +125,13 @@ __device__ __forceinline__ float amp_wg_max(float m, float* slot) {
 #endif
 template <int C, int TL>
 __global__ __launch_bounds__(256, C == 16 ? AMP_LB16 : 2) void k_amp_unit(AmpP p) {
-    static_assert(C == 16 || C == 32, "K = 32 of v_mfma_f32_16x16x32_f16 = two taps of 16 channels or one tap of 32");
+    static_assert(C == 16, "K = 32 of v_mfma_f32_16x16x32_f16 = two taps of 16 channels (the 32-channel instantiation of round 5 -- half the "
+                           "positions per tile -- lost to the four launches it replaced and was removed in round 6)");
     typedef AmpGeom<C, TL> G;
     constexpr int NCH = G::NCH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* XS = (float*)smem;                                    // x tile, later c1
-    uint4* AP = (uint4*)(smem + (size_t)G::R0 * C * 4);          // operand planes [2][RA][NCH]
+    uint4* AP = (uint4*)(smem + (size_t)G::XR * C * 4);          // operand planes [2][RA][NCH]
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, t0 = blockIdx.x * TL;
@@ -155,6 +162,8 @@ __global__ __launch_bounds__(256, C == 16 ? AMP_LB16 : 2) void k_amp_unit(AmpP p
         *(float4*)(XS + row * C + 4 * q) = v;
         vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
+    // rows behind the tile: read by the last 16-row run of the snake phases (discarded outputs); zero, never another phase's planes or stale LDS
+    for (int e = R0 * (C / 4) + tid; e < G::XR * (C / 4); e += 256) *(float4*)(XS + e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     const float xmax = amp_wg_max(vmax, red);                    // (the barriers inside also publish the tile)
 
     // operand scale from a bound of the snake's output, and the snake itself on `nrows_out` rows starting at global row `out_row0`
@@ -300,8 +309,8 @@ extern "C" int egr_amp_unit_h2(const float* x, float* y, int B, int L, int C, in
                                const float* bias2, const float* filt, int aa_taps, void* stream) {
     EGR_CHECK(x && y && x != y && alpha1 && beta1 && alpha2 && beta2 && w1_h2 && w2_h2 && filt, EGR_ERR_ARG, "egr_amp_unit_h2: null argument");
     EGR_CHECK(B >= 1 && B <= 65535 && L >= 16 && w1_scale > 0.f && w2_scale > 0.f, EGR_ERR_ARG, "egr_amp_unit_h2: bad shape / scale");
-    if ((C != 16 && C != 32) || aa_taps != 12 || k < 1 || k > 11 || (k & 1) == 0 || d < 1 || d * (k - 1) / 2 > AMP_MAXH1 || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15)) {
-        set_error("egr_amp_unit_h2: C = %d, k = %d, d = %d, %d FIR taps do not qualify (C = 16 or 32, odd k <= 11, d (k - 1) / 2 <= %d, 12 taps)", C, k, d, aa_taps, AMP_MAXH1);
+    if (C != 16 || aa_taps != 12 || k < 1 || k > 11 || (k & 1) == 0 || d < 1 || d * (k - 1) / 2 > AMP_MAXH1 || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15)) {
+        set_error("egr_amp_unit_h2: C = %d, k = %d, d = %d, %d FIR taps do not qualify (C = 16, odd k <= 11, d (k - 1) / 2 <= %d, 12 taps)", C, k, d, aa_taps, AMP_MAXH1);
         return EGR_ERR_UNSUPPORTED;
     }
     AmpP p;
@@ -309,18 +318,13 @@ extern "C" int egr_amp_unit_h2(const float* x, float* y, int B, int L, int C, in
     p.w1 = (const uint4*)w1_h2; p.w2 = (const uint4*)w2_h2; p.bias1 = bias1; p.bias2 = bias2;
     p.inv_ws1 = 1.0f / w1_scale; p.inv_ws2 = 1.0f / w2_scale;
     p.B = B; p.L = L; p.k = k; p.d = d;
-    // tile lengths: 43 KB (C = 16, 256 rows) / 54 KB (C = 32, 128 rows) of LDS per workgroup -- two or three workgroups per CU
-    if (C == 16) {
+    {
         // tile length 240: the snake phases hand out (16-row run, channel) items to 256 threads, and snake2's 240 + 2 h2 <= 250 rows are exactly
         // one round (snake1: two); 256 rows waste half of a second round (+8 ... +17 % per unit), 496 rows halve the occupancy (+10 ... +20 %):
         // profiles/r05/flashsr_kernel_experiments.log item 5
         constexpr int TL = AMP_TL16;
         constexpr size_t lds = (size_t)AmpGeom<16, TL>::LDS;
         hipLaunchKernelGGL((k_amp_unit<16, TL>), dim3((unsigned)((L + TL - 1) / TL), (unsigned)B), dim3(256), lds, (hipStream_t)stream, p);
-    } else {
-        constexpr int TL = 128;
-        constexpr size_t lds = (size_t)AmpGeom<32, TL>::LDS;
-        hipLaunchKernelGGL((k_amp_unit<32, TL>), dim3((unsigned)((L + TL - 1) / TL), (unsigned)B), dim3(256), lds, (hipStream_t)stream, p);
     }
     EGR_HIP(hipGetLastError());
     return EGR_OK;

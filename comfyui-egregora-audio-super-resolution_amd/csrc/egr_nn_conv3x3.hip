@@ -20,198 +20,10 @@
 // to put the row's maximum somewhere in [1, 2^15), and the bound is within a few bits of the true maximum.
 namespace egr {
 
-// (C3_ABL_NOEPI / _NOB / _NOHALO / _NOMMA: timing-only ablation builds of this kernel, tools/build_variant.sh + tools/r05_conv3x3_ablation.sh;
-// their results are wrong by construction.  profiles/r05/flashsr_kernel_experiments.log item 2)
-template <int BN, int CC, bool GN>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_is(ConvP p) {
-    typedef S3Cfg<128, BN> TC;
-    constexpr int TM = TC::TM, TN = TC::TN, NCH = CC / 8, NSL = CC / 16, PW = 34, PR = 6, RMAX = PR * PW;
-    constexpr int NP = 2;
-    static_assert(CC == 32, "one tap of a channel chunk = two 16-k weight slabs = one barrier");
-    __shared__ uint4 As[NP][RMAX * NCH];
-    __shared__ uint4 Bs[2][NSL][NP][BN * 2];     // the weight tiles of one TAP of the chunk (32 k): one barrier per 24 MFMAs per wave
-    __shared__ float os_tab[128];
-    __shared__ unsigned om_tab[1];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wm0 = (wave / TC::WN) * (128 / TC::WM), wn0 = (wave % TC::WN) * (BN / TC::WN);
-    const int tiles_x = p.W / 32;
-    const int b = blockIdx.z, ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, n0 = blockIdx.y * BN;
-    const int y0 = ty * 4, x0 = tx * 32;
-    const float* xb = p.x + (size_t)b * p.H * p.W * p.Cin;
-    const unsigned abits = p.row_amax[(size_t)b * EGR_ROW_AMAX_STRIDE];
-    const float a_scale = h2_row_scale(abits);
-    if (tid < 128) os_tab[tid] = h2_row_inv(abits);
-    if (tid == 0) om_tab[0] = 0u;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    constexpr int NBQ = 2 * NP * BN;             // chunks of ONE 16-k slab
-    const size_t b_slab = (size_t)p.Cout * 2 * NP;
-    const int cpt = p.Cin / 16;                  // slabs per tap in the weight pack
-#define C3_BSETUP(I, OFF, SLOT, OK)                                                                               \
-    size_t OFF;                                                                                                      \
-    int SLOT;                                                                                                        \
-    bool OK;                                                                                                         \
-    {                                                                                                                \
-        const int e = tid + 256 * (I);                                                                               \
-        const int plane = e / (2 * BN), rem = e - plane * 2 * BN, nl = rem >> 1, half = rem & 1;                     \
-        OK = e < NBQ && n0 + nl < p.Cout;                                                                            \
-        SLOT = plane * (BN * 2) + nl * 2 + (half ^ ((nl >> 3) & 1));                                                 \
-        OFF = ((size_t)plane * p.Cout + n0 + nl) * 2 + half;                                                         \
-    }
-    C3_BSETUP(0, boff0, bslot0, bok0)
-    C3_BSETUP(1, boff1, bslot1, bok1)
-#undef C3_BSETUP
-    static_assert(NBQ <= 512, "two weight chunks per thread and slab");
-    const uint4* zq = (const uint4*)p.zeros;
-    struct StageB { uint4 b0, b1, b2, b3; };     // (b0, b1): slab 0 of the tap, (b2, b3): slab 1
-    StageB sA, sB;
-    sA.b0 = sA.b1 = sA.b2 = sA.b3 = sB.b0 = sB.b1 = sB.b2 = sB.b3 = make_uint4(0, 0, 0, 0);
-    const int nchunks = p.Cin / CC, wtotal = nchunks * 9;       // wide slabs: (chunk, tap)
-    auto load_b = [&](int ws, StageB& r) {
-        const int cc = ws / 9, tap = ws - cc * 9;
-        const uint4* base = p.w3 + (size_t)(tap * cpt + cc * NSL) * b_slab;
-        r.b0 = bok0 ? base[boff0] : zq[0];
-        r.b2 = bok0 ? base[b_slab + boff0] : zq[0];
-        if (256 < NBQ) {
-            r.b1 = bok1 ? base[boff1] : zq[0];
-            r.b3 = bok1 ? base[b_slab + boff1] : zq[0];
-        }
-    };
-    auto store_b = [&](int buf, const StageB& r) {
-        if (tid < NBQ) { Bs[buf][0][0][bslot0] = r.b0; Bs[buf][1][0][bslot0] = r.b2; }
-        if (tid + 256 < NBQ) { Bs[buf][0][0][bslot1] = r.b1; Bs[buf][1][0][bslot1] = r.b3; }
-    };
-    const int li = lane & 31, lk = lane >> 5;
-    const int ob_slot = li * 2 + (lk ^ ((li >> 3) & 1));
-
-    // one tap of one channel chunk; `nx` holds the weight tiles of wide slab ws + 1 and is refilled with those of ws + 3
-    auto slab = [&](int ws, StageB& nx) {
-        const int cur = ws & 1;
-        const int cc = ws / 9, tap = ws - cc * 9;
-#ifdef C3_ABL_NOHALO
-        if (ws == 0) {
-#else
-        if (tap == 0) {                          // new channel chunk: its halo patch -> LDS
-#endif
-            const int c0 = cc * CC;
-            constexpr int NIT = (RMAX * NCH + 255) / 256;
-            float4 hu[NIT], hv[NIT];
-#pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const int e = tid + 256 * i;
-                const int r = e / NCH, ch = e - r * NCH, pr = r / PW, pc = r - pr * PW;
-                const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
-                const bool ok = e < RMAX * NCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const float* src = ok ? xb + ((size_t)iy * p.W + ix) * p.Cin + c0 + ch * 8 : p.zeros;
-                hu[i] = *(const float4*)src;
-                hv[i] = *(const float4*)(src + 4);
-            }
-#pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const int e = tid + 256 * i;
-                if (e < RMAX * NCH) {
-                    const int r = e / NCH, ch = e - r * NCH;
-                    if (GN) {
-                        const int pr = r / PW, pc = r - pr * PW;
-                        const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
-                        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                        const float* gs = p.gn_scale + (size_t)b * p.Cin + c0 + ch * 8;
-                        const float* gh = p.gn_shift + (size_t)b * p.Cin + c0 + ch * 8;
-                        const float4 sa = *(const float4*)gs, sb = *(const float4*)(gs + 4), ha = *(const float4*)gh, hb = *(const float4*)(gh + 4);
-                        float v[8] = {fmaf(hu[i].x, sa.x, ha.x), fmaf(hu[i].y, sa.y, ha.y), fmaf(hu[i].z, sa.z, ha.z), fmaf(hu[i].w, sa.w, ha.w),
-                                      fmaf(hv[i].x, sb.x, hb.x), fmaf(hv[i].y, sb.y, hb.y), fmaf(hv[i].z, sb.z, hb.z), fmaf(hv[i].w, sb.w, hb.w)};
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            if (p.gn_silu) v[q] = v[q] / (1.f + __expf(-v[q]));
-                            if (!ok) v[q] = 0.f;                 // zero padding applies AFTER the normalisation
-                        }
-                        hu[i] = make_float4(v[0], v[1], v[2], v[3]);
-                        hv[i] = make_float4(v[4], v[5], v[6], v[7]);
-                    }
-                    uint4 q[3];
-                    split_x8<1>(hu[i], hv[i], a_scale, q);
-                    const int slot = r * NCH + (ch ^ ((r / (16 / NCH)) & (NCH - 1)));
-                    As[0][slot] = q[0];
-                    As[1][slot] = q[1];
-                }
-            }
-        }
-        __syncthreads();                         // weight tiles `cur` (stored one iteration ago) and the halo patch are visible
-        const int ky = tap / 3, kx = tap - ky * 3;
-        uint4 bq[NSL][TN][2], aq[NSL][TM][2];
-#pragma unroll
-        for (int cs = 0; cs < NSL; ++cs) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int q = 0; q < NP; ++q) bq[cs][j][q] = Bs[cur][cs][q][(wn0 + j * 32) * 2 + ob_slot];
-            const int ch = cs * 2 + lk;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int r = ((wm0 >> 5) + i + ky) * PW + li + kx;       // sub-tile (wm0 / 32 + i) = image row y0 + that
-                const int slot = r * NCH + (ch ^ ((r / (16 / NCH)) & (NCH - 1)));
-#pragma unroll
-                for (int q = 0; q < NP; ++q) aq[cs][i][q] = As[q][slot];
-            }
-        }
-#ifndef C3_ABL_NOB
-        if (ws + 1 < wtotal) store_b(cur ^ 1, nx);
-        if (ws + 3 < wtotal) load_b(ws + 3, nx);
-#endif
-        // weights as the first operand: transposed accumulators, 16-byte stores (conv_epilogue_t)
-#define C3_MMA(CS, QA, QB)                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =            \
-        __builtin_amdgcn_mfma_f32_32x32x16_f16(as_hf(bq[CS][j][QB]), as_hf(aq[CS][i][QA]), acc[i][j], 0, 0, 0);
-#ifndef C3_ABL_NOMMA
-        C3_MMA(0, 1, 0)
-        C3_MMA(0, 0, 1)
-        C3_MMA(0, 0, 0)
-        C3_MMA(1, 1, 0)
-        C3_MMA(1, 0, 1)
-        C3_MMA(1, 0, 0)
-#else
-        _Pragma("unroll") for (int cs = 0; cs < NSL; ++cs) _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) { acc[i][j][q] += __uint_as_float(bq[cs][j][q].x ^ aq[cs][i][q].y); acc[i][j][q + 2] += __uint_as_float(bq[cs][j][q].z ^ aq[cs][i][q].w); }
-#endif
-#undef C3_MMA
-        if (tap == 8) __syncthreads();           // last tap of the chunk: everyone is done with the halo patch
-    };
-
-    load_b(0, sA);
-    store_b(0, sA);
-    if (1 < wtotal) load_b(1, sA);
-    if (2 < wtotal) load_b(2, sB);
-    int ws = 0;
-    for (; ws + 1 < wtotal; ws += 2) {
-        slab(ws, sA);
-        slab(ws + 1, sB);
-    }
-    if (ws < wtotal) slab(ws, sA);
-    // tile rows are image rows: GEMM row of (sub-tile t, pixel px) = (b H + y0 + t) W + x0 + px -> row stride W between sub-tiles
-    unsigned* const om = p.out_amax ? om_tab : nullptr;
-    // (sub-tile rows start at multiples of 32 in x: m / 32 is the partial-statistics unit (b H + y) (W / 32) + x / 32)
-#ifdef C3_ABL_NOEPI
-    {   // one value per thread keeps the accumulators alive
-        float sacc = 0.f;
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
-        if (sacc == 1.2345e-30f) p.y[tid] = sacc;
-    }
-#else
-    conv_epilogue_t<TM, TN>(p, acc, (b * p.H + y0) * p.W + x0, n0, wm0, wn0, os_tab, om, p.W, p.gn_part);
-    if (om) out_amax_commit(p, om_tab, (b * p.H + y0) * p.W + x0, 1);
-#endif
-}
-
-// ---- k_conv3x3_isp: the same convolution with the halo patch of channel chunk c + 1 prepared WHILE chunk c multiplies ----
-// k_conv3x3_is stops its matrix pipe at every chunk boundary: the global loads of the 6 x 34 patch (an HBM / MALL round trip), the
-// fused GroupNorm + SiLU (an IEEE division per element), the operand split and the LDS stores all sit between two barriers -- about
+// ---- k_conv3x3_isp: the halo patch of channel chunk c + 1 is prepared WHILE chunk c multiplies ----
+// Round 4's k_conv3x3_is (removed in round 6; profiles/r05/flashsr_kernel_experiments.log item 2 has its ablation) stopped its matrix pipe
+// at every chunk boundary: the global loads of the 6 x 34 patch (an HBM / MALL round trip), the
+// fused GroupNorm + SiLU (an IEEE division per element), the operand split and the LDS stores all sat between two barriers -- about
 // a third of a workgroup's time, with nothing to cover it but the second workgroup of the CU.  Here the patch is DOUBLE-buffered in
 // LDS (2 x 26 KB; the weight tiles shrink to one 16-k slab per buffer, 16 KB: 68.5 KB per workgroup, still two per CU) and every
 // step of the phase is a compile-time position in the slab sequence of the PREVIOUS chunk.  A chunk is 18 slabs (9 taps x two
@@ -422,37 +234,34 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_isp(ConvP p) {
     if (om) out_amax_commit(p, om_tab, (b * p.H + y0) * p.W + x0, 1);
 }
 
-// true when the input-stationary 3x3 kernel applies (scheme 1, big images); launches it
+// the instantiation launch_conv3x3_is picks for (Cout, fused GroupNorm, SiLU): what the per-kernel profile and profiles/traffic.json key on
+const char* conv3x3_is_name(int cout, bool gn, bool silu) {
+    const bool wide = cout > 64;
+    if (gn && silu) return wide ? "k_conv3x3_isp<128, 32, true, true>" : "k_conv3x3_isp<64, 32, true, true>";
+    if (gn) return wide ? "k_conv3x3_isp<128, 32, true, false>" : "k_conv3x3_isp<64, 32, true, false>";
+    return wide ? "k_conv3x3_isp<128, 32, false, false>" : "k_conv3x3_isp<64, 32, false, false>";
+}
+
+// true when the input-stationary 3x3 kernel applies (scheme 1, big images, Cin <= 512, one image < 2^31 elements); launches it
 bool launch_conv3x3_is(const ConvP& p, hipStream_t st) {
     static const bool off = getenv("EGR_S3_CONV3X3") && atoi(getenv("EGR_S3_CONV3X3")) == 0;
     if (off || !p.sch || !p.w3 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.dil != 1 || p.pad_t != 1 || p.pad_l != 1 || p.up2 ||
         p.OH != p.H || p.OW != p.W || (p.W % 32) != 0 || (p.H % 4) != 0 || (p.Cin % 32) != 0 || (p.Cout % 4) != 0 || p.ksplit > 1 ||
         p.zs_nzb > 0 || p.nz > 1 || p.osy != 1 || p.osx != 1 || p.OHF != p.OH || p.OWF != p.OW || p.bias_b || p.B > 65535 ||
-        p.rows_div != p.H * p.W || (long long)(p.H / 4) * (p.W / 32) * p.B < 512)
+        p.rows_div != p.H * p.W || (long long)(p.H / 4) * (p.W / 32) * p.B < 512 ||
+        (size_t)p.H * p.W * p.Cin >= ((size_t)1 << 31) || p.Cin > C3P_MAX_CIN)
         return false;
     const int bn = p.Cout > 64 ? 128 : 64;
     const dim3 grid((p.H / 4) * (p.W / 32), (p.Cout + bn - 1) / bn, p.B);
-    // EGR_S3_CONV3X3 = 1: the round-4 kernel (halo phase between two barriers); default: the pipelined one (k_conv3x3_isp)
-    static const bool piped = !(getenv("EGR_S3_CONV3X3") && atoi(getenv("EGR_S3_CONV3X3")) == 1);
-    if (piped && (size_t)p.H * p.W * p.Cin < ((size_t)1 << 31) && p.Cin <= C3P_MAX_CIN) {
-        if (p.gn_scale && p.gn_silu) {
-            if (bn == 128) hipLaunchKernelGGL((k_conv3x3_isp<128, 32, true, true>), grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((k_conv3x3_isp<64, 32, true, true>), grid, dim3(256), 0, st, p);
-        } else if (p.gn_scale) {
-            if (bn == 128) hipLaunchKernelGGL((k_conv3x3_isp<128, 32, true, false>), grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((k_conv3x3_isp<64, 32, true, false>), grid, dim3(256), 0, st, p);
-        } else {
-            if (bn == 128) hipLaunchKernelGGL((k_conv3x3_isp<128, 32, false, false>), grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((k_conv3x3_isp<64, 32, false, false>), grid, dim3(256), 0, st, p);
-        }
-        return true;
-    }
-    if (p.gn_scale) {
-        if (bn == 128) hipLaunchKernelGGL((k_conv3x3_is<128, 32, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((k_conv3x3_is<64, 32, true>), grid, dim3(256), 0, st, p);
+    if (p.gn_scale && p.gn_silu) {
+        if (bn == 128) hipLaunchKernelGGL((k_conv3x3_isp<128, 32, true, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_conv3x3_isp<64, 32, true, true>), grid, dim3(256), 0, st, p);
+    } else if (p.gn_scale) {
+        if (bn == 128) hipLaunchKernelGGL((k_conv3x3_isp<128, 32, true, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_conv3x3_isp<64, 32, true, false>), grid, dim3(256), 0, st, p);
     } else {
-        if (bn == 128) hipLaunchKernelGGL((k_conv3x3_is<128, 32, false>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((k_conv3x3_is<64, 32, false>), grid, dim3(256), 0, st, p);
+        if (bn == 128) hipLaunchKernelGGL((k_conv3x3_isp<128, 32, false, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_conv3x3_isp<64, 32, false, false>), grid, dim3(256), 0, st, p);
     }
     return true;
 }

@@ -561,7 +561,8 @@ int egr_flashsr_warmup(egr_flashsr* h, int rows, void* stream);
  * snake = the anti-aliased activation of egr_snake_aa (12-tap FIR), conv1 = k taps at dilation d, conv2 = k taps at dilation 1, both
  * 'same'-padded with zeros; w?_h2 = egr_split2h_pack(slab-major pack of the conv weight, w?_scale).  Stands in for the four launches
  * (snake, conv, snake, conv + residual) of the upstream vocoder's AMP unit as the reference reaches it through FlashSR.__call__
- * (egregora_audio_super_resolution.py:361-369).  EGR_ERR_UNSUPPORTED (nothing launched) for shapes outside C = 16, odd k <= 11. */
+ * (egregora_audio_super_resolution.py:361-369).  EGR_ERR_UNSUPPORTED (nothing launched) outside C = 16, odd k <= 11, d (k - 1) / 2 <= 25,
+ * aa_taps = 12; EGR_ERR_ARG for L < 16 or B outside 1 .. 65535; x and y 16-byte aligned. */
 int egr_amp_unit_h2(const float* x, float* y, int B, int L, int C, int k, int d, const float* alpha1, const float* beta1, const void* w1_h2,
                     float w1_scale, const float* bias1, const float* alpha2, const float* beta2, const void* w2_h2, float w2_scale,
                     const float* bias2, const float* filt, int aa_taps, void* stream);

@@ -1,4 +1,4 @@
-"""The fused AMP unit of the vocoder's 16-channel stage (csrc/egr_nn_amp.hip, egr_amp_unit_h2; 16 and 32 channels):
+"""The fused AMP unit of the vocoder's 16-channel stage (csrc/egr_nn_amp.hip, egr_amp_unit_h2; round 6 removed the slower 32-channel instantiation):
     y = conv2(snake2(conv1(snake1(x)))) + x
 against (a) the float64 composite of oracle.flashsr_torch (_act_aa + F.conv1d: what the upstream vocoder's AMP unit computes as the
 reference reaches it through FlashSR.__call__, /root/reference/egregora_audio_super_resolution.py:361-369) and (b) the four launches it
@@ -48,9 +48,12 @@ def ref64(x, prm, k, d, filt):
     return (t + xd).permute(0, 2, 1).contiguous()
 
 
-@pytest.mark.parametrize("Cc,k,d,L", [(16, 3, 1, 1000), (16, 7, 3, 4133), (16, 11, 5, 2048), (16, 11, 1, 300), (16, 7, 5, 256), (16, 3, 3, 17),
-                                      (32, 3, 1, 1000), (32, 7, 3, 2133), (32, 11, 5, 1024), (32, 11, 1, 129), (32, 7, 5, 128), (32, 3, 5, 16)])
-def test_fused_amp_unit_vs_float64_and_vs_the_four_launches(pack, Cc, k, d, L):
+@pytest.mark.parametrize("Cc,k,d,L,big", [(16, 3, 1, 1000, 0), (16, 7, 3, 4133, 0), (16, 11, 5, 2048, 0), (16, 11, 1, 300, 0), (16, 7, 5, 256, 0), (16, 3, 3, 17, 0),
+                                          (16, 11, 5, 500, 0), (16, 3, 5, 16, 0),
+                                          # snake arguments far outside v_sin_f32's +-256 revolutions (alpha ~ 4, |x| ~ 50: ~1800 revolutions);
+                                          # without the range reduction the fused unit dropped the sin^2 term there and the four launches did not
+                                          (16, 7, 3, 1000, 1), (16, 3, 1, 333, 1)])
+def test_fused_amp_unit_vs_float64_and_vs_the_four_launches(pack, Cc, k, d, L, big):
     from egregora_amd import flashsr_arch as A, native
     lib = native.lib()
     native.require_device()
@@ -58,7 +61,9 @@ def test_fused_amp_unit_vs_float64_and_vs_the_four_launches(pack, Cc, k, d, L):
     B = 4
     g = torch.Generator().manual_seed(100 * k + d)
     x = torch.randn(B, L, Cc, generator=g) * (10.0 ** -torch.arange(B).float()).view(B, 1, 1)           # rows at 0 / -20 / -40 / -60 dB
-    prm = {"a1": 0.3 * torch.randn(Cc, generator=g), "b1": 0.3 * torch.randn(Cc, generator=g), "a2": 0.3 * torch.randn(Cc, generator=g),
+    if big:
+        x = x * 50.0
+    prm = {"a1": (4.0 if big else 0.0) + 0.3 * torch.randn(Cc, generator=g), "b1": 0.3 * torch.randn(Cc, generator=g), "a2": 0.3 * torch.randn(Cc, generator=g),
            "b2": 0.3 * torch.randn(Cc, generator=g), "w1": torch.randn(Cc, Cc, k, generator=g) / math.sqrt(Cc * k), "c1": 0.1 * torch.randn(Cc, generator=g),
            "w2": torch.randn(Cc, Cc, k, generator=g) / math.sqrt(Cc * k), "c2": 0.1 * torch.randn(Cc, generator=g)}
     filt = torch.from_numpy(A.kaiser_sinc_filter(12))
@@ -91,7 +96,10 @@ def test_fused_amp_unit_vs_float64_and_vs_the_four_launches(pack, Cc, k, d, L):
         e_4 = float((y4[i].double().cpu() - ref).norm() / ref.norm())
         m_f = float((y[i].double().cpu() - ref).abs().max() / ref.abs().max())
         print(f"C {Cc} k {k} d {d} L {L} row {i}: fused rel L2 {e_f:.2e} (max {m_f:.2e} of the peak), four fp32-grade launches {e_4:.2e}")
-        assert e_f <= 1.5 * e_4 + 3e-7, (Cc, k, d, L, i, e_f, e_4)
+        # relative to the launches it replaces AND absolute (measured 0.7 - 2.7e-7).  With huge snake arguments the float32 product u * alpha
+        # itself is good to 1e-4 revolutions (ANY float32 implementation: the chain's e_4 shows it), so there only the relative gate and
+        # "the sin^2 term is there" (a dropped term is an error of order 1 / beta) apply
+        assert e_f <= 1.5 * e_4 + 3e-7 and (e_f <= 5e-7 or (big and e_f <= 2e-3)), (Cc, k, d, L, i, e_f, e_4)
     # a row's result depends on that row alone
     y1 = torch.empty(1, L, Cc, device="cuda")
     native.check(lib.egr_amp_unit_h2(p(xg[2:3].contiguous()), p(y1), 1, L, Cc, k, d, p(dev["a1"]), p(dev["b1"]), p(packs["w1"][1]), packs["w1"][2], p(dev["c1"]),

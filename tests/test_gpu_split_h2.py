@@ -551,7 +551,8 @@ def test_input_stationary_3x3_with_fused_groupnorm_vs_float64(eng):
             e2 = float((y[i].double().cpu() - ref[i]).norm() / ref[i].norm())
             e1 = float((y1[i].double().cpu() - ref[i]).norm() / ref[i].norm())
             # (the f32 kernel starts from the float32 ROUNDING of the normalised tensor, the fused loader normalises in fp32 itself)
-            assert e2 <= 1.25 * e1 + 2e-7, (B, H, W, Ci, Co, i, e1, e2)
+            print(f"input-stationary 3x3 + GroupNorm, row {i} of {B}: rel L2 vs float64 {e2:.2e} (f32-MFMA kernel {e1:.2e})")
+            assert e2 <= 1.25 * e1 + 2e-7 and e2 <= 5e-7, (B, H, W, Ci, Co, i, e1, e2)      # relative to the f32-MFMA kernel AND absolute
     # too few tiles / W % 32 != 0: refused, nothing launched
     x = torch.randn(1, 8, 48, 32, generator=g).cuda()
     y = torch.empty(1, 8, 48, 128, device="cuda")
