@@ -25,17 +25,22 @@ namespace egr {
 // at every chunk boundary: the global loads of the 6 x 34 patch (an HBM / MALL round trip), the
 // fused GroupNorm + SiLU (an IEEE division per element), the operand split and the LDS stores all sat between two barriers -- about
 // a third of a workgroup's time, with nothing to cover it but the second workgroup of the CU.  Here the patch is DOUBLE-buffered in
-// LDS (2 x 26 KB; the weight tiles shrink to one 16-k slab per buffer, 16 KB: 68.5 KB per workgroup, still two per CU) and every
+// LDS (2 x 26 KB) and every
 // step of the phase is a compile-time position in the slab sequence of the PREVIOUS chunk.  A chunk is 18 slabs (9 taps x two
-// 16-k halves: an even number, so the weight buffer and the register stage of every slab are compile-time constants and each slab
+// 16-k halves: an even number, so the weight register buffer of every slab is a compile-time constant and each slab
 // is ONE basic block):
 //   slab 0              the patch of chunk c + 1 is requested (8 float4 per thread);
 //   slabs 4, 6, 8, 10   one of the thread's four patch items per slab is normalised, activated (x * rcp(1 + exp(-x)): v_rcp_f32,
 //                       1 ulp -- the operand keeps 22 bits), split into its two fp16 terms and stored into the OTHER patch buffer:
 //                       ~70 VALU instructions and two ds_write_b128 next to the slab's 12 MFMAs, in the matrix pipe's shadow;
 //   the barrier that opens chunk c + 1 publishes the patch -- nothing of the phase is left between barriers.
-// Weight tiles are fetched and stored unconditionally (the last slabs re-fetch the last tile): no run-time branch inside a slab.
 #define C3P_MAX_CIN 512                                      // channels whose GroupNorm coefficients the kernel stages in LDS
+// Round 6: the weight fragments go from L2 / L1 STRAIGHT into the MFMA operand registers -- lane (n = li, k-half = lk) of the operand
+// layout owns 16 contiguous bytes of the [slab][plane][Cout][16] pack, a wave-load is 1 KB of consecutive addresses -- one slab ahead, in a
+// register double buffer of the size the LDS staging registers of round 5 had.  No weight tiles in LDS (57 KB instead of 74 KB), half the
+// operand ds_read_b128 per MFMA, and ONE workgroup barrier per channel chunk (the patch hand-over) instead of one per slab: 4 instead of
+// 72.  3.52 -> 3.39 ms per 26-row layer stand-alone, same bits (profiles/r06/conv3x3_weights_in_registers.txt); the kernel runs at the
+// board's power limit like the GEMM, so what it bought is the energy of the LDS traffic it no longer makes.
 template <int BN, int CC, bool GN, bool SILU>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_isp(ConvP p) {
     typedef S3Cfg<128, BN> TC;
@@ -43,7 +48,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_isp(ConvP p) {
     constexpr int NP = 2, NIT = (RMAX * NCH + 255) / 256, SPC = 9 * NSL;      // SPC: slabs per chunk
     static_assert(CC == 32 && NIT == 4 && 256 % NCH == 0 && SPC % 2 == 0, "four patch items per thread, all of one 8-channel group");
     __shared__ uint4 As[2][NP][RMAX * NCH + 8];           // (+ 8 dump slots: threads without a fourth patch item store there, branch-free)
-    __shared__ uint4 Bs[2][NP][BN * 2];
     __shared__ float os_tab[128];
     __shared__ unsigned om_tab[1];
     // GroupNorm scale / shift of this image's channels, staged once: the conversion slabs read them with ds_read (lgkmcnt) -- a global
@@ -75,45 +79,25 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_isp(ConvP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // ---- weight tiles: one 16-k slab = NP planes x BN channels x 2 halves 16-byte chunks, up to two per thread ----
-    constexpr int NBQ = 2 * NP * BN;
-    static_assert(NBQ <= 512, "two weight chunks per thread and slab");
-    const size_t b_slab = (size_t)p.Cout * 2 * NP;
+    const size_t b_slab = (size_t)p.Cout * 2 * NP;     // 16-byte chunks of one 16-k slab of the weight pack
     const int cpt = p.Cin / 16;                  // slabs per tap in the weight pack
-#define C3_BSETUP(I, OFF, SLOT, OK)                                                                               \
-    size_t OFF;                                                                                                      \
-    int SLOT;                                                                                                        \
-    bool OK;                                                                                                         \
-    {                                                                                                                \
-        const int e = tid + 256 * (I);                                                                               \
-        const int plane = e / (2 * BN), rem = e - plane * 2 * BN, nl = rem >> 1, half = rem & 1;                     \
-        OK = e < NBQ && n0 + nl < p.Cout;                                                                            \
-        SLOT = plane * (BN * 2) + nl * 2 + (half ^ ((nl >> 3) & 1));                                                 \
-        OFF = ((size_t)plane * p.Cout + n0 + nl) * 2 + half;                                                         \
-    }
-    C3_BSETUP(0, boff0, bslot0, bok0)
-    C3_BSETUP(1, boff1, bslot1, bok1)
-#undef C3_BSETUP
     const uint4* zq = (const uint4*)p.zeros;
-    struct StageB { uint4 b0, b1; };
-    StageB sA, sB;
-    sA.b0 = sA.b1 = sB.b0 = sB.b1 = make_uint4(0, 0, 0, 0);
     const int nchunks = p.Cin / CC;
-    // the tile of slab s of chunk cc (s may run past the chunk: the next chunk's first slabs; past the end: the last tile again)
-    auto load_b = [&](int cc, int s, StageB& r) {
+    const int li = lane & 31, lk = lane >> 5;
+    // this lane's fragment of (plane q, column sub-tile j) of a slab sits at base[bw_off + (q Cout + 32 j) 2]; the tile of slab s of chunk cc
+    // (s may run past the chunk: the next chunk's first slab; past the end: the last tile again -- no run-time branch inside a slab)
+    uint4 bwA[TN][NP], bwB[TN][NP];
+    const size_t bw_off = ((size_t)n0 + wn0 + li) * 2 + lk;
+    auto load_bw = [&](int cc, int s, uint4 (&dst)[TN][NP]) {
         if (s >= SPC) { s -= SPC; ++cc; }
         if (cc >= nchunks) { cc = nchunks - 1; s = SPC - 1; }
         const int tap = s / NSL, cs = s - tap * NSL;
-        const uint4* base = p.w3 + (size_t)(tap * cpt + cc * NSL + cs) * b_slab;
-        r.b0 = bok0 ? base[boff0] : zq[0];
-        if (256 < NBQ) r.b1 = bok1 ? base[boff1] : zq[0];
+        const uint4* base = p.w3 + (size_t)(tap * cpt + cc * NSL + cs) * b_slab + bw_off;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) dst[j][q] = (n0 + wn0 + j * 32 + li < p.Cout) ? base[((size_t)q * p.Cout + j * 32) * 2] : zq[0];
     };
-    auto store_b = [&](int buf, const StageB& r) {
-        if (NBQ >= 256 || tid < NBQ) Bs[buf][0][bslot0] = r.b0;            // (compile-time true for the wide tile: no exec-mask branch)
-        if (NBQ >= 512 || tid + 256 < NBQ) Bs[buf][0][bslot1] = r.b1;
-    };
-    const int li = lane & 31, lk = lane >> 5;
-    const int ob_slot = li * 2 + (lk ^ ((li >> 3) & 1));
 
     // ---- the thread's four patch items: the same pixels for every channel chunk ----
     const int hch = tid & (NCH - 1);
@@ -164,19 +148,18 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_isp(ConvP p) {
         As[abuf][1][slot] = q[1];
     };
 
-    // slab S (compile-time) of chunk cc: tap S / 2, 16-k half S % 2; reads weight buffer S & 1 and patch buffer cc & 1; the register
-    // stage of its parity holds the tile of slab S + 1 and is refilled with that of S + 3
+    // slab S (compile-time) of chunk cc: tap S / 2, 16-k half S % 2; multiplies the weight fragments of register buffer S & 1 with patch
+    // buffer cc & 1 and requests the fragments of slab S + 1 into the other register buffer
     auto slab = [&](auto s_c, int cc) {
         constexpr int S = decltype(s_c)::value, cur = S & 1, TAP = S / NSL, CS = S % NSL;
         constexpr int ky = TAP / 3, kx = TAP - ky * 3;
-        StageB& nx = cur ? sB : sA;
         const int ab = cc & 1;
-        __syncthreads();                         // weight tile `cur` (stored one slab ago) and, at slab 0, the patch of this chunk are visible
+        if (S == 0) __syncthreads();             // the patch of this chunk is visible, every wave is done with the previous chunk's
         uint4 bq[TN][2], aq[TM][2];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) bq[j][q] = Bs[cur][q][(wn0 + j * 32) * 2 + ob_slot];
+            for (int q = 0; q < NP; ++q) bq[j][q] = cur ? bwB[j][q] : bwA[j][q];
         const int ch = CS * 2 + lk;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -185,8 +168,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_isp(ConvP p) {
 #pragma unroll
             for (int q = 0; q < NP; ++q) aq[i][q] = As[ab][q][slot];
         }
-        store_b(cur ^ 1, nx);
-        load_b(cc, S + 3, nx);
+        if (cur) load_bw(cc, S + 1, bwA); else load_bw(cc, S + 1, bwB);          // the fragments of the NEXT slab: a whole slab of MFMAs to land
         if (S == 0) halo_issue(cc + 1);
         if (S == 4) halo_finish(hu0, hv0, hok0, hslot0, cc + 1, ab ^ 1);
         if (S == 6) halo_finish(hu1, hv1, hok1, hslot1, cc + 1, ab ^ 1);
@@ -220,10 +202,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_isp(ConvP p) {
 
     // prologue: the patch of chunk 0 and the first weight tiles
     halo_issue(0);
-    load_b(0, 0, sA);
-    store_b(0, sA);
-    load_b(0, 1, sA);
-    load_b(0, 2, sB);
+    load_bw(0, 0, bwA);
     halo_finish(hu0, hv0, hok0, hslot0, 0, 0);
     halo_finish(hu1, hv1, hok1, hslot1, 0, 0);
     halo_finish(hu2, hv2, hok2, hslot2, 0, 0);

@@ -136,17 +136,21 @@ def _tune_pipelines(L, plan, x_ct, out, thr, flags, max_iterations):
     if best is None:
         if max_iterations < TUNE_MIN_JOB:
             return
-        t = {}
-        for mode in (1, 0):
-            native.check(L.egr_fatllama_set_graph(C.c_void_p(plan), mode), "egr_fatllama_set_graph")
-            for rep in range(2):                              # the first run captures the graph
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                native.check(L.egr_fatllama_enhance(C.c_void_p(plan), native.ptr(x_ct), native.ptr(out), TUNE_ITERS, thr, flags,
-                                                    native.stream_ptr()), "egr_fatllama_enhance")
-                torch.cuda.synchronize()
-                t[mode] = time.perf_counter() - t0
-        best = _TUNED[key] = 1 if t[1] <= t[0] else 0
+        t = {1: float("inf"), 0: float("inf")}
+        for rnd in range(2):                                  # the modes alternate: a shader clock still ramping up must not favour the later one
+            for mode in (1, 0):
+                native.check(L.egr_fatllama_set_graph(C.c_void_p(plan), mode), "egr_fatllama_set_graph")
+                for rep in range(3):                          # the first run of a mode captures the graph / warms the path
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    native.check(L.egr_fatllama_enhance(C.c_void_p(plan), native.ptr(x_ct), native.ptr(out), TUNE_ITERS, thr, flags,
+                                                        native.stream_ptr()), "egr_fatllama_enhance")
+                    torch.cuda.synchronize()
+                    if rep or rnd:
+                        t[mode] = min(t[mode], time.perf_counter() - t0)
+        # graph replay is the default; plain launches only where they win clearly (round 6: a two-run timing picked the slower mode in three
+        # of six bench processes -- 35.8 instead of 29.9 ms per 800-iteration stereo minute, profiles/r06/same_box_ab_*.txt)
+        best = _TUNED[key] = 0 if t[0] < 0.93 * t[1] else 1
     native.check(L.egr_fatllama_set_graph(C.c_void_p(plan), best), "egr_fatllama_set_graph")
 
 

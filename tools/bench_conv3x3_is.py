@@ -42,5 +42,5 @@ for _ in range(reps): run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 fl = 2.0 * B * H * W * Co * K
-print(f"EGR_S3_CONV3X3={os.environ.get('EGR_S3_CONV3X3', '')!r}: {ms:.3f} ms per launch, {fl / ms / 1e9:.1f} TFLOP/s fp32-equivalent, "
+print(f"EGR_C3_BREG={os.environ.get('EGR_C3_BREG', '')!r}: {ms:.3f} ms per launch, {fl / ms / 1e9:.1f} TFLOP/s fp32-equivalent, "
       f"{3 * fl / ms / 1e9:.0f} executed f16; checksum {float(y.double().sum()):.6e} {float(y.double().abs().max()):.6e}")
