@@ -56,6 +56,20 @@ def synth(seed, n, channels=2, sr=SR):
     return (0.5 * x / np.max(np.abs(x))).astype(np.float32)
 
 
+def csrc_sha():
+    """sha256 over the library's sources (csrc/*.{hip,h,cpp,inc}, Makefile, the public header): profiles/traffic.json records the value
+    of the build it profiled, so a bench line can say whether its `traffic` figures belong to the library that produced its times
+    (there is no .git on the GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = ROOT / "comfyui-egregora-audio-super-resolution_amd" / "csrc"
+    files = sorted([f for f in d.iterdir() if f.suffix in (".hip", ".h", ".cpp", ".inc") or f.name == "Makefile"]) + [ROOT / "include" / "egregora_amd.h"]
+    for f in files:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -506,7 +520,11 @@ def main():
         try:                # HBM bytes per launch from the committed PMC passes (tools/make_traffic_json.py)
             tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
             tk = tj.get("kernels", {})
-            traffic_src = "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %s (a committed profile of an earlier run of this command, NOT measured in this run)" % tj.get("source", tj.get("_note", "an earlier round").split("source: ")[-1].split(";")[0])
+            sha_now, sha_prof = csrc_sha(), tj.get("csrc_sha")
+            traffic_src = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %s (a committed profile of an earlier run of this command, NOT "
+                           "measured in this run); library sources then %s, now %s: %s" %
+                           (tj.get("source", tj.get("_note", "an earlier round").split("source: ")[-1].split(";")[0]), sha_prof, sha_now,
+                            "SAME build" if sha_prof == sha_now else "the library has CHANGED since that profile"))
             cands = ["k_row_wl<16, 12, 0>", "k_row_wl", "k_row<false, 1>", "k_row<false, 0>", "k_row<false>"] if dom.startswith("k_row") else ["k_col_wl", "k_col<1, 2>", "k_col<1, 0>", "k_col<1>"]
             if not wl:
                 cands = cands[1:]

@@ -24,10 +24,23 @@ for ctr, dirs in (("FETCH_SIZE", ("pmc_fetch", "pz_pmc_fetch")), ("WRITE_SIZE", 
                 acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
         for k, v in acc.items():
             per[ctr].setdefault(k, v[0] / max(v[1], 1) * 1024.0)
+def csrc_sha():
+    import hashlib, pathlib
+    root = pathlib.Path(__file__).resolve().parents[1]
+    h = hashlib.sha256()
+    d = root / "comfyui-egregora-audio-super-resolution_amd" / "csrc"
+    files = sorted([f for f in d.iterdir() if f.suffix in (".hip", ".h", ".cpp", ".inc") or f.name == "Makefile"]) + [root / "include" / "egregora_amd.h"]
+    for f in files:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 out = {"_note": "HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from the rocprofv3 PMC passes (separate runs; FETCH x2 gfx950 correction per "
                 f"MI355X_MICROARCH.md section HBM); source: {tag}/chain60_summary.txt; Fat-Llama loop kernels are per ONE-channel launch "
                 "(two channel pipelines run concurrently)",
        "source": f"{tag} ({src}), library built from commit {build}",
+       "csrc_sha": csrc_sha(),          # bench.py compares it with the sources it runs on (same function)
        "kernels": {}}
 for k in sorted(set(per["FETCH_SIZE"]) | set(per["WRITE_SIZE"])):
     f, w = per["FETCH_SIZE"].get(k, 0.0), per["WRITE_SIZE"].get(k, 0.0)
