@@ -225,6 +225,8 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
     const bool fast2 = SCHED == 1 && !MAXONLY && !self && !p.phat && !p.band && !p.gain && !p.soft && p.max2 == nullptr;
     dcplx wk_next = p.wk[fast2 ? 2 * threadIdx.x : (threadIdx.x < (unsigned)L ? threadIdx.x : 0)];   // first pair twiddle(s) of this thread
     dcplx wk_next1 = p.wk[fast2 ? 2 * threadIdx.x + 1 : 0];
+    float max2v = 0.f;                       // the carried spectrum maximum, requested before the transform (an L2 miss: egr_fatllama_wl.h)
+    if (!MAXONLY && p.max2) max2v = fl_max2_read(p.max2, ch);
     EGR_STAMP(p, 0);
     if (SCHED == 1) {                     // 16-byte state loads (two elements; a pair never straddles a pad position)
         for (int e = 2 * threadIdx.x; e < L; e += 2 * blockDim.x) {
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(SCHED ? 512 : 1024, SCHED ? EGR_FL_SCHED_WAVES : 1)
     const double scd = p.inv_M_d;
     float thr2 = p.thr2, tlev = p.thr;
     if (!MAXONLY && p.max2) {
-        tlev = p.thr * sqrtf(fl_max2_read(p.max2, ch));
+        tlev = p.thr * sqrtf(max2v);
         thr2 = tlev * tlev;
     }
     if (!MAXONLY && p.max2_zero && blockIdx.x == 0 && threadIdx.x < EGR_FL_MAX_SUB) fl_max2_clear(p.max2_zero, ch, threadIdx.x);

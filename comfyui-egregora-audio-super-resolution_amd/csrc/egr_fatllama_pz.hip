@@ -364,6 +364,15 @@ static const PzColWlEntry kPzColWl[] = {PZ_COLWL_LIST(PZ_COLWL_ENTRY)};
 
 // Carried maximum of the relative threshold (PzHook::max2_next): per-wave maxima to LDS in front of a barrier the kernel has anyway,
 // ONE commit per workgroup and channel behind it; workgroup g = 0 of a state clears the ring slot two iterations ahead.
+// the carried maxima of this state's channel(s), requested at the kernel's top (an L2 miss -- the slots were written by memory-side atomics --
+// that the inverse transform in front of the hook covers)
+__device__ __forceinline__ void pz_max_prefetch(const PzP& p, const PzHook& h, int st, float& m2a, float& m2b) {
+    m2a = m2b = 0.f;
+    if (!h.max2) return;
+    const int cha = p.kind == 1 ? st : 2 * st, chb = p.kind == 1 ? st : 2 * st + 1;
+    m2a = fl_max2_read(h.max2, cha);
+    m2b = p.kind == 1 ? m2a : fl_max2_read(h.max2, chb < p.C ? chb : cha);
+}
 __device__ __forceinline__ void pz_max_stage(const PzHook& h, float mxa, float mxb, float* red) {
     if (!h.max2_next) return;
     mxa = wave_max(mxa); mxb = wave_max(mxb);
@@ -386,9 +395,10 @@ __device__ __forceinline__ void pz_max_commit(const PzP& p, const PzHook& h, int
 // The pair hook of the spectrum pass on natural-order positions p = i nc + c of a tile pair held in LDS; index k = p - s is valid
 // for 0 <= k < D.  at(i, slot): element i of right column t at slot t, of left column t at slot TC + t.  Shared by k_pzpair (stages
 // in place, interleaved tile) and k_pzpair_wl (rows of the thread-per-(row class, column) layout).
+// m2a / m2b: max |X|^2 of this iteration's spectrum for the state's channel(s) (relative threshold; pz_max_prefetch at the kernel's top)
 template <bool MAXONLY, class AT>
 __device__ __forceinline__ void pz_pair_hook(const PzP& p, const PzHook& h, AT at, int st, int rs, unsigned rmask, unsigned selfmask,
-                                             float& mxa, float& mxb) {
+                                             float& mxa, float& mxb, float m2a = 0.f, float m2b = 0.f) {
     const int TC = p.TC, lg = p.TClog2, L = p.L, nc = p.nc;
     const unsigned long long D = p.D;
     const long long s = p.s;
@@ -397,8 +407,8 @@ __device__ __forceinline__ void pz_pair_hook(const PzP& p, const PzHook& h, AT a
     const bool hasb = chb < p.C;
     double ta = (double)h.thr, tb = (double)h.thr;
     if (!MAXONLY && h.max2) {
-        ta = (double)(h.thr * sqrtf(fl_max2_read(h.max2, cha)));
-        tb = p.kind == 1 ? ta : (double)(h.thr * sqrtf(fl_max2_read(h.max2, hasb ? chb : cha)));
+        ta = (double)(h.thr * sqrtf(m2a));
+        tb = p.kind == 1 ? ta : (double)(h.thr * sqrtf(m2b));
     }
     const double ta2 = ta * ta, tb2 = tb * tb;
     const double sgn = p.odd ? -1.0 : 1.0;          // w[D - k] = (-1)^D w[k]
@@ -516,6 +526,8 @@ __global__ __launch_bounds__(F::MAXT, F::MINW2) void k_pzpair(PzP p, PzHook h, c
     const int TC = p.TC, lg = p.TClog2, L = p.L, nc = p.nc, TC2 = 2 * TC;
     cplx* cur = (cplx*)EGR_LDS_BASE(smem);
     cplx* W = work + (size_t)st * p.P;
+    float m2a, m2b;
+    pz_max_prefetch(p, h, st, m2a, m2b);
     const unsigned long long D = p.D;
     const long long s = p.s;
     const int rs = (p.c0 + g * TC) % nc;
@@ -554,7 +566,7 @@ __global__ __launch_bounds__(F::MAXT, F::MINW2) void k_pzpair(PzP p, PzHook h, c
     const bool hasb = chb < p.C;
     float mxa = 0.f, mxb = 0.f;
     const int nel = L * TC;
-    pz_pair_hook<MAXONLY>(p, h, [&](int i, int slot) { return cur + (size_t)i * TC2 + slot; }, st, rs, rmask, selfmask, mxa, mxb);
+    pz_pair_hook<MAXONLY>(p, h, [&](int i, int slot) { return cur + (size_t)i * TC2 + slot; }, st, rs, rmask, selfmask, mxa, mxb, m2a, m2b);
     if (MAXONLY) {
         mxa = block_max(mxa, red);
         if (p.kind == 2 && hasb) mxb = block_max(mxb, red);
@@ -606,6 +618,8 @@ __global__ __launch_bounds__((PzColWl<LA, LB>::THREADS)) void k_pzpair_wl(PzP p,
     const int tid = threadIdx.x;
     const int b = tid >> 3, cl = tid & 7;
     for (int e = tid; e < L; e += G::THREADS) ts[e] = tab[e];
+    float m2a, m2b;
+    pz_max_prefetch(p, h, st, m2a, m2b);
     const unsigned long long D = p.D;
     const long long s = p.s;
     const int rs = (p.c0 + g * TC) % nc;
@@ -659,7 +673,7 @@ __global__ __launch_bounds__((PzColWl<LA, LB>::THREADS)) void k_pzpair_wl(PzP p,
     }
     __syncthreads();
     float mxa = 0.f, mxb = 0.f;
-    pz_pair_hook<false>(p, h, [&](int i, int slot) { const int q = i / LA; return lds + ((i - q * LA) * LBP + q) * TC2 + slot; }, st, rs, rmask, selfmask, mxa, mxb);
+    pz_pair_hook<false>(p, h, [&](int i, int slot) { const int q = i / LA; return lds + ((i - q * LA) * LBP + q) * TC2 + slot; }, st, rs, rmask, selfmask, mxa, mxb, m2a, m2b);
     pz_max_stage(h, mxa, mxb, red);
     __syncthreads();
     pz_max_commit(p, h, st, g, red);

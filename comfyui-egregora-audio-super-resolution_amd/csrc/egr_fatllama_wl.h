@@ -88,14 +88,20 @@ __device__ __forceinline__ float wl_pair_hook(const cplx Za, const cplx Zb, cons
     if (HOOK == 1) {
         // the comparison on squares as in the default hook; the soft gain 1 - t / |X| through v_rsq_f32 (1 ulp: 6e-8 of a gain <= 1) --
         // round 5's two correctly rounded sqrtf and two divisions per pair were a tenth of the kernel
+        // (hook 1 costs the C3 stage 2.6 ms over hook 0 with the two channel pipelines overlapped and 1.1 ms with one pipeline, whatever the
+        // threshold gates and whether soft / hard is a run-time branch or an instantiation of its own (tried: hook 3): not this arithmetic --
+        // tools/r06_hook_times.py, profiles/r06/relative_threshold_timing.txt)
         const float mk2 = Xk.x * Xk.x + Xk.y * Xk.y, mm2 = Xm.x * Xm.x + Xm.y * Xm.y;
-        float gk = mk2 > thr2x4 ? 1.f : 0.f, gm = mm2 > thr2x4 ? 1.f : 0.f;
-        if (soft) {
-            if (mk2 > thr2x4) gk = 1.f - tlevx2 * __builtin_amdgcn_rsqf(mk2);
-            if (mm2 > thr2x4) gm = 1.f - tlevx2 * __builtin_amdgcn_rsqf(mm2);
+        const bool kk = mk2 > thr2x4, km = mm2 > thr2x4;
+        if (!soft) {
+            if (!kk) Xk = make_float2(0.f, 0.f);
+            if (!km) Xm = make_float2(0.f, 0.f);
+            mxn = 0.25f * fmaxf(kk ? mk2 : 0.f, km ? mm2 : 0.f);                          // max |S(X)|^2: the next iteration's spectrum
+        } else {
+            const float gk = kk ? 1.f - tlevx2 * __builtin_amdgcn_rsqf(mk2) : 0.f, gm = km ? 1.f - tlevx2 * __builtin_amdgcn_rsqf(mm2) : 0.f;
+            Xk.x *= gk; Xk.y *= gk; Xm.x *= gm; Xm.y *= gm;
+            mxn = 0.25f * fmaxf(gk * gk * mk2, gm * gm * mm2);                            // |g X|^2 = g^2 |X|^2
         }
-        Xk.x *= gk; Xk.y *= gk; Xm.x *= gm; Xm.y *= gm;
-        mxn = 0.25f * fmaxf(Xk.x * Xk.x + Xk.y * Xk.y, Xm.x * Xm.x + Xm.y * Xm.y);      // max |S(X)|^2: the next iteration's spectrum
     } else {
         if (!(Xk.x * Xk.x + Xk.y * Xk.y > thr2x4)) Xk = make_float2(0.f, 0.f);
         if (!(Xm.x * Xm.x + Xm.y * Xm.y > thr2x4)) Xm = make_float2(0.f, 0.f);
@@ -180,6 +186,11 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
     // the pair twiddles W_N^(o + R k), k = k1 + N1 l + N1 Q d: a geometric run in double over d (ratio W_(2L)^(N1 Q) = W_(2Q))
     dcplx wrun = make_double2(1.0, 0.0);
     if (lact) wrun = dcmul(tw2d(p.wo, (unsigned)oa), p.wk[k1 + N1 * l]);
+    // the carried spectrum maximum is requested HERE: the slots were written by atomics of the previous iteration's launch (memory side), so
+    // the read is a miss of this XCD's L2 -- a microsecond that the forward transform below covers; behind the first barrier it was on every
+    // workgroup's critical path
+    float max2v = 0.f;
+    if (HOOK == 1 && p.max2) max2v = fl_max2_read(p.max2, ch);
     EGR_STAMP(p, 0);
 
     // ---- cross step, forward: global -> radix N1 -> twiddle -> LDS blocks
@@ -265,7 +276,7 @@ __global__ __launch_bounds__((WlRow<N1, Q>::THREADS)) void k_row_wl(RowP p, WlRo
     EGR_STAMP(p, 2);
     float thr2 = p.thr2, tlev = p.thr;
     if (HOOK == 1 && p.max2) {                   // level relative to this iteration's spectrum maximum: carried from the previous
-        tlev = p.thr * sqrtf(fl_max2_read(p.max2, ch));      // iteration's hook, or written by k_row_wl<.., 2> (iteration 0)
+        tlev = p.thr * sqrtf(max2v);                         // iteration's hook, or written by k_row_wl<.., 2> (iteration 0)
         thr2 = tlev * tlev;
     }
     if (HOOK == 1 && p.max2_zero && blockIdx.x == 0 && tid < EGR_FL_MAX_SUB) fl_max2_clear(p.max2_zero, ch, tid);
