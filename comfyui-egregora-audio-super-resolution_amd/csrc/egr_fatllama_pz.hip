@@ -25,6 +25,9 @@
 // The pair hook runs in double precision (the chirp values are double table products, so |w|^2 = 1 to 1e-16 and nothing
 // compounds over the iterations); Bhat = FFT_P(b) / P is computed once per plan by a double-precision transform on the device
 // and rounded to float once.
+#ifndef EGR_BFLY_HILO
+#define EGR_BFLY_HILO 15          // the register butterflies' cos / sin constants as two floats (egr_fft_device.h), as in egr_fatllama.hip
+#endif
 #include "egr_fatllama_int.h"
 
 namespace egr {
@@ -108,6 +111,22 @@ __device__ __forceinline__ cplx dmulc_f(dcplx a, dcplx w, double sc) {    // a *
     return make_float2((float)(sc * (a.x * w.x + a.y * w.y)), (float)(sc * (a.y * w.x - a.x * w.y)));
 }
 
+// Round 6: the four-step twiddle products of the thread-per-(row class, column) kernels in double (the run `cur` is double anyway): a
+// float-rounded twiddle is a gain |W|^2 - 1 ~ 6e-8 applied in the same direction every iteration (egr_fatllama_wl.h EGR_WL_HILO), and the
+// register butterflies' constants as two floats (EGR_BFLY_HILO below) -- N = 2 880 002, 800 iterations against the float64 loop:
+// max 2.91 -> 1.00, rms 0.635 -> 0.193 (the float32 Bluestein oracle: 2.70 / 0.543), plain LSD 6.8e-3 -> 4.2e-3 dB, 103.7 -> 108.4 ms per stereo stage; the
+// odd length (channel pairs) rms 0.490 -> 0.156, 150.3 -> 155.9 ms (profiles/r06/chirpz_precision.txt: the butterfly constants are nine tenths of it)
+#ifndef EGR_PZ_TWD
+#define EGR_PZ_TWD 1
+#endif
+__device__ __forceinline__ cplx pz_tw_mul(cplx v, dcplx w) {         // v * w
+    if (EGR_PZ_TWD) { const double x = (double)v.x, y = (double)v.y; return make_float2((float)(x * w.x - y * w.y), (float)(x * w.y + y * w.x)); }
+    return cmul(v, make_float2((float)w.x, (float)w.y));
+}
+__device__ __forceinline__ cplx pz_tw_mulc(cplx v, dcplx w) {        // v * conj(w)
+    if (EGR_PZ_TWD) { const double x = (double)v.x, y = (double)v.y; return make_float2((float)(x * w.x + y * w.y), (float)(y * w.x - x * w.y)); }
+    return cmulc(v, make_float2((float)w.x, (float)w.y));
+}
 #ifndef EGR_PZ_TWPOW
 #define EGR_PZ_TWPOW true
 #endif
@@ -316,7 +335,7 @@ __global__ __launch_bounds__((PzColWl<LA, LB>::THREADS)) void k_pzcol_wl(PzP p, 
         dcplx cur = w0;
 #pragma unroll
         for (int a = 0; a < LA; ++a) {
-            v[a] = cmulc(v[a], make_float2((float)cur.x, (float)cur.y));
+            v[a] = pz_tw_mulc(v[a], cur);
             cur = dcmul(cur, wst);
         }
         wl_bfly_inv<LA>(v);                              // v[c] = Z[c][b]
@@ -350,7 +369,7 @@ __global__ __launch_bounds__((PzColWl<LA, LB>::THREADS)) void k_pzcol_wl(PzP p, 
         dcplx cur = w0;
 #pragma unroll
         for (int a = 0; a < LA; ++a) {
-            W[(size_t)(LB * a + b) * nc] = cmul(v[a], make_float2((float)cur.x, (float)cur.y));
+            W[(size_t)(LB * a + b) * nc] = pz_tw_mul(v[a], cur);
             cur = dcmul(cur, wst);
         }
     }
@@ -403,8 +422,6 @@ __device__ __forceinline__ void pz_pair_hook(const PzP& p, const PzHook& h, AT a
     const unsigned long long D = p.D;
     const long long s = p.s;
     // ---- pair hook on natural-order positions p = i nc + c; index k = p - s is valid for 0 <= k < D ----
-    const int cha = p.kind == 1 ? st : 2 * st, chb = p.kind == 1 ? st : 2 * st + 1;
-    const bool hasb = chb < p.C;
     double ta = (double)h.thr, tb = (double)h.thr;
     if (!MAXONLY && h.max2) {
         ta = (double)(h.thr * sqrtf(m2a));
@@ -647,7 +664,7 @@ __global__ __launch_bounds__((PzColWl<LA, LB>::THREADS)) void k_pzpair_wl(PzP p,
             dcplx cur = w0;
 #pragma unroll
             for (int a = 0; a < LA; ++a) {
-                v[a] = cmulc(v[a], make_float2((float)cur.x, (float)cur.y));
+                v[a] = pz_tw_mulc(v[a], cur);
                 cur = dcmul(cur, wst);
             }
             wl_bfly_inv<LA>(v);
@@ -699,7 +716,7 @@ __global__ __launch_bounds__((PzColWl<LA, LB>::THREADS)) void k_pzpair_wl(PzP p,
         dcplx cur = w0;
 #pragma unroll
         for (int a = 0; a < LA; ++a) {
-            W[(size_t)(LB * a + b) * nc] = cmul(v[a], make_float2((float)cur.x, (float)cur.y));
+            W[(size_t)(LB * a + b) * nc] = pz_tw_mul(v[a], cur);
             cur = dcmul(cur, wst);
         }
     }
