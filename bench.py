@@ -127,7 +127,15 @@ def cpu_baseline_fatllama(x, budget_s, gpu_c1=None):
             t0 = time.perf_counter()
             ofl.node_run(c1, sr1, 50, 0.6, 1411, True, True)
             c1_one = time.perf_counter() - t0
-    lsd_c1 = gpu_c1(c1, sr1, out_c1) if gpu_c1 is not None else None
+    lsd_c1 = lsd_c1_raw = None
+    if gpu_c1 is not None:
+        # ... and the same comparison BEFORE the final PCM_16 quantiser (normalised float outputs of the two loops): what the loops differ by;
+        # the post-quantisation figure is +-1 LSB flips on ~2 % of samples of an eight-tone signal over a -40 dB floor
+        xi1 = ofl.pcm16_write(c1).astype(np.float32)
+        f1 = ofl.upscale_factor(sr1, 1, 1411)
+        with sfft.set_workers(cores):
+            raw_c1 = ofl.enhance_channels(xi1, f1, 50, 0.6, True, True)
+        lsd_c1, lsd_c1_raw = gpu_c1(c1, sr1, out_c1, raw_c1, f1)
     c1_med = float(np.median(c1_runs))
     return {"value": audio_c3 / (per_all * 800 * x.shape[0]), "unit": "audio-sec/sec", "cores": cores, "kind": "port",
             "cpu_model": cpu_model(),
@@ -138,10 +146,11 @@ def cpu_baseline_fatllama(x, budget_s, gpu_c1=None):
             "workers_1": {"sec_per_iteration_channel": per_one, "value": audio_c3 / (per_one * 800 * x.shape[0])},
             "c1": {"seconds_median": c1_med, "runs": len(c1_runs), "xrt": 10.0 / c1_med, "workers": cores,
                    "workers_1_seconds": c1_one, "workers_1_xrt": (10.0 / c1_one) if c1_one else None,
-                   "lsd_vs_gpu_db": lsd_c1,
+                   "lsd_vs_gpu_db_before_pcm16": lsd_c1_raw, "lsd_vs_gpu_db_after_pcm16": lsd_c1,
                    "lsd_note": "the reference's LSD (egregora_audio_eval_pack.py:389-411, device kernel device_ops.lsd) between the CPU "
-                               "restatement's and the device's C1 node outputs after the PCM_16 hop (both are k/32768; +-1 LSB flips "
-                               "on ~2 % of samples)"}}
+                               "restatement's and the device's C1 outputs: before_pcm16 = the two loops' normalised float outputs (what the "
+                               "arithmetic differs by); after_pcm16 = the node outputs behind the final PCM_16 hop (both k/32768: +-1 LSB "
+                               "flips on ~2 % of samples of an eight-tone signal over a -40 dB floor -- the quantiser, not the loop)"}}
 
 
 def free_port():
@@ -672,11 +681,14 @@ def main():
                     out[k + "_one_gpu_override"] = out.pop(k)
             out["note"] = "EGREGORA_BENCH_ONE_GPU=1: all %d ranks on ONE device, gloo collectives -- a path check, not a measurement" % world
         if not args.no_cpu_baseline and world == 1:
-            def gpu_c1(c1, sr1, cpu_out):
+            def gpu_c1(c1, sr1, cpu_out, cpu_raw, f1):
                 from packload import load_pack as _lp
                 node = _lp().NODE_CLASS_MAPPINGS["EgregoraFatLlamaCPU"]()
                 (res,) = node.run("wav", 50, 0.6, 1411, AUDIO={"waveform": torch.from_numpy(c1)[None], "sample_rate": sr1})
-                return device_ops.lsd(torch.from_numpy(np.ascontiguousarray(cpu_out)).cuda(), res["waveform"][0].cuda().contiguous())[0]
+                after = device_ops.lsd(torch.from_numpy(np.ascontiguousarray(cpu_out)).cuda(), res["waveform"][0].cuda().contiguous())[0]
+                raw = fe.enhance_device(torch.from_numpy(c1).cuda(), f1, 50, 0.6, True, True, pcm_in=True, node_post=False)
+                before = device_ops.lsd(torch.from_numpy(np.ascontiguousarray(cpu_raw)).cuda(), raw.contiguous())[0]
+                return after, before
             out["cpu_baseline"] = cpu_baseline_fatllama(x_all[:, :SEG].cpu().numpy(), args.cpu_budget, gpu_c1)
         print(json.dumps(out))
     if dist:

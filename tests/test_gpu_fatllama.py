@@ -400,7 +400,9 @@ def test_c3_full_length_800_iterations_against_the_oracle(pack):
         # round 6: at the packed length the loop kernels carry their twiddles and butterfly constants as two floats /
         # double runs (csrc/egr_fatllama_wl.h EGR_WL_HILO) and sit BELOW the float32 oracle's own error (measured 0.59x max, 0.86x rms,
         # plain LSD 7.4e-4 dB; round 5: 1.51x / 2.27x / 2.2e-3 dB against gates of 2x / 2.5x / 3x the oracle's LSD)
-        kmax, krms = (1.5, 1.5) if n == 2880000 else (2.0, 2.5)
+        # (round 6, chirp-z: butterfly constants as two floats and the four-step twiddle products in double -- max 1.00 / rms 0.193 against the Bluestein
+        # oracle's 2.70 / 0.543, plain LSD 4.2e-3 dB against its 1.2e-2: the gates, 2x / 2.5x / 1x the oracle's until round 5, now sit BELOW the oracle)
+        kmax, krms = (1.5, 1.5) if n == 2880000 else (0.75, 0.75)
         assert mg <= kmax * ref_err[0] and mg <= 5e-4 * scale, (n, mg, ref_err, scale)
         assert rg <= krms * ref_err[1] + 1e-9 * scale, (n, rg, ref_err)
         if n == 2880000:
@@ -408,7 +410,7 @@ def test_c3_full_length_800_iterations_against_the_oracle(pack):
         # (at N + 2 the Bluestein round-off floor of ANY float32 run leaves only ~2 % of the bins 80 dB above it -- the float32 oracle's
         # plain LSD is 1.2e-2 dB there; the device's chirp-z path must be no worse than the oracle and meet 1e-3 dB on what is resolvable)
         assert lg <= 1e-3 and kept >= (0.3 if n == 2880000 else 0.01), (n, lg, kept)
-        assert lg_plain <= (3.0 if n == 2880000 else 1.0) * lo_plain, (n, lg_plain, lo_plain)
+        assert lg_plain <= (3.0 if n == 2880000 else 0.6) * lo_plain, (n, lg_plain, lo_plain)
 
 
 def test_60_s_plus_1_sample_stereo_800_iterations_against_float64(pack):
@@ -436,8 +438,9 @@ def test_60_s_plus_1_sample_stereo_800_iterations_against_float64(pack):
           f"LSD vs float64 plain {lg_plain:.2e} dB, over the {kept:.1%} resolvable bins {lg:.2e} dB")
     assert np.isfinite(got).all()
     o_max, o_rms, o_lsd = oracle32_at_n_plus_2()
-    assert mg <= 2.0 * o_max and mg <= 5e-4 * scale and rg <= 2.5 * o_rms, (mg, rg, scale)
-    assert lg <= 1e-3 and kept >= 0.01 and lg_plain <= o_lsd, (lg, kept, lg_plain)
+    # (round 6: measured max 0.86 / rms 0.156 / plain LSD 3.3e-3 dB -- a third of the float32 oracle's own errors at N + 2; gates were 2x / 2.5x / 1x the oracle's)
+    assert mg <= 0.75 * o_max and mg <= 5e-4 * scale and rg <= 0.75 * o_rms, (mg, rg, scale)
+    assert lg <= 1e-3 and kept >= 0.01 and lg_plain <= 0.6 * o_lsd, (lg, kept, lg_plain)
 
 
 @pytest.mark.parametrize("n,iters,plan", [(2646000, 800, (441, 3000, 1)), (1323000, 800, (441, 1500, 1)), (5760000, 400, (625, 4608, 1)),
