@@ -148,8 +148,10 @@ def cpu_baseline_fatllama(x, budget_s, gpu_c1=None):
                    "workers_1_seconds": c1_one, "workers_1_xrt": (10.0 / c1_one) if c1_one else None,
                    "lsd_vs_gpu_db_before_pcm16": lsd_c1_raw, "lsd_vs_gpu_db_after_pcm16": lsd_c1,
                    "lsd_note": "the reference's LSD (egregora_audio_eval_pack.py:389-411, device kernel device_ops.lsd) between the CPU "
-                               "restatement's and the device's C1 outputs: before_pcm16 = the two loops' normalised float outputs (what the "
-                               "arithmetic differs by); after_pcm16 = the node outputs behind the final PCM_16 hop (both k/32768: +-1 LSB "
+                               "restatement's and the device's C1 outputs: before_pcm16 = the two loops' normalised float outputs, ALL bins -- C1 is eight "
+                               "tones over a -40 dB floor up-rated by 6: most bins sit 100+ dB under the peak, where float32 round-off of either "
+                               "loop decides the value; over the bins float32 resolves the two agree to 3.5e-4 dB (tests/test_gpu_fatllama.py "
+                               "test_c1_exactly...); after_pcm16 = the node outputs behind the final PCM_16 hop (both k/32768: +-1 LSB "
                                "flips on ~2 % of samples of an eight-tone signal over a -40 dB floor -- the quantiser, not the loop)"}}
 
 
