@@ -77,3 +77,33 @@ def test_compute_nodes_fail_loudly_without_gpu(pack):
     node = pack.NODE_CLASS_MAPPINGS["EgregoraFatLlamaGPU"]()
     with pytest.raises(RuntimeError, match="No AMD GPU|no CPU fallback"):
         node.run("wav", 1, 0.6, 1411, True, True, AUDIO={"waveform": torch.zeros(1, 1, 64), "sample_rate": 48000})
+
+
+def test_flag_values_in_the_header_equal_the_python_binding(pack):
+    """The EGR_FL_* flag bits of egr_fatllama_enhance (include/egregora_amd.h) and the constants native.py / fatllama_engine.py pass."""
+    from egregora_amd import fatllama_engine as fe, native
+    txt = (ROOT / "include" / "egregora_amd.h").read_text()
+    hdr = {m.group(1): int(m.group(2), 16) for m in re.finditer(r"#define\s+(EGR_FL_[A-Z_]+)\s+0x([0-9a-fA-F]+)u", txt)}
+    want = {"EGR_FL_NORMALIZE": native.FL_NORMALIZE, "EGR_FL_AUTOSCALE": native.FL_AUTOSCALE, "EGR_FL_PCM_IN": native.FL_PCM_IN,
+            "EGR_FL_NODE_POST": native.FL_NODE_POST, "EGR_FL_THR_RELATIVE": native.FL_THR_RELATIVE, "EGR_FL_THR_SOFT": native.FL_THR_SOFT,
+            "EGR_FL_NO_INIT_THR": native.FL_NO_INIT_THR, "EGR_FL_ZERO_STUFF": native.FL_ZERO_STUFF, "EGR_FL_INTERP_LINSPACE": native.FL_INTERP_LINSPACE,
+            "EGR_FL_THR_RECOMPUTE": native.FL_THR_RECOMPUTE, "EGR_FL_DEFER_FINALIZE": native.FL_DEFER_FINALIZE}
+    assert hdr == want, (hdr, want)
+    assert len(set(want.values())) == len(want) and all(v & (v - 1) == 0 for v in want.values())          # distinct single bits
+    assert fe.variant_flags("relative,recompute") == native.FL_THR_RELATIVE | native.FL_THR_RECOMPUTE
+    assert fe.variant_flags("") == 0
+    with pytest.raises(RuntimeError):
+        fe.variant_flags("relative,no_such_variant")
+
+
+def test_committed_counter_profile_belongs_to_these_sources():
+    """profiles/traffic.json (the PMC passes bench.py's roofline objects quote) records the hash of the library sources it was taken on; the
+    bench line says whether it matches the sources it runs on.  At the end of a round the two must agree: a kernel change after the last
+    profile makes the `traffic` figures somebody else's."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_for_sha", ROOT / "bench.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+    assert tj.get("csrc_sha") == mod.csrc_sha(), (tj.get("csrc_sha"), mod.csrc_sha(), tj.get("source"))
