@@ -47,7 +47,7 @@ def variant_flags(names=None) -> int:
     return flags
 
 _PLANS: "OrderedDict[tuple, int]" = OrderedDict()
-_MAX_PLANS = 4
+_MAX_PLANS = 8          # (a plan of 60 s stereo holds 46 MB; EGREGORA_DEVICES adds one per device)
 
 
 def upscale_factor(sr: int, channels: int, target_bitrate_kbps: int) -> int:
@@ -56,11 +56,12 @@ def upscale_factor(sr: int, channels: int, target_bitrate_kbps: int) -> int:
     return max(1, int(round((target_bitrate_kbps * 1000.0) / src_bps)))
 
 
-def _plan(n_in: int, channels: int, factor: int, device: int, m1_hint: int = 0, tc_hint: int = 0, split=None, n_out=None):
+def _plan(n_in: int, channels: int, factor: int, device: int, m1_hint: int = 0, tc_hint: int = 0, split=None, n_out=None, slot: int = 0):
     """split = (m1, m2, m3) forces an explicit factorisation of N/2 (m3 = 1: two levels); split = "chirpz" forces the paired chirp-z
     path that lengths without a packed-real plan take automatically ("chirpz1" / "chirpz2": its even/odd-packing / channel-pair
-    kind), split = "bluestein" the legacy full-complex chirp-z."""
-    key = (n_in, channels, factor, device, m1_hint, tc_hint, split, n_out)
+    kind), split = "bluestein" the legacy full-complex chirp-z.  slot: a plan of its own for the same shape (a plan holds the loop's
+    state and serves one caller at a time: enhance_devices gives every position of EGREGORA_DEVICES its own, also when an index repeats)."""
+    key = (n_in, channels, factor, device, m1_hint, tc_hint, split, n_out, slot)
     h = _PLANS.get(key)
     if h is not None:
         _PLANS.move_to_end(key)
@@ -229,6 +230,71 @@ def enhance_channel_parallel(x_ct: torch.Tensor, factor: int, max_iterations: in
     return shard.sharded_channels(be, x_ct.shape[0], group=group, gather=gather)
 
 
+def enhance_devices(x_ct: torch.Tensor, factor: int, max_iterations: int, threshold_value: float, normalize: bool, autoscale: bool,
+                    pcm_in: bool, node_post: bool, devs, variant=None, n_out=None) -> torch.Tensor:
+    """Channel-parallel Fat-Llama inside ONE process (what a ComfyUI host is): position i of `devs` (the
+    EGREGORA_DEVICES list; at most as many as there are channels work) takes a contiguous block of channels on a host thread bound to its
+    device -- a peer copy of its channels in, egr_fatllama_enhance with EGR_FL_DEFER_FINALIZE on a plan of its own, its joint peak read
+    back (4 bytes), the maximum over the blocks taken on the host, egr_fatllama_finalize with it, a peer copy of its output rows into the
+    result on x_ct's device.  Same arithmetic as shard.sharded_channels across processes: bit-identical to enhance_device for even
+    lengths.  UNMEASURED on two physical GPUs in this repository's test pool (EGREGORA_DEVICES=0,0 exercises it on one)."""
+    import threading
+    from . import shard
+    if not (x_ct.is_cuda and x_ct.dtype == torch.float32 and x_ct.dim() == 2):
+        raise RuntimeError("enhance_devices wants a [C,T] float32 tensor on the GPU")
+    x_ct = x_ct.contiguous()
+    Cn, T = x_ct.shape
+    home = x_ct.device
+    t_out = T * factor if n_out is None else int(n_out)
+    flags = ((native.FL_NORMALIZE if normalize else 0) | (native.FL_AUTOSCALE if autoscale else 0) |
+             (native.FL_PCM_IN if pcm_in else 0) | (native.FL_NODE_POST if node_post else 0) | variant_flags(variant))
+    jobs = [(i, d, lo, hi) for i, (d, (lo, hi)) in enumerate(zip(devs, shard.block_bounds(Cn, min(len(devs), Cn)))) if hi > lo]
+    out = torch.empty((Cn, t_out), dtype=torch.float32, device=home)
+    torch.cuda.current_stream(home).synchronize()            # x_ct is complete before another device's stream reads it
+    L = native.lib()
+    peaks = [0.0] * len(jobs)
+    gate = threading.Barrier(len(jobs))
+    errors = []
+    # the plans are made (or found) HERE, on the caller's thread, one per position of the list: the workers only run
+    plans = []
+    for (slot, d, lo, hi) in jobs:
+        with torch.cuda.device(d):
+            plans.append(_plan(T, hi - lo, factor, d, 0, 0, None, n_out, slot=slot + 1))
+    if len(set(plans)) != len(plans) or any(pl not in _PLANS.values() for pl in plans):
+        raise RuntimeError("enhance_devices: the plan cache is too small for one plan per device (raise fatllama_engine._MAX_PLANS)")
+
+    def work(j, slot, d, lo, hi):
+        try:
+            with torch.cuda.device(d):
+                dev = torch.device("cuda", d)
+                xb = x_ct[lo:hi].to(dev, non_blocking=True).contiguous() if dev != home else x_ct[lo:hi].contiguous()
+                plan = plans[j]
+                y = torch.empty((hi - lo, t_out), dtype=torch.float32, device=dev)
+                native.check(L.egr_fatllama_enhance(C.c_void_p(plan), native.ptr(xb), native.ptr(y), int(max_iterations), float(threshold_value),
+                                                    flags | native.FL_DEFER_FINALIZE, native.stream_ptr()), "egr_fatllama_enhance")
+                jp = torch.zeros(1, dtype=torch.float32, device=dev)
+                native.check(L.egr_fatllama_joint_peak(C.c_void_p(plan), flags, native.ptr(jp), native.stream_ptr()), "egr_fatllama_joint_peak")
+                peaks[j] = float(jp.item())                  # (synchronises this device's stream)
+                gate.wait()                                  # every block's peak is in: the joint peak is their maximum (exact)
+                jp.fill_(max(peaks))
+                native.check(L.egr_fatllama_finalize(C.c_void_p(plan), native.ptr(y), flags, native.ptr(jp), native.stream_ptr()), "egr_fatllama_finalize")
+                out[lo:hi].copy_(y, non_blocking=True)       # a peer copy into the home device's tensor
+                torch.cuda.current_stream().synchronize()
+        except BaseException as ex:      # noqa: BLE001 -- re-raised in the caller's thread
+            errors.append(ex)
+            gate.abort()
+
+    threads = [threading.Thread(target=work, args=(j,) + job, name=f"fatllama-dev{job[1]}") for j, job in enumerate(jobs)][1:]
+    for t in threads:
+        t.start()
+    work(0, *jobs[0])
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return out
+
+
 def kernel_times(n_in: int, channels: int, factor: int, device: int = 0):
     L = native.lib()
     plan = _plan(n_in, channels, factor, device)
@@ -262,6 +328,12 @@ def node_run(cs: torch.Tensor, sr: int, max_iterations: int, threshold_value: fl
     if "ratio_then_int" in variant_names():          # SPEC.md factor_mode: the ratio is applied before int()
         r = upscale_ratio(int(sr), x.shape[0], int(target_bitrate_kbps))
         n_out, sr_out, f = int(x.shape[1] * r), int(int(sr) * r), 1
-    y = enhance_device(x, f, int(max_iterations), float(threshold_value), bool(toggle_normalize),
-                       bool(toggle_autoscale), pcm_in=True, node_post=True, n_out=n_out)
+    from . import flashsr_engine
+    devs = flashsr_engine.devices()
+    if len(devs) > 1 and x.shape[0] >= 2:            # EGREGORA_DEVICES: one channel block per device, one 4-byte exchange
+        y = enhance_devices(x, f, int(max_iterations), float(threshold_value), bool(toggle_normalize), bool(toggle_autoscale),
+                            pcm_in=True, node_post=True, devs=devs, n_out=n_out)
+    else:
+        y = enhance_device(x, f, int(max_iterations), float(threshold_value), bool(toggle_normalize),
+                           bool(toggle_autoscale), pcm_in=True, node_post=True, n_out=n_out)
     return y, sr_out

@@ -71,3 +71,23 @@ def test_two_ranks_one_channel_each_equal_the_single_plan_call(world, C, n, vari
             assert float(np.max(np.abs(y - want))) <= 2.0 / 32768.0 and float(np.mean(y != want)) < 0.05
         rows += mine.shape[0]
     assert rows == C
+
+
+@pytest.mark.parametrize("n,devices", [(48000, "0,0"), (96000, "0,0,0")])
+def test_devices_list_splits_the_channels_inside_one_process(pack, monkeypatch, n, devices):
+    """EGREGORA_DEVICES (the in-process form a ComfyUI host uses): the Fat-Llama node gives every position of the list a channel block on a
+    host thread of its own -- here two / three positions on the test box's one GPU -- and the result is the single-plan node result bit for
+    bit (even lengths); the peaks meet on the host (4 bytes per block)."""
+    from egregora_amd import fatllama_engine as fe
+    cs = torch.from_numpy(_signal(2, n))
+    monkeypatch.delenv("EGREGORA_DEVICES", raising=False)
+    want, sr1 = fe.node_run(cs, 48000, 60, 0.6, 1536, True, True)
+    monkeypatch.setenv("EGREGORA_DEVICES", devices)
+    got, sr2 = fe.node_run(cs, 48000, 60, 0.6, 1536, True, True)
+    torch.cuda.synchronize()
+    assert sr1 == sr2 == 48000 and got.shape == want.shape and got.device == want.device
+    assert torch.equal(got, want)
+    x = torch.from_numpy(_signal(2, n)).cuda()
+    a = fe.enhance_devices(x, 1, 30, 0.02, True, True, True, True, devs=[0, 0], variant="relative,soft")
+    b = fe.enhance_device(x, 1, 30, 0.02, True, True, True, True, variant="relative,soft")
+    assert torch.equal(a, b)
