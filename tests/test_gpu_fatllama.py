@@ -605,3 +605,17 @@ def test_carried_spectrum_maximum_equals_the_recomputed_one(pack, C, n, f, iters
         assert kept > 1e-5 and num / den < 1e-6, (variant, kept, num / den)
         if "soft" in variant:
             assert float(np.max(np.abs(got - want))) <= 2e-5 * float(np.max(np.abs(want)))
+
+
+@pytest.mark.parametrize("iters", [1, 2, 3, 24, 25, 26, 27, 50, 51, 52, 53, 76, 77, 101])
+@pytest.mark.parametrize("C,n", [(2, 9600), (2, 2 * 1013 * 4), (4, 4801)])
+def test_carried_maximum_at_every_graph_and_ring_boundary(pack, C, n, iters):
+    """The ring of 25 maximum slots and the captured 25-iteration graph meet at iteration counts around multiples of 25 (the packed loop replays
+    (iters - 1) // 25 graphs once iters > 50 and runs the rest as plain launches; the chirp-z loop keeps iteration 0 outside the graph): every
+    count from 1 to 101 that sits on such an edge, soft shrink relative to the maximum (the level changes every iteration: a slot read one
+    iteration early or late shows), against the maximum pass per iteration."""
+    x = synth(C, n, seed=n + iters, scale=8000.0)
+    got = run_gpu(pack, x, 1, iters, 0.03, variant="relative,soft")
+    ref = run_gpu(pack, x, 1, iters, 0.03, variant="relative,soft,recompute")
+    peak = float(np.max(np.abs(ref)))
+    assert np.isfinite(got).all() and float(np.max(np.abs(got - ref))) <= 5e-6 * peak, (C, n, iters, float(np.max(np.abs(got - ref))) / peak)
