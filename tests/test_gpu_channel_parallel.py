@@ -91,3 +91,27 @@ def test_devices_list_splits_the_channels_inside_one_process(pack, monkeypatch, 
     a = fe.enhance_devices(x, 1, 30, 0.02, True, True, True, True, devs=[0, 0], variant="relative,soft")
     b = fe.enhance_device(x, 1, 30, 0.02, True, True, True, True, variant="relative,soft")
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("variant,normalize,autoscale,node_post", [("", True, False, True), ("relative,soft", True, True, True), ("", False, True, False), ("", False, False, False)])
+def test_deferred_finalize_equals_the_one_call_form_without_a_process_group(pack, variant, normalize, autoscale, node_post):
+    """egr_fatllama_enhance with EGR_FL_DEFER_FINALIZE + egr_fatllama_joint_peak + egr_fatllama_finalize on ONE plan (no process group: what
+    shard.sharded_channels does for world 1) is the one-call form bit for bit, for every combination of the finalising flags -- including none
+    (finalize is then a no-op) and a NULL foreign peak."""
+    import ctypes as C
+    from egregora_amd import fatllama_engine as fe, native
+    x = torch.from_numpy(_signal(2, 24000)).cuda()
+    thr = 0.02 if variant else 0.6
+    want = fe.enhance_device(x, 1, 20, thr, normalize, autoscale, True, node_post, variant=variant)
+    got = fe.enhance_channel_parallel(x, 1, 20, thr, normalize, autoscale, True, node_post, variant=variant)
+    assert torch.equal(got, want)
+    # the same through the raw entry points with joint_dev = NULL
+    L = native.lib()
+    flags = ((native.FL_NORMALIZE if normalize else 0) | (native.FL_AUTOSCALE if autoscale else 0) | native.FL_PCM_IN |
+             (native.FL_NODE_POST if node_post else 0) | fe.variant_flags(variant))
+    plan = fe._plan(24000, 2, 1, 0)
+    y = torch.empty_like(x)
+    native.check(L.egr_fatllama_enhance(C.c_void_p(plan), native.ptr(x), native.ptr(y), 20, thr, flags | native.FL_DEFER_FINALIZE, native.stream_ptr()), "enhance")
+    native.check(L.egr_fatllama_finalize(C.c_void_p(plan), native.ptr(y), flags, C.c_void_p(0), native.stream_ptr()), "finalize")
+    torch.cuda.synchronize()
+    assert torch.equal(y, want)
